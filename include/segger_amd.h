@@ -1,0 +1,251 @@
+/*
+ * segger_amd.h -- C ABI of libsegger_amd.so: hand-written gfx950 (MI355X) HIP
+ * kernels for segger's GNN hot path (heterogeneous GATv2 message passing over
+ * transcript<->boundary graphs + the transcript->cell edge-scoring heads).
+ *
+ * The reference (dpeerlab/segger) has no FFI for this path: the arithmetic is
+ * reached through Python calls into torch_geometric / torch_scatter / torch
+ * CUDA kernels.  Each entry point below names the reference call site (file:line
+ * under /root/reference) whose third-party kernel(s) it replaces.
+ *
+ * Conventions (every entry point):
+ *   - returns SEGGER_OK (0) or a negative SEGGER_E* code; segger_last_error()
+ *     returns a thread-local message for the last failure on this thread;
+ *   - never throws, never allocates or frees device memory, never synchronises:
+ *     work is only enqueued on `stream` (a hipStream_t; NULL = default stream);
+ *   - all pointers are DEVICE pointers borrowed for the duration of the enqueued
+ *     work; outputs and workspaces are caller-allocated
+ *     (sizes from the matching *_workspace_bytes());
+ *   - sizes / offsets / leading dimensions are int64_t (cf. the >2^31 element
+ *     hazard in reference src/segger/_patches.py:1-9); node ids inside CSR
+ *     arrays are int32_t, so one batch holds < 2^31 nodes and < 2^31 edges
+ *     per edge type;
+ *   - "ld_*" = row stride in ELEMENTS of the tensor's dtype; rows must be
+ *     16-byte aligned (ld * sizeof(elem) % 16 == 0 and base % 16 == 0);
+ *   - feature tensors are row-major [n, heads*channels] in `dtype`
+ *     (SEGGER_F32 / SEGGER_BF16 / SEGGER_F16); all accumulation is fp32;
+ *     parameters (att, bias) and their gradients are fp32.
+ */
+#ifndef SEGGER_AMD_H
+#define SEGGER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEGGER_ABI_VERSION 1
+
+enum segger_status {
+  SEGGER_OK = 0,
+  SEGGER_EINVAL = -1,       /* bad argument (null pointer, negative size, misaligned ld) */
+  SEGGER_EUNSUPPORTED = -2, /* valid but not implemented (heads/channels combination, dtype) */
+  SEGGER_EHIP = -3,         /* a HIP runtime call failed; message has hipGetErrorString */
+  SEGGER_EWORKSPACE = -4    /* workspace too small */
+};
+
+enum segger_dtype { SEGGER_F32 = 0, SEGGER_BF16 = 1, SEGGER_F16 = 2 };
+
+typedef void* segger_stream_t; /* hipStream_t */
+
+int segger_abi_version(void);
+const char* segger_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * Compressed sparse rows of one edge type.
+ *   rows = the node the kernel iterates over, col = the node it gathers.
+ *   eid[slot] = position of that edge in the caller's COO edge_index, used
+ *   (a) for outputs indexed by original edge id, (b) as the dropout counter so
+ *   forward, dst-side backward and src-side backward draw the same mask.
+ * ---------------------------------------------------------------------- */
+typedef struct segger_csr {
+  const int64_t* indptr; /* [n_rows + 1] */
+  const int32_t* col;    /* [n_edges] */
+  const int32_t* eid;    /* [n_edges] */
+  int64_t n_rows;
+  int64_t n_cols;
+  int64_t n_edges;
+} segger_csr;
+
+/*
+ * segger_csr_from_coo: stable sort of COO edges by `row`, producing indptr /
+ * col / eid.  Replaces what PyG does implicitly per layer with scatter
+ * kernels keyed on edge_index[1] (GATv2Conv.propagate; constructed at
+ * src/segger/models/ist_encoder.py:111-124) and torch_scatter.scatter_max's
+ * keying on edge_index[0] (src/segger/models/lightning_model.py:280-284):
+ * built ONCE per batch and shared by all layers, forward and backward.
+ *   row, colv : [n_edges] int64 (edge_index rows as PyG stores them)
+ *   n_invalid : optional device int32; receives the number of edges whose row
+ *               or col id is out of range (such ids are clamped to 0 so later
+ *               kernels cannot fault; the host wrapper raises on n_invalid>0).
+ */
+size_t segger_csr_from_coo_workspace_bytes(int64_t n_edges, int64_t n_rows);
+int segger_csr_from_coo(const int64_t* row, const int64_t* colv, int64_t n_edges,
+                        int64_t n_rows, int64_t n_cols,
+                        int64_t* indptr, int32_t* col, int32_t* eid,
+                        int32_t* n_invalid,
+                        void* workspace, size_t workspace_bytes,
+                        segger_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * GATv2 attention aggregation (the roofline kernel).
+ *
+ * Replaces torch_geometric.nn.GATv2Conv.edge_update + utils.softmax + message
+ * + aggregate('add') + bias (PyG 2.7.0), i.e. everything in the conv AFTER
+ * lin_l / lin_r, for one edge type of segger's HeteroConv
+ * (src/segger/models/ist_encoder.py:109-134,183-189), with the following GELU
+ * (ist_encoder.py:325) optionally fused:
+ *
+ *   e[i->j,h]  = sum_c att[h,c] * leaky_relu(x_l[i,h,c] + x_r[j,h,c], slope)
+ *   a[i->j,h]  = softmax over the in-edges of j ;  a *= keep/(1-p) (dropout)
+ *   pre[j,h,c] = sum_i a[i->j,h] * x_l[i,h,c] + bias[h,c]
+ *   out        = apply_gelu ? gelu_erf(pre) : pre
+ *
+ * A destination without in-edges gets pre = bias.
+ * Dropout (ist_encoder.py:116,123; training only): keep(e,h) =
+ *   (mix32(mix32((eid*H+h) ^ seed_lo) + seed_hi) >> 8) >= floor(p * 2^24),
+ *   mix32(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16.
+ * ---------------------------------------------------------------------- */
+typedef struct segger_gatv2_fwd_args {
+  segger_csr by_dst;      /* rows = destination nodes, col = source ids */
+  const void* x_l;        /* [n_src, H*C] lin_l(x_src) */
+  int64_t ld_xl;
+  const void* x_r;        /* [n_dst, H*C] lin_r(x_dst) */
+  int64_t ld_xr;
+  const float* att;       /* [H*C] */
+  const float* bias;      /* [H*C] or NULL */
+  int32_t heads;
+  int32_t channels;
+  int32_t dtype;          /* segger_dtype of x_l, x_r, out, pre */
+  int32_t apply_gelu;
+  float negative_slope;   /* 0.2 in GATv2Conv */
+  float dropout_p;        /* 0 = eval */
+  uint64_t seed;
+  void* out;              /* [n_dst, H*C] */
+  int64_t ld_out;
+  void* pre;              /* [n_dst, H*C] pre-activation for backward; NULL = skip
+                             (may alias out when !apply_gelu) */
+  int64_t ld_pre;
+  float* lse;             /* [n_dst, H] log2(sum exp2(e*log2(e))) per (dst, head), kernel units;
+                             NULL = skip */
+  float* alpha;           /* [n_edges, H] attention (after dropout) by ORIGINAL edge id; NULL = skip
+                             (SkipGAT.attention_weights, ist_encoder.py:146-158,192-211) */
+} segger_gatv2_fwd_args;
+
+int segger_gatv2_fwd(const segger_gatv2_fwd_args* args, segger_stream_t stream);
+
+/*
+ * Backward of the above (replaces autograd through the PyG ops).  Two atomic-free
+ * passes: a destination-side pass (CSR by dst) producing grad_pre, grad_xr,
+ * grad_att, grad_bias, and a source-side pass (CSR by src) producing grad_xl.
+ * Attention coefficients are recomputed from x_l, x_r and `lse`; no [E,H,C]
+ * tensor is ever materialised.  Outputs are WRITTEN (not accumulated).
+ */
+typedef struct segger_gatv2_bwd_args {
+  segger_csr by_dst;      /* as in forward */
+  segger_csr by_src;      /* rows = source nodes, col = destination ids (same edges) */
+  const void* x_l;
+  int64_t ld_xl;
+  const void* x_r;
+  int64_t ld_xr;
+  const float* att;
+  const float* bias;      /* may be NULL */
+  int32_t heads;
+  int32_t channels;
+  int32_t dtype;
+  int32_t apply_gelu;
+  float negative_slope;
+  float dropout_p;
+  uint64_t seed;
+  const void* grad_out;   /* [n_dst, H*C] dL/d out */
+  int64_t ld_go;
+  const void* pre;        /* [n_dst, H*C] from forward */
+  int64_t ld_pre;
+  const float* lse;       /* [n_dst, H] from forward */
+  void* grad_pre;         /* [n_dst, H*C] scratch+output: dL/d pre (dtype) */
+  int64_t ld_gp;
+  float* dsum;            /* [n_dst, H] scratch: sum_c grad_pre * (pre - bias) */
+  void* grad_xl;          /* [n_src, H*C] */
+  int64_t ld_gxl;
+  void* grad_xr;          /* [n_dst, H*C] */
+  int64_t ld_gxr;
+  float* grad_att;        /* [H*C] */
+  float* grad_bias;       /* [H*C] or NULL */
+  void* workspace;        /* segger_gatv2_bwd_workspace_bytes() */
+  size_t workspace_bytes;
+} segger_gatv2_bwd_args;
+
+size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads, int32_t channels);
+int segger_gatv2_bwd(const segger_gatv2_bwd_args* args, segger_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Prediction head: cosine similarity on tx->bd candidate edges + per-transcript
+ * arg-max + assignment.  Replaces torch.cosine_similarity on two gathered
+ * [Ep, C] tensors, torch_scatter.scatter_max and the masked fancy-indexing of
+ * src/segger/models/lightning_model.py:275-293.
+ *   ties -> lowest original edge id (torch_scatter CPU semantics);
+ *   transcript without candidate edges -> max_sim 0, max_eid n_edges, seg -1.
+ * ---------------------------------------------------------------------- */
+typedef struct segger_edge_argmax_args {
+  segger_csr by_src;      /* rows = transcripts, col = boundary ids */
+  const void* z_src;      /* [n_rows, C] */
+  int64_t ld_zs;
+  const void* z_dst;      /* [n_cols, C] */
+  int64_t ld_zd;
+  int32_t channels;
+  int32_t dtype;
+  float eps;              /* 1e-8 (torch.cosine_similarity) */
+  int32_t use_min_similarity;
+  float min_similarity;
+  const int64_t* dst_index; /* [n_cols] boundary 'index' attribute; NULL = identity */
+  float* max_sim;         /* [n_rows] */
+  int64_t* max_eid;       /* [n_rows] */
+  int64_t* seg_idx;       /* [n_rows] dst_index[col of arg-max] or -1 */
+  float* sim;             /* [n_edges] per-edge cosine by ORIGINAL edge id; NULL = skip */
+} segger_edge_argmax_args;
+
+int segger_edge_cos_argmax(const segger_edge_argmax_args* args, segger_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Training head: triplet margin loss over tx-belongs-bd edges with sampled
+ * negative boundaries.  Replaces 3 gathers + torch.nn.TripletMarginLoss
+ * (margin, p=2, eps=1e-6, mean) at src/segger/models/lightning_model.py:182-187
+ * and its autograd.
+ *   loss = mean_e max(||a-p+eps|| - ||a-n+eps|| + margin, 0)
+ * fwd writes partial sums; `loss` receives the mean.  bwd accumulates
+ * (fp32 atomics) into grad_a / grad_b, which the caller zero-fills.
+ * ---------------------------------------------------------------------- */
+typedef struct segger_triplet_args {
+  const int64_t* src;     /* [n_edges] anchor rows of z_a */
+  const int64_t* pos;     /* [n_edges] positive rows of z_b */
+  const int64_t* neg;     /* [n_edges] negative rows of z_b */
+  int64_t n_edges;
+  const void* z_a;        /* [n_a, C] */
+  int64_t ld_za;
+  int64_t n_a;
+  const void* z_b;        /* [n_b, C] */
+  int64_t ld_zb;
+  int64_t n_b;
+  int32_t channels;
+  int32_t dtype;
+  float margin;
+  float eps;
+  float* loss;            /* [1] */
+  float grad_scale;       /* bwd: dL/dloss (the 1/n_edges is applied inside) */
+  const float* grad_scale_dev; /* bwd: optional DEVICE scalar multiplied into grad_scale (avoids a host sync) */
+  float* grad_a;          /* [n_a, C] fp32, bwd only */
+  float* grad_b;          /* [n_b, C] fp32, bwd only */
+  void* workspace;
+  size_t workspace_bytes;
+} segger_triplet_args;
+
+size_t segger_triplet_workspace_bytes(int64_t n_edges);
+int segger_triplet_fwd(const segger_triplet_args* args, segger_stream_t stream);
+int segger_triplet_bwd(const segger_triplet_args* args, segger_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGGER_AMD_H */

@@ -1,0 +1,155 @@
+"""ctypes binding of libsegger_amd.so (C ABI in include/segger_amd.h).
+
+There is NO fallback: if the shared library is missing or a call fails, the
+product raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C segger_amd/csrc -j8``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch  # noqa: F401  (must be imported first: the library binds to torch's libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsegger_amd.so")
+ABI_VERSION = 1
+
+SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
+DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
+
+
+class SeggerAmdError(RuntimeError):
+    pass
+
+
+c_i64p = C.c_void_p
+vp = C.c_void_p
+
+
+class Csr(C.Structure):
+    _fields_ = [("indptr", vp), ("col", vp), ("eid", vp),
+                ("n_rows", C.c_int64), ("n_cols", C.c_int64), ("n_edges", C.c_int64)]
+
+
+class GatFwdArgs(C.Structure):
+    _fields_ = [
+        ("by_dst", Csr),
+        ("x_l", vp), ("ld_xl", C.c_int64),
+        ("x_r", vp), ("ld_xr", C.c_int64),
+        ("att", vp), ("bias", vp),
+        ("heads", C.c_int32), ("channels", C.c_int32), ("dtype", C.c_int32), ("apply_gelu", C.c_int32),
+        ("negative_slope", C.c_float), ("dropout_p", C.c_float), ("seed", C.c_uint64),
+        ("out", vp), ("ld_out", C.c_int64),
+        ("pre", vp), ("ld_pre", C.c_int64),
+        ("lse", vp), ("alpha", vp),
+    ]
+
+
+class GatBwdArgs(C.Structure):
+    _fields_ = [
+        ("by_dst", Csr), ("by_src", Csr),
+        ("x_l", vp), ("ld_xl", C.c_int64),
+        ("x_r", vp), ("ld_xr", C.c_int64),
+        ("att", vp), ("bias", vp),
+        ("heads", C.c_int32), ("channels", C.c_int32), ("dtype", C.c_int32), ("apply_gelu", C.c_int32),
+        ("negative_slope", C.c_float), ("dropout_p", C.c_float), ("seed", C.c_uint64),
+        ("grad_out", vp), ("ld_go", C.c_int64),
+        ("pre", vp), ("ld_pre", C.c_int64),
+        ("lse", vp),
+        ("grad_pre", vp), ("ld_gp", C.c_int64),
+        ("dsum", vp),
+        ("grad_xl", vp), ("ld_gxl", C.c_int64),
+        ("grad_xr", vp), ("ld_gxr", C.c_int64),
+        ("grad_att", vp), ("grad_bias", vp),
+        ("workspace", vp), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class EdgeArgmaxArgs(C.Structure):
+    _fields_ = [
+        ("by_src", Csr),
+        ("z_src", vp), ("ld_zs", C.c_int64),
+        ("z_dst", vp), ("ld_zd", C.c_int64),
+        ("channels", C.c_int32), ("dtype", C.c_int32),
+        ("eps", C.c_float), ("use_min_similarity", C.c_int32), ("min_similarity", C.c_float),
+        ("dst_index", vp),
+        ("max_sim", vp), ("max_eid", vp), ("seg_idx", vp), ("sim", vp),
+    ]
+
+
+class TripletArgs(C.Structure):
+    _fields_ = [
+        ("src", vp), ("pos", vp), ("neg", vp), ("n_edges", C.c_int64),
+        ("z_a", vp), ("ld_za", C.c_int64), ("n_a", C.c_int64),
+        ("z_b", vp), ("ld_zb", C.c_int64), ("n_b", C.c_int64),
+        ("channels", C.c_int32), ("dtype", C.c_int32),
+        ("margin", C.c_float), ("eps", C.c_float),
+        ("loss", vp), ("grad_scale", C.c_float), ("grad_scale_dev", vp),
+        ("grad_a", vp), ("grad_b", vp),
+        ("workspace", vp), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+# every symbol include/segger_amd.h declares: name -> (restype, argtypes)
+EXPORTS = {
+    "segger_abi_version": (C.c_int, []),
+    "segger_last_error": (C.c_char_p, []),
+    "segger_csr_from_coo_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
+    "segger_csr_from_coo": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, C.c_size_t, vp]),
+    "segger_gatv2_fwd": (C.c_int, [C.POINTER(GatFwdArgs), vp]),
+    "segger_gatv2_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "segger_gatv2_bwd": (C.c_int, [C.POINTER(GatBwdArgs), vp]),
+    "segger_edge_cos_argmax": (C.c_int, [C.POINTER(EdgeArgmaxArgs), vp]),
+    "segger_triplet_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "segger_triplet_fwd": (C.c_int, [C.POINTER(TripletArgs), vp]),
+    "segger_triplet_bwd": (C.c_int, [C.POINTER(TripletArgs), vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the library once; raise loudly when it is absent or stale."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SeggerAmdError(
+            f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU/PyTorch "
+            f"fallback for this path. Run `make -C {os.path.join(_HERE, 'csrc')} -j8`.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
+    for name, (res, args) in EXPORTS.items():
+        if not hasattr(lib, name):
+            raise SeggerAmdError(f"{LIB_PATH} does not export {name}; rebuild it")
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.segger_abi_version()
+    if v != ABI_VERSION:
+        raise SeggerAmdError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().segger_last_error().decode("utf-8", "replace")
+        raise SeggerAmdError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_cuda(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SeggerAmdError(
+                "segger_amd runs on MI355X only: got a CPU tensor and there is no CPU fallback "
+                "(the CPU oracle under oracle/ is test infrastructure, not a code path)")

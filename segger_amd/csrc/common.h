@@ -1,0 +1,180 @@
+// Shared device/host helpers for libsegger_amd (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/segger_amd.h"
+
+namespace segger {
+
+// ---------------------------------------------------------------- errors ---
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define SEGGER_REQUIRE(cond, ...)                 \
+  do {                                            \
+    if (!(cond)) {                                \
+      ::segger::set_error(__VA_ARGS__);           \
+      return SEGGER_EINVAL;                       \
+    }                                             \
+  } while (0)
+
+#define SEGGER_HIP(call)                                        \
+  do {                                                          \
+    hipError_t _e = (call);                                     \
+    if (_e != hipSuccess) return ::segger::hip_fail(_e, #call); \
+  } while (0)
+
+#define SEGGER_LAUNCH_CHECK(name)                                   \
+  do {                                                              \
+    hipError_t _e = hipGetLastError();                              \
+    if (_e != hipSuccess) return ::segger::hip_fail(_e, name);      \
+  } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+constexpr int kWave = 64;
+constexpr int kNumXcd = 8;
+
+// ------------------------------------------------------- element types -----
+struct bf16_t { uint16_t v; };
+struct f16_t  { uint16_t v; };
+
+typedef float    f32x2 __attribute__((ext_vector_type(2)));
+typedef float    f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16   b16x2 __attribute__((ext_vector_type(2)));
+
+// Load / store 8 consecutive channels as fp32.  p must be 16-byte aligned.
+template <typename T> struct Vec8;
+
+template <> struct Vec8<float> {
+  static __device__ __forceinline__ void load(const float* p, float (&f)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
+    f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  }
+  static __device__ __forceinline__ void store(float* p, const float (&f)[8]) {
+    f32x4 a = {f[0], f[1], f[2], f[3]};
+    f32x4 b = {f[4], f[5], f[6], f[7]};
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+  }
+};
+
+template <> struct Vec8<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float (&f)[8]) {
+    u32x4 r = *reinterpret_cast<const u32x4*>(p);
+    f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+    f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+    f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+    f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) {
+    // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
+    f32x2 v = {a, b};
+    b16x2 h = __builtin_convertvector(v, b16x2);
+    return __builtin_bit_cast(uint32_t, h);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, const float (&f)[8]) {
+    u32x4 r = {pack(f[0], f[1]), pack(f[2], f[3]), pack(f[4], f[5]), pack(f[6], f[7])};
+    *reinterpret_cast<u32x4*>(p) = r;
+  }
+};
+
+template <> struct Vec8<f16_t> {
+  static __device__ __forceinline__ void unpack(uint32_t w, float& a, float& b) {
+    h16x2 h = __builtin_bit_cast(h16x2, w);
+    a = static_cast<float>(h.x); b = static_cast<float>(h.y);
+  }
+  static __device__ __forceinline__ void load(const f16_t* p, float (&f)[8]) {
+    u32x4 r = *reinterpret_cast<const u32x4*>(p);
+    unpack(r.x, f[0], f[1]); unpack(r.y, f[2], f[3]);
+    unpack(r.z, f[4], f[5]); unpack(r.w, f[6], f[7]);
+  }
+  static __device__ __forceinline__ uint32_t pack(float a, float b) {
+    h16x2 h = {static_cast<_Float16>(a), static_cast<_Float16>(b)};
+    return __builtin_bit_cast(uint32_t, h);
+  }
+  static __device__ __forceinline__ void store(f16_t* p, const float (&f)[8]) {
+    u32x4 r = {pack(f[0], f[1]), pack(f[2], f[3]), pack(f[4], f[5]), pack(f[6], f[7])};
+    *reinterpret_cast<u32x4*>(p) = r;
+  }
+};
+
+// ------------------------------------------------------- cross-lane --------
+// DPP within a 16-lane row (ctrl must be a compile-time constant).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, false);
+}
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // lane i <-> 7-i within 8
+constexpr int kDppMirror = 0x140;     // lane i <-> 15-i within 16
+constexpr int kDppRowBcast0 = 0x150;  // row_newbcast:n (gfx90a+): lane n of each row -> whole row
+
+// Sum over aligned blocks of N consecutive lanes (N = 1,2,4,8,16), result in every lane.
+template <int N>
+__device__ __forceinline__ float lane_block_sum(float v) {
+  if constexpr (N >= 2)  v += dpp_f<kDppXor1>(v);
+  if constexpr (N >= 4)  v += dpp_f<kDppXor2>(v);
+  if constexpr (N >= 8)  v += dpp_f<kDppHalfMirror>(v);
+  if constexpr (N >= 16) v += dpp_f<kDppMirror>(v);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+  v = lane_block_sum<16>(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+
+// ------------------------------------------------------- math --------------
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+
+// exact (erf) GELU, torch.nn.functional.gelu(approximate='none')
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// counter-based attention-dropout mask (include/segger_amd.h)
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool dropout_keep(uint32_t eid, uint32_t heads, uint32_t h,
+                                             uint32_t seed_lo, uint32_t seed_hi, uint32_t thr) {
+  const uint32_t c = eid * heads + h;
+  return (mix32(mix32(c ^ seed_lo) + seed_hi) >> 8) >= thr;
+}
+
+// XCD-aware block remap: consecutive logical blocks land on the same XCD (blocks
+// are dealt round-robin over the 8 XCDs), so neighbouring rows share one L2.
+// Launch a grid padded to a multiple of 8; returns -1 for the padding blocks.
+__device__ __forceinline__ int64_t xcd_remap(int64_t bid, int64_t nblocks_padded, int64_t nblocks) {
+  const int64_t per = nblocks_padded / kNumXcd;
+  const int64_t b = (bid % kNumXcd) * per + bid / kNumXcd;
+  return b < nblocks ? b : -1;
+}
+static inline int64_t pad_to_xcd(int64_t nblocks) { return (nblocks + kNumXcd - 1) / kNumXcd * kNumXcd; }
+
+}  // namespace segger

@@ -1,0 +1,106 @@
+// segger_csr_from_coo: COO edge_index -> CSR (indptr, col, eid) by a stable
+// device radix sort on the row id.  Built once per batch and edge type.
+#include "common.h"
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace segger {
+namespace {
+
+__global__ __launch_bounds__(256) void csr_prepare_kernel(const int64_t* __restrict__ row, const int64_t* __restrict__ colv,
+                                                         int64_t n_edges, int64_t n_rows, int64_t n_cols,
+                                                         uint32_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                                         int32_t* __restrict__ n_invalid) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_edges) return;
+  int64_t r = row[e];
+  const int64_t c = colv[e];
+  const bool bad = r < 0 || r >= n_rows || c < 0 || c >= n_cols;
+  if (bad) {
+    if (n_invalid) atomicAdd(n_invalid, 1);
+    if (r < 0 || r >= n_rows) r = 0;
+  }
+  keys[e] = (uint32_t)r;
+  vals[e] = (int32_t)e;
+}
+
+__global__ __launch_bounds__(256) void csr_finalize_kernel(const uint32_t* __restrict__ keys_sorted, const int32_t* __restrict__ eid,
+                                                          const int64_t* __restrict__ colv, int64_t n_edges, int64_t n_rows,
+                                                          int64_t n_cols, int64_t* __restrict__ indptr, int32_t* __restrict__ col) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_edges) return;
+  int64_t c = colv[eid[s]];
+  if (c < 0 || c >= n_cols) c = 0;
+  col[s] = (int32_t)c;
+  const int64_t k = keys_sorted[s];
+  const int64_t kprev = s > 0 ? (int64_t)keys_sorted[s - 1] : -1;
+  for (int64_t r = kprev + 1; r <= k; ++r) indptr[r] = s;      // first slot of row k; empty rows before it
+  if (s == n_edges - 1)
+    for (int64_t r = k + 1; r <= n_rows; ++r) indptr[r] = n_edges;
+}
+
+int key_bits(int64_t n_rows) {
+  int b = 1;
+  while (b < 32 && (1LL << b) < n_rows) ++b;
+  return b;
+}
+
+size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t sort_temp_bytes(int64_t n_edges, int64_t n_rows) {
+  size_t bytes = 0;
+  uint32_t* k = nullptr;
+  int32_t* v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n_edges, 0, key_bits(n_rows), (hipStream_t)0);
+  return bytes;
+}
+
+}  // namespace
+}  // namespace segger
+
+using namespace segger;
+
+extern "C" size_t segger_csr_from_coo_workspace_bytes(int64_t n_edges, int64_t n_rows) {
+  if (n_edges <= 0) return 256;
+  return 3 * align_up((size_t)n_edges * 4) + align_up(sort_temp_bytes(n_edges, n_rows)) + 256;
+}
+
+extern "C" int segger_csr_from_coo(const int64_t* row, const int64_t* colv, int64_t n_edges, int64_t n_rows, int64_t n_cols,
+                                   int64_t* indptr, int32_t* col, int32_t* eid, int32_t* n_invalid,
+                                   void* workspace, size_t workspace_bytes, segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGGER_REQUIRE(n_edges >= 0 && n_rows >= 0 && n_cols >= 0, "segger_csr_from_coo: negative size");
+  SEGGER_REQUIRE(n_edges < 0x7fffffffLL && n_rows < 0x7fffffffLL && n_cols < 0x7fffffffLL,
+                 "segger_csr_from_coo: more than 2^31-1 edges/rows/cols in one batch");
+  SEGGER_REQUIRE(indptr != nullptr, "segger_csr_from_coo: indptr is NULL");
+  if (n_invalid) SEGGER_HIP(hipMemsetAsync(n_invalid, 0, sizeof(int32_t), stream));
+  if (n_edges == 0) {
+    SEGGER_HIP(hipMemsetAsync(indptr, 0, (size_t)(n_rows + 1) * sizeof(int64_t), stream));
+    return SEGGER_OK;
+  }
+  SEGGER_REQUIRE(row && colv && col && eid, "segger_csr_from_coo: NULL edge array");
+  SEGGER_REQUIRE(n_rows > 0 && n_cols > 0, "segger_csr_from_coo: edges given but no rows/cols");
+  const size_t need = segger_csr_from_coo_workspace_bytes(n_edges, n_rows);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("segger_csr_from_coo: workspace %zu < %zu bytes", workspace_bytes, need);
+    return SEGGER_EWORKSPACE;
+  }
+  const size_t seg = align_up((size_t)n_edges * 4);
+  char* base = static_cast<char*>(workspace);
+  uint32_t* keys_in = reinterpret_cast<uint32_t*>(base);
+  uint32_t* keys_out = reinterpret_cast<uint32_t*>(base + seg);
+  int32_t* vals_in = reinterpret_cast<int32_t*>(base + 2 * seg);
+  void* temp = base + 3 * seg;
+  size_t temp_bytes = sort_temp_bytes(n_edges, n_rows);
+
+  const unsigned nblk = (unsigned)((n_edges + 255) / 256);
+  hipLaunchKernelGGL(csr_prepare_kernel, dim3(nblk), dim3(256), 0, stream, row, colv, n_edges, n_rows, n_cols,
+                     keys_in, vals_in, n_invalid);
+  SEGGER_LAUNCH_CHECK("csr_prepare_kernel");
+  SEGGER_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, eid, (size_t)n_edges, 0,
+                                       key_bits(n_rows), stream));
+  hipLaunchKernelGGL(csr_finalize_kernel, dim3(nblk), dim3(256), 0, stream, keys_out, eid, colv, n_edges, n_rows, n_cols,
+                     indptr, col);
+  SEGGER_LAUNCH_CHECK("csr_finalize_kernel");
+  return SEGGER_OK;
+}

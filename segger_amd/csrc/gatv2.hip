@@ -1,0 +1,178 @@
+// Host launchers for the fused GATv2 kernels (C ABI: include/segger_amd.h).
+#include "gatv2_launch.h"
+
+namespace segger {
+
+// grad_att / grad_bias = column sums of the slab  [nblocks][2*HC]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int64_t nblocks, int width,
+                                                         int hc, float* __restrict__ grad_att, float* __restrict__ grad_bias) {
+  // one block per chunk of 64 columns; the 4 waves split the slab rows
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int colx = blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (colx < width)
+    for (int64_t r = wave; r < nblocks; r += 4) s += slab[r * width + colx];
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && colx < width) {
+    const float t = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+    if (colx < hc) grad_att[colx] = t;
+    else if (grad_bias) grad_bias[colx - hc] = t;
+  }
+}
+
+namespace {
+
+// average-degree threshold above which the NG groups of a wave split ONE row
+constexpr double kWavePerRowDegree = 32.0;
+
+int launch(Pass pass, GatParams& p, int dtype, int heads, int channels, bool wpr, hipStream_t stream) {
+  typedef int (*fn_t)(GatParams&, int, int, bool, hipStream_t);
+  static const fn_t table[3][3] = {
+      {gatv2_launch_fwd_f32, gatv2_launch_fwd_bf16, gatv2_launch_fwd_f16},
+      {gatv2_launch_bwd_dst_f32, gatv2_launch_bwd_dst_bf16, gatv2_launch_bwd_dst_f16},
+      {gatv2_launch_bwd_src_f32, gatv2_launch_bwd_src_bf16, gatv2_launch_bwd_src_f16}};
+  if (dtype < 0 || dtype > 2) { set_error("gatv2: unknown dtype %d", dtype); return SEGGER_EINVAL; }
+  return table[(int)pass][dtype](p, heads, channels, wpr, stream);
+}
+
+size_t elem_size(int dtype) { return dtype == SEGGER_F32 ? 4 : 2; }
+
+int check_rows(const char* name, const void* ptr, int64_t ld, int dtype, int hc) {
+  SEGGER_REQUIRE(ptr != nullptr, "gatv2: %s is NULL", name);
+  SEGGER_REQUIRE(aligned16(ptr), "gatv2: %s is not 16-byte aligned", name);
+  SEGGER_REQUIRE(ld >= hc, "gatv2: ld of %s (%lld) < heads*channels (%d)", name, (long long)ld, hc);
+  SEGGER_REQUIRE((ld * (int64_t)elem_size(dtype)) % 16 == 0, "gatv2: row stride of %s is not a multiple of 16 bytes", name);
+  return SEGGER_OK;
+}
+
+int check_csr(const char* name, const segger_csr& g) {
+  SEGGER_REQUIRE(g.n_rows >= 0 && g.n_cols >= 0 && g.n_edges >= 0, "gatv2: negative size in %s", name);
+  SEGGER_REQUIRE(g.n_rows < 0x7fffffffLL && g.n_cols < 0x7fffffffLL && g.n_edges < 0x7fffffffLL,
+                 "gatv2: %s exceeds 2^31-1 rows/cols/edges per batch", name);
+  SEGGER_REQUIRE(g.indptr != nullptr, "gatv2: %s.indptr is NULL", name);
+  SEGGER_REQUIRE(g.n_edges == 0 || g.col != nullptr, "gatv2: %s.col is NULL", name);
+  return SEGGER_OK;
+}
+
+void set_dropout(GatParams& p, float dropout_p, uint64_t seed) {
+  p.drop_thr = 0; p.drop_scale = 1.f;
+  if (dropout_p > 0.f) {
+    p.drop_thr = (uint32_t)((double)dropout_p * 16777216.0);
+    p.drop_scale = 1.0f / (1.0f - dropout_p);
+  }
+  p.seed_lo = (uint32_t)(seed & 0xffffffffu);
+  p.seed_hi = (uint32_t)(seed >> 32);
+}
+
+bool use_wave_per_row(const segger_csr& g) {
+  return g.n_rows > 0 && (double)g.n_edges / (double)g.n_rows >= kWavePerRowDegree;
+}
+
+}  // namespace
+}  // namespace segger
+
+using namespace segger;
+
+#define CHECK_RC(expr) do { int _rc = (expr); if (_rc != SEGGER_OK) return _rc; } while (0)
+
+extern "C" int segger_gatv2_fwd(const segger_gatv2_fwd_args* a, segger_stream_t stream) {
+  SEGGER_REQUIRE(a != nullptr, "segger_gatv2_fwd: args is NULL");
+  SEGGER_REQUIRE(a->heads > 0 && a->channels > 0, "segger_gatv2_fwd: heads/channels must be positive");
+  const int hc = a->heads * a->channels;
+  CHECK_RC(check_csr("by_dst", a->by_dst));
+  SEGGER_REQUIRE(a->att != nullptr, "segger_gatv2_fwd: att is NULL");
+  SEGGER_REQUIRE(a->negative_slope >= 0.f && a->negative_slope <= 1.f, "segger_gatv2_fwd: negative_slope must be in [0,1]");
+  SEGGER_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "segger_gatv2_fwd: dropout_p must be in [0,1)");
+  if (a->by_dst.n_rows == 0) return SEGGER_OK;
+  CHECK_RC(check_rows("x_r", a->x_r, a->ld_xr, a->dtype, hc));
+  CHECK_RC(check_rows("out", a->out, a->ld_out, a->dtype, hc));
+  if (a->by_dst.n_edges > 0) CHECK_RC(check_rows("x_l", a->x_l, a->ld_xl, a->dtype, hc));
+  if (a->pre) {
+    CHECK_RC(check_rows("pre", a->pre, a->ld_pre, a->dtype, hc));
+    SEGGER_REQUIRE(!(a->pre == a->out && a->apply_gelu), "segger_gatv2_fwd: pre may alias out only without GELU");
+  }
+  SEGGER_REQUIRE(!(a->dropout_p > 0.f || a->alpha) || a->by_dst.n_edges == 0 || a->by_dst.eid != nullptr,
+                 "segger_gatv2_fwd: by_dst.eid is required for dropout / alpha output");
+  GatParams p{};
+  p.indptr = a->by_dst.indptr; p.col = a->by_dst.col; p.eid = a->by_dst.eid;
+  p.n_rows = a->by_dst.n_rows; p.n_edges = a->by_dst.n_edges;
+  p.xl = a->x_l; p.ld_xl = a->ld_xl; p.xr = a->x_r; p.ld_xr = a->ld_xr;
+  p.att = a->att; p.bias = a->bias;
+  p.out = a->out; p.ld_out = a->ld_out; p.pre = a->pre; p.ld_pre = a->ld_pre;
+  p.lse = a->lse; p.alpha = a->alpha;
+  p.slope = a->negative_slope; p.apply_gelu = a->apply_gelu; p.rows_per_wave_iter = 1;
+  set_dropout(p, a->dropout_p, a->seed);
+  return launch(Pass::Fwd, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), (hipStream_t)stream);
+}
+
+extern "C" size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads, int32_t channels) {
+  if (n_dst <= 0 || heads <= 0 || channels <= 0) return 16;
+  // upper bound over both modes: wave-per-row has the most blocks (4 rows per block-iteration)
+  const int64_t blocks = (n_dst + 4 * kBwdRowIters - 1) / (4 * kBwdRowIters) + kNumXcd;
+  return (size_t)blocks * 2 * heads * channels * sizeof(float);
+}
+
+extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGGER_REQUIRE(a != nullptr, "segger_gatv2_bwd: args is NULL");
+  SEGGER_REQUIRE(a->heads > 0 && a->channels > 0, "segger_gatv2_bwd: heads/channels must be positive");
+  const int hc = a->heads * a->channels;
+  CHECK_RC(check_csr("by_dst", a->by_dst));
+  CHECK_RC(check_csr("by_src", a->by_src));
+  SEGGER_REQUIRE(a->by_dst.n_edges == a->by_src.n_edges && a->by_dst.n_rows == a->by_src.n_cols &&
+                 a->by_dst.n_cols == a->by_src.n_rows, "segger_gatv2_bwd: by_dst and by_src describe different graphs");
+  SEGGER_REQUIRE(a->att && a->grad_att, "segger_gatv2_bwd: att / grad_att is NULL");
+  SEGGER_REQUIRE(a->negative_slope >= 0.f && a->negative_slope <= 1.f, "segger_gatv2_bwd: negative_slope must be in [0,1]");
+  SEGGER_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "segger_gatv2_bwd: dropout_p must be in [0,1)");
+  const int64_t n_dst = a->by_dst.n_rows, n_src = a->by_src.n_rows, n_edges = a->by_dst.n_edges;
+  if (n_dst > 0) {
+    CHECK_RC(check_rows("x_r", a->x_r, a->ld_xr, a->dtype, hc));
+    CHECK_RC(check_rows("grad_out", a->grad_out, a->ld_go, a->dtype, hc));
+    CHECK_RC(check_rows("pre", a->pre, a->ld_pre, a->dtype, hc));
+    CHECK_RC(check_rows("grad_pre", a->grad_pre, a->ld_gp, a->dtype, hc));
+    CHECK_RC(check_rows("grad_xr", a->grad_xr, a->ld_gxr, a->dtype, hc));
+    SEGGER_REQUIRE(a->lse && a->dsum, "segger_gatv2_bwd: lse / dsum is NULL");
+  }
+  if (n_src > 0) {
+    CHECK_RC(check_rows("x_l", a->x_l, a->ld_xl, a->dtype, hc));
+    CHECK_RC(check_rows("grad_xl", a->grad_xl, a->ld_gxl, a->dtype, hc));
+  }
+  SEGGER_REQUIRE(!(a->dropout_p > 0.f) || n_edges == 0 || (a->by_dst.eid && a->by_src.eid),
+                 "segger_gatv2_bwd: eid arrays are required for dropout");
+  const size_t need = segger_gatv2_bwd_workspace_bytes(n_dst, a->heads, a->channels);
+  if (a->workspace == nullptr || a->workspace_bytes < need) {
+    set_error("segger_gatv2_bwd: workspace %zu < %zu bytes", a->workspace_bytes, need);
+    return SEGGER_EWORKSPACE;
+  }
+
+  GatParams p{};
+  p.xl = a->x_l; p.ld_xl = a->ld_xl; p.xr = a->x_r; p.ld_xr = a->ld_xr;
+  p.att = a->att; p.bias = a->bias;
+  p.pre = const_cast<void*>(a->pre); p.ld_pre = a->ld_pre; p.lse = const_cast<float*>(a->lse);
+  p.gout = a->grad_out; p.ld_go = a->ld_go; p.gpre = a->grad_pre; p.ld_gp = a->ld_gp; p.dsum = a->dsum;
+  p.gxl = a->grad_xl; p.ld_gxl = a->ld_gxl; p.gxr = a->grad_xr; p.ld_gxr = a->ld_gxr;
+  p.slab = static_cast<float*>(a->workspace);
+  p.slope = a->negative_slope; p.apply_gelu = a->apply_gelu;
+  set_dropout(p, a->dropout_p, a->seed);
+
+  // ---- destination side ------------------------------------------------------
+  p.indptr = a->by_dst.indptr; p.col = a->by_dst.col; p.eid = a->by_dst.eid;
+  p.n_rows = n_dst; p.n_edges = n_edges; p.rows_per_wave_iter = kBwdRowIters;
+  if (n_dst > 0) {
+    CHECK_RC(launch(Pass::BwdDst, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), stream));
+    const int width = 2 * hc;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((width + 63) / 64), dim3(256), 0, stream,
+                       p.slab, p.nblocks, width, hc, a->grad_att, a->grad_bias);
+    SEGGER_LAUNCH_CHECK("slab_reduce_kernel");
+  } else {
+    SEGGER_HIP(hipMemsetAsync(a->grad_att, 0, hc * sizeof(float), stream));
+    if (a->grad_bias) SEGGER_HIP(hipMemsetAsync(a->grad_bias, 0, hc * sizeof(float), stream));
+  }
+  // ---- source side -----------------------------------------------------------
+  p.indptr = a->by_src.indptr; p.col = a->by_src.col; p.eid = a->by_src.eid;
+  p.n_rows = n_src; p.rows_per_wave_iter = 1;
+  if (n_src > 0) CHECK_RC(launch(Pass::BwdSrc, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_src), stream));
+  return SEGGER_OK;
+}

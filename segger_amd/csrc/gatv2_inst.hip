@@ -1,0 +1,63 @@
+// One (pass, dtype) slice of the fused GATv2 kernels.  Build with
+//   -DSEGGER_INST_PASS={0 fwd,1 bwd_dst,2 bwd_src} -DSEGGER_INST_DTYPE={0 f32,1 bf16,2 f16}
+#include "gatv2_launch.h"
+
+#if SEGGER_INST_DTYPE == 0
+#define INST_T float
+#define INST_TN f32
+#elif SEGGER_INST_DTYPE == 1
+#define INST_T bf16_t
+#define INST_TN bf16
+#else
+#define INST_T f16_t
+#define INST_TN f16
+#endif
+#if SEGGER_INST_PASS == 0
+#define INST_KERNEL gatv2_fwd_kernel
+#define INST_PN fwd
+#elif SEGGER_INST_PASS == 1
+#define INST_KERNEL gatv2_bwd_dst_kernel
+#define INST_PN bwd_dst
+#else
+#define INST_KERNEL gatv2_bwd_src_kernel
+#define INST_PN bwd_src
+#endif
+#define INST_CAT2(a, b, c) gatv2_launch_##a##_##b
+#define INST_CAT(a, b) INST_CAT2(a, b, )
+#define INST_NAME INST_CAT(INST_PN, INST_TN)
+
+namespace segger {
+namespace {
+
+template <int H, int LPH, bool WPR>
+int launch_one(GatParams& p, hipStream_t stream) {
+  using G = Geo<H, LPH>;
+  const int64_t rows_per_wave = WPR ? 1 : G::NG;
+  const int iters = (SEGGER_INST_PASS == 1) ? p.rows_per_wave_iter : 1;
+  const int64_t rows_per_block = 4 * rows_per_wave * iters;
+  p.nblocks = (p.n_rows + rows_per_block - 1) / rows_per_block;
+  p.nblocks_padded = pad_to_xcd(p.nblocks);
+  if (p.nblocks == 0) return SEGGER_OK;
+  if (p.nblocks_padded > 0x7fffffffLL) {
+    set_error("gatv2: %lld rows need more than 2^31 blocks", (long long)p.n_rows);
+    return SEGGER_EUNSUPPORTED;
+  }
+  hipLaunchKernelGGL((INST_KERNEL<INST_T, H, LPH, WPR>), dim3((unsigned)p.nblocks_padded), dim3(256), 0, stream, p);
+  SEGGER_LAUNCH_CHECK("gatv2 kernel launch");
+  return SEGGER_OK;
+}
+
+}  // namespace
+
+int INST_NAME(GatParams& p, int heads, int channels, bool wpr, hipStream_t stream) {
+#define X(H, LPH)                                      \
+  if (heads == H && channels == LPH * 8)               \
+    return wpr ? launch_one<H, LPH, true>(p, stream) : launch_one<H, LPH, false>(p, stream);
+  SEGGER_GEOMETRIES(X)
+#undef X
+  set_error("gatv2: heads=%d channels=%d has no specialised kernel (supported: channels in {32,64}, heads in {1,2,3,4})",
+            heads, channels);
+  return SEGGER_EUNSUPPORTED;
+}
+
+}  // namespace segger

@@ -1,0 +1,548 @@
+// Fused GATv2 attention aggregation for gfx950: forward, destination-side
+// backward and source-side backward.  See DESIGN.md "Kernels" for the layout.
+//
+// Geometry.  A feature row has H*C channels; every lane owns 8 consecutive
+// channels (one 16-byte load for bf16/f16, two for f32), so a row is covered by
+// LPR = H*C/8 lanes and a head by LPH = C/8 lanes.  Lanes are grouped in
+// power-of-two groups of GS >= LPR lanes; a wave holds NG = 64/GS groups and
+// therefore gathers NG neighbour rows per load instruction (flagship H=2,C=64:
+// GS=16, 4 rows = 1 KiB per wave-instruction).
+//   * group-per-row mode (WPR=false): each group owns one CSR row and walks its
+//     edges; used when the average degree is small (tx-neighbors-tx, k~15).
+//   * wave-per-row mode (WPR=true): the NG groups split one row's edges and
+//     merge their online-softmax states at the end; used for high-degree rows
+//     (tx-belongs-bd: tens to hundreds of transcripts per nucleus).
+// Neighbour ids are fetched GS (or 64) at a time with one coalesced load and
+// handed to the gathering lanes by DPP row-broadcast (GS=16) or ds_bpermute.
+#pragma once
+#include "common.h"
+
+namespace segger {
+
+constexpr int kEdgeUnroll = 4;   // neighbour rows in flight per lane
+
+// minimum resident waves per SIMD the register allocator must leave room for
+// (second __launch_bounds__ argument: 512 VGPRs / waves, granule 8)
+#ifndef SEGGER_FWD_WAVES
+#define SEGGER_FWD_WAVES 4
+#endif
+#ifndef SEGGER_BWD_DST_WAVES
+#define SEGGER_BWD_DST_WAVES 2
+#endif
+#ifndef SEGGER_BWD_SRC_WAVES
+#define SEGGER_BWD_SRC_WAVES 3
+#endif
+
+template <int H_, int LPH_>
+struct Geo {
+  static constexpr int H = H_;
+  static constexpr int LPH = LPH_;
+  static constexpr int C = LPH * 8;
+  static constexpr int HC = H * C;
+  static constexpr int LPR = H * LPH;
+  static constexpr int GS = LPR <= 1 ? 1 : LPR <= 2 ? 2 : LPR <= 4 ? 4 : LPR <= 8 ? 8 : LPR <= 16 ? 16 : LPR <= 32 ? 32 : 64;
+  static constexpr int NG = 64 / GS;
+  static_assert(LPR <= 64, "row does not fit one wave");
+};
+
+struct GatParams {
+  // graph (rows = the node this kernel iterates over)
+  const int64_t* indptr;
+  const int32_t* col;
+  const int32_t* eid;
+  int64_t n_rows;
+  int64_t n_edges;
+  // features
+  const void* xl; int64_t ld_xl;
+  const void* xr; int64_t ld_xr;
+  const float* att;
+  const float* bias;
+  // forward outputs
+  void* out; int64_t ld_out;
+  void* pre; int64_t ld_pre;     // fwd: output (nullable); bwd: input
+  float* lse;                    // fwd: output (nullable); bwd: input
+  float* alpha;
+  // backward
+  const void* gout; int64_t ld_go;
+  void* gpre; int64_t ld_gp;     // dst pass: output; src pass: input
+  float* dsum;                   // dst pass: output; src pass: input
+  void* gxl; int64_t ld_gxl;
+  void* gxr; int64_t ld_gxr;
+  float* slab;                   // [nblocks][2][HC] partial grad_att | grad_bias
+  // scalars
+  float slope;
+  float drop_scale;              // 1/(1-p)
+  uint32_t drop_thr;             // floor(p * 2^24); 0 = no dropout
+  uint32_t seed_lo, seed_hi;
+  int32_t apply_gelu;
+  int32_t rows_per_wave_iter;    // dst pass: row batches each wave walks
+  int64_t nblocks, nblocks_padded;
+};
+
+// ---- neighbour-id hand-off -------------------------------------------------
+// One coalesced load fetches GS (group-per-row) or 64 (wave-per-row) neighbour
+// ids; lane `slot` holds the id every lane of the group needs next.
+//  * GS == 16, group-per-row: the group is one DPP row.  The ids of the next U
+//    edges always sit in lanes 0..U-1 of the row (row_newbcast:u) because the
+//    id register is rotated by U lanes (row_ror:U) after every batch.
+//  * otherwise: ds_bpermute with a computed slot.
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+constexpr int kDppRowRor0 = 0x120;   // row_ror:n
+
+// Row walker shared by the three kernels.  Calls body(valid[U], nbr[U], eid[U])
+// for successive batches of U edges of this group's share of row [beg,end).
+// All lanes of a group see identical arguments.  In wave-per-row mode the loop
+// is wave-uniform and a group may be handed a batch with valid[0] == false.
+template <int GS, bool WPR, bool NEED_EID, typename Body>
+__device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
+                                         int64_t beg, int64_t end, int lane, int grp, int gl, Body&& body) {
+  constexpr int U = kEdgeUnroll;
+  constexpr int NG = 64 / GS;
+  constexpr int CHUNK = WPR ? 64 : GS;      // ids fetched per coalesced load (per wave / per group)
+  constexpr bool kDpp = !WPR && GS == 16;
+  static_assert(GS % U == 0, "group size must be a multiple of the edge unroll");
+  for (int64_t e0 = beg; e0 < end; e0 += CHUNK) {
+    const int me = WPR ? lane : gl;
+    int myc = 0, myeid = 0;
+    if (e0 + me < end) {
+      myc = col[e0 + me];
+      if constexpr (NEED_EID) myeid = eid[e0 + me];
+    }
+#pragma unroll 1
+    for (int t = 0; t < GS; t += U) {
+      // wave-per-row: uniform over the wave (end is); group-per-row: uniform over the group,
+      // and every id a group reads lives in its own lanes
+      if ((WPR ? e0 + (int64_t)t * NG : e0 + t) >= end) break;
+      bool valid[U];
+      int nbr[U], ed[U];
+      static_for<U>([&](auto u_c) {
+        constexpr int u = decltype(u_c)::value;
+        const int T = t + u;
+        const int64_t e = WPR ? (e0 + (int64_t)T * NG + grp) : (e0 + T);
+        valid[u] = e < end;
+        if constexpr (kDpp) {
+          nbr[u] = dpp_i<kDppRowBcast0 + u>(myc);
+          ed[u] = NEED_EID ? dpp_i<kDppRowBcast0 + u>(myeid) : 0;
+        } else {
+          const int slot = WPR ? (T * NG + grp) : (grp * GS + T);
+          nbr[u] = __builtin_amdgcn_ds_bpermute(slot << 2, myc);
+          ed[u] = NEED_EID ? __builtin_amdgcn_ds_bpermute(slot << 2, myeid) : 0;
+        }
+      });
+      body(valid, nbr, ed);
+      if constexpr (kDpp) {
+        myc = dpp_i<kDppRowRor0 + 16 - U>(myc);   // lane i <- lane i+U
+        if constexpr (NEED_EID) myeid = dpp_i<kDppRowRor0 + 16 - U>(myeid);
+      }
+    }
+  }
+}
+
+// Raw (unconverted) 8-channel fragment: keeps the U in-flight gathers in their
+// storage width (4 VGPRs for bf16/f16) until they are consumed.
+template <typename T> struct Raw8 {
+  u32x4 r;
+  __device__ __forceinline__ void load(const T* p) { r = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void zero() { r = u32x4{0u, 0u, 0u, 0u}; }
+  __device__ __forceinline__ void get(float (&f)[8]) const;
+};
+template <> __device__ __forceinline__ void Raw8<bf16_t>::get(float (&f)[8]) const {
+  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+  f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+  f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void Raw8<f16_t>::get(float (&f)[8]) const {
+  Vec8<f16_t>::unpack(r.x, f[0], f[1]); Vec8<f16_t>::unpack(r.y, f[2], f[3]);
+  Vec8<f16_t>::unpack(r.z, f[4], f[5]); Vec8<f16_t>::unpack(r.w, f[6], f[7]);
+}
+template <> struct Raw8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) {
+    a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  __device__ __forceinline__ void zero() { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
+  __device__ __forceinline__ void get(float (&f)[8]) const {
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  }
+};
+
+// attention logit (natural units) of one edge for this lane's head
+template <int LPH>
+__device__ __forceinline__ float edge_logit(const float (&v)[8], const float (&xr)[8], const float (&att)[8], float slope) {
+  float p = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float t = v[k] + xr[k];
+    p = fmaf(att[k], fmaxf(t, slope * t), p);     // leaky_relu for 0 <= slope <= 1
+  }
+  return lane_block_sum<LPH>(p);
+}
+
+struct LaneGeo {
+  int lane, wave, grp, gl, h, ch0;
+  bool lane_on;
+};
+template <typename G>
+__device__ __forceinline__ LaneGeo lane_geo() {
+  LaneGeo g;
+  g.lane = threadIdx.x & 63; g.wave = threadIdx.x >> 6;
+  g.grp = g.lane / G::GS; g.gl = g.lane % G::GS;
+  g.lane_on = g.gl < G::LPR;                 // GS > LPR when H*C/8 is not a power of two
+  g.h = g.lane_on ? g.gl / G::LPH : 0;       // idle lanes shadow lane 0 and never store
+  g.ch0 = g.lane_on ? g.gl * 8 : 0;
+  return g;
+}
+
+// ============================================================================
+// Forward
+// ============================================================================
+template <typename T, int H, int LPH, bool WPR>
+__global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatParams p) {
+  using G = Geo<H, LPH>;
+  constexpr int GS = G::GS, NG = G::NG, U = kEdgeUnroll;
+  const int64_t blk = xcd_remap(blockIdx.x, p.nblocks_padded, p.nblocks);
+  if (blk < 0) return;
+  const LaneGeo L = lane_geo<G>();
+  const int h = L.h, ch0 = L.ch0;
+  const bool head_leader = L.lane_on && (L.gl % LPH) == 0;
+  const int64_t row = WPR ? (blk * 4 + L.wave) : ((blk * 4 + L.wave) * NG + L.grp);
+  const bool row_ok = row < p.n_rows;
+  const T* __restrict__ xl = static_cast<const T*>(p.xl);
+  const bool dropout = p.drop_thr != 0;
+  const bool want_alpha = p.alpha != nullptr;
+  const float slope = p.slope;
+
+  float att[8], xr[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { att[k] = p.att[ch0 + k]; xr[k] = 0.f; }
+  int64_t beg = 0, end = 0;
+  if (row_ok) {
+    beg = p.indptr[row];
+    end = p.indptr[row + 1];
+    Vec8<T>::load(static_cast<const T*>(p.xr) + row * p.ld_xr + ch0, xr);
+  }
+
+  // online softmax state, base-2 units
+  float m = -INFINITY, s = 0.f, acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+
+  auto body = [&](const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
+    if (!valid[0]) return;
+    Raw8<T> raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (valid[u]) raw[u].load(xl + (int64_t)nbr[u] * p.ld_xl + ch0);
+      else raw[u].zero();
+    }
+    float e[U];
+    float mx = m;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float v[8];
+      raw[u].get(v);
+      e[u] = valid[u] ? edge_logit<LPH>(v, xr, att, slope) * kLog2e : -INFINITY;
+      mx = fmaxf(mx, e[u]);
+    }
+    const float sc = fast_exp2(m - mx);      // m = -inf -> 0 ; mx is finite because valid[0]
+    s *= sc;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] *= sc;
+    m = mx;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float pe = fast_exp2(e[u] - mx);  // invalid -> 0
+      s += pe;
+      float w = pe;
+      if (dropout) w = dropout_keep((uint32_t)ed[u], H, h, p.seed_lo, p.seed_hi, p.drop_thr) ? pe * p.drop_scale : 0.f;
+      if (want_alpha && valid[u] && head_leader) p.alpha[(int64_t)ed[u] * H + h] = e[u];
+      float v[8];
+      raw[u].get(v);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = fmaf(w, v[k], acc[k]);
+    }
+  };
+  if (dropout || want_alpha)
+    walk_row<GS, WPR, true>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+  else
+    walk_row<GS, WPR, false>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+
+  if constexpr (WPR) {
+    // merge the NG groups' online-softmax states
+#pragma unroll
+    for (int off = GS; off < 64; off <<= 1) {
+      const float m_o = __shfl_xor(m, off, 64);
+      const float s_o = __shfl_xor(s, off, 64);
+      const float mn = fmaxf(m, m_o);
+      const float a = (m == mn) ? 1.f : fast_exp2(m - mn);
+      const float b = (m_o == mn) ? 1.f : fast_exp2(m_o - mn);
+      s = s * a + s_o * b;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float acc_o = __shfl_xor(acc[k], off, 64);
+        acc[k] = acc[k] * a + acc_o * b;
+      }
+      m = mn;
+    }
+  }
+
+  const float lse = m + fast_log2(s);          // -inf for a destination without in-edges
+  const float inv = s > 0.f ? 1.0f / s : 0.f;
+  if (row_ok && L.lane_on && (!WPR || L.grp == 0)) {
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = acc[k] * inv + (p.bias ? p.bias[ch0 + k] : 0.f);
+    if (p.pre && (p.pre != p.out || p.apply_gelu))
+      Vec8<T>::store(static_cast<T*>(p.pre) + row * p.ld_pre + ch0, o);
+    if (p.apply_gelu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = gelu_erf(o[k]);
+    }
+    Vec8<T>::store(static_cast<T*>(p.out) + row * p.ld_out + ch0, o);
+    if (p.lse && head_leader) p.lse[row * H + h] = lse;
+  }
+
+  if (want_alpha && row_ok && head_leader) {
+    // second sweep over this row's edges: logits -> normalised (dropped-out) coefficients.
+    // Every lane re-reads exactly the entries it stored itself in the main loop
+    // (edge (e - beg) % NG == grp in wave-per-row mode), so program order suffices.
+    const int step = WPR ? NG : 1;
+    for (int64_t e = beg + (WPR ? L.grp : 0); e < end; e += step) {
+      const int64_t id = p.eid[e];
+      float a = fast_exp2(p.alpha[id * H + h] - lse);
+      if (dropout) a = dropout_keep((uint32_t)id, H, h, p.seed_lo, p.seed_hi, p.drop_thr) ? a * p.drop_scale : 0.f;
+      p.alpha[id * H + h] = a;
+    }
+  }
+}
+
+// ============================================================================
+// Backward, destination side:  grad_pre, dsum, grad_xr, partial grad_att / grad_bias
+//   g      = grad_out * gelu'(pre)                    (or grad_out)
+//   D[j,h] = sum_c g[j,h,c] * (pre[j,h,c] - bias)     = sum_i a_ij * dL/da_ij
+//   de_ij  = a_ij * (keep/(1-p) * <g_j, x_l[i]>_h - D[j,h])
+//   grad_xr[j] = sum_i de_ij * att * lrelu'(x_l[i] + x_r[j])
+//   grad_att   = sum_ij de_ij * lrelu(x_l[i] + x_r[j]) ;  grad_bias = sum_j g[j]
+// ============================================================================
+template <typename T, int H, int LPH, bool WPR>
+__global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kernel(GatParams p) {
+  using G = Geo<H, LPH>;
+  constexpr int GS = G::GS, NG = G::NG, U = kEdgeUnroll, HC = G::HC;
+  __shared__ float red[4][2][HC];
+  const int64_t blk = xcd_remap(blockIdx.x, p.nblocks_padded, p.nblocks);
+  if (blk < 0) return;
+  const LaneGeo L = lane_geo<G>();
+  const int h = L.h, ch0 = L.ch0;
+  const bool head_leader = L.lane_on && (L.gl % LPH) == 0;
+  const T* __restrict__ xl = static_cast<const T*>(p.xl);
+  const bool dropout = p.drop_thr != 0;
+  constexpr int RPW = WPR ? 1 : NG;            // rows per wave per iteration
+  const float slope = p.slope;
+
+  float att[8], datt[8], dbias[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { att[k] = p.att[ch0 + k]; datt[k] = 0.f; dbias[k] = 0.f; }
+
+#pragma unroll 1
+  for (int it = 0; it < p.rows_per_wave_iter; ++it) {
+    const int64_t rbase = ((blk * 4 + L.wave) * (int64_t)p.rows_per_wave_iter + it) * RPW;
+    if (rbase >= p.n_rows) break;              // wave-uniform
+    const int64_t row = rbase + (WPR ? 0 : L.grp);
+    const bool row_ok = row < p.n_rows;
+
+    float xr[8], g[8], dxr[8];
+    float D = 0.f, lse = 0.f;
+    int64_t beg = 0, end = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { xr[k] = 0.f; g[k] = 0.f; dxr[k] = 0.f; }
+    if (row_ok) {
+      beg = p.indptr[row]; end = p.indptr[row + 1];
+      float gy[8], pr[8];
+      Vec8<T>::load(static_cast<const T*>(p.xr) + row * p.ld_xr + ch0, xr);
+      Vec8<T>::load(static_cast<const T*>(p.gout) + row * p.ld_go + ch0, gy);
+      Vec8<T>::load(static_cast<const T*>(p.pre) + row * p.ld_pre + ch0, pr);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        g[k] = p.apply_gelu ? gy[k] * gelu_erf_grad(pr[k]) : gy[k];
+        D = fmaf(g[k], pr[k] - (p.bias ? p.bias[ch0 + k] : 0.f), D);
+      }
+      lse = p.lse[row * H + h];
+    }
+    D = lane_block_sum<LPH>(D);
+    const bool writer = row_ok && L.lane_on && (!WPR || L.grp == 0);
+    if (writer) {
+      Vec8<T>::store(static_cast<T*>(p.gpre) + row * p.ld_gp + ch0, g);
+      if (head_leader) p.dsum[row * H + h] = D;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) dbias[k] += g[k];
+    }
+
+    auto body = [&](const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
+      if (!valid[0]) return;
+      Raw8<T> raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (valid[u]) raw[u].load(xl + (int64_t)nbr[u] * p.ld_xl + ch0);
+        else raw[u].zero();
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float v[8];
+        raw[u].get(v);
+        float pl = 0.f, da = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float t = v[k] + xr[k];
+          pl = fmaf(att[k], fmaxf(t, slope * t), pl);
+          da = fmaf(g[k], v[k], da);
+        }
+        pl = lane_block_sum<LPH>(pl);
+        da = lane_block_sum<LPH>(da);
+        const float a = valid[u] ? fast_exp2(pl * kLog2e - lse) : 0.f;
+        if (dropout) da = dropout_keep((uint32_t)ed[u], H, h, p.seed_lo, p.seed_hi, p.drop_thr) ? da * p.drop_scale : 0.f;
+        const float de = a * (da - D);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float t = v[k] + xr[k];
+          dxr[k] = fmaf(de, t > 0.f ? att[k] : att[k] * slope, dxr[k]);
+          datt[k] = fmaf(de, fmaxf(t, slope * t), datt[k]);
+        }
+      }
+    };
+    if (dropout)
+      walk_row<GS, WPR, true>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+    else
+      walk_row<GS, WPR, false>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+
+    if constexpr (WPR) {
+#pragma unroll
+      for (int off = GS; off < 64; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dxr[k] += __shfl_xor(dxr[k], off, 64);
+      }
+    }
+    if (writer) Vec8<T>::store(static_cast<T*>(p.gxr) + row * p.ld_gxr + ch0, dxr);
+  }
+
+  // block partials of grad_att / grad_bias -> slab[blk]
+#pragma unroll
+  for (int off = GS; off < 64; off <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      datt[k] += __shfl_xor(datt[k], off, 64);
+      dbias[k] += __shfl_xor(dbias[k], off, 64);
+    }
+  }
+  if (L.grp == 0 && L.lane_on) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { red[L.wave][0][ch0 + k] = datt[k]; red[L.wave][1][ch0 + k] = dbias[k]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * HC; i += 256) {
+    const int which = i / HC, c = i % HC;
+    p.slab[blk * (2 * HC) + i] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+  }
+}
+
+// ============================================================================
+// Backward, source side:  grad_xl   (rows = sources, col = destinations)
+//   grad_xl[i] = sum_j  keep/(1-p) * a_ij * g[j]  +  de_ij * att * lrelu'(x_l[i] + x_r[j])
+// ============================================================================
+template <typename T, int H, int LPH, bool WPR>
+__global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kernel(GatParams p) {
+  using G = Geo<H, LPH>;
+  constexpr int GS = G::GS, NG = G::NG, U = kEdgeUnroll;
+  const int64_t blk = xcd_remap(blockIdx.x, p.nblocks_padded, p.nblocks);
+  if (blk < 0) return;
+  const LaneGeo L = lane_geo<G>();
+  const int h = L.h, ch0 = L.ch0;
+  const int64_t row = WPR ? (blk * 4 + L.wave) : ((blk * 4 + L.wave) * NG + L.grp);
+  const bool row_ok = row < p.n_rows;
+  const T* __restrict__ xr_base = static_cast<const T*>(p.xr);
+  const T* __restrict__ g_base = static_cast<const T*>(p.gpre);
+  const bool dropout = p.drop_thr != 0;
+  const float slope = p.slope;
+
+  float att[8], v[8], acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { att[k] = p.att[ch0 + k]; acc[k] = 0.f; v[k] = 0.f; }
+  int64_t beg = 0, end = 0;
+  if (row_ok) {
+    beg = p.indptr[row]; end = p.indptr[row + 1];
+    Vec8<T>::load(static_cast<const T*>(p.xl) + row * p.ld_xl + ch0, v);
+  }
+
+  auto body = [&](const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
+    if (!valid[0]) return;
+    Raw8<T> rxr[U], rg[U];
+    float lse[U], D[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (valid[u]) {
+        rxr[u].load(xr_base + (int64_t)nbr[u] * p.ld_xr + ch0);
+        rg[u].load(g_base + (int64_t)nbr[u] * p.ld_gp + ch0);
+        lse[u] = p.lse[(int64_t)nbr[u] * H + h];
+        D[u] = p.dsum[(int64_t)nbr[u] * H + h];
+      } else {
+        rxr[u].zero(); rg[u].zero(); lse[u] = 0.f; D[u] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float xr[8], g[8];
+      rxr[u].get(xr);
+      rg[u].get(g);
+      float pl = 0.f, da = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float t = v[k] + xr[k];
+        pl = fmaf(att[k], fmaxf(t, slope * t), pl);
+        da = fmaf(g[k], v[k], da);
+      }
+      pl = lane_block_sum<LPH>(pl);
+      da = lane_block_sum<LPH>(da);
+      const float a = valid[u] ? fast_exp2(pl * kLog2e - lse[u]) : 0.f;
+      float a_eff = a;
+      if (dropout) {
+        const bool keep = dropout_keep((uint32_t)ed[u], H, h, p.seed_lo, p.seed_hi, p.drop_thr);
+        da = keep ? da * p.drop_scale : 0.f;
+        a_eff = keep ? a * p.drop_scale : 0.f;
+      }
+      const float de = a * (da - D[u]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float t = v[k] + xr[k];
+        acc[k] = fmaf(a_eff, g[k], acc[k]);
+        acc[k] = fmaf(de, t > 0.f ? att[k] : att[k] * slope, acc[k]);
+      }
+    }
+  };
+  if (dropout)
+    walk_row<GS, WPR, true>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+  else
+    walk_row<GS, WPR, false>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+
+  if constexpr (WPR) {
+#pragma unroll
+    for (int off = GS; off < 64; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
+    }
+  }
+  if (row_ok && L.lane_on && (!WPR || L.grp == 0))
+    Vec8<T>::store(static_cast<T*>(p.gxl) + row * p.ld_gxl + ch0, acc);
+}
+
+// grad_att / grad_bias = column sums of the slab  [nblocks][2*HC]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int64_t nblocks, int width,
+                                                         int hc, float* __restrict__ grad_att, float* __restrict__ grad_bias);
+
+}  // namespace segger

@@ -1,0 +1,33 @@
+// Per-(pass, dtype) launch entry points.  Each is instantiated in its own
+// translation unit (gatv2_inst.hip compiled with -DSEGGER_INST_PASS/-DSEGGER_INST_DTYPE)
+// so the build parallelises; gatv2.hip holds the C ABI and argument checks.
+#pragma once
+#include "gatv2_kernels.h"
+
+namespace segger {
+
+enum class Pass : int { Fwd = 0, BwdDst = 1, BwdSrc = 2 };
+
+// destination rows walked per wave in the dst-side backward (amortises the
+// per-block grad_att / grad_bias partial slab)
+constexpr int kBwdRowIters = 4;
+
+// (heads, channels/8) combinations with a specialised kernel
+#define SEGGER_GEOMETRIES(X) \
+  X(1, 4) X(2, 4) X(3, 4) X(4, 4) \
+  X(1, 8) X(2, 8) X(3, 8) X(4, 8)
+
+#define SEGGER_DECL_LAUNCH(name) \
+  int name(GatParams& p, int heads, int channels, bool wave_per_row, hipStream_t stream);
+SEGGER_DECL_LAUNCH(gatv2_launch_fwd_f32)
+SEGGER_DECL_LAUNCH(gatv2_launch_fwd_bf16)
+SEGGER_DECL_LAUNCH(gatv2_launch_fwd_f16)
+SEGGER_DECL_LAUNCH(gatv2_launch_bwd_dst_f32)
+SEGGER_DECL_LAUNCH(gatv2_launch_bwd_dst_bf16)
+SEGGER_DECL_LAUNCH(gatv2_launch_bwd_dst_f16)
+SEGGER_DECL_LAUNCH(gatv2_launch_bwd_src_f32)
+SEGGER_DECL_LAUNCH(gatv2_launch_bwd_src_bf16)
+SEGGER_DECL_LAUNCH(gatv2_launch_bwd_src_f16)
+#undef SEGGER_DECL_LAUNCH
+
+}  // namespace segger

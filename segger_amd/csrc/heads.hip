@@ -1,0 +1,299 @@
+// Scoring heads: fused cosine-similarity + per-transcript arg-max + assignment
+// (prediction) and the triplet margin loss over tx-belongs-bd edges (training).
+#include "common.h"
+
+namespace segger {
+namespace {
+
+// ---------------------------------------------------------------------------
+// Row fragments: a row of C channels is covered by LPC lanes x 8 channels when
+// C == 8*LPC (LPC a power of two <= 16), otherwise by one wave striding channels.
+// ---------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ float load1(const T* p);
+template <> __device__ __forceinline__ float load1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float load1<bf16_t>(const bf16_t* p) { return __uint_as_float((uint32_t)p->v << 16); }
+template <> __device__ __forceinline__ float load1<f16_t>(const f16_t* p) {
+  return static_cast<float>(__builtin_bit_cast(_Float16, p->v));
+}
+
+struct ArgmaxParams {
+  const int64_t* indptr; const int32_t* col; const int32_t* eid;
+  int64_t n_rows, n_edges;
+  const void* zs; int64_t ld_zs;
+  const void* zd; int64_t ld_zd;
+  int channels;
+  float eps; int use_min; float min_sim;
+  const int64_t* dst_index;
+  float* max_sim; int64_t* max_eid; int64_t* seg_idx; float* sim;
+};
+
+template <typename T, int LPC>
+__global__ __launch_bounds__(256) void edge_cos_argmax_kernel(ArgmaxParams p) {
+  constexpr int RPW = 64 / LPC;                       // rows per wave
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane / LPC, gl = lane % LPC;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * RPW + grp;
+  if (row >= p.n_rows) return;                        // group-uniform; DPP sums stay inside the group
+  const T* zs = static_cast<const T*>(p.zs) + row * p.ld_zs + gl * 8;
+  const T* zd = static_cast<const T*>(p.zd) + gl * 8;
+  float a[8];
+  Vec8<T>::load(zs, a);
+  float na = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) na = fmaf(a[k], a[k], na);
+  na = fmaxf(sqrtf(lane_block_sum<LPC>(na)), p.eps);
+  const int64_t beg = p.indptr[row], end = p.indptr[row + 1];
+  float best = -INFINITY;
+  int64_t best_eid = p.n_edges, best_col = -1;
+  for (int64_t e = beg; e < end; ++e) {
+    const int64_t j = p.col[e];
+    float b[8];
+    Vec8<T>::load(zd + j * p.ld_zd, b);
+    float dot = 0.f, nb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { dot = fmaf(a[k], b[k], dot); nb = fmaf(b[k], b[k], nb); }
+    dot = lane_block_sum<LPC>(dot);
+    nb = fmaxf(sqrtf(lane_block_sum<LPC>(nb)), p.eps);
+    const float s = dot / (na * nb);
+    const int64_t id = p.eid ? (int64_t)p.eid[e] : e;
+    if (p.sim && gl == 0) p.sim[id] = s;
+    if (s > best) { best = s; best_eid = id; best_col = j; }   // slots of a row are in edge-id order: first max wins
+  }
+  if (gl == 0) {
+    const bool any = best_col >= 0;
+    bool valid = any;
+    if (p.use_min) valid = valid && (best >= p.min_sim);
+    p.max_sim[row] = any ? best : 0.f;
+    p.max_eid[row] = best_eid;
+    p.seg_idx[row] = valid ? (p.dst_index ? p.dst_index[best_col] : best_col) : -1;
+  }
+}
+
+// any channel count: one wave per row, lanes stride the channels
+template <typename T>
+__global__ __launch_bounds__(256) void edge_cos_argmax_generic_kernel(ArgmaxParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= p.n_rows) return;
+  const T* zs = static_cast<const T*>(p.zs) + row * p.ld_zs;
+  float na = 0.f;
+  for (int c = lane; c < p.channels; c += 64) { const float v = load1(zs + c); na = fmaf(v, v, na); }
+  na = fmaxf(sqrtf(wave_sum(na)), p.eps);
+  const int64_t beg = p.indptr[row], end = p.indptr[row + 1];
+  float best = -INFINITY;
+  int64_t best_eid = p.n_edges, best_col = -1;
+  for (int64_t e = beg; e < end; ++e) {
+    const int64_t j = p.col[e];
+    const T* zd = static_cast<const T*>(p.zd) + j * p.ld_zd;
+    float dot = 0.f, nb = 0.f;
+    for (int c = lane; c < p.channels; c += 64) {
+      const float x = load1(zs + c), y = load1(zd + c);
+      dot = fmaf(x, y, dot); nb = fmaf(y, y, nb);
+    }
+    dot = wave_sum(dot);
+    nb = fmaxf(sqrtf(wave_sum(nb)), p.eps);
+    const float s = dot / (na * nb);
+    const int64_t id = p.eid ? (int64_t)p.eid[e] : e;
+    if (p.sim && lane == 0) p.sim[id] = s;
+    if (s > best) { best = s; best_eid = id; best_col = j; }
+  }
+  if (lane == 0) {
+    const bool any = best_col >= 0;
+    bool valid = any;
+    if (p.use_min) valid = valid && (best >= p.min_sim);
+    p.max_sim[row] = any ? best : 0.f;
+    p.max_eid[row] = best_eid;
+    p.seg_idx[row] = valid ? (p.dst_index ? p.dst_index[best_col] : best_col) : -1;
+  }
+}
+
+template <typename T>
+int launch_argmax(const ArgmaxParams& p, hipStream_t stream) {
+  const int C = p.channels;
+  auto go = [&](auto lpc_c) {
+    constexpr int LPC = decltype(lpc_c)::value;
+    const int64_t rows_per_block = 4 * (64 / LPC);
+    const int64_t nb = (p.n_rows + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL((edge_cos_argmax_kernel<T, LPC>), dim3((unsigned)nb), dim3(256), 0, stream, p);
+  };
+  const bool vec_ok = (C % 8 == 0) && aligned16(p.zs) && aligned16(p.zd) &&
+                      (p.ld_zs * sizeof(T)) % 16 == 0 && (p.ld_zd * sizeof(T)) % 16 == 0;
+  if (vec_ok && C == 8) go(std::integral_constant<int, 1>{});
+  else if (vec_ok && C == 16) go(std::integral_constant<int, 2>{});
+  else if (vec_ok && C == 32) go(std::integral_constant<int, 4>{});
+  else if (vec_ok && C == 64) go(std::integral_constant<int, 8>{});
+  else if (vec_ok && C == 128) go(std::integral_constant<int, 16>{});
+  else {
+    const int64_t nb = (p.n_rows + 3) / 4;
+    hipLaunchKernelGGL((edge_cos_argmax_generic_kernel<T>), dim3((unsigned)nb), dim3(256), 0, stream, p);
+  }
+  SEGGER_LAUNCH_CHECK("edge_cos_argmax kernel");
+  return SEGGER_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Triplet margin loss
+// ---------------------------------------------------------------------------
+struct TripletParams {
+  const int64_t* src; const int64_t* pos; const int64_t* neg; int64_t n_edges;
+  const void* za; int64_t ld_za; const void* zb; int64_t ld_zb;
+  int channels; float margin, eps;
+  float* partial;        // [nblocks]
+  float scale;           // bwd: grad_scale / n_edges
+  const float* scale_dev; // bwd: optional device multiplier
+  float* ga; float* gb;  // bwd: [n_a, C], [n_b, C] fp32
+};
+
+// one wave per edge-slot batch: lanes stride the channels (any C); a wave handles
+// kTripletEdgesPerWave edges one after another
+constexpr int kTripletEdgesPerBlock = 64;
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void triplet_kernel(TripletParams p) {
+  __shared__ float wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = p.channels;
+  const T* za = static_cast<const T*>(p.za);
+  const T* zb = static_cast<const T*>(p.zb);
+  // sub-wave groups of 16 lanes, one edge each (C=64 -> 4 channels per lane)
+  const int grp = lane >> 4, gl = lane & 15;
+  float acc = 0.f;
+  const int64_t e_base = (int64_t)blockIdx.x * kTripletEdgesPerBlock;
+#pragma unroll 1
+  for (int i = wave * 4 + grp; i < kTripletEdgesPerBlock; i += 16) {
+    const int64_t e = e_base + i;
+    const bool ok = e < p.n_edges;                    // group-uniform
+    const int64_t ia = ok ? p.src[e] : 0, ip = ok ? p.pos[e] : 0, in = ok ? p.neg[e] : 0;
+    float sp = 0.f, sn = 0.f;
+    if (ok)
+      for (int c = gl; c < C; c += 16) {
+        const float a = load1(za + ia * p.ld_za + c);
+        const float dp = a - load1(zb + ip * p.ld_zb + c) + p.eps;
+        const float dn = a - load1(zb + in * p.ld_zb + c) + p.eps;
+        sp = fmaf(dp, dp, sp); sn = fmaf(dn, dn, sn);
+      }
+    sp = lane_block_sum<16>(sp);
+    sn = lane_block_sum<16>(sn);
+    const float dap = sqrtf(sp), dan = sqrtf(sn);
+    const float l = dap - dan + p.margin;
+    if (!BWD) {
+      if (ok && gl == 0) acc += fmaxf(l, 0.f);
+    } else if (ok && l > 0.f) {
+      const float sc = p.scale_dev ? p.scale * p.scale_dev[0] : p.scale;
+      const float ip_ = dap > 0.f ? sc / dap : 0.f;
+      const float in_ = dan > 0.f ? sc / dan : 0.f;
+      for (int c = gl; c < C; c += 16) {
+        const float a = load1(za + ia * p.ld_za + c);
+        const float dp = (a - load1(zb + ip * p.ld_zb + c) + p.eps) * ip_;
+        const float dn = (a - load1(zb + in * p.ld_zb + c) + p.eps) * in_;
+        atomicAdd(p.ga + ia * C + c, dp - dn);
+        atomicAdd(p.gb + ip * C + c, -dp);
+        atomicAdd(p.gb + in * C + c, dn);
+      }
+    }
+  }
+  if (!BWD) {
+    acc = wave_sum(acc);
+    if (lane == 0) wsum[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) p.partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void triplet_finish_kernel(const float* __restrict__ partial, int64_t n, float inv_n,
+                                                            float* __restrict__ loss) {
+  __shared__ float wsum[4];
+  float s = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) loss[0] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_n;
+}
+
+int64_t triplet_blocks(int64_t n_edges) { return (n_edges + kTripletEdgesPerBlock - 1) / kTripletEdgesPerBlock; }
+
+}  // namespace
+}  // namespace segger
+
+using namespace segger;
+
+extern "C" int segger_edge_cos_argmax(const segger_edge_argmax_args* a, segger_stream_t stream) {
+  SEGGER_REQUIRE(a != nullptr, "segger_edge_cos_argmax: args is NULL");
+  const segger_csr& g = a->by_src;
+  SEGGER_REQUIRE(g.n_rows >= 0 && g.n_edges >= 0 && g.n_cols >= 0, "segger_edge_cos_argmax: negative size");
+  SEGGER_REQUIRE(g.n_rows < 0x7fffffffLL && g.n_edges < 0x7fffffffLL, "segger_edge_cos_argmax: batch too large");
+  SEGGER_REQUIRE(a->channels > 0, "segger_edge_cos_argmax: channels must be positive");
+  if (g.n_rows == 0) return SEGGER_OK;
+  SEGGER_REQUIRE(g.indptr && (g.n_edges == 0 || g.col), "segger_edge_cos_argmax: NULL graph array");
+  SEGGER_REQUIRE(a->z_src && (g.n_edges == 0 || a->z_dst), "segger_edge_cos_argmax: NULL embedding");
+  SEGGER_REQUIRE(a->ld_zs >= a->channels && a->ld_zd >= a->channels, "segger_edge_cos_argmax: ld < channels");
+  SEGGER_REQUIRE(a->max_sim && a->max_eid && a->seg_idx, "segger_edge_cos_argmax: NULL output");
+  ArgmaxParams p{g.indptr, g.col, g.eid, g.n_rows, g.n_edges, a->z_src, a->ld_zs, a->z_dst, a->ld_zd, a->channels,
+                 a->eps, a->use_min_similarity, a->min_similarity, a->dst_index, a->max_sim, a->max_eid, a->seg_idx, a->sim};
+  switch (a->dtype) {
+    case SEGGER_F32:  return launch_argmax<float>(p, (hipStream_t)stream);
+    case SEGGER_BF16: return launch_argmax<bf16_t>(p, (hipStream_t)stream);
+    case SEGGER_F16:  return launch_argmax<f16_t>(p, (hipStream_t)stream);
+    default: set_error("segger_edge_cos_argmax: unknown dtype %d", a->dtype); return SEGGER_EINVAL;
+  }
+}
+
+extern "C" size_t segger_triplet_workspace_bytes(int64_t n_edges) {
+  return (size_t)(n_edges > 0 ? triplet_blocks(n_edges) : 1) * sizeof(float) + 16;
+}
+
+static int triplet_common(const segger_triplet_args* a, bool bwd, hipStream_t stream) {
+  SEGGER_REQUIRE(a != nullptr, "segger_triplet: args is NULL");
+  SEGGER_REQUIRE(a->n_edges >= 0 && a->channels > 0, "segger_triplet: bad sizes");
+  SEGGER_REQUIRE(a->n_edges < 0x7fffffffLL * kTripletEdgesPerBlock, "segger_triplet: too many edges");
+  if (!bwd) SEGGER_REQUIRE(a->loss != nullptr, "segger_triplet_fwd: loss is NULL");
+  if (a->n_edges == 0) {
+    // torch: mean over zero elements is NaN; segger never calls the loss with no edges
+    // (lightning_model.py:173 guards num_bd <= 1 only).  We return 0.
+    if (!bwd) SEGGER_HIP(hipMemsetAsync(a->loss, 0, sizeof(float), stream));
+    return SEGGER_OK;
+  }
+  SEGGER_REQUIRE(a->src && a->pos && a->neg && a->z_a && a->z_b, "segger_triplet: NULL input");
+  SEGGER_REQUIRE(a->ld_za >= a->channels && a->ld_zb >= a->channels, "segger_triplet: ld < channels");
+  const int64_t nb = triplet_blocks(a->n_edges);
+  TripletParams p{a->src, a->pos, a->neg, a->n_edges, a->z_a, a->ld_za, a->z_b, a->ld_zb, a->channels, a->margin, a->eps,
+                  static_cast<float*>(a->workspace), 0.f, nullptr, a->grad_a, a->grad_b};
+  if (!bwd) {
+    const size_t need = segger_triplet_workspace_bytes(a->n_edges);
+    if (!a->workspace || a->workspace_bytes < need) {
+      set_error("segger_triplet_fwd: workspace %zu < %zu bytes", a->workspace_bytes, need);
+      return SEGGER_EWORKSPACE;
+    }
+  } else {
+    SEGGER_REQUIRE(a->grad_a && a->grad_b, "segger_triplet_bwd: NULL gradient buffer");
+    p.scale = a->grad_scale / (float)a->n_edges;
+    p.scale_dev = a->grad_scale_dev;
+  }
+  dim3 grid((unsigned)nb), block(256);
+#define LAUNCH(T)                                                                         \
+  do {                                                                                    \
+    if (bwd) hipLaunchKernelGGL((triplet_kernel<T, true>), grid, block, 0, stream, p);    \
+    else     hipLaunchKernelGGL((triplet_kernel<T, false>), grid, block, 0, stream, p);   \
+  } while (0)
+  switch (a->dtype) {
+    case SEGGER_F32:  LAUNCH(float); break;
+    case SEGGER_BF16: LAUNCH(bf16_t); break;
+    case SEGGER_F16:  LAUNCH(f16_t); break;
+    default: set_error("segger_triplet: unknown dtype %d", a->dtype); return SEGGER_EINVAL;
+  }
+#undef LAUNCH
+  SEGGER_LAUNCH_CHECK("triplet_kernel");
+  if (!bwd) {
+    hipLaunchKernelGGL(triplet_finish_kernel, dim3(1), dim3(256), 0, stream, p.partial, nb, 1.0f / (float)a->n_edges, a->loss);
+    SEGGER_LAUNCH_CHECK("triplet_finish_kernel");
+  }
+  return SEGGER_OK;
+}
+
+extern "C" int segger_triplet_fwd(const segger_triplet_args* a, segger_stream_t stream) {
+  return triplet_common(a, false, (hipStream_t)stream);
+}
+extern "C" int segger_triplet_bwd(const segger_triplet_args* a, segger_stream_t stream) {
+  return triplet_common(a, true, (hipStream_t)stream);
+}

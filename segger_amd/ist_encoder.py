@@ -1,0 +1,274 @@
+"""MI355X-native ``ISTEncoder``: same module tree, parameter names and forward
+contract as reference ``src/segger/models/ist_encoder.py`` (so reference
+state dicts load), with the PyG ``HeteroConv``/``GATv2Conv`` message passing
+replaced by the fused HIP kernels of ``libsegger_amd.so``.
+
+Reference map
+-------------
+``sinusoidal_embedding``      ist_encoder.py:22-31
+``Positional2dEmbedder``      ist_encoder.py:33-79
+``SkipGAT``                   ist_encoder.py:82-211   (HeteroConv of GATv2Conv, dropout 0.2)
+``ISTEncoder``                ist_encoder.py:214-333
+
+Differences that are deliberate: the never-used
+``('bd','contains','tx')`` conv is not built (it has no edges in segger's data
+and its lazy parameters are never materialised); the per-graph min/max loop of
+the positional embedder (one host sync per graph, ``:69-73``) is a single
+segmented reduction.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+from torch.nn import Embedding, Linear, Module, ModuleDict, ModuleList, Parameter, Sequential, SiLU
+from torch.nn import functional as F
+
+from . import ops
+from .graph import EdgeGraph, edge_graph
+from .hetero import TX_BD, TX_TX, EdgeType
+
+GAT_DROPOUT = 0.2          # ist_encoder.py:116,123
+NEGATIVE_SLOPE = 0.2       # GATv2Conv default
+
+
+def pyg_key(edge_type: EdgeType) -> str:
+    """torch_geometric's ModuleDict key for a tuple (state-dict compatibility)."""
+    return "<" + "___".join(edge_type) + ">"
+
+
+def sinusoidal_embedding(x: Tensor, dim: int, max_period: float = 1000) -> Tensor:
+    """cos|sin features of a flat tensor (ist_encoder.py:22-31); fp32 like the reference."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32, device=x.device) / half)
+    args = x[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+class Positional2dEmbedder(Module):
+    """Per-graph min-max normalised (x, y) -> 2 x sinusoid(256) -> shared MLP -> concat."""
+
+    def __init__(self, hidden_size: int, frequency_embedding_size: int = 256):
+        super().__init__()
+        self.dim = hidden_size // 2
+        self.mlp = Sequential(
+            Linear(frequency_embedding_size, self.dim, bias=True),
+            SiLU(),
+            Linear(self.dim, self.dim, bias=True),
+        )
+        self.frequency_embedding_size = frequency_embedding_size
+
+    @staticmethod
+    def normalize(pos: Tensor, batch: Optional[Tensor], num_graphs: Optional[int] = None) -> Tensor:
+        pos = pos.float()
+        if batch is None:                                   # ist_encoder.py:62-64 (no epsilon)
+            pos = pos - pos.min(dim=0).values
+            return pos / pos.max(dim=0).values
+        if num_graphs is None:
+            num_graphs = int(batch.max()) + 1 if batch.numel() else 0
+        idx = batch.long()[:, None].expand(-1, 2)
+        mins = torch.full((num_graphs, 2), float("inf"), device=pos.device).scatter_reduce_(0, idx, pos, "amin")
+        maxs = torch.full((num_graphs, 2), float("-inf"), device=pos.device).scatter_reduce_(0, idx, pos, "amax")
+        lo, hi = mins[batch.long()], maxs[batch.long()]
+        return (pos - lo) / (hi - lo + 1e-8)                # ist_encoder.py:74
+
+    def forward(self, pos: Tensor, batch: Optional[Tensor] = None, *, num_graphs: Optional[int] = None,
+                dtype: torch.dtype = torch.float32) -> Tensor:
+        pos = self.normalize(pos, batch, num_graphs)
+        n = pos.shape[0]
+        freq = sinusoidal_embedding(pos.flatten(), self.frequency_embedding_size, max_period=10000)
+        freq = freq.reshape(n, 2, self.frequency_embedding_size).to(dtype)
+        l0, l2 = self.mlp[0], self.mlp[2]
+        h = F.silu(F.linear(freq, l0.weight.to(dtype), l0.bias.to(dtype)))
+        h = F.linear(h, l2.weight.to(dtype), l2.bias.to(dtype))
+        return h.flatten(-2)
+
+
+class GATv2Conv(Module):
+    """Parameter holder with torch_geometric.nn.GATv2Conv's names and shapes
+    (``lin_l``, ``lin_r``: [H*C, in] + bias; ``att``: [1, H, C]; ``bias``: [H*C]).
+    The arithmetic lives in :func:`segger_amd.ops.gatv2_aggregate`."""
+
+    def __init__(self, in_channels: Tuple[int, int], out_channels: int, heads: int,
+                 negative_slope: float = NEGATIVE_SLOPE, dropout: float = GAT_DROPOUT):
+        super().__init__()
+        self.in_channels, self.out_channels, self.heads = in_channels, out_channels, heads
+        self.negative_slope, self.dropout = negative_slope, dropout
+        self.lin_l = Linear(in_channels[0], heads * out_channels, bias=True)
+        self.lin_r = Linear(in_channels[1], heads * out_channels, bias=True)
+        self.att = Parameter(torch.empty(1, heads, out_channels))
+        self.bias = Parameter(torch.empty(heads * out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # PyG: glorot for lin weights and att, zeros for biases
+        for lin in (self.lin_l, self.lin_r):
+            torch.nn.init.xavier_uniform_(lin.weight)
+            torch.nn.init.zeros_(lin.bias)
+        a = math.sqrt(6.0 / (self.att.size(-2) + self.att.size(-1)))
+        torch.nn.init.uniform_(self.att, -a, a)
+        torch.nn.init.zeros_(self.bias)
+
+    def forward(self, x: Tuple[Tensor, Tensor], graph: EdgeGraph, *, apply_gelu: bool = False, seed: int = 0,
+                return_attention_weights: bool = False):
+        x_src, x_dst = x
+        dt = x_src.dtype
+        xl = F.linear(x_src, self.lin_l.weight.to(dt), self.lin_l.bias.to(dt))
+        xr = F.linear(x_dst, self.lin_r.weight.to(dt), self.lin_r.bias.to(dt))
+        p = self.dropout if self.training else 0.0
+        return ops.gatv2_aggregate(xl, xr, self.att, self.bias, graph, self.heads, self.out_channels,
+                                   apply_gelu=apply_gelu, negative_slope=self.negative_slope,
+                                   dropout_p=p, seed=seed, return_alpha=return_attention_weights)
+
+
+class _HeteroConv(Module):
+    """Holds ``convs`` under PyG's mangled keys so ``state_dict`` matches HeteroConv."""
+
+    def __init__(self, convs: Dict[EdgeType, Module]):
+        super().__init__()
+        self.convs = ModuleDict({pyg_key(k): v for k, v in convs.items()})
+
+    def __getitem__(self, et: EdgeType) -> Module:
+        return self.convs[pyg_key(et)]
+
+
+class SkipGAT(Module):
+    """One hetero GATv2 layer over tx-neighbors-tx and tx-belongs-bd
+    (ist_encoder.py:82-211) + the GELU that follows it in ISTEncoder (``:325``),
+    fused.  ``attention_weights`` holds tx-neighbors-tx coefficients of the last
+    forward when ``store_attention`` is set (the reference's forward hook)."""
+
+    def __init__(self, in_channels: Tuple[int, int], out_channels: int, n_heads: int,
+                 add_self_loops_tx: bool = False):
+        super().__init__()
+        if add_self_loops_tx:
+            raise NotImplementedError("add_self_loops_tx=True is never used by segger (ist_encoder.py:104)")
+        self.out_channels, self.n_heads = out_channels, n_heads
+        self.conv = _HeteroConv({
+            TX_TX: GATv2Conv((in_channels[0], in_channels[0]), out_channels, n_heads),
+            TX_BD: GATv2Conv((in_channels[0], in_channels[1]), out_channels, n_heads),
+        })
+        self.store_attention = False
+        self._attn_weights: Dict[EdgeType, Tensor] = {}
+
+    def forward(self, x_dict: Dict[str, Tensor], edge_index_dict: Dict[EdgeType, Tensor], *,
+                graphs: Optional[Dict[EdgeType, EdgeGraph]] = None, apply_gelu: bool = False,
+                seed: int = 0) -> Dict[str, Tensor]:
+        for et in (TX_TX, TX_BD):
+            if et not in edge_index_dict:
+                raise KeyError(f"edge type {et} missing from edge_index_dict: segger's HeteroConv would "
+                               f"drop node type '{et[2]}' and fail in the next layer")
+        x_tx, x_bd = x_dict["tx"], x_dict["bd"]
+        if graphs is None:
+            graphs = {et: edge_graph(None, et, edge_index_dict[et], x_dict[et[0]].shape[0], x_dict[et[2]].shape[0])
+                      for et in (TX_TX, TX_BD)}
+        tt, tb = self.conv[TX_TX], self.conv[TX_BD]
+        dt = x_tx.dtype
+        # one fused projection for the three linear maps that read x_tx
+        w_tx = torch.cat([tt.lin_l.weight, tt.lin_r.weight, tb.lin_l.weight], 0).to(dt)
+        b_tx = torch.cat([tt.lin_l.bias, tt.lin_r.bias, tb.lin_l.bias], 0).to(dt)
+        xp_tx = F.linear(x_tx, w_tx, b_tx)
+        xp_bd = F.linear(x_bd, tb.lin_r.weight.to(dt), tb.lin_r.bias.to(dt))
+        p = tt.dropout if self.training else 0.0
+        y_tx, y_bd, alpha = ops.hetero_gat_layer(
+            xp_tx, xp_bd, tt.att, tt.bias, tb.att, tb.bias, graphs[TX_TX], graphs[TX_BD],
+            self.n_heads, self.out_channels, apply_gelu=apply_gelu, negative_slope=tt.negative_slope,
+            dropout_p=p, seed_tt=2 * seed, seed_tb=2 * seed + 1, return_alpha=self.store_attention)
+        if self.store_attention:
+            self._attn_weights[TX_TX] = alpha
+        return {"tx": y_tx, "bd": y_bd}
+
+    @property
+    def attention_weights(self) -> Dict[EdgeType, Tensor]:
+        if not self._attn_weights:
+            raise AttributeError("Attention weights are empty. Please perform a forward pass.")
+        return self._attn_weights
+
+
+class _HeteroDictLinear(Module):
+    """``lins.{type}`` naming of torch_geometric.nn.HeteroDictLinear."""
+
+    def __init__(self, in_channels: int, out_channels: int, types=("tx", "bd")):
+        super().__init__()
+        self.lins = ModuleDict({t: Linear(in_channels, out_channels, bias=True) for t in types})
+
+    def forward(self, x_dict: Dict[str, Tensor]) -> Dict[str, Tensor]:
+        out = {}
+        for k, x in x_dict.items():
+            lin = self.lins[k]
+            out[k] = F.linear(x, lin.weight.to(x.dtype), lin.bias.to(x.dtype))
+        return out
+
+
+class ISTEncoder(Module):
+    """Same constructor and ``forward(x_dict, edge_index_dict, pos_dict, batch_dict)``
+    as the reference (ist_encoder.py:219-333).
+
+    Extra keyword-only knobs (not in the reference): ``bd_in_channels`` (the
+    reference's lazy ``Linear(-1, in)`` is materialised on first forward when
+    this is None), ``compute_dtype`` (activations; parameters stay fp32).
+    """
+
+    def __init__(self, n_genes: int, in_channels: int = 16, hidden_channels: int = 32, out_channels: int = 32,
+                 n_mid_layers: int = 3, n_heads: int = 3, normalize_embeddings: bool = True,
+                 use_positional_embeddings: bool = True, *, bd_in_channels: Optional[int] = None,
+                 compute_dtype: torch.dtype = torch.float32):
+        super().__init__()
+        self.normalize_embeddings = normalize_embeddings
+        self.use_positional_embeddings = use_positional_embeddings
+        self.compute_dtype = compute_dtype
+        self.hparams = dict(n_genes=n_genes, in_channels=in_channels, hidden_channels=hidden_channels,
+                            out_channels=out_channels, n_mid_layers=n_mid_layers, n_heads=n_heads,
+                            normalize_embeddings=normalize_embeddings,
+                            use_positional_embeddings=use_positional_embeddings)
+        self.in_channels, self.n_heads = in_channels, n_heads
+        self.lin_first = ModuleDict({"tx": Embedding(n_genes, in_channels)})
+        if bd_in_channels is not None:
+            self.lin_first["bd"] = Linear(bd_in_channels, in_channels)
+        self.pos_emb = Positional2dEmbedder(in_channels)
+        f0 = 2 * in_channels if use_positional_embeddings else in_channels
+        self.conv_layers = ModuleList()
+        self.conv_layers.append(SkipGAT((f0, f0), hidden_channels, n_heads))
+        for _ in range(n_mid_layers):
+            self.conv_layers.append(SkipGAT((hidden_channels * n_heads,) * 2, hidden_channels, n_heads))
+        last_in = hidden_channels * n_heads
+        self.conv_layers.append(SkipGAT((last_in, last_in), out_channels, n_heads))
+        self.lin_last = _HeteroDictLinear(out_channels * n_heads, out_channels, types=("tx", "bd"))
+        self._step = 0          # advances the dropout seed every training forward
+
+    def _materialize_bd(self, d_in: int, device) -> None:
+        if "bd" not in self.lin_first:
+            self.lin_first["bd"] = Linear(d_in, self.in_channels).to(device)
+
+    def forward(self, x_dict: Dict[str, Tensor], edge_index_dict: Dict[EdgeType, Tensor],
+                pos_dict: Dict[str, Tensor], batch_dict: Dict[str, Tensor], *,
+                num_graphs: Optional[int] = None, cache: Optional[dict] = None) -> Dict[str, Tensor]:
+        dt = self.compute_dtype
+        self._materialize_bd(x_dict["bd"].shape[-1], x_dict["bd"].device)
+        bd_lin = self.lin_first["bd"]
+        x = {
+            "tx": self.lin_first["tx"](x_dict["tx"].long()).to(dt),
+            "bd": F.linear(x_dict["bd"].to(dt), bd_lin.weight.to(dt), bd_lin.bias.to(dt)),
+        }
+        if self.use_positional_embeddings:
+            x = {k: torch.cat((v, self.pos_emb(pos_dict[k], batch_dict.get(k), num_graphs=num_graphs, dtype=dt)), -1)
+                 for k, v in x.items()}
+        x = {k: F.gelu(v) for k, v in x.items()}
+
+        graphs = {et: edge_graph(cache, et, edge_index_dict[et], x[et[0]].shape[0], x[et[2]].shape[0])
+                  for et in (TX_TX, TX_BD) if et in edge_index_dict}
+        if self.training:
+            self._step += 1
+        for li, layer in enumerate(self.conv_layers):
+            seed = (self._step << 8) + li
+            x = layer(x, edge_index_dict, graphs=graphs, apply_gelu=True, seed=seed)   # conv + GELU (:324-325)
+
+        x = self.lin_last(x)
+        if self.normalize_embeddings:
+            x = {k: F.normalize(v.float(), dim=-1).to(dt) for k, v in x.items()}
+        return x

@@ -1,0 +1,217 @@
+"""``LitISTEncoder`` for MI355X: constructor, ``forward`` / ``get_losses`` /
+``training_step`` / ``validation_step`` / ``predict_step`` /
+``configure_optimizers`` as in reference
+``src/segger/models/lightning_model.py:19-303`` -- so ``segger segment`` can
+build it from the same CLI-parsed arguments -- over the HIP kernels:
+
+* ``forward``       -> :class:`segger_amd.ist_encoder.ISTEncoder`
+* ``predict_step``  -> fused cosine / arg-max / assignment kernel (``:275-293``)
+* segmentation loss -> fused triplet kernel (``:178-187``); the BCE variant
+  (``:190-207``) keeps torch ops on the device embeddings.
+
+``lightning`` is used when importable; otherwise a minimal stand-in base class
+provides ``log`` / ``trainer`` / ``current_epoch`` / ``device`` so the module
+can be driven by a plain loop (bench.py, tests).
+"""
+from __future__ import annotations
+
+import math
+from typing import Any, Optional
+
+import torch
+from torch import Tensor
+from torch.nn import BCEWithLogitsLoss
+
+from . import ops
+from .graph import batch_cache, edge_graph
+from .hetero import TX_BD, TX_NB_BD
+from .ist_encoder import ISTEncoder
+from .triplet_loss import MetricLoss, TripletLoss
+
+try:  # pragma: no cover - lightning is not in the build image
+    from lightning import LightningModule as _Base
+    _HAVE_LIGHTNING = True
+except Exception:  # noqa: BLE001
+    _HAVE_LIGHTNING = False
+
+    class _Base(torch.nn.Module):
+        """The slice of LightningModule this path touches."""
+
+        def __init__(self):
+            super().__init__()
+            self.trainer = None
+            self.current_epoch = 0
+            self.logged: dict = {}
+            self.hparams: dict = {}
+
+        def save_hyperparameters(self, **kw):
+            import inspect
+            frame = inspect.currentframe().f_back
+            args = {k: v for k, v in frame.f_locals.items() if k not in ("self", "__class__") and not k.startswith("_")}
+            self.hparams = args
+
+        def log(self, name, value, **kw):
+            self.logged[name] = value
+
+        @property
+        def device(self):
+            try:
+                return next(self.parameters()).device
+            except StopIteration:
+                return torch.device("cpu")
+
+        def setup(self, stage):
+            return None
+
+
+class LitISTEncoder(_Base):
+    def __init__(
+        self,
+        n_genes: int,
+        in_channels: int,
+        hidden_channels: int = 64,
+        out_channels: int = 64,
+        n_mid_layers: int = 2,
+        n_heads: int = 2,
+        learning_rate: float = 1e-3,
+        sg_loss_type: str = 'triplet',
+        tx_margin: float = 0.3,
+        sg_margin: float = 0.4,
+        tx_weight_start: float = 1.,
+        tx_weight_end: float = 1.,
+        bd_weight_start: float = 1.,
+        bd_weight_end: float = 1.,
+        sg_weight_start: float = 0.,
+        sg_weight_end: float = 0.5,
+        update_gene_embedding: bool = True,
+        use_positional_embeddings: bool = True,
+        normalize_embeddings: bool = True,
+    ):
+        super().__init__()
+        self.save_hyperparameters()
+        if sg_loss_type not in ("triplet", "bce"):
+            # the reference raises this from setup() (:120-124); failing at construction is stricter
+            raise ValueError(f"Unrecognized segmentation loss: '{sg_loss_type}'. "
+                             f"Acceptable values are 'triplet' and 'bce'.")
+        self.model = ISTEncoder(
+            n_genes=n_genes, in_channels=in_channels, hidden_channels=hidden_channels,
+            out_channels=out_channels, n_mid_layers=n_mid_layers, n_heads=n_heads,
+            normalize_embeddings=normalize_embeddings,
+            use_positional_embeddings=use_positional_embeddings,
+        )
+        self.learning_rate = learning_rate
+        self._sg_loss_type = sg_loss_type
+        self._tx_margin = tx_margin
+        self._sg_margin = sg_margin
+        self._w_start = torch.tensor([tx_weight_start, bd_weight_start, sg_weight_start])
+        self._w_end = torch.tensor([tx_weight_end, bd_weight_end, sg_weight_end])
+        self._freeze_gene_embedding = not update_gene_embedding
+        self.loss_tx = None
+        self.loss_bd = None
+        self._max_epochs_override: Optional[int] = None
+
+    # ------------------------------------------------------------------ setup
+    def set_similarities(self, tx_similarity: Tensor, bd_similarity: Tensor) -> None:
+        """What ``setup`` takes from the datamodule (lightning_model.py:109-115)."""
+        self.loss_tx = TripletLoss(tx_similarity, margin=self._tx_margin)
+        self.loss_bd = MetricLoss(bd_similarity)
+
+    def setup(self, stage):
+        dm = getattr(self.trainer, "datamodule", None)
+        if dm is None or not (hasattr(dm, "tx_similarity") and hasattr(dm, "bd_similarity")):
+            raise TypeError(
+                f"Expected data module to be `ISTDataModule` but got {type(dm).__name__}.")
+        if hasattr(dm, "gene_embedding"):                                    # :95-106
+            w = dm.gene_embedding
+            if not isinstance(w, Tensor):                                    # polars frame in segger
+                from importlib import import_module
+                fields = import_module("segger.io.fields").StandardTranscriptFields()
+                w = w.drop(fields.feature).to_torch()
+            self.model.lin_first['tx'] = torch.nn.Embedding.from_pretrained(
+                w.to(torch.float), freeze=self._freeze_gene_embedding)
+        self.set_similarities(dm.tx_similarity, dm.bd_similarity)
+        return super().setup(stage)
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, batch) -> dict:
+        return self.model(
+            batch.x_dict, batch.edge_index_dict, batch.pos_dict, batch.batch_dict,
+            num_graphs=getattr(batch, "num_graphs", None), cache=batch_cache(batch),
+        )
+
+    def _scheduled_weights(self, w_start: Tensor, w_end: Tensor, normalize: bool = True) -> Tensor:
+        """Cosine ramp (lightning_model.py:136-149).  Stays on the host: three floats."""
+        trainer_max = self._max_epochs_override
+        if trainer_max is None:
+            trainer_max = getattr(self.trainer, "max_epochs", 1) or 1
+        max_epochs = max(1, trainer_max - 1)
+        t = min(self.current_epoch, max_epochs) / max_epochs
+        alpha = 0.5 * (1.0 + math.cos(math.pi * t))
+        w = w_end + (w_start - w_end) * alpha
+        if normalize:
+            w = w / (w.sum() + 1e-8)
+        return w
+
+    def _segmentation_loss(self, embeddings, batch, dst_neg: Optional[Tensor] = None) -> Tensor:
+        src_pos, dst_pos = batch[TX_BD].edge_index
+        z_tx, z_bd = embeddings['tx'], embeddings['bd']
+        num_bd = z_bd.size(0)
+        n = src_pos.size(0)
+        if num_bd <= 1:                                                      # :173-175
+            return torch.tensor(0.0, device=z_bd.device, requires_grad=True)
+        if dst_neg is None:                                                  # :178-180
+            dst_neg = (dst_pos + torch.randint(1, num_bd, (n,), device=dst_pos.device)) % num_bd
+        if self._sg_loss_type == 'triplet':
+            return ops.triplet_edge_loss(z_tx, z_bd, src_pos, dst_pos, dst_neg, self._sg_margin, eps=1e-6)
+        # BCE on dot-product logits (:190-207); unique/inverse in the reference only dedups gathers
+        src = torch.cat([src_pos, src_pos]).long()
+        dst = torch.cat([dst_pos, dst_neg]).long()
+        logits = (z_tx.float()[src] * z_bd.float()[dst]).sum(dim=-1)
+        labels = torch.cat([torch.ones(n, device=logits.device), torch.zeros(n, device=logits.device)])
+        return BCEWithLogitsLoss()(logits, labels)
+
+    def get_losses(self, batch, dst_neg: Optional[Tensor] = None):
+        """(loss_tx, loss_bd, loss_sg, loss), lightning_model.py:151-213."""
+        if self.loss_tx is None or self.loss_bd is None:
+            raise RuntimeError("call setup() (or set_similarities) before computing losses")
+        embeddings = self.forward(batch)
+        tx_mask = batch['tx']['mask']
+        bd_mask = batch['bd']['mask'] & (batch['bd']['cluster'] >= 0)
+        loss_tx = self.loss_tx.forward(embeddings['tx'][tx_mask], batch['tx']['cluster'][tx_mask])
+        loss_bd = self.loss_bd.forward(embeddings['bd'][bd_mask], batch['bd']['cluster'][bd_mask])
+        loss_sg = self._segmentation_loss(embeddings, batch, dst_neg)
+        w_tx, w_bd, w_sg = (float(v) for v in self._scheduled_weights(self._w_start, self._w_end))
+        loss = w_tx * loss_tx + w_bd * loss_bd + w_sg * loss_sg
+        return loss_tx, loss_bd, loss_sg, loss
+
+    def _step(self, batch, prefix: str) -> Tensor:
+        loss_tx, loss_bd, loss_sg, loss = self.get_losses(batch)
+        bs = getattr(batch, "num_graphs", 1)
+        for name, v in (("loss_tx", loss_tx), ("loss_bd", loss_bd), ("loss_sg", loss_sg)):
+            self.log(f"{prefix}:{name}", v, prog_bar=True, batch_size=bs)
+        return loss
+
+    def training_step(self, batch, batch_idx: int) -> Tensor:
+        return self._step(batch, "train")
+
+    def validation_step(self, batch, batch_idx: int) -> Tensor:
+        return self._step(batch, "val")
+
+    # ---------------------------------------------------------------- predict
+    @torch.no_grad()
+    def predict_step(self, batch, batch_idx: int, min_similarity: Optional[float] = None):
+        """-> (tx_index, seg_idx, max_sim, gene_id) on the CPU, filtered by
+        ``predict_mask`` (lightning_model.py:263-298)."""
+        embeddings = self.forward(batch)
+        z_tx, z_bd = embeddings['tx'], embeddings['bd']
+        ei = batch[TX_NB_BD].edge_index
+        n_tx = batch['tx'].num_nodes
+        g = edge_graph(batch_cache(batch), TX_NB_BD, ei, n_tx, z_bd.shape[0], need_by_dst=False)
+        max_sim, _, seg_idx, _ = ops.edge_cos_argmax(
+            g.by_src, z_tx, z_bd, dst_index=batch['bd']['index'], min_similarity=min_similarity)
+        mask = batch['tx']['predict_mask']
+        out = (batch['tx']['index'][mask], seg_idx[mask], max_sim[mask], batch['tx']['x'][mask])
+        return tuple(t.cpu() for t in out)
+
+    def configure_optimizers(self) -> torch.optim.Optimizer:
+        return torch.optim.Adam(self.parameters(), lr=self.learning_rate)

@@ -1,0 +1,325 @@
+"""Host-side operators over the C ABI: raw launch helpers + autograd Functions.
+
+Everything here enqueues HIP kernels from ``libsegger_amd.so`` on torch's
+current stream; torch is used for device memory and autograd plumbing only.
+There is no CPU path (see ``_lib.require_cuda``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import DTYPE_CODE
+from .graph import EdgeCSR, EdgeGraph
+
+
+# --------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------
+def _rows(t: Tensor, width: int, name: str) -> Tuple[int, int]:
+    """(data_ptr, row stride in elements) of a [n, width] tensor whose last dim is dense."""
+    if t.dim() != 2 or t.shape[1] != width:
+        raise ValueError(f"{name}: expected [n, {width}], got {tuple(t.shape)}")
+    if t.shape[0] > 1 and t.stride(1) != 1:
+        raise ValueError(f"{name}: last dimension must be contiguous")
+    ld = t.stride(0) if t.shape[0] > 1 else max(width, t.stride(0))
+    return t.data_ptr(), int(ld)
+
+
+def _f32_vec(t: Optional[Tensor], n: int, name: str) -> Optional[Tensor]:
+    if t is None:
+        return None
+    t = t.detach().reshape(-1)
+    if t.numel() != n:
+        raise ValueError(f"{name}: expected {n} elements, got {t.numel()}")
+    return t.to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------------
+# GATv2 aggregation: raw launches
+# --------------------------------------------------------------------------
+def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias: Optional[Tensor],
+                     heads: int, channels: int, out: Tensor, *, pre: Optional[Tensor] = None,
+                     lse: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
+                     apply_gelu: bool = False, negative_slope: float = 0.2,
+                     dropout_p: float = 0.0, seed: int = 0) -> None:
+    _lib.require_cuda(xl, xr, att, out)
+    lib = _lib.load()
+    hc = heads * channels
+    if not (xl.dtype == xr.dtype == out.dtype) or xl.dtype not in DTYPE_CODE:
+        raise TypeError(f"gatv2: x_l/x_r/out must share a dtype in {list(DTYPE_CODE)}")
+    a = _lib.GatFwdArgs()
+    a.by_dst = by_dst.c_struct()
+    a.x_l, a.ld_xl = _rows(xl, hc, "x_l")
+    a.x_r, a.ld_xr = _rows(xr, hc, "x_r")
+    if xl.shape[0] != by_dst.n_cols or xr.shape[0] != by_dst.n_rows or out.shape[0] != by_dst.n_rows:
+        raise ValueError("gatv2: feature row counts do not match the graph")
+    keep = (_f32_vec(att, hc, "att"), _f32_vec(bias, hc, "bias"))
+    a.att, a.bias = keep[0].data_ptr(), _lib.ptr(keep[1])
+    a.heads, a.channels, a.dtype, a.apply_gelu = heads, channels, DTYPE_CODE[xl.dtype], int(apply_gelu)
+    a.negative_slope, a.dropout_p, a.seed = negative_slope, dropout_p, seed & 0xFFFFFFFFFFFFFFFF
+    a.out, a.ld_out = _rows(out, hc, "out")
+    if pre is not None:
+        a.pre, a.ld_pre = _rows(pre, hc, "pre")
+    a.lse, a.alpha = _lib.ptr(lse), _lib.ptr(alpha)
+    with torch.cuda.device(xl.device):
+        rc = lib.segger_gatv2_fwd(C.byref(a), _lib.stream_ptr(xl.device))
+    _lib.check(rc, "segger_gatv2_fwd")
+
+
+def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optional[Tensor],
+                     heads: int, channels: int, grad_out: Tensor, pre: Tensor, lse: Tensor,
+                     grad_xl: Tensor, grad_xr: Tensor, *, apply_gelu: bool, negative_slope: float = 0.2,
+                     dropout_p: float = 0.0, seed: int = 0) -> Tuple[Tensor, Tensor]:
+    """Writes grad_xl / grad_xr (views allowed); returns (grad_att[HC], grad_bias[HC]) fp32."""
+    _lib.require_cuda(xl, xr, grad_out)
+    lib = _lib.load()
+    hc = heads * channels
+    dev, dt = xl.device, xl.dtype
+    n_dst = g.n_dst
+    a = _lib.GatBwdArgs()
+    a.by_dst, a.by_src = g.by_dst.c_struct(), g.by_src.c_struct()
+    a.x_l, a.ld_xl = _rows(xl, hc, "x_l")
+    a.x_r, a.ld_xr = _rows(xr, hc, "x_r")
+    keep = (_f32_vec(att, hc, "att"), _f32_vec(bias, hc, "bias"))
+    a.att, a.bias = keep[0].data_ptr(), _lib.ptr(keep[1])
+    a.heads, a.channels, a.dtype, a.apply_gelu = heads, channels, DTYPE_CODE[dt], int(apply_gelu)
+    a.negative_slope, a.dropout_p, a.seed = negative_slope, dropout_p, seed & 0xFFFFFFFFFFFFFFFF
+    if grad_out.dtype != dt:
+        grad_out = grad_out.to(dt)
+    if grad_out.dim() == 2 and grad_out.shape[0] > 1 and grad_out.stride(1) != 1:
+        grad_out = grad_out.contiguous()
+    a.grad_out, a.ld_go = _rows(grad_out, hc, "grad_out")
+    a.pre, a.ld_pre = _rows(pre, hc, "pre")
+    a.lse = lse.data_ptr()
+    grad_pre = torch.empty((n_dst, hc), dtype=dt, device=dev)
+    dsum = torch.empty((n_dst, heads), dtype=torch.float32, device=dev)
+    a.grad_pre, a.ld_gp = _rows(grad_pre, hc, "grad_pre")
+    a.dsum = dsum.data_ptr()
+    a.grad_xl, a.ld_gxl = _rows(grad_xl, hc, "grad_xl")
+    a.grad_xr, a.ld_gxr = _rows(grad_xr, hc, "grad_xr")
+    gparams = torch.empty((2, hc), dtype=torch.float32, device=dev)
+    a.grad_att, a.grad_bias = gparams[0].data_ptr(), gparams[1].data_ptr()
+    ws_bytes = lib.segger_gatv2_bwd_workspace_bytes(n_dst, heads, channels)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
+    with torch.cuda.device(dev):
+        rc = lib.segger_gatv2_bwd(C.byref(a), _lib.stream_ptr(dev))
+    _lib.check(rc, "segger_gatv2_bwd")
+    return gparams[0], gparams[1]
+
+
+class _GatV2Aggregate(torch.autograd.Function):
+    """One edge type: (x_l, x_r, att, bias) -> out [n_dst, H*C] (GELU optionally fused)."""
+
+    @staticmethod
+    def forward(ctx, xl, xr, att, bias, graph: EdgeGraph, heads, channels, apply_gelu,
+                negative_slope, dropout_p, seed, want_alpha):
+        hc = heads * channels
+        dev, dt = xl.device, xl.dtype
+        n_dst = graph.n_dst
+        need_grad = any(ctx.needs_input_grad[:4])
+        out = torch.empty((n_dst, hc), dtype=dt, device=dev)
+        pre = torch.empty((n_dst, hc), dtype=dt, device=dev) if (need_grad and apply_gelu) else None
+        lse = torch.empty((n_dst, heads), dtype=torch.float32, device=dev) if need_grad else None
+        alpha = torch.empty((graph.n_edges, heads), dtype=torch.float32, device=dev) if want_alpha else None
+        gatv2_fwd_launch(graph.by_dst, xl, xr, att, bias, heads, channels, out, pre=pre, lse=lse, alpha=alpha,
+                         apply_gelu=apply_gelu, negative_slope=negative_slope, dropout_p=dropout_p, seed=seed)
+        if need_grad:
+            ctx.save_for_backward(xl, xr, att, bias, pre if apply_gelu else out, lse)
+            ctx.graph, ctx.cfg = graph, (heads, channels, apply_gelu, negative_slope, dropout_p, seed)
+        if want_alpha:
+            ctx.mark_non_differentiable(alpha)
+            return out, alpha
+        return out, None
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_alpha):
+        xl, xr, att, bias, pre, lse = ctx.saved_tensors
+        heads, channels, apply_gelu, slope, p, seed = ctx.cfg
+        g = ctx.graph
+        hc = heads * channels
+        gxl = torch.empty((g.n_src, hc), dtype=xl.dtype, device=xl.device)
+        gxr = torch.empty((g.n_dst, hc), dtype=xl.dtype, device=xl.device)
+        gatt, gbias = gatv2_bwd_launch(g, xl, xr, att, bias, heads, channels, grad_out, pre, lse, gxl, gxr,
+                                       apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed)
+        gatt = gatt.reshape(att.shape).to(att.dtype)
+        gbias = gbias.reshape(bias.shape).to(bias.dtype) if bias is not None else None
+        return gxl, gxr, gatt, gbias, None, None, None, None, None, None, None, None
+
+
+def gatv2_aggregate(xl: Tensor, xr: Tensor, att: Tensor, bias: Optional[Tensor], graph: EdgeGraph,
+                    heads: int, channels: int, *, apply_gelu: bool = False, negative_slope: float = 0.2,
+                    dropout_p: float = 0.0, seed: int = 0, return_alpha: bool = False):
+    out, alpha = _GatV2Aggregate.apply(xl, xr, att, bias, graph, heads, channels, apply_gelu,
+                                       negative_slope, dropout_p, seed, return_alpha)
+    return (out, alpha) if return_alpha else out
+
+
+class _HeteroGatLayer(torch.autograd.Function):
+    """segger's HeteroConv layer as one autograd node.
+
+    ``xp_tx`` = [lin_l(tx-tx) | lin_r(tx-tx) | lin_l(tx-bd)] (x_tx), one fused
+    projection [Nt, 3*HC]; ``xp_bd`` = lin_r(tx-bd)(x_bd) [Nb, HC].  The three
+    backward passes write their slices of one [Nt, 3*HC] gradient, so the
+    projection's backward is a single GEMM (no slice-zero-add chains).
+    """
+
+    @staticmethod
+    def forward(ctx, xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb, g_tt: EdgeGraph, g_tb: EdgeGraph,
+                heads, channels, apply_gelu, slope, dropout_p, seed_tt, seed_tb, want_alpha):
+        hc = heads * channels
+        dev, dt = xp_tx.device, xp_tx.dtype
+        need_grad = any(ctx.needs_input_grad[:6])
+        xl_tt, xr_tt, xl_tb = xp_tx[:, :hc], xp_tx[:, hc:2 * hc], xp_tx[:, 2 * hc:]
+        nt, nb = xp_tx.shape[0], xp_bd.shape[0]
+        y_tx = torch.empty((nt, hc), dtype=dt, device=dev)
+        y_bd = torch.empty((nb, hc), dtype=dt, device=dev)
+        mk = lambda n: torch.empty((n, hc), dtype=dt, device=dev) if (need_grad and apply_gelu) else None
+        pre_tx, pre_bd = mk(nt), mk(nb)
+        lse_tx = torch.empty((nt, heads), dtype=torch.float32, device=dev) if need_grad else None
+        lse_bd = torch.empty((nb, heads), dtype=torch.float32, device=dev) if need_grad else None
+        alpha = torch.empty((g_tt.n_edges, heads), dtype=torch.float32, device=dev) if want_alpha else None
+        gatv2_fwd_launch(g_tt.by_dst, xl_tt, xr_tt, att_tt, bias_tt, heads, channels, y_tx, pre=pre_tx, lse=lse_tx,
+                         alpha=alpha, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tt)
+        gatv2_fwd_launch(g_tb.by_dst, xl_tb, xp_bd, att_tb, bias_tb, heads, channels, y_bd, pre=pre_bd, lse=lse_bd,
+                         apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tb)
+        if need_grad:
+            ctx.save_for_backward(xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb,
+                                  pre_tx if apply_gelu else y_tx, pre_bd if apply_gelu else y_bd, lse_tx, lse_bd)
+            ctx.graphs = (g_tt, g_tb)
+            ctx.cfg = (heads, channels, apply_gelu, slope, dropout_p, seed_tt, seed_tb)
+        if want_alpha:
+            ctx.mark_non_differentiable(alpha)
+        return y_tx, y_bd, alpha
+
+    @staticmethod
+    def backward(ctx, gy_tx, gy_bd, _ga):
+        xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb, pre_tx, pre_bd, lse_tx, lse_bd = ctx.saved_tensors
+        heads, channels, apply_gelu, slope, p, seed_tt, seed_tb = ctx.cfg
+        g_tt, g_tb = ctx.graphs
+        hc = heads * channels
+        gxp_tx = torch.empty_like(xp_tx)
+        gxp_bd = torch.empty_like(xp_bd)
+        if gy_tx is None:
+            gy_tx = torch.zeros_like(pre_tx)
+        if gy_bd is None:
+            gy_bd = torch.zeros_like(pre_bd)
+        gatt_tt, gbias_tt = gatv2_bwd_launch(
+            g_tt, xp_tx[:, :hc], xp_tx[:, hc:2 * hc], att_tt, bias_tt, heads, channels, gy_tx, pre_tx, lse_tx,
+            gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc], apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tt)
+        gatt_tb, gbias_tb = gatv2_bwd_launch(
+            g_tb, xp_tx[:, 2 * hc:], xp_bd, att_tb, bias_tb, heads, channels, gy_bd, pre_bd, lse_bd,
+            gxp_tx[:, 2 * hc:], gxp_bd, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb)
+        r = lambda gt, ref: gt.reshape(ref.shape).to(ref.dtype) if ref is not None else None
+        return (gxp_tx, gxp_bd, r(gatt_tt, att_tt), r(gbias_tt, bias_tt), r(gatt_tb, att_tb), r(gbias_tb, bias_tb),
+                None, None, None, None, None, None, None, None, None, None)
+
+
+def hetero_gat_layer(xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb, g_tt, g_tb, heads, channels, *,
+                     apply_gelu=True, negative_slope=0.2, dropout_p=0.0, seed_tt=0, seed_tb=0, return_alpha=False):
+    return _HeteroGatLayer.apply(xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb, g_tt, g_tb, heads, channels,
+                                 apply_gelu, negative_slope, dropout_p, seed_tt, seed_tb, return_alpha)
+
+
+# --------------------------------------------------------------------------
+# Prediction head
+# --------------------------------------------------------------------------
+@torch.no_grad()
+def edge_cos_argmax(by_src: EdgeCSR, z_src: Tensor, z_dst: Tensor, *, dst_index: Optional[Tensor] = None,
+                    min_similarity: Optional[float] = None, eps: float = 1e-8, return_sim: bool = False):
+    """-> (max_sim[f32 Ns], max_eid[i64 Ns], seg_idx[i64 Ns], sim[f32 E] | None)."""
+    _lib.require_cuda(z_src, z_dst)
+    lib = _lib.load()
+    dev = z_src.device
+    if z_src.dtype != z_dst.dtype or z_src.dtype not in DTYPE_CODE:
+        raise TypeError("edge_cos_argmax: z_src / z_dst must share a supported dtype")
+    c = int(z_src.shape[1])
+    n = by_src.n_rows
+    if z_src.shape[0] != n or z_dst.shape[0] != by_src.n_cols or z_dst.shape[1] != c:
+        raise ValueError("edge_cos_argmax: embedding shapes do not match the graph")
+    a = _lib.EdgeArgmaxArgs()
+    a.by_src = by_src.c_struct()
+    a.z_src, a.ld_zs = _rows(z_src, c, "z_src")
+    a.z_dst, a.ld_zd = _rows(z_dst, c, "z_dst")
+    a.channels, a.dtype, a.eps = c, DTYPE_CODE[z_src.dtype], eps
+    a.use_min_similarity = int(min_similarity is not None)
+    a.min_similarity = float(min_similarity) if min_similarity is not None else 0.0
+    di = None
+    if dst_index is not None:
+        di = dst_index.to(device=dev, dtype=torch.int64).contiguous()
+        if di.numel() != by_src.n_cols:
+            raise ValueError("edge_cos_argmax: dst_index has the wrong length")
+        a.dst_index = di.data_ptr()
+    max_sim = torch.empty(n, dtype=torch.float32, device=dev)
+    max_eid = torch.empty(n, dtype=torch.int64, device=dev)
+    seg = torch.empty(n, dtype=torch.int64, device=dev)
+    sim = torch.empty(by_src.n_edges, dtype=torch.float32, device=dev) if return_sim else None
+    a.max_sim, a.max_eid, a.seg_idx, a.sim = max_sim.data_ptr(), max_eid.data_ptr(), seg.data_ptr(), _lib.ptr(sim)
+    with torch.cuda.device(dev):
+        rc = lib.segger_edge_cos_argmax(C.byref(a), _lib.stream_ptr(dev))
+    _lib.check(rc, "segger_edge_cos_argmax")
+    return max_sim, max_eid, seg, sim
+
+
+# --------------------------------------------------------------------------
+# Triplet margin loss over edges
+# --------------------------------------------------------------------------
+def _triplet_args(src, pos, neg, za, zb, margin, eps):
+    a = _lib.TripletArgs()
+    a.src, a.pos, a.neg, a.n_edges = src.data_ptr(), pos.data_ptr(), neg.data_ptr(), int(src.numel())
+    c = int(za.shape[1])
+    a.z_a, a.ld_za = _rows(za, c, "z_a")
+    a.z_b, a.ld_zb = _rows(zb, c, "z_b")
+    a.n_a, a.n_b = int(za.shape[0]), int(zb.shape[0])
+    a.channels, a.dtype, a.margin, a.eps = c, DTYPE_CODE[za.dtype], margin, eps
+    return a
+
+
+class _TripletEdgeLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, za, zb, src, pos, neg, margin, eps):
+        _lib.require_cuda(za, zb, src)
+        lib = _lib.load()
+        dev = za.device
+        if za.dtype != zb.dtype or za.dtype not in DTYPE_CODE:
+            raise TypeError("triplet_edge_loss: z_a / z_b must share a supported dtype")
+        src, pos, neg = (t.to(torch.int64).contiguous() for t in (src, pos, neg))
+        a = _triplet_args(src, pos, neg, za, zb, margin, eps)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        ws_bytes = lib.segger_triplet_workspace_bytes(a.n_edges)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        a.loss, a.workspace, a.workspace_bytes = loss.data_ptr(), ws.data_ptr(), ws_bytes
+        with torch.cuda.device(dev):
+            rc = lib.segger_triplet_fwd(C.byref(a), _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_triplet_fwd")
+        ctx.save_for_backward(za, zb, src, pos, neg)
+        ctx.cfg = (margin, eps)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        za, zb, src, pos, neg = ctx.saved_tensors
+        margin, eps = ctx.cfg
+        lib = _lib.load()
+        dev = za.device
+        a = _triplet_args(src, pos, neg, za, zb, margin, eps)
+        ga = torch.zeros(za.shape, dtype=torch.float32, device=dev)
+        gb = torch.zeros(zb.shape, dtype=torch.float32, device=dev)
+        a.grad_a, a.grad_b = ga.data_ptr(), gb.data_ptr()
+        gs = g.detach().to(torch.float32).reshape(1).contiguous()   # upstream scalar stays on the device
+        a.grad_scale, a.grad_scale_dev = 1.0, gs.data_ptr()
+        with torch.cuda.device(dev):
+            rc = lib.segger_triplet_bwd(C.byref(a), _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_triplet_bwd")
+        return ga.to(za.dtype), gb.to(zb.dtype), None, None, None, None, None
+
+
+def triplet_edge_loss(za: Tensor, zb: Tensor, src: Tensor, pos: Tensor, neg: Tensor,
+                      margin: float, eps: float = 1e-6) -> Tensor:
+    """mean_e max(||za[src]-zb[pos]+eps|| - ||za[src]-zb[neg]+eps|| + margin, 0)."""
+    return _TripletEdgeLoss.apply(za, zb, src, pos, neg, float(margin), float(eps))

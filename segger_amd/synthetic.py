@@ -1,0 +1,151 @@
+"""Synthetic transcript / nucleus graphs shaped like segger's HeteroData tiles.
+
+Follows SURVEY.md 8(d): nuclei uniformly on an L x L field (L = 10 um *
+sqrt(Nb)), every transcript drawn around a true cell with a 3 um Gaussian,
+gene ~ Categorical(profile[type(cell)]), ``bd.x`` = type mean + noise, and the
+three edge stores of reference ``src/segger/data/utils/heterodata.py:138-162``:
+
+* ``tx-neighbors-tx``: exact kNN incl. self, source = query point, target =
+  neighbour (``data/utils/neighbors.py:77-82,145-156``; scipy KDTree like the
+  reference);
+* ``tx-belongs-bd``  : transcripts within ``belongs_radius`` of their own centre;
+* ``tx-neighbors-bd``: up to ``pred_k`` nearest centres within ``pred_radius``.
+
+Node ids are Morton-sorted so tiles are spatially coherent, as segger's
+quadtree tiles are (``data/tiling.py:198-233``).  Everything is generated on the
+CPU from one seed; the result is a :class:`segger_amd.hetero.HeteroBatch`.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .hetero import HeteroBatch, TX_TX, TX_BD, TX_NB_BD
+
+
+@dataclass
+class SyntheticSpec:
+    n_tx: int = 1000
+    n_bd: int = 100
+    k_tx: int = 5
+    n_genes: int = 256
+    n_types: int = 8
+    bd_dim: int = 128
+    belongs_radius: float = 3.0     # ~39 % of transcripts (1 - exp(-r^2 / 2 sigma^2))
+    pred_k: int = 3
+    pred_radius: float = 8.0
+    sigma: float = 3.0
+    n_graphs: int = 1               # >1: square grid of tiles -> batch vector
+    seed: int = 0
+
+
+# the BASELINE.json configurations
+C1 = SyntheticSpec(n_tx=1_000, n_bd=100, k_tx=5)
+C2 = SyntheticSpec(n_tx=1_000_000, n_bd=10_000, k_tx=15)
+
+
+def _morton(xy: np.ndarray, lo: float, hi: float) -> np.ndarray:
+    q = np.clip(((xy - lo) / (hi - lo) * 65535.0), 0, 65535).astype(np.uint64)
+
+    def spread(v):
+        v = (v | (v << np.uint64(8))) & np.uint64(0x00FF00FF)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x0F0F0F0F)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x33333333)
+        v = (v | (v << np.uint64(1))) & np.uint64(0x55555555)
+        return v
+    return spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1))
+
+
+def make_graph(spec: SyntheticSpec = C1, return_aux: bool = False):
+    from scipy.spatial import cKDTree
+
+    rng = np.random.default_rng(spec.seed)
+    Nt, Nb, T, G = spec.n_tx, spec.n_bd, spec.n_types, spec.n_genes
+    L = 10.0 * np.sqrt(Nb)
+
+    centres = rng.uniform(0, L, size=(Nb, 2))
+    centres = centres[np.argsort(_morton(centres, -4 * spec.sigma, L + 4 * spec.sigma), kind="stable")]
+    bd_type = rng.integers(0, T, size=Nb)
+    profiles = rng.dirichlet(np.full(G, 0.3), size=T)
+    type_mean = rng.normal(size=(T, spec.bd_dim))
+    bd_x = type_mean[bd_type] + 0.5 * rng.normal(size=(Nb, spec.bd_dim))
+
+    cell = rng.integers(0, Nb, size=Nt)
+    pos = centres[cell] + spec.sigma * rng.normal(size=(Nt, 2))
+    order = np.argsort(_morton(pos, -4 * spec.sigma, L + 4 * spec.sigma), kind="stable")
+    cell, pos = cell[order], pos[order]
+    # gene per transcript: inverse-CDF sampling from its cell type's profile
+    cdf = np.cumsum(profiles, axis=1)
+    cdf[:, -1] = 1.0
+    u = rng.random(Nt)
+    ttype = bd_type[cell]
+    gene = np.empty(Nt, dtype=np.int64)
+    for t in range(T):
+        m = ttype == t
+        gene[m] = np.searchsorted(cdf[t], u[m])
+    gene = np.minimum(gene, G - 1)
+    gene_cluster = profiles.argmax(0)            # cluster of a gene = its dominant type
+
+    # --- edges ---------------------------------------------------------------
+    tree = cKDTree(pos, leafsize=64)
+    k = min(spec.k_tx, Nt)
+    _, nbr = tree.query(pos, k=k, workers=-1)
+    nbr = nbr.reshape(Nt, k)
+    ett = np.stack([np.repeat(np.arange(Nt), k), nbr.reshape(-1)])       # src = query, dst = neighbour
+
+    d_own = np.linalg.norm(pos - centres[cell], axis=1)
+    inside = np.nonzero(d_own < spec.belongs_radius)[0]
+    etb = np.stack([inside, cell[inside]])
+
+    ctree = cKDTree(centres, leafsize=32)
+    pk = min(spec.pred_k, Nb)
+    dist, cidx = ctree.query(pos, k=pk, distance_upper_bound=spec.pred_radius, workers=-1)
+    dist, cidx = dist.reshape(Nt, pk), cidx.reshape(Nt, pk)
+    ok = np.isfinite(dist)
+    ep = np.stack([np.repeat(np.arange(Nt), pk)[ok.reshape(-1)], cidx[ok]])
+
+    # --- graph ids (square grid of tiles) ------------------------------------
+    g = int(round(np.sqrt(spec.n_graphs)))
+    assert g * g == spec.n_graphs, "n_graphs must be a square number"
+
+    def graph_id(p):
+        gx = np.clip((p[:, 0] / L * g).astype(np.int64), 0, g - 1)
+        gy = np.clip((p[:, 1] / L * g).astype(np.int64), 0, g - 1)
+        return gy * g + gx
+
+    b = HeteroBatch(num_graphs=spec.n_graphs)
+    tx, bd = b["tx"], b["bd"]
+    tx["x"] = torch.from_numpy(gene).to(torch.int32)
+    tx["pos"] = torch.from_numpy(pos).to(torch.float32)
+    tx["batch"] = torch.from_numpy(graph_id(pos))
+    tx["cluster"] = torch.from_numpy(gene_cluster[gene]).to(torch.int64)
+    tx["index"] = torch.arange(Nt, dtype=torch.int64)
+    tx["mask"] = torch.ones(Nt, dtype=torch.bool)
+    tx["predict_mask"] = torch.ones(Nt, dtype=torch.bool)
+    bd["x"] = torch.from_numpy(bd_x).to(torch.float32)
+    bd["pos"] = torch.from_numpy(centres).to(torch.float32)
+    bd["batch"] = torch.from_numpy(graph_id(centres))
+    bd["cluster"] = torch.from_numpy(bd_type).to(torch.int32)
+    bd["index"] = torch.arange(Nb, dtype=torch.int32)
+    bd["mask"] = torch.ones(Nb, dtype=torch.bool)
+    b[TX_TX]["edge_index"] = torch.from_numpy(ett).to(torch.int64)
+    b[TX_BD]["edge_index"] = torch.from_numpy(etb).to(torch.int64)
+    b[TX_NB_BD]["edge_index"] = torch.from_numpy(ep).to(torch.int64)
+    if not return_aux:
+        return b
+    # cluster similarity matrices (what ISTDataModule exposes as tx_similarity /
+    # bd_similarity, reference data/utils/anndata.py:105-128): cosine similarity
+    # of the type profiles / type means, in [-1, 1]
+    pn = profiles - profiles.mean(1, keepdims=True)
+    pn /= np.linalg.norm(pn, axis=1, keepdims=True)
+    tn = type_mean / np.linalg.norm(type_mean, axis=1, keepdims=True)
+    aux = {
+        "label": torch.from_numpy((ep[1] == cell[ep[0]])),       # true tx->cell edge
+        "cell": torch.from_numpy(cell),
+        "tx_similarity": torch.from_numpy(pn @ pn.T).to(torch.float32),
+        "bd_similarity": torch.from_numpy(tn @ tn.T).to(torch.float32),
+    }
+    return b, aux

@@ -1,0 +1,99 @@
+"""Cluster-aware metric losses on embeddings (``loss_tx`` / ``loss_bd``).
+
+Restates reference ``src/segger/models/triplet_loss.py``: positives / negatives
+are sampled per anchor from clusters drawn with probability proportional to the
+cluster similarity / dissimilarity (``FastTripletSelector``, ``:8-125``), then a
+triplet margin loss (``TripletLoss``, ``:128-160``) or a cosine-vs-distance MSE
+(``MetricLoss``, ``:163-204``) is taken.  All tensors stay on the embeddings'
+device; sampling uses torch's device RNG exactly where the reference does
+(four ``torch.rand`` draws per call, in the same order).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import Tensor
+from torch.nn import functional as F
+
+
+class FastTripletSelector:
+    _MIN_PROB = 1e-8
+
+    @torch.no_grad()
+    def __init__(self, cluster_similarity: Tensor):
+        s = cluster_similarity.clone().float()
+        s.fill_diagonal_(1)
+        self.similarity = s.clamp_min(self._MIN_PROB)
+        self.dissimilarity = (-s).clamp_min(self._MIN_PROB)
+
+    @staticmethod
+    def _cdf(m: Tensor) -> Tensor:
+        c = torch.cumsum(m / m.sum(dim=1, keepdim=True), dim=1)
+        c[:, -1] = 1.0
+        return c
+
+    @torch.no_grad()
+    def sample_triplets(self, labels: Tensor, uniforms: Optional[Tuple[Tensor, Tensor, Tensor, Tensor]] = None):
+        """-> positives, negatives, dists_pos, dists_neg (all [N]).  ``uniforms`` overrides the
+        four U[0,1) draws (positive cluster, positive member, negative cluster, negative member)."""
+        dev = labels.device
+        labels = labels.long()
+        n = labels.numel()
+        sim, dis = self.similarity.to(dev), self.dissimilarity.to(dev)
+        n_clusters = sim.shape[0]
+        counts = torch.bincount(labels, minlength=n_clusters)
+        offsets = counts.cumsum(0) - counts
+        members = torch.argsort(labels, stable=True)          # anchors grouped by cluster
+        present = torch.nonzero(counts > 0).flatten()
+        slot_of = torch.full((n_clusters,), -1, dtype=torch.long, device=dev)
+        slot_of[present] = torch.arange(present.numel(), device=dev)
+        row = slot_of[labels]
+        cdf_pos = self._cdf(sim[present][:, present])
+        cdf_neg = self._cdf(dis[present][:, present])
+        if uniforms is None:
+            u = [torch.rand(n, device=dev) for _ in range(4)]
+            # reference draw order: cluster(pos), member(pos), cluster(neg), member(neg)
+        else:
+            u = [t.to(dev) for t in uniforms]
+
+        def draw(cdf: Tensor, u_cluster: Tensor, u_member: Tensor) -> Tensor:
+            k = torch.searchsorted(cdf[row], u_cluster.unsqueeze(-1)).squeeze(-1)
+            cl = present[k]
+            within = (u_member * counts[cl].float()).floor().long()
+            return members[offsets[cl] + within]
+
+        positives = draw(cdf_pos, u[0], u[1])
+        negatives = draw(cdf_neg, u[2], u[3])
+        dists = 1.0 - sim
+        return positives, negatives, dists[labels, labels[positives]], dists[labels, labels[negatives]]
+
+
+class TripletLoss(torch.nn.TripletMarginLoss):
+    def __init__(self, cluster_similarity: Tensor, margin: float = 1.0, **kwargs):
+        super().__init__(margin=margin, **kwargs)
+        self.selector = FastTripletSelector(cluster_similarity)
+
+    def forward(self, embeddings: Tensor, labels: Tensor):  # type: ignore[override]
+        if labels.numel() == 0:
+            return 0.0
+        pos, neg, _, _ = self.selector.sample_triplets(labels)
+        e = embeddings.float()
+        return super().forward(e, e[pos], e[neg])
+
+
+class MetricLoss:
+    def __init__(self, cluster_similarity: Tensor):
+        self.selector = FastTripletSelector(cluster_similarity)
+
+    def forward(self, embeddings: Tensor, labels: Tensor):
+        if labels.numel() == 0:
+            return 0.0
+        pos, neg, d_pos, d_neg = self.selector.sample_triplets(labels)
+        e = embeddings.float()
+        cos_pos = torch.cosine_similarity(e, e[pos])
+        cos_neg = torch.cosine_similarity(e, e[neg])
+        return (F.mse_loss(cos_pos, 1 - d_pos.float(), reduction="mean")
+                + F.mse_loss(cos_neg, 1 - d_neg.float(), reduction="mean"))
+
+    __call__ = forward

@@ -1,0 +1,183 @@
+"""Parity of the fused GATv2 HIP kernels (through the C ABI) with the CPU oracle.
+
+Tolerances (stated per SURVEY.md 8(d)): the oracle runs in float64 on the SAME
+(storage-rounded) inputs.
+  float32 storage : |d| <= 2e-5 + 2e-5*|ref|   (v_exp_f32 / fp32 accumulation order)
+  bf16 storage    : |d| <= 2e-2 + 2e-2*|ref|   (outputs are rounded to bf16: 2^-9 relative)
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: (2e-5, 2e-5), torch.bfloat16: (2e-2, 2e-2), torch.float16: (3e-3, 3e-3)}
+
+
+def close(got, ref, dtype, scale=1.0, what=""):
+    atol, rtol = TOL[dtype]
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    err = (got - ref).abs()
+    bound = scale * (atol + rtol * ref.abs())
+    bad = err > bound
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max err {err.max():.3e} (ref max {ref.abs().max():.3e})"
+
+
+def random_graph(n_src, n_dst, n_edges, seed, isolated=True):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n_src, (n_edges,), generator=g)
+    lo = 1 if (isolated and n_dst > 1) else 0          # dst 0 stays without in-edges
+    dst = torch.randint(lo, n_dst, (n_edges,), generator=g)
+    return torch.stack([src, dst])
+
+
+def oracle_conv(oracle, xl, xr, ei, att, bias, H, gelu, keep=None, p=0.0):
+    """float64 oracle on already-projected features (identity lin_l / lin_r)."""
+    hc = xl.shape[1]
+    eye, zero = torch.eye(hc, dtype=torch.float64), torch.zeros(hc, dtype=torch.float64)
+    out, alpha = oracle.gatv2_conv(xl, xr, ei, eye, zero, eye, zero, att, bias, H,
+                                   dropout_p=p, dropout_keep=keep, return_alpha=True)
+    return (torch.nn.functional.gelu(out) if gelu else out), out, alpha
+
+
+CASES = [
+    # (H, C, n_src, n_dst, E)   low degree -> group-per-row ; high degree -> wave-per-row
+    (2, 64, 300, 257, 3000),
+    (2, 64, 50, 7, 1500),
+    (3, 32, 120, 90, 700),
+    (1, 32, 64, 33, 400),
+    (4, 64, 40, 21, 300),
+    (1, 64, 40, 5, 900),
+    (4, 32, 64, 3, 600),
+    (3, 64, 33, 40, 200),
+    (2, 32, 80, 64, 0),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,C,n_src,n_dst,E", CASES)
+@pytest.mark.parametrize("gelu", [False, True])
+def test_gatv2_forward_backward(oracle, cuda, dtype, H, C, n_src, n_dst, E, gelu):
+    from segger_amd import ops
+    from segger_amd.graph import build_edge_graph
+    hc = H * C
+    g = torch.Generator().manual_seed(H * 1000 + C + E)
+    ei = random_graph(n_src, n_dst, E, seed=E + H)
+    xl = torch.randn(n_src, hc, generator=g).to(dtype)
+    xr = torch.randn(n_dst, hc, generator=g).to(dtype)
+    att = torch.randn(hc, generator=g) * 0.3
+    bias = torch.randn(hc, generator=g) * 0.1
+    gy = torch.randn(n_dst, hc, generator=g).to(dtype)
+
+    # ---- oracle (float64, autograd) -------------------------------------------
+    o = [t.double().requires_grad_(True) for t in (xl, xr, att, bias)]
+    y_ref, pre_ref, alpha_ref = oracle_conv(oracle, o[0], o[1], ei, o[2], o[3], H, gelu)
+    y_ref.backward(gy.double())
+
+    # ---- HIP ---------------------------------------------------------------------
+    d = [t.to(cuda).requires_grad_(True) for t in (xl, xr, att, bias)]
+    graph = build_edge_graph(ei.to(cuda), n_src, n_dst)
+    y, alpha = ops.gatv2_aggregate(d[0], d[1], d[2], d[3], graph, H, C, apply_gelu=gelu, return_alpha=True)
+    y.backward(gy.to(cuda))
+    torch.cuda.synchronize()
+
+    close(y, y_ref, dtype, what="out")
+    close(alpha, alpha_ref, torch.float32 if dtype == torch.float32 else dtype, what="alpha")
+    deg = max(1.0, E / max(n_dst, 1))
+    close(d[0].grad, o[0].grad, dtype, scale=4.0, what="grad_xl")
+    close(d[1].grad, o[1].grad, dtype, scale=4.0 * deg ** 0.5, what="grad_xr")
+    # parameter gradients sum over all edges / rows: scale the absolute tolerance with sqrt(count)
+    close(d[2].grad, o[2].grad, dtype, scale=4.0 * max(1.0, E) ** 0.5, what="grad_att")
+    close(d[3].grad, o[3].grad, dtype, scale=4.0 * max(1.0, n_dst) ** 0.5, what="grad_bias")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,C,n_src,n_dst,E", [(2, 64, 200, 150, 2500), (2, 64, 60, 6, 1200), (3, 32, 90, 70, 900)])
+def test_gatv2_dropout_matches_explicit_mask(oracle, cuda, dtype, H, C, n_src, n_dst, E):
+    """Training-mode attention dropout: the kernel's counter-based mask equals the oracle's
+    restatement, forward and both backward passes regenerate the same mask."""
+    from segger_amd import ops
+    from segger_amd.graph import build_edge_graph
+    hc, p, seed = H * C, 0.2, 0x1234_5678_9ABC
+    g = torch.Generator().manual_seed(7 + E)
+    ei = random_graph(n_src, n_dst, E, seed=3)
+    xl = torch.randn(n_src, hc, generator=g).to(dtype)
+    xr = torch.randn(n_dst, hc, generator=g).to(dtype)
+    att = torch.randn(hc, generator=g) * 0.3
+    bias = torch.randn(hc, generator=g) * 0.1
+    gy = torch.randn(n_dst, hc, generator=g).to(dtype)
+    keep = oracle.dropout_keep_mask(seed, E, H, p)
+    assert 0.7 < keep.float().mean() < 0.9
+
+    o = [t.double().requires_grad_(True) for t in (xl, xr, att, bias)]
+    y_ref, _, alpha_ref = oracle_conv(oracle, o[0], o[1], ei, o[2], o[3], H, True, keep=keep, p=p)
+    y_ref.backward(gy.double())
+
+    d = [t.to(cuda).requires_grad_(True) for t in (xl, xr, att, bias)]
+    graph = build_edge_graph(ei.to(cuda), n_src, n_dst)
+    y, alpha = ops.gatv2_aggregate(d[0], d[1], d[2], d[3], graph, H, C, apply_gelu=True,
+                                   dropout_p=p, seed=seed, return_alpha=True)
+    y.backward(gy.to(cuda))
+    torch.cuda.synchronize()
+    assert torch.equal((alpha.cpu() != 0), keep & (alpha_ref != 0)), "dropout mask differs"
+    close(y, y_ref, dtype, what="out")
+    close(alpha, alpha_ref, dtype, what="alpha")
+    close(d[0].grad, o[0].grad, dtype, scale=4.0, what="grad_xl")
+    close(d[1].grad, o[1].grad, dtype, scale=16.0, what="grad_xr")
+    close(d[2].grad, o[2].grad, dtype, scale=4.0 * E ** 0.5, what="grad_att")
+
+
+def test_gatv2_known_answer(cuda):
+    """Hand-derived: 1 destination, 2 in-edges, H=1, C=32 with only channel 0/1 non-zero.
+    x_r = 0, att = e_0: logits are leaky_relu(x_l[i,0]); softmax over {1.0, -1.0 -> -0.2}."""
+    import math
+    from segger_amd import ops
+    from segger_amd.graph import build_edge_graph
+    H, C = 1, 32
+    xl = torch.zeros(2, C); xl[0, 0], xl[0, 1] = 1.0, 2.0; xl[1, 0], xl[1, 1] = -1.0, 4.0
+    xr = torch.zeros(1, C)
+    att = torch.zeros(C); att[0] = 1.0
+    bias = torch.zeros(C); bias[1] = 0.5
+    ei = torch.tensor([[0, 1, 1], [0, 0, 0]])            # duplicate edge 1->0 counts twice
+    e = [1.0, -0.2, -0.2]
+    w = [math.exp(v) for v in e]
+    a = [v / sum(w) for v in w]
+    want0 = a[0] * 1.0 + (a[1] + a[2]) * -1.0
+    want1 = a[0] * 2.0 + (a[1] + a[2]) * 4.0 + 0.5
+    graph = build_edge_graph(ei.to(cuda), 2, 1)
+    out, alpha = ops.gatv2_aggregate(xl.to(cuda), xr.to(cuda), att.to(cuda), bias.to(cuda), graph, H, C, return_alpha=True)
+    assert abs(out[0, 0].item() - want0) < 1e-6 and abs(out[0, 1].item() - want1) < 1e-6
+    assert torch.allclose(alpha.cpu().flatten(), torch.tensor(a, dtype=torch.float32), atol=1e-6)
+
+
+def test_gatv2_edge_order_invariance_and_isolated(cuda):
+    """Permuting the COO edge list changes nothing (up to fp32 summation order); a destination
+    without in-edges returns the bias."""
+    from segger_amd import ops
+    from segger_amd.graph import build_edge_graph
+    H, C, n_src, n_dst, E = 2, 64, 100, 60, 900
+    g = torch.Generator().manual_seed(0)
+    ei = random_graph(n_src, n_dst, E, seed=11)
+    perm = torch.randperm(E, generator=g)
+    xl, xr = torch.randn(n_src, H * C, generator=g), torch.randn(n_dst, H * C, generator=g)
+    att, bias = torch.randn(H * C, generator=g) * 0.3, torch.randn(H * C, generator=g)
+    outs = []
+    for e in (ei, ei[:, perm]):
+        graph = build_edge_graph(e.to(cuda), n_src, n_dst)
+        outs.append(ops.gatv2_aggregate(xl.to(cuda), xr.to(cuda), att.to(cuda), bias.to(cuda), graph, H, C))
+    assert torch.allclose(outs[0], outs[1], atol=1e-5, rtol=1e-5)
+    assert torch.equal(outs[0][0].cpu(), bias)          # dst 0 is isolated by construction
+
+
+def test_rejects_bad_arguments(cuda):
+    from segger_amd import ops, _lib
+    from segger_amd.graph import build_edge_graph
+    ei = torch.tensor([[0, 1], [0, 5]])
+    with pytest.raises(IndexError):
+        build_edge_graph(ei.to(cuda), 2, 2)
+    graph = build_edge_graph(torch.tensor([[0, 1], [0, 1]]).to(cuda), 2, 2)
+    x = torch.randn(2, 40, device=cuda)
+    with pytest.raises(_lib.SeggerAmdError, match="no specialised kernel"):
+        ops.gatv2_aggregate(x, x, torch.randn(40, device=cuda), None, graph, 1, 40)
+    with pytest.raises(_lib.SeggerAmdError, match="no CPU fallback"):
+        ops.gatv2_aggregate(x.cpu(), x.cpu(), torch.randn(40), None, graph, 1, 40)
