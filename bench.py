@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Headline benchmark: tx->cell edges scored per second, training step (fwd+bwd+Adam),
+on the BASELINE.json C2 tile (1M transcripts, 10k nuclei, k=15), bf16 storage.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one synthetic tile per rank (weak
+scaling: every rank owns a tile of the same size, different seed): encoder
+forward, the three losses, backward, one flat-bucket gradient all-reduce (N>1),
+Adam.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE
+JSON line (schema: task contract + `roofline` + `cpu_baseline`).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def gat_fwd_algorithmic_bytes(n_edges, n_dst, hc, elem):
+    """E*(HC*s + 4) + Nd*(2*HC*s + 4)."""
+    return n_edges * (hc * elem + 4) + n_dst * (2 * hc * elem + 4)
+
+
+def gat_bwd_algorithmic_bytes(n_edges, n_dst, n_src, hc, heads, elem):
+    """E*(2*HC*s + 8) + Nd*(3*HC*s + 16*H) + Ns*(HC*s)."""
+    return n_edges * (2 * hc * elem + 8) + n_dst * (3 * hc * elem + 16 * heads) + n_src * hc * elem
+
+
+def time_kernel(fn, iters=20, warm=3):
+    """Average device time per call (ms) with HIP events on torch's current stream,
+    which is the stream the C ABI launches on."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(iters):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / iters
+
+
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:  # noqa: BLE001
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))           # the GPU box gives 16 cores per GPU
+
+
+def cpu_baseline(sample_tx=10_000, sample_bd=100, k=15, budget_s=25.0):
+    """The oracle (pure-torch CPU restatement of the PyG path, fp32) timed on the
+    host cores over a bounded sample of the same workload: fwd + seg loss + bwd."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import segger_oracle as O
+    from segger_amd.synthetic import SyntheticSpec, make_graph
+    from segger_amd import LitISTEncoder
+    spec = SyntheticSpec(n_tx=sample_tx, n_bd=sample_bd, k_tx=k, seed=123)
+    b = make_graph(spec)
+    torch.manual_seed(0)
+    m = LitISTEncoder(n_genes=spec.n_genes, in_channels=128)
+    m.model._materialize_bd(spec.bd_dim, "cpu")
+    sd = {k_: v.detach().clone().requires_grad_(True) for k_, v in m.state_dict().items()}
+    ei = b[O.TX_BD].edge_index
+    n_bd = spec.n_bd
+    neg = (ei[1] + torch.randint(1, n_bd, (ei.shape[1],))) % n_bd
+    torch.set_num_threads(host_threads())
+
+    def step():
+        z = O.ist_encoder_forward(sd, b.x_dict, b.edge_index_dict, b.pos_dict, b.batch_dict, n_heads=2)
+        loss = O.segmentation_loss(z["tx"], z["bd"], ei, neg, "triplet", 0.4)
+        loss.backward()
+        for v in sd.values():
+            v.grad = None
+    t_all = time.perf_counter()
+    step()                                   # warm-up
+    log(f"[bench] cpu_baseline warm-up step {time.perf_counter() - t_all:.1f}s")
+    ts = []
+    while len(ts) < 5 and (not ts or time.perf_counter() - t_all + ts[-1] < budget_s):
+        t = time.perf_counter(); step(); ts.append(time.perf_counter() - t)
+        log(f"[bench] cpu_baseline step {ts[-1]:.2f}s")
+    reps = len(ts)
+    dt = sorted(ts)[len(ts) // 2]
+    etb = int(ei.shape[1])
+    mp_edges = 4 * (int(b[O.TX_TX].edge_index.shape[1]) + etb)
+    return {
+        "value": 2 * etb / dt, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+        "sample": f"oracle fp32 fwd+seg-loss+bwd on a {sample_tx}-tx/{sample_bd}-bd k={k} tile "
+                  f"(Etb={etb}), median of {reps} after 1 warm-up, {dt:.2f} s/step",
+        "mp_edges_per_s": mp_edges / dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n-tx", type=int, default=1_000_000)
+    ap.add_argument("--n-bd", type=int, default=10_000)
+    ap.add_argument("--k", type=int, default=15)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropout", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from segger_amd import LitISTEncoder, TX_TX, TX_BD, TX_NB_BD, ops
+    from segger_amd.dp import FlatGradBucket, broadcast_parameters
+    from segger_amd.graph import batch_cache, edge_graph
+    from segger_amd.synthetic import SyntheticSpec, make_graph
+
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    spec = SyntheticSpec(n_tx=args.n_tx, n_bd=args.n_bd, k_tx=args.k, seed=rank)
+    t = time.perf_counter()
+    batch_cpu, aux = make_graph(spec, return_aux=True)
+    log(f"[bench r{rank}] synthetic tile built in {time.perf_counter() - t:.1f}s: {batch_cpu}")
+    batch = batch_cpu.to(dev)
+    ett = int(batch[TX_TX].edge_index.shape[1])
+    etb = int(batch[TX_BD].edge_index.shape[1])
+    ep = int(batch[TX_NB_BD].edge_index.shape[1])
+
+    torch.manual_seed(0)
+    model = LitISTEncoder(n_genes=spec.n_genes, in_channels=128)
+    model.model._materialize_bd(spec.bd_dim, "cpu")
+    model.model.compute_dtype = dtype
+    model = model.to(dev)
+    model.set_similarities(aux["tx_similarity"].to(dev), aux["bd_similarity"].to(dev))
+    model._max_epochs_override = 20
+    model.current_epoch = 10           # mid-schedule: all three loss weights non-zero
+    model.train(not args.no_dropout)
+    broadcast_parameters(model)
+    opt = model.configure_optimizers()
+    bucket = FlatGradBucket(model.parameters())
+
+    def step():
+        bucket.zero_()
+        loss = model.training_step(batch, 0)
+        loss.backward()
+        bucket.reattach()
+        bucket.all_reduce_mean()
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stats = torch.tensor([dt, float(etb), float(ett), float(ep)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        sums = stats[1:].clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dt, (etb_all, ett_all, ep_all) = float(tmax[0]), [float(v) for v in sums]
+    else:
+        etb_all, ett_all, ep_all = float(etb), float(ett), float(ep)
+    loss_val = float(loss)
+
+    # ---- roofline of the dominant kernel: tx-neighbors-tx aggregation, forward -------------------
+    roof, extra = None, {}
+    if rank == 0:
+        H, C = 2, 64
+        hc, elem = H * C, (2 if dtype == torch.bfloat16 else 4)
+        n_tx, n_bd = spec.n_tx, spec.n_bd
+        g_tt = edge_graph(batch_cache(batch), TX_TX, batch[TX_TX].edge_index, n_tx, n_tx)
+        gen = torch.Generator(device=dev).manual_seed(0)
+        xp = torch.randn(n_tx, 3 * hc, device=dev, generator=gen).to(dtype)
+        att = torch.randn(hc, device=dev, generator=gen) * 0.3
+        bias = torch.zeros(hc, device=dev)
+        out = torch.empty(n_tx, hc, dtype=dtype, device=dev)
+        pre = torch.empty_like(out)
+        lse = torch.empty(n_tx, H, device=dev)
+        fwd = lambda: ops.gatv2_fwd_launch(g_tt.by_dst, xp[:, :hc], xp[:, hc:2 * hc], att, bias, H, C, out,
+                                           pre=pre, lse=lse, apply_gelu=True)
+        ms_fwd = time_kernel(fwd)
+        gy = torch.randn(n_tx, hc, device=dev, generator=gen).to(dtype)
+        gxp = torch.empty_like(xp)
+        bwd = lambda: ops.gatv2_bwd_launch(g_tt, xp[:, :hc], xp[:, hc:2 * hc], att, bias, H, C, gy, pre, lse,
+                                           gxp[:, :hc], gxp[:, hc:2 * hc], apply_gelu=True)
+        ms_bwd = time_kernel(bwd)
+        b_fwd = gat_fwd_algorithmic_bytes(ett, n_tx, hc, elem)
+        b_bwd = gat_bwd_algorithmic_bytes(ett, n_tx, n_tx, hc, H, elem)
+        ach = b_fwd / (ms_fwd * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "gatv2_fwd_kernel<bf16,H=2,C=64> (tx-neighbors-tx aggregation)",
+                "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_launch": b_fwd, "ms_per_launch": ms_fwd}
+        tr = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tr):
+            try:
+                roof["traffic"] = json.load(open(tr)).get("gatv2_fwd_bytes_per_launch")
+                roof["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc, separate run)"
+            except Exception:  # noqa: BLE001
+                pass
+        ach_b = b_bwd / (ms_bwd * 1e-3) / 1e9
+        extra = {"gatv2_bwd_tx_tx": {"achieved": ach_b, "frac": ach_b / HBM_PEAK_GBS, "unit": "GB/s",
+                                     "algorithmic_bytes_per_launch": b_bwd, "ms_per_launch": ms_bwd}}
+        log(f"[bench] gatv2 fwd {ms_fwd:.3f} ms ({ach:.0f} GB/s alg.), bwd {ms_bwd:.3f} ms ({ach_b:.0f} GB/s alg.)")
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline()
+        except Exception as e:  # noqa: BLE001
+            cpu = {"value": None, "error": repr(e)}
+
+    if rank == 0:
+        n_layers = 4
+        res = {
+            "metric": "edges scored/sec (tx->cell) fwd+bwd",
+            "value": 2.0 * etb_all * args.steps / dt,
+            "unit": "edges/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"C2: single Xenium-scale tile per GPU, {args.n_tx} tx, {args.n_bd} nuclei, "
+                                   f"k={args.k} kNN (Ett={ett}, Etb={etb}, Ep={ep}), training step fwd+bwd+Adam, "
+                                   f"attention dropout {'off' if args.no_dropout else '0.2'}",
+                       "tiles_per_step": world, "parallelism": f"dp{world}"},
+            "mp_edges_per_s": n_layers * (ett_all + etb_all) * args.steps / dt,
+            "loss": loss_val,
+            "roofline": roof, "roofline_other": extra, "cpu_baseline": cpu,
+        }
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -245,6 +245,18 @@ size_t segger_triplet_workspace_bytes(int64_t n_edges);
 int segger_triplet_fwd(const segger_triplet_args* args, segger_stream_t stream);
 int segger_triplet_bwd(const segger_triplet_args* args, segger_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Positional embedder, stage 1: per-graph min / max of node positions.
+ * Replaces the Python loop over graphs in Positional2dEmbedder.forward
+ * (src/segger/models/ist_encoder.py:66-73: one boolean mask, two reductions and a
+ * host sync per graph).
+ *   pos   : [n, 2] fp32 ;  batch : [n] int64 graph id per node, or NULL (one graph)
+ *   mins / maxs : [n_graphs, 2] fp32 ; a graph without nodes gets (0, 0) as in the
+ *   reference; ids outside [0, n_graphs) are ignored.
+ * ---------------------------------------------------------------------- */
+int segger_segment_minmax(const float* pos, const int64_t* batch, int64_t n, int64_t n_graphs,
+                          float* mins, float* maxs, segger_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -311,7 +311,7 @@ class FastTripletSelectorOracle:
         labels = labels.long()
         counts = torch.bincount(labels, minlength=C)
         offsets = torch.cat([torch.zeros(1, dtype=torch.long), counts.cumsum(0)])[:-1]
-        sorted_idx = torch.argsort(labels, stable=True)
+        sorted_idx = torch.argsort(labels)      # unstable, as the reference (:41): order inside a cluster is implementation-defined
         present = torch.nonzero(counts > 0).flatten()
         def cdf(m):
             m = m[present][:, present]

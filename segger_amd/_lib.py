@@ -105,6 +105,7 @@ EXPORTS = {
     "segger_triplet_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "segger_triplet_fwd": (C.c_int, [C.POINTER(TripletArgs), vp]),
     "segger_triplet_bwd": (C.c_int, [C.POINTER(TripletArgs), vp]),
+    "segger_segment_minmax": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

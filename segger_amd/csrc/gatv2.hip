@@ -3,23 +3,34 @@
 
 namespace segger {
 
-// grad_att / grad_bias = column sums of the slab  [nblocks][2*HC]
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int64_t nblocks, int width,
-                                                         int hc, float* __restrict__ grad_att, float* __restrict__ grad_bias) {
-  // one block per chunk of 64 columns; the 4 waves split the slab rows
-  __shared__ float part[4][64];
+// grad_att / grad_bias = column sums of the slab [nblocks][width], in two deterministic stages:
+// stage 1: kSlabSplits row ranges x 64-column chunks -> part[kSlabSplits][width]; stage 2: sum the splits.
+constexpr int kSlabSplits = 128;
+
+__global__ __launch_bounds__(256) void slab_reduce_stage1(const float* __restrict__ slab, int64_t nblocks, int width,
+                                                         float* __restrict__ part) {
+  __shared__ float sm[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int colx = blockIdx.x * 64 + lane;
+  const int64_t per = (nblocks + kSlabSplits - 1) / kSlabSplits;
+  const int64_t r0 = (int64_t)blockIdx.y * per;
+  const int64_t r1 = r0 + per < nblocks ? r0 + per : nblocks;
   float s = 0.f;
   if (colx < width)
-    for (int64_t r = wave; r < nblocks; r += 4) s += slab[r * width + colx];
-  part[wave][lane] = s;
+    for (int64_t r = r0 + wave; r < r1; r += 4) s += slab[r * width + colx];
+  sm[wave][lane] = s;
   __syncthreads();
-  if (wave == 0 && colx < width) {
-    const float t = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-    if (colx < hc) grad_att[colx] = t;
-    else if (grad_bias) grad_bias[colx - hc] = t;
-  }
+  if (wave == 0 && colx < width) part[(int64_t)blockIdx.y * width + colx] = sm[0][lane] + sm[1][lane] + sm[2][lane] + sm[3][lane];
+}
+
+__global__ __launch_bounds__(256) void slab_reduce_stage2(const float* __restrict__ part, int width, int hc,
+                                                         float* __restrict__ grad_att, float* __restrict__ grad_bias) {
+  const int colx = blockIdx.x * 256 + threadIdx.x;
+  if (colx >= width) return;
+  float t = 0.f;
+  for (int r = 0; r < kSlabSplits; ++r) t += part[(int64_t)r * width + colx];
+  if (colx < hc) grad_att[colx] = t;
+  else if (grad_bias) grad_bias[colx - hc] = t;
 }
 
 namespace {
@@ -111,7 +122,7 @@ extern "C" size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads,
   if (n_dst <= 0 || heads <= 0 || channels <= 0) return 16;
   // upper bound over both modes: wave-per-row has the most blocks (4 rows per block-iteration)
   const int64_t blocks = (n_dst + 4 * kBwdRowIters - 1) / (4 * kBwdRowIters) + kNumXcd;
-  return (size_t)blocks * 2 * heads * channels * sizeof(float);
+  return (size_t)(blocks + kSlabSplits) * 2 * heads * channels * sizeof(float);
 }
 
 extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t stream_) {
@@ -163,9 +174,12 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
   if (n_dst > 0) {
     CHECK_RC(launch(Pass::BwdDst, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), stream));
     const int width = 2 * hc;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((width + 63) / 64), dim3(256), 0, stream,
-                       p.slab, p.nblocks, width, hc, a->grad_att, a->grad_bias);
-    SEGGER_LAUNCH_CHECK("slab_reduce_kernel");
+    float* part = p.slab + p.nblocks * width;          // behind the per-block slabs
+    hipLaunchKernelGGL(slab_reduce_stage1, dim3((width + 63) / 64, kSlabSplits), dim3(256), 0, stream,
+                       p.slab, p.nblocks, width, part);
+    hipLaunchKernelGGL(slab_reduce_stage2, dim3((width + 255) / 256), dim3(256), 0, stream,
+                       part, width, hc, a->grad_att, a->grad_bias);
+    SEGGER_LAUNCH_CHECK("slab_reduce kernels");
   } else {
     SEGGER_HIP(hipMemsetAsync(a->grad_att, 0, hc * sizeof(float), stream));
     if (a->grad_bias) SEGGER_HIP(hipMemsetAsync(a->grad_bias, 0, hc * sizeof(float), stream));

@@ -541,8 +541,4 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
     Vec8<T>::store(static_cast<T*>(p.gxl) + row * p.ld_gxl + ch0, acc);
 }
 
-// grad_att / grad_bias = column sums of the slab  [nblocks][2*HC]
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int64_t nblocks, int width,
-                                                         int hc, float* __restrict__ grad_att, float* __restrict__ grad_bias);
-
 }  // namespace segger

@@ -10,7 +10,7 @@ enum class Pass : int { Fwd = 0, BwdDst = 1, BwdSrc = 2 };
 
 // destination rows walked per wave in the dst-side backward (amortises the
 // per-block grad_att / grad_bias partial slab)
-constexpr int kBwdRowIters = 4;
+constexpr int kBwdRowIters = 8;
 
 // (heads, channels/8) combinations with a specialised kernel
 #define SEGGER_GEOMETRIES(X) \

@@ -1,0 +1,104 @@
+// Positional embedder, stage 1: per-graph min / max of node positions.
+// Replaces the Python loop over graphs (one boolean mask + two reductions + a
+// host sync per graph) of reference src/segger/models/ist_encoder.py:66-73.
+#include "common.h"
+
+namespace segger {
+namespace {
+
+// order-preserving float atomics on plain global words initialised to +inf / -inf
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
+  if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else          atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else          atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(256) void minmax_init_kernel(float* mins, float* maxs, int64_t n2) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n2) { mins[i] = INFINITY; maxs[i] = -INFINITY; }
+}
+
+constexpr int kNodesPerThread = 16;
+
+struct MM { float lx, ly, hx, hy; };
+
+__device__ __forceinline__ void flush(float* mins, float* maxs, int64_t g, const MM& m) {
+  atomic_min_f32(mins + 2 * g, m.lx); atomic_min_f32(mins + 2 * g + 1, m.ly);
+  atomic_max_f32(maxs + 2 * g, m.hx); atomic_max_f32(maxs + 2 * g + 1, m.hy);
+}
+
+// Graph ids of a PyG Batch are sorted, so a block's contiguous chunk of nodes
+// nearly always belongs to one graph: lanes accumulate privately, a wave whose
+// lanes all hold the same graph reduces with shuffles and issues 4 atomics.
+__global__ __launch_bounds__(256) void segment_minmax_kernel(const float* __restrict__ pos, const int64_t* __restrict__ batch,
+                                                            int64_t n, int64_t n_graphs, float* mins, float* maxs) {
+  const int64_t base = (int64_t)blockIdx.x * (256 * kNodesPerThread);
+  int64_t cur = -1;
+  MM m{INFINITY, INFINITY, -INFINITY, -INFINITY};
+  for (int i = 0; i < kNodesPerThread; ++i) {
+    const int64_t v = base + (int64_t)i * 256 + threadIdx.x;
+    if (v >= n) break;
+    int64_t g = batch ? batch[v] : 0;
+    if (g < 0 || g >= n_graphs) continue;          // ignored, like an unmatched mask in the reference loop
+    const float2 p = *reinterpret_cast<const float2*>(pos + 2 * v);
+    if (g != cur) {
+      if (cur >= 0) flush(mins, maxs, cur, m);
+      cur = g;
+      m = MM{p.x, p.y, p.x, p.y};
+    } else {
+      m.lx = fminf(m.lx, p.x); m.ly = fminf(m.ly, p.y);
+      m.hx = fmaxf(m.hx, p.x); m.hy = fmaxf(m.hy, p.y);
+    }
+  }
+  const int cur32 = (int)cur;                      // n_graphs < 2^31 (checked on the host)
+  const int first = __shfl(cur32, 0, 64);
+  const bool uniform = __all(cur32 == first);
+  if (uniform) {
+    if (first < 0) return;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      m.lx = fminf(m.lx, __shfl_xor(m.lx, off, 64)); m.ly = fminf(m.ly, __shfl_xor(m.ly, off, 64));
+      m.hx = fmaxf(m.hx, __shfl_xor(m.hx, off, 64)); m.hy = fmaxf(m.hy, __shfl_xor(m.hy, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) flush(mins, maxs, first, m);
+  } else if (cur >= 0) {
+    flush(mins, maxs, cur, m);
+  }
+}
+
+// graphs without nodes keep (0, 0) as in the reference (ist_encoder.py:67-68)
+__global__ __launch_bounds__(256) void minmax_fixup_kernel(float* mins, float* maxs, int64_t n2) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n2 && mins[i] == INFINITY && maxs[i] == -INFINITY) { mins[i] = 0.f; maxs[i] = 0.f; }
+}
+
+}  // namespace
+}  // namespace segger
+
+using namespace segger;
+
+extern "C" int segger_segment_minmax(const float* pos, const int64_t* batch, int64_t n, int64_t n_graphs,
+                                     float* mins, float* maxs, segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGGER_REQUIRE(n >= 0 && n_graphs >= 0, "segger_segment_minmax: negative size");
+  SEGGER_REQUIRE(n_graphs < 0x7fffffffLL, "segger_segment_minmax: too many graphs");
+  if (n_graphs == 0) return SEGGER_OK;
+  SEGGER_REQUIRE(mins && maxs, "segger_segment_minmax: NULL output");
+  SEGGER_REQUIRE(n == 0 || pos, "segger_segment_minmax: pos is NULL");
+  SEGGER_REQUIRE((reinterpret_cast<uintptr_t>(pos) & 7u) == 0, "segger_segment_minmax: pos must be 8-byte aligned");
+  const int64_t n2 = 2 * n_graphs;
+  const unsigned gb = (unsigned)((n2 + 255) / 256);
+  hipLaunchKernelGGL(minmax_init_kernel, dim3(gb), dim3(256), 0, stream, mins, maxs, n2);
+  if (n > 0) {
+    const int64_t per = 256 * kNodesPerThread;
+    const int64_t nb = (n + per - 1) / per;
+    SEGGER_REQUIRE(nb < 0x7fffffffLL, "segger_segment_minmax: too many nodes");
+    hipLaunchKernelGGL(segment_minmax_kernel, dim3((unsigned)nb), dim3(256), 0, stream, pos, batch, n, n_graphs, mins, maxs);
+  }
+  hipLaunchKernelGGL(minmax_fixup_kernel, dim3(gb), dim3(256), 0, stream, mins, maxs, n2);
+  SEGGER_LAUNCH_CHECK("segment_minmax kernels");
+  return SEGGER_OK;
+}

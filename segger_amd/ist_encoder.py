@@ -71,9 +71,7 @@ class Positional2dEmbedder(Module):
             return pos / pos.max(dim=0).values
         if num_graphs is None:
             num_graphs = int(batch.max()) + 1 if batch.numel() else 0
-        idx = batch.long()[:, None].expand(-1, 2)
-        mins = torch.full((num_graphs, 2), float("inf"), device=pos.device).scatter_reduce_(0, idx, pos, "amin")
-        maxs = torch.full((num_graphs, 2), float("-inf"), device=pos.device).scatter_reduce_(0, idx, pos, "amax")
+        mins, maxs = ops.segment_minmax(pos, batch, num_graphs)     # one HIP pass, no per-graph sync
         lo, hi = mins[batch.long()], maxs[batch.long()]
         return (pos - lo) / (hi - lo + 1e-8)                # ist_encoder.py:74
 

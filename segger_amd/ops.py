@@ -323,3 +323,28 @@ def triplet_edge_loss(za: Tensor, zb: Tensor, src: Tensor, pos: Tensor, neg: Ten
                       margin: float, eps: float = 1e-6) -> Tensor:
     """mean_e max(||za[src]-zb[pos]+eps|| - ||za[src]-zb[neg]+eps|| + margin, 0)."""
     return _TripletEdgeLoss.apply(za, zb, src, pos, neg, float(margin), float(eps))
+
+
+# --------------------------------------------------------------------------
+# Positional embedder: per-graph min / max
+# --------------------------------------------------------------------------
+@torch.no_grad()
+def segment_minmax(pos: Tensor, batch: Optional[Tensor], num_graphs: int) -> Tuple[Tensor, Tensor]:
+    """-> (mins[num_graphs, 2], maxs[num_graphs, 2]) fp32 of ``pos`` grouped by ``batch``."""
+    _lib.require_cuda(pos)
+    lib = _lib.load()
+    dev = pos.device
+    pos = pos.to(torch.float32).contiguous()
+    if pos.dim() != 2 or pos.shape[1] != 2:
+        raise ValueError("segment_minmax: pos must be [n, 2]")
+    if batch is not None:
+        batch = batch.to(device=dev, dtype=torch.int64).contiguous()
+        if batch.numel() != pos.shape[0]:
+            raise ValueError("segment_minmax: batch / pos length mismatch")
+    mins = torch.empty((num_graphs, 2), dtype=torch.float32, device=dev)
+    maxs = torch.empty((num_graphs, 2), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.segger_segment_minmax(pos.data_ptr(), _lib.ptr(batch), int(pos.shape[0]), int(num_graphs),
+                                       mins.data_ptr(), maxs.data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "segger_segment_minmax")
+    return mins, maxs

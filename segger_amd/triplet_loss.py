@@ -44,7 +44,9 @@ class FastTripletSelector:
         n_clusters = sim.shape[0]
         counts = torch.bincount(labels, minlength=n_clusters)
         offsets = counts.cumsum(0) - counts
-        members = torch.argsort(labels, stable=True)          # anchors grouped by cluster
+        # default (unstable) argsort, the very call the reference makes (triplet_loss.py:41): the order of
+        # equal labels is implementation-defined and decides WHICH member of the drawn cluster is returned
+        members = torch.argsort(labels)
         present = torch.nonzero(counts > 0).flatten()
         slot_of = torch.full((n_clusters,), -1, dtype=torch.long, device=dev)
         slot_of[present] = torch.arange(present.numel(), device=dev)

@@ -1,0 +1,74 @@
+"""The N>1 path on the CPU: world_size-2 gloo processes exercise the flat gradient bucket
+(all-reduce mean, parameter broadcast) that bench.py / training use over RCCL on the GPUs."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from segger_amd import LitISTEncoder
+    from segger_amd.dp import FlatGradBucket, broadcast_parameters
+    torch.manual_seed(100 + rank)                       # ranks start from different weights
+    m = LitISTEncoder(n_genes=12, in_channels=16, hidden_channels=8, out_channels=8)
+    m.model._materialize_bd(6, "cpu")
+    broadcast_parameters(m, src=0)
+    w0 = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    gathered = [torch.empty_like(w0) for _ in range(world)]
+    dist.all_gather(gathered, w0)
+    same_weights = all(torch.equal(gathered[0], g) for g in gathered)
+    bucket = FlatGradBucket(m.parameters())
+    bucket.zero_()
+    # stand-in for backward: rank-dependent gradients written through p.grad (views of the bucket)
+    for i, p in enumerate(bucket.params):
+        p.grad.add_(torch.full_like(p, float((rank + 1) * (i + 1))))
+    views_ok = all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in bucket.params)
+    bucket.all_reduce_mean()
+    want = sum(r + 1 for r in range(world)) / world
+    grads_ok = all(torch.allclose(p.grad, torch.full_like(p, want * (i + 1))) for i, p in enumerate(bucket.params))
+    # zero_grad(set_to_none) then reattach keeps the bucket authoritative
+    for p in bucket.params:
+        p.grad = None
+    bucket.reattach()
+    reattach_ok = all(p.grad is not None and p.grad.data_ptr() >= bucket.flat.data_ptr() for p in bucket.params)
+    opt = m.configure_optimizers()
+    opt.step()
+    w1 = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    dist.all_gather(gathered, w1)
+    in_sync = all(torch.equal(gathered[0], g) for g in gathered)
+    if rank == 0:
+        out.put((same_weights, views_ok, grads_ok, reattach_ok, in_sync, bucket.flat.numel()))
+    dist.destroy_process_group()
+
+
+def test_flat_bucket_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    same_weights, views_ok, grads_ok, reattach_ok, in_sync, n = res
+    assert same_weights and views_ok and grads_ok and reattach_ok and in_sync and n > 1000
+
+
+def test_single_process_is_a_noop():
+    from segger_amd.dp import FlatGradBucket
+    lin = torch.nn.Linear(3, 2)
+    b = FlatGradBucket(lin.parameters())
+    lin(torch.ones(1, 3)).sum().backward()
+    before = b.flat.clone()
+    b.all_reduce_mean()                                  # no process group: nothing happens
+    assert torch.equal(before, b.flat) and b.flat.abs().sum() > 0

@@ -1,0 +1,211 @@
+"""Model-level parity on the GPU: ISTEncoder / LitISTEncoder (HIP path through the C ABI)
+against the CPU oracle on identical HeteroData-contract inputs and identical weights.
+
+Tolerances: fp32 compute, unit-norm 64-d embeddings after 4 layers -> atol 5e-5;
+bf16 compute -> atol 3e-2 on embeddings / cosine scores (2e-2 on scores
+for a single kernel; four stacked bf16 layers round four times)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def build(spec, dev, dtype=torch.float32, heads=2, hidden=64, in_channels=128, **kw):
+    from segger_amd import LitISTEncoder
+    from segger_amd.synthetic import make_graph
+    b, aux = make_graph(spec, return_aux=True)
+    torch.manual_seed(1)
+    m = LitISTEncoder(n_genes=spec.n_genes, in_channels=in_channels, hidden_channels=hidden, out_channels=hidden,
+                      n_heads=heads, **kw)
+    m.model._materialize_bd(spec.bd_dim, "cpu")
+    # non-trivial biases / attention so every term is exercised
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bias"):
+                p.normal_(0, 0.1)
+    sd = {k: v.detach().clone().double() for k, v in m.state_dict().items()}
+    m.model.compute_dtype = dtype
+    m = m.to(dev)
+    m.set_similarities(aux["tx_similarity"].to(dev), aux["bd_similarity"].to(dev))
+    return m, sd, b, aux
+
+
+@pytest.mark.parametrize("n_graphs", [1, 4])
+@pytest.mark.parametrize("heads,hidden", [(2, 64), (3, 32)])
+def test_encoder_matches_oracle_fp32(oracle, cuda, n_graphs, heads, hidden):
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=1000, n_bd=100, k_tx=5, n_graphs=n_graphs, seed=3)
+    m, sd, b, _ = build(spec, cuda, heads=heads, hidden=hidden)
+    m.eval()
+    z = m(b.to(cuda))
+    z_ref = oracle.ist_encoder_forward(sd, b.x_dict, b.edge_index_dict, b.pos_dict, b.batch_dict, n_heads=heads)
+    for k in ("tx", "bd"):
+        assert z[k].shape == z_ref[k].shape
+        err = (z[k].double().cpu() - z_ref[k]).abs().max().item()
+        assert err < 5e-5, f"{k}: max abs err {err}"
+
+
+def test_encoder_without_positional_embeddings_and_normalisation(oracle, cuda):
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=600, n_bd=50, k_tx=4, seed=5)
+    m, sd, b, _ = build(spec, cuda, use_positional_embeddings=False, normalize_embeddings=False)
+    m.eval()
+    z = m(b.to(cuda))
+    z_ref = oracle.ist_encoder_forward(sd, b.x_dict, b.edge_index_dict, b.pos_dict, b.batch_dict, n_heads=2,
+                                       use_positional_embeddings=False, normalize_embeddings=False)
+    for k in ("tx", "bd"):
+        ref = z_ref[k]
+        assert torch.allclose(z[k].double().cpu(), ref, atol=2e-5 * max(1.0, ref.abs().max().item()), rtol=1e-4)
+
+
+def test_encoder_bf16_close_to_oracle_and_auroc(oracle, cuda):
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=20000, n_bd=400, k_tx=15, seed=7)
+    m, sd, b, aux = build(spec, cuda, dtype=torch.bfloat16)
+    m.eval()
+    z = m(b.to(cuda))
+    z_ref = oracle.ist_encoder_forward({k: v.float() for k, v in sd.items()}, b.x_dict, b.edge_index_dict,
+                                       b.pos_dict, b.batch_dict, n_heads=2)
+    for k in ("tx", "bd"):
+        err = (z[k].float().cpu() - z_ref[k]).abs().max().item()
+        assert err < 3e-2, f"{k}: max abs err {err}"
+    ei = b[oracle.TX_NB_BD].edge_index
+    s_ref = oracle.edge_scores(z_ref["tx"], z_ref["bd"], ei)
+    s_hip = oracle.edge_scores(z["tx"].float().cpu(), z["bd"].float().cpu(), ei)
+    assert (s_ref - s_hip).abs().max() < 3e-2
+    a_ref, a_hip = oracle.auroc(s_ref, aux["label"]), oracle.auroc(s_hip, aux["label"])
+    assert abs(a_ref - a_hip) < 1e-3, (a_ref, a_hip)      # BASELINE.json: edge-AUROC within 1e-3 of reference
+
+
+def test_predict_step_matches_oracle(oracle, cuda):
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=3000, n_bd=120, k_tx=6, n_graphs=4, seed=11)
+    m, sd, b, _ = build(spec, cuda)
+    m.eval()
+    g = torch.Generator().manual_seed(0)
+    b["tx"]["predict_mask"] = torch.rand(spec.n_tx, generator=g) < 0.7
+    b["tx"]["index"] = torch.randperm(10 * spec.n_tx, generator=g)[: spec.n_tx]
+    b["bd"]["index"] = (torch.randperm(spec.n_bd, generator=g) + 7).to(torch.int32)
+    for min_sim in (None, 0.3):
+        out = m.predict_step(b.to(cuda), 0, min_similarity=min_sim)
+        ref = oracle.predict_step(sd, b, n_heads=2, min_similarity=min_sim)
+        assert all(not t.is_cuda for t in out)
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[3], ref[3])
+        assert torch.allclose(out[2].double(), ref[2], atol=5e-5)
+        # assignments can only differ where the two best candidates are within rounding of each other
+        assert (out[1] == ref[1]).float().mean() > 0.998
+        assert out[1].dtype == torch.int64 and out[2].dtype == torch.float32
+
+
+def test_training_losses_and_gradients_match_oracle(oracle, cuda):
+    """get_losses with the sampled negatives given: loss_sg and d loss_sg / d parameters equal the
+    oracle's autograd through its PyG-style ops (dropout off)."""
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=1500, n_bd=80, k_tx=6, n_graphs=1, seed=13)
+    m, sd, b, _ = build(spec, cuda)
+    m.eval()                                   # no attention dropout; gradients still flow
+    ei = b[oracle.TX_BD].edge_index
+    g = torch.Generator().manual_seed(2)
+    neg = (ei[1] + torch.randint(1, spec.n_bd, (ei.shape[1],), generator=g)) % spec.n_bd
+    bg = b.to(cuda)
+    z = m(bg)
+    loss = m._segmentation_loss(z, bg, neg.to(cuda))
+    loss.backward()
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    z_ref = oracle.ist_encoder_forward(sdr, b.x_dict, b.edge_index_dict, b.pos_dict, b.batch_dict, n_heads=2)
+    loss_ref = oracle.segmentation_loss(z_ref["tx"], z_ref["bd"], ei, neg, "triplet", 0.4)
+    loss_ref.backward()
+    assert abs(loss.item() - loss_ref.item()) < 2e-5
+    named = dict(m.named_parameters())
+    checked = 0
+    for k, ref in sdr.items():
+        if ref.grad is None or k not in named:
+            continue
+        got = named[k].grad.double().cpu()
+        scale = max(ref.grad.abs().max().item(), 1e-8)
+        err = (got - ref.grad).abs().max().item()
+        assert err < 2e-3 * scale + 1e-7, f"{k}: grad err {err} (scale {scale})"
+        checked += 1
+    assert checked >= 40
+
+
+def test_bce_segmentation_loss_matches_oracle(oracle, cuda):
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=800, n_bd=60, k_tx=5, seed=17)
+    m, sd, b, _ = build(spec, cuda, sg_loss_type="bce")
+    m.eval()
+    ei = b[oracle.TX_BD].edge_index
+    neg = (ei[1] + 1) % spec.n_bd
+    bg = b.to(cuda)
+    loss = m._segmentation_loss(m(bg), bg, neg.to(cuda))
+    z_ref = oracle.ist_encoder_forward(sd, b.x_dict, b.edge_index_dict, b.pos_dict, b.batch_dict, n_heads=2)
+    ref = oracle.segmentation_loss(z_ref["tx"], z_ref["bd"], ei, neg, "bce")
+    assert abs(loss.item() - ref.item()) < 2e-5
+
+
+def test_training_mode_dropout_matches_oracle_with_same_mask(oracle, cuda):
+    """Training forward (attention dropout 0.2): the oracle, given the masks the kernels' counter-based
+    generator defines for each layer / edge type, reproduces the embeddings."""
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=1200, n_bd=70, k_tx=6, seed=19)
+    m, sd, b, _ = build(spec, cuda)
+    m.train()
+    z = m(b.to(cuda))
+    step = m.model._step
+    keep = {}
+    for li in range(4):
+        seed = (step << 8) + li
+        keep[(li, oracle.TX_TX)] = oracle.dropout_keep_mask(2 * seed, b[oracle.TX_TX].edge_index.shape[1], 2, 0.2)
+        keep[(li, oracle.TX_BD)] = oracle.dropout_keep_mask(2 * seed + 1, b[oracle.TX_BD].edge_index.shape[1], 2, 0.2)
+    z_ref = oracle.ist_encoder_forward(sd, b.x_dict, b.edge_index_dict, b.pos_dict, b.batch_dict, n_heads=2,
+                                       dropout_p=0.2, dropout_keep=keep)
+    for k in ("tx", "bd"):
+        assert (z[k].double().cpu() - z_ref[k]).abs().max() < 5e-5
+    z2 = m(b.to(cuda))                          # a new step draws a new mask
+    assert (z2["tx"] - z["tx"]).abs().max() > 1e-4
+
+
+def test_full_training_step_runs_and_learns(cuda):
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=4000, n_bd=150, k_tx=8, seed=23)
+    m, _, b, _ = build(spec, cuda, dtype=torch.bfloat16)
+    m.train()
+    m._max_epochs_override, m.current_epoch = 20, 19
+    opt = m.configure_optimizers()
+    bg = b.to(cuda)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        loss = m.training_step(bg, 0)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(torch.isfinite(torch.tensor(losses)))
+    assert min(losses[-3:]) < losses[0]
+    assert {"train:loss_tx", "train:loss_bd", "train:loss_sg"} <= set(m.logged)
+
+
+def test_c2_scale_properties(cuda):
+    """BASELINE C2-sized tile (bf16): size-independent properties of the aggregation kernels --
+    attention rows sum to 1, outputs are convex combinations (bounded by the row-wise extrema of x_l),
+    permuting the edge list changes nothing beyond fp32 summation order."""
+    from segger_amd import ops
+    from segger_amd.graph import build_edge_graph
+    n, k, H, C = 1_000_000, 15, 2, 64
+    g = torch.Generator(device=cuda).manual_seed(0)
+    src = torch.arange(n, device=cuda).repeat_interleave(k)
+    dst = (src + torch.randint(-2000, 2000, (n * k,), device=cuda, generator=g)).clamp_(0, n - 1)
+    ei = torch.stack([src, dst])
+    xl = torch.randn(n, H * C, device=cuda, generator=g).to(torch.bfloat16)
+    xr = torch.randn(n, H * C, device=cuda, generator=g).to(torch.bfloat16)
+    att = torch.randn(H * C, device=cuda, generator=g) * 0.3
+    graph = build_edge_graph(ei, n, n)
+    out, alpha = ops.gatv2_aggregate(xl, xr, att, None, graph, H, C, return_alpha=True)
+    rowsum = torch.zeros(n, H, device=cuda).index_add_(0, dst, alpha)
+    has = torch.zeros(n, device=cuda).index_add_(0, dst, torch.ones_like(dst, dtype=torch.float32)) > 0
+    assert torch.allclose(rowsum[has], torch.ones_like(rowsum[has]), atol=1e-4)
+    assert (out[~has] == 0).all()
+    assert out.float().abs().max() <= xl.float().abs().max() * 1.01
+    perm = torch.randperm(n * k, device=cuda, generator=g)
+    out2 = ops.gatv2_aggregate(xl, xr, att, None, build_edge_graph(ei[:, perm], n, n), H, C)
+    assert (out.float() - out2.float()).abs().max() < 2e-2

@@ -1,0 +1,191 @@
+"""Host-side logic on the CPU: C-ABI surface, data contract, synthetic generator, module tree,
+metric-loss sampling, loud failure without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "segger_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(segger_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from segger_amd import _lib
+    lib = _lib.load()                      # loads without a GPU; no compute call is made
+    names = header_functions()
+    assert len(names) >= 12
+    assert sorted(_lib.EXPORTS) == names, "ctypes binding and header disagree"
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/segger_amd.h but not exported"
+    assert lib.segger_abi_version() == 1
+    assert lib.segger_csr_from_coo_workspace_bytes(0, 10) > 0
+    assert lib.segger_gatv2_bwd_workspace_bytes(1000, 2, 64) >= 1000 // 32 * 2 * 128 * 4
+    assert lib.segger_triplet_workspace_bytes(1000) >= 16 * 4
+
+
+def test_argument_errors_are_reported_not_thrown():
+    from segger_amd import _lib
+    lib = _lib.load()
+    a = _lib.GatFwdArgs()
+    a.heads, a.channels = 2, 64
+    rc = lib.segger_gatv2_fwd(ctypes.byref(a), None)       # NULL indptr: rejected on the host, nothing launched
+    assert rc == -1 and b"indptr" in lib.segger_last_error()
+    assert lib.segger_gatv2_fwd(None, None) == -1
+    t = _lib.TripletArgs(); t.n_edges, t.channels = -1, 64
+    assert lib.segger_triplet_fwd(ctypes.byref(t), None) == -1
+
+
+def test_product_fails_loudly_on_cpu_tensors():
+    from segger_amd import LitISTEncoder, _lib
+    from segger_amd.synthetic import C1, make_graph
+    b = make_graph(C1)
+    m = LitISTEncoder(n_genes=C1.n_genes, in_channels=32)
+    with pytest.raises(_lib.SeggerAmdError, match="no CPU fallback"):
+        m(b)
+
+
+def test_missing_library_raises(monkeypatch, tmp_path):
+    from segger_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libsegger_amd.so"))
+    with pytest.raises(_lib.SeggerAmdError, match="not built"):
+        _lib.load()
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "segger_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "segger_oracle" not in src and "import oracle" not in src, f
+
+
+def test_state_dict_keys_follow_the_reference():
+    from segger_amd import LitISTEncoder
+    m = LitISTEncoder(n_genes=10, in_channels=16, hidden_channels=8, out_channels=8, n_mid_layers=2, n_heads=2)
+    m.model._materialize_bd(5, "cpu")
+    keys = set(m.state_dict())
+    want = {"model.lin_first.tx.weight", "model.lin_first.bd.weight", "model.lin_first.bd.bias",
+            "model.pos_emb.mlp.0.weight", "model.pos_emb.mlp.2.bias",
+            "model.conv_layers.0.conv.convs.<tx___neighbors___tx>.lin_l.weight",
+            "model.conv_layers.3.conv.convs.<tx___belongs___bd>.att",
+            "model.conv_layers.2.conv.convs.<tx___belongs___bd>.lin_r.bias",
+            "model.conv_layers.1.conv.convs.<tx___neighbors___tx>.bias",
+            "model.lin_last.lins.tx.weight", "model.lin_last.lins.bd.bias"}
+    assert want <= keys
+    sd = m.state_dict()
+    assert sd["model.conv_layers.0.conv.convs.<tx___neighbors___tx>.lin_l.weight"].shape == (16, 32)   # [H*C, 2*in]
+    assert sd["model.conv_layers.1.conv.convs.<tx___belongs___bd>.att"].shape == (1, 2, 8)
+    assert sd["model.lin_last.lins.tx.weight"].shape == (8, 16)
+    assert len(m.model.conv_layers) == 4
+    import inspect
+    sig = inspect.signature(LitISTEncoder.__init__)
+    assert list(sig.parameters)[1:] == [
+        "n_genes", "in_channels", "hidden_channels", "out_channels", "n_mid_layers", "n_heads", "learning_rate",
+        "sg_loss_type", "tx_margin", "sg_margin", "tx_weight_start", "tx_weight_end", "bd_weight_start",
+        "bd_weight_end", "sg_weight_start", "sg_weight_end", "update_gene_embedding",
+        "use_positional_embeddings", "normalize_embeddings"]
+    assert sig.parameters["sg_margin"].default == 0.4 and sig.parameters["n_heads"].default == 2
+    with pytest.raises(ValueError, match="Unrecognized segmentation loss"):
+        LitISTEncoder(n_genes=3, in_channels=8, sg_loss_type="hinge")
+    assert isinstance(m.configure_optimizers(), torch.optim.Adam)
+
+
+def test_setup_requires_datamodule_similarities():
+    from segger_amd import LitISTEncoder
+
+    class T:  # noqa: D401
+        max_epochs = 20
+        datamodule = object()
+    m = LitISTEncoder(n_genes=3, in_channels=8)
+    m.trainer = T()
+    with pytest.raises(TypeError, match="ISTDataModule"):
+        m.setup("fit")
+
+    class DM:
+        tx_similarity = torch.eye(3)
+        bd_similarity = torch.eye(3)
+    T.datamodule = DM()
+    m.setup("fit")
+    assert m.loss_tx is not None and m.loss_bd is not None
+
+
+def test_scheduled_weights_match_oracle(oracle):
+    from segger_amd import LitISTEncoder
+    m = LitISTEncoder(n_genes=3, in_channels=8)
+    m._max_epochs_override = 20
+    for epoch in (0, 5, 19, 40):
+        m.current_epoch = epoch
+        w = m._scheduled_weights(m._w_start, m._w_end)
+        assert torch.allclose(w, oracle.scheduled_weights(m._w_start, m._w_end, epoch, 20), atol=1e-7)
+
+
+def test_hetero_batch_contract_and_collate():
+    from segger_amd.hetero import TX_BD, TX_NB_BD, TX_TX, collate
+    from segger_amd.synthetic import SyntheticSpec, make_graph
+    tiles = [make_graph(SyntheticSpec(n_tx=50 + 10 * i, n_bd=6 + i, k_tx=3, seed=i)) for i in range(3)]
+    b = collate(tiles)
+    assert b.num_graphs == 3 and b["tx"].num_nodes == 50 + 60 + 70 and b["bd"].num_nodes == 6 + 7 + 8
+    assert set(b.edge_index_dict) == {TX_TX, TX_BD, TX_NB_BD}
+    assert b.batch_dict["tx"].bincount().tolist() == [50, 60, 70]
+    e2 = tiles[2][TX_BD].edge_index
+    got = b[TX_BD].edge_index[:, -e2.shape[1]:]
+    assert torch.equal(got[0], e2[0] + 110) and torch.equal(got[1], e2[1] + 13)
+    assert b.x_dict["tx"].dtype == torch.int32 and b.pos_dict["bd"].shape == (21, 2)
+    assert b["tx"]["mask"].all() and b["tx"].predict_mask.dtype == torch.bool
+
+
+def test_synthetic_graph_invariants():
+    from segger_amd.hetero import TX_BD, TX_NB_BD, TX_TX
+    from segger_amd.synthetic import SyntheticSpec, make_graph
+    spec = SyntheticSpec(n_tx=2000, n_bd=64, k_tx=7, n_graphs=4, seed=9)
+    b, aux = make_graph(spec, return_aux=True)
+    b2 = make_graph(spec)
+    assert torch.equal(b[TX_TX].edge_index, b2[TX_TX].edge_index) and torch.equal(b["tx"].pos, b2["tx"].pos)
+    ett = b[TX_TX].edge_index
+    assert ett.shape == (2, 2000 * 7)
+    assert torch.equal(ett[0], torch.arange(2000).repeat_interleave(7))        # source = query point, out-degree k
+    assert ((ett[0] == ett[1]).view(2000, 7).sum(1) == 1).all()                # kNN includes self
+    etb = b[TX_BD].edge_index
+    assert torch.equal(aux["cell"][etb[0]], etb[1]) and 0.25 < etb.shape[1] / 2000 < 0.55
+    ep = b[TX_NB_BD].edge_index
+    assert ep[0].bincount(minlength=2000).max() <= 3 and 0.3 < aux["label"].float().mean() < 0.9
+    assert b.batch_dict["tx"].max() == 3 and b["tx"].x.max() < spec.n_genes
+    assert torch.allclose(aux["tx_similarity"].diagonal(), torch.ones(8), atol=1e-5)
+
+
+def test_product_selector_matches_reference_vectors():
+    """segger_amd.triplet_loss (device-agnostic torch code) against vectors produced by the reference file."""
+    from segger_amd.triplet_loss import FastTripletSelector, MetricLoss, TripletLoss
+    z = np.load(os.path.join(GOLD, "triplet_selector.npz"))
+    sim, labels = torch.from_numpy(z["similarity"]), torch.from_numpy(z["labels"])
+    emb = torch.from_numpy(z["embeddings"])
+    torch.manual_seed(int(z["seed"]))
+    pos, neg, dp, dn = FastTripletSelector(sim).sample_triplets(labels)
+    assert np.array_equal(pos.numpy(), z["positives"]) and np.array_equal(neg.numpy(), z["negatives"])
+    assert np.allclose(dp.numpy(), z["dists_pos"]) and np.allclose(dn.numpy(), z["dists_neg"])
+    torch.manual_seed(int(z["seed"]))
+    assert abs(float(TripletLoss(sim, margin=float(z["margin"])).forward(emb, labels)) - float(z["triplet_loss"])) < 1e-6
+    torch.manual_seed(int(z["seed"]))
+    assert abs(float(MetricLoss(sim).forward(emb, labels)) - float(z["metric_loss"])) < 1e-6
+    assert TripletLoss(sim).forward(emb[:0], labels[:0]) == 0.0
+
+
+def test_assign_tiles_balances_load():
+    from segger_amd.dp import assign_tiles
+    w = [9, 7, 6, 5, 5, 4, 3, 1]
+    parts = assign_tiles(w, 3)
+    assert sorted(i for p in parts for i in p) == list(range(8))
+    loads = [sum(w[i] for i in p) for p in parts]
+    assert max(loads) - min(loads) <= 2
+    assert assign_tiles(w, 3) == parts and assign_tiles([], 2) == [[], []]

@@ -1,0 +1,170 @@
+"""The oracle against hand-derived known answers, its own committed golden vectors, and the
+reference-generated triplet-selector vectors (CPU only)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ---------------------------------------------------------------- known answers
+def test_gatv2_known_answer_two_edges(oracle):
+    """1 destination, H=1, C=2: e = att . leaky_relu(x_l[i] + x_r[0]); softmax; weighted sum + bias."""
+    x_src = torch.tensor([[1.0, 2.0], [-3.0, 0.5]], dtype=torch.float64)
+    x_dst = torch.tensor([[0.5, -1.0]], dtype=torch.float64)
+    eye, z = torch.eye(2, dtype=torch.float64), torch.zeros(2, dtype=torch.float64)
+    att = torch.tensor([0.7, -0.4], dtype=torch.float64)
+    bias = torch.tensor([0.1, 0.2], dtype=torch.float64)
+    ei = torch.tensor([[0, 1], [0, 0]])
+    out, alpha = oracle.gatv2_conv(x_src, x_dst, ei, eye, z, eye, z, att, bias, 1, return_alpha=True)
+    lr = lambda v: v if v > 0 else 0.2 * v
+    e0 = 0.7 * lr(1.5) - 0.4 * lr(1.0)
+    e1 = 0.7 * lr(-2.5) - 0.4 * lr(-0.5)
+    a0 = math.exp(e0) / (math.exp(e0) + math.exp(e1))
+    want = [a0 * 1.0 + (1 - a0) * -3.0 + 0.1, a0 * 2.0 + (1 - a0) * 0.5 + 0.2]
+    assert torch.allclose(alpha.flatten(), torch.tensor([a0, 1 - a0], dtype=torch.float64), atol=1e-12)
+    assert torch.allclose(out[0], torch.tensor(want, dtype=torch.float64), atol=1e-12)
+
+
+def test_gatv2_isolated_duplicate_and_permutation(oracle):
+    g = torch.Generator().manual_seed(0)
+    H, C, ns, nd = 2, 4, 9, 6
+    xs, xd = torch.randn(ns, 5, generator=g, dtype=torch.float64), torch.randn(nd, 7, generator=g, dtype=torch.float64)
+    wl, wr = torch.randn(H * C, 5, generator=g, dtype=torch.float64), torch.randn(H * C, 7, generator=g, dtype=torch.float64)
+    bl, br = torch.randn(H * C, generator=g, dtype=torch.float64), torch.randn(H * C, generator=g, dtype=torch.float64)
+    att, bias = torch.randn(H * C, generator=g, dtype=torch.float64), torch.randn(H * C, generator=g, dtype=torch.float64)
+    ei = torch.tensor([[0, 1, 1, 2, 3, 4, 8], [1, 1, 1, 2, 2, 5, 5]])        # dst 0,3,4 isolated; edge 1->1 twice
+    out, alpha = oracle.gatv2_conv(xs, xd, ei, wl, bl, wr, br, att, bias, H, return_alpha=True)
+    for j in (0, 3, 4):
+        assert torch.equal(out[j], bias)                                     # isolated dst = bias
+    assert torch.equal(alpha[1], alpha[2])                                   # duplicates count twice
+    sums = torch.zeros(nd, H, dtype=torch.float64).index_add_(0, ei[1], alpha)
+    assert torch.allclose(sums[[1, 2, 5]], torch.ones(3, H, dtype=torch.float64), atol=1e-12)
+    perm = torch.tensor([6, 2, 0, 5, 3, 1, 4])
+    out_p = oracle.gatv2_conv(xs, xd, ei[:, perm], wl, bl, wr, br, att, bias, H)
+    assert torch.allclose(out, out_p, atol=1e-12)
+    out_e = oracle.gatv2_conv(xs, xd, ei[:, :0], wl, bl, wr, br, att, bias, H)  # empty edge store
+    assert torch.equal(out_e, bias.expand(nd, -1))
+
+
+def test_scatter_max_semantics(oracle):
+    src = torch.tensor([0.3, 0.9, 0.9, -0.5, 0.1])
+    idx = torch.tensor([2, 0, 0, 3, 2])
+    out, arg = oracle.scatter_max(src, idx, 5)
+    assert out.tolist() == pytest.approx([0.9, 0.0, 0.3, -0.5, 0.0])
+    assert arg.tolist() == [1, 5, 0, 3, 5]          # tie -> lowest edge id; untouched -> (0, E)
+    out, arg = oracle.scatter_max(src[:0], idx[:0], 3)
+    assert out.tolist() == [0, 0, 0] and arg.tolist() == [0, 0, 0]
+
+
+def test_predict_assign_known(oracle):
+    z_tx = torch.tensor([[1.0, 0.0], [0.0, 1.0], [1.0, 1.0]], dtype=torch.float64)
+    z_bd = torch.tensor([[1.0, 0.0], [0.0, 2.0]], dtype=torch.float64)
+    ei = torch.tensor([[0, 0, 1], [0, 1, 1]])
+    seg, sim = oracle.predict_assign(z_tx, z_bd, ei, torch.tensor([10, 20], dtype=torch.int32))
+    assert seg.tolist() == [10, 20, -1] and sim.tolist() == pytest.approx([1.0, 1.0, 0.0])
+    seg, _ = oracle.predict_assign(z_tx, z_bd, ei, torch.tensor([10, 20], dtype=torch.int32), min_similarity=1.5)
+    assert seg.tolist() == [-1, -1, -1]
+
+
+def test_positional_embedding_batched_equals_unbatched_for_one_graph(oracle):
+    g = torch.Generator().manual_seed(1)
+    pos = torch.rand(50, 2, generator=g, dtype=torch.float64) * 100
+    w1, b1 = torch.randn(8, 256, generator=g, dtype=torch.float64) / 16, torch.randn(8, generator=g, dtype=torch.float64)
+    w2, b2 = torch.randn(8, 8, generator=g, dtype=torch.float64), torch.randn(8, generator=g, dtype=torch.float64)
+    a = oracle.positional_2d_embed(pos, None, w1, b1, w2, b2)
+    b = oracle.positional_2d_embed(pos, torch.zeros(50, dtype=torch.long), w1, b1, w2, b2)
+    assert a.shape == (50, 16) and torch.allclose(a, b, atol=1e-8)          # differs only by the 1e-8 epsilon
+    n = oracle.normalize_positions(pos, torch.zeros(50, dtype=torch.long))
+    assert n.min() == 0 and abs(n.max().item() - 1) < 1e-9
+    e = oracle.sinusoidal_embedding(torch.tensor([0.0, 1.0], dtype=torch.float64), 256, 10000)
+    assert torch.allclose(e[0, :128], torch.ones(128, dtype=torch.float64)) and torch.allclose(e[0, 128:], torch.zeros(128, dtype=torch.float64))
+    assert abs(e[1, 0].item() - math.cos(1.0)) < 1e-12 and abs(e[1, 128].item() - math.sin(1.0)) < 1e-12
+
+
+def test_triplet_margin_loss_equals_torch(oracle):
+    g = torch.Generator().manual_seed(2)
+    a, p, n = (torch.randn(40, 8, generator=g, dtype=torch.float64) for _ in range(3))
+    ref = torch.nn.TripletMarginLoss(margin=0.4)(a, p, n)
+    assert abs(oracle.triplet_margin_loss(a, p, n, 0.4).item() - ref.item()) < 1e-12
+
+
+def test_scheduled_weights(oracle):
+    ws, we = torch.tensor([1.0, 1.0, 0.0]), torch.tensor([1.0, 1.0, 0.5])
+    w0 = oracle.scheduled_weights(ws, we, 0, 20)
+    assert torch.allclose(w0, torch.tensor([0.5, 0.5, 0.0]), atol=1e-7)
+    w_end = oracle.scheduled_weights(ws, we, 19, 20)
+    assert torch.allclose(w_end, torch.tensor([0.4, 0.4, 0.2]), atol=1e-7)
+    w_late = oracle.scheduled_weights(ws, we, 50, 20)
+    assert torch.equal(w_end, w_late)
+    w1 = oracle.scheduled_weights(ws, we, 0, 1)          # max(1, max_epochs - 1) guard
+    assert torch.isfinite(w1).all()
+
+
+def test_dropout_mask_statistics_and_determinism(oracle):
+    k1 = oracle.dropout_keep_mask(123, 20000, 2, 0.2)
+    assert k1.shape == (20000, 2) and abs(k1.float().mean().item() - 0.8) < 0.01
+    assert torch.equal(k1, oracle.dropout_keep_mask(123, 20000, 2, 0.2))
+    assert not torch.equal(k1, oracle.dropout_keep_mask(124, 20000, 2, 0.2))
+    assert oracle.dropout_keep_mask(1, 100, 2, 0.0).all()
+
+
+def test_auroc(oracle):
+    s = torch.tensor([0.1, 0.4, 0.35, 0.8])
+    y = torch.tensor([0, 0, 1, 1])
+    assert abs(oracle.auroc(s, y) - 0.75) < 1e-12
+    assert abs(oracle.auroc(torch.tensor([0.5, 0.5]), torch.tensor([0, 1])) - 0.5) < 1e-12
+
+
+# ---------------------------------------------------------------- golden vectors
+def load_encoder_golden():
+    from segger_amd.hetero import HeteroBatch
+    z = np.load(os.path.join(GOLD, "encoder_small.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w::")}
+    b = HeteroBatch(num_graphs=4)
+    for k in z.files:
+        if k.startswith("in::edge::"):
+            b[tuple(k[len("in::edge::"):].split("__"))]["edge_index"] = torch.from_numpy(z[k])
+        elif k.startswith("in::tx::") or k.startswith("in::bd::"):
+            _, nt, a = k.split("::")
+            b[nt][a] = torch.from_numpy(z[k])
+    return z, sd, b
+
+
+def test_oracle_reproduces_encoder_golden(oracle):
+    z, sd, b = load_encoder_golden()
+    sdd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    out, attn = oracle.ist_encoder_forward(sdd, b.x_dict, b.edge_index_dict, b.pos_dict, b.batch_dict, n_heads=2,
+                                           return_attention=True)
+    assert np.allclose(out["tx"].detach().numpy(), z["out::z_tx"], atol=1e-12)
+    assert np.allclose(out["bd"].detach().numpy(), z["out::z_bd"], atol=1e-12)
+    assert np.allclose(attn[(0, oracle.TX_TX)].detach().numpy(), z["out::alpha0_tx_tx"], atol=1e-12)
+    loss = oracle.segmentation_loss(out["tx"], out["bd"], b[oracle.TX_BD].edge_index, torch.from_numpy(z["in::neg"]), "triplet", 0.4)
+    assert abs(loss.item() - float(z["out::loss_sg"])) < 1e-12
+    loss.backward()
+    for k, v in sdd.items():
+        assert np.allclose(v.grad.numpy(), z[f"grad::{k}"], rtol=1e-5, atol=1e-9), k
+    pred = oracle.predict_step({k: v.detach() for k, v in sdd.items()}, b, n_heads=2)
+    assert np.array_equal(pred[0].numpy(), z["out::pred_tx_index"]) and np.array_equal(pred[1].numpy(), z["out::pred_seg"])
+    assert np.allclose(pred[2].numpy(), z["out::pred_sim"], atol=1e-12)
+    # float32 oracle (what the CPU baseline times) agrees with the float64 answer to fp32 accuracy
+    o32 = oracle.ist_encoder_forward(sd, b.x_dict, b.edge_index_dict, b.pos_dict, b.batch_dict, n_heads=2)
+    assert np.abs(o32["tx"].numpy() - z["out::z_tx"]).max() < 2e-5
+
+
+def test_oracle_selector_matches_reference_vectors(oracle):
+    """triplet_selector.npz was produced by the reference's own triplet_loss.py (see make_golden.py)."""
+    z = np.load(os.path.join(GOLD, "triplet_selector.npz"))
+    sim, labels = torch.from_numpy(z["similarity"]), torch.from_numpy(z["labels"])
+    emb = torch.from_numpy(z["embeddings"])
+    torch.manual_seed(int(z["seed"]))
+    u = [torch.rand(labels.numel()) for _ in range(4)]     # the reference's four draws, in its order
+    pos, neg, dp, dn = oracle.FastTripletSelectorOracle(sim).sample(labels, *u)
+    assert np.array_equal(pos.numpy(), z["positives"]) and np.array_equal(neg.numpy(), z["negatives"])
+    assert np.allclose(dp.numpy(), z["dists_pos"]) and np.allclose(dn.numpy(), z["dists_neg"])
+    lt = oracle.tx_triplet_loss(emb, pos, neg, float(z["margin"]))
+    lm = oracle.bd_metric_loss(emb, pos, neg, dp, dn)
+    assert abs(lt.item() - float(z["triplet_loss"])) < 1e-6 and abs(lm.item() - float(z["metric_loss"])) < 1e-6
