@@ -257,6 +257,22 @@ int segger_triplet_bwd(const segger_triplet_args* args, segger_stream_t stream);
 int segger_segment_minmax(const float* pos, const int64_t* batch, int64_t n, int64_t n_graphs,
                           float* mins, float* maxs, segger_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Tall-skinny projection on the matrix cores (v_mfma_f32_32x32x16):
+ *     y[n, m_out] = x[n, k_in] * w[m_out, k_in]^T (+ bias)
+ * Replaces the cuBLAS GEMMs behind PyG's Linear for GATv2Conv.lin_l / lin_r
+ * (constructed at src/segger/models/ist_encoder.py:111-124), HeteroDictLinear
+ * (ist_encoder.py:282-286,328) and, called with w = W^T, their data gradients.
+ * Every workgroup owns 128 rows and ALL m_out columns, so x is read from HBM once.
+ *   dtype: SEGGER_BF16 / SEGGER_F16 (x, w, y); bias fp32 or NULL; fp32 accumulation.
+ *   k_in in {64, 128, 256, 384}; m_out a multiple of 64; w contiguous [m_out, k_in].
+ * segger_linear_supported() tells the host whether a shape is covered (others go to
+ * the vendor GEMM library).
+ * ---------------------------------------------------------------------- */
+int segger_linear_supported(int32_t k_in, int32_t m_out, int32_t dtype);
+int segger_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy,
+                      int64_t n_rows, int32_t k_in, int32_t m_out, int32_t dtype, segger_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,28 @@
+"""Times the three GATv2 kernels on the C2 tile (tx-neighbors-tx, bf16, H=2, C=64)."""
+import sys, os, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from segger_amd import ops, TX_TX
+from segger_amd.graph import build_edge_graph
+from segger_amd.synthetic import SyntheticSpec, make_graph
+dev = torch.device('cuda')
+n = int(os.environ.get('N_TX', 1_000_000))
+b = make_graph(SyntheticSpec(n_tx=n, n_bd=n // 100, k_tx=15, seed=0))
+ei = b[TX_TX].edge_index.to(dev)
+g = build_edge_graph(ei, n, n)
+H, C = 2, 64; hc = H * C
+gen = torch.Generator(device=dev).manual_seed(0)
+xp = torch.randn(n, 3 * hc, device=dev, generator=gen).bfloat16()
+att = torch.randn(hc, device=dev, generator=gen) * 0.3
+bias = torch.zeros(hc, device=dev)
+out = torch.empty(n, hc, dtype=torch.bfloat16, device=dev); pre = torch.empty_like(out)
+lse = torch.empty(n, H, device=dev)
+gy = torch.randn(n, hc, device=dev, generator=gen).bfloat16(); gxp = torch.empty_like(xp)
+p = float(os.environ.get('DROP', 0.0))
+fwd = lambda: ops.gatv2_fwd_launch(g.by_dst, xp[:, :hc], xp[:, hc:2*hc], att, bias, H, C, out, pre=pre, lse=lse, apply_gelu=True, dropout_p=p, seed=5)
+bwd = lambda: ops.gatv2_bwd_launch(g, xp[:, :hc], xp[:, hc:2*hc], att, bias, H, C, gy, pre, lse, gxp[:, :hc], gxp[:, hc:2*hc], apply_gelu=True, dropout_p=p, seed=5)
+def t(fn, it=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); a = torch.cuda.Event(True); e = torch.cuda.Event(True); a.record()
+    for _ in range(it): fn()
+    e.record(); torch.cuda.synchronize(); return a.elapsed_time(e) / it
+print(os.environ.get('SEGGER_AMD_LIB', 'default'), 'drop', p, 'fwd %.3f ms  bwd(dst+src) %.3f ms' % (t(fwd), t(bwd)), flush=True)

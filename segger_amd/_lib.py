@@ -13,7 +13,8 @@ from typing import Optional
 import torch  # noqa: F401  (must be imported first: the library binds to torch's libamdhip64.so.7)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsegger_amd.so")
+# SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
 ABI_VERSION = 1
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
@@ -106,6 +107,8 @@ EXPORTS = {
     "segger_triplet_fwd": (C.c_int, [C.POINTER(TripletArgs), vp]),
     "segger_triplet_bwd": (C.c_int, [C.POINTER(TripletArgs), vp]),
     "segger_segment_minmax": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp, vp]),
+    "segger_linear_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "segger_linear_fwd": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

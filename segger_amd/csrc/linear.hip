@@ -1,0 +1,192 @@
+// Tall-skinny projection GEMM on the matrix cores:  Y[n, M] = X[n, K] * W[M, K]^T (+ bias)
+// for n ~ 10^6 node rows and small K, M (<= 384): the lin_l / lin_r / lin_last maps
+// of the encoder and their data-gradients (dX = dY * W, called with W^T).
+//
+// The op is HBM-bound (2*n*(K+M) bytes against 2*n*K*M flops at K,M <= 384), so the
+// design goal is "read X once, write Y once":
+//   * one workgroup (4 waves) owns 128 consecutive rows and produces ALL M columns,
+//     so X is never re-read per column tile;
+//   * a wave keeps its 32 rows of X as MFMA B-operand fragments in registers for
+//     the whole block (K/16 x 4 VGPRs), loaded straight from global memory;
+//   * W is streamed through LDS in chunks of 64 output columns shared by the 4
+//     waves (row stride K*2+16 B: conflict-free ds_read_b128 of A fragments), with
+//     the next chunk prefetched into registers under the MFMAs;
+//   * D = W_tile * X_tile^T  (v_mfma_f32_32x32x16): a lane owns one DATA ROW and
+//     4-column groups, so the epilogue packs 4 bf16 -> ds_write_b64 into a wave-private
+//     LDS tile and streams it out as full 128-byte row segments (16 B per lane).
+#include "common.h"
+
+namespace segger {
+namespace {
+
+typedef __bf16   bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8  __attribute__((ext_vector_type(8)));
+typedef float    f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kRowsPerBlock = 128;
+constexpr int kChunk = 64;             // output columns per W chunk
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+  static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<f16_t> {
+  static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+};
+
+struct LinearParams {
+  const void* x; int64_t ldx;
+  const void* w;            // [m_out, K] row-major, same dtype as x
+  const float* bias;        // [m_out] or NULL
+  void* y; int64_t ldy;
+  int64_t n_rows;
+  int m_out;
+};
+
+template <typename T, int K>
+__global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
+  constexpr int NK = K / 16;                       // k-steps
+  constexpr int WSTRIDE = K * 2 + 16;              // bytes per LDS row of W
+  constexpr int ESTRIDE = kChunk * 2 + 16;         // bytes per LDS row of the epilogue tile
+  constexpr int PIECES = kChunk * K * 2 / 16;      // 16-byte pieces per W chunk
+  constexpr int PPT = PIECES / 256;                // pieces per thread
+  static_assert(PIECES % 256 == 0, "chunk must split evenly over the block");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kChunk * WSTRIDE + 4 * 32 * ESTRIDE];
+  unsigned char* lds_w = lds;
+  unsigned char* lds_e = lds + kChunk * WSTRIDE;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * kRowsPerBlock + wave * 32;
+  const T* __restrict__ x = static_cast<const T*>(p.x);
+  const T* __restrict__ w = static_cast<const T*>(p.w);
+  T* __restrict__ y = static_cast<T*>(p.y);
+
+  // ---- X fragments: lane (r,h) holds X[row0+r][16s+8h .. +8) for every k-step s -----------------
+  u32x4 xb[NK];
+  {
+    int64_t row = row0 + r;
+    if (row >= p.n_rows) row = p.n_rows - 1;       // clamp: loaded, never stored
+    const T* xr = x + row * p.ldx + 8 * h;
+#pragma unroll
+    for (int s = 0; s < NK; ++s) xb[s] = *reinterpret_cast<const u32x4*>(xr + 16 * s);
+  }
+
+  // ---- W chunk staging ------------------------------------------------------------------------------
+  u32x4 wreg[PPT];
+  auto w_fetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int piece = tid + 256 * i;
+      const int wrow = piece / (K / 8), wcol = piece % (K / 8);
+      wreg[i] = *reinterpret_cast<const u32x4*>(w + (int64_t)(c0 + wrow) * K + wcol * 8);
+    }
+  };
+  auto w_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int piece = tid + 256 * i;
+      const int wrow = piece / (K / 8), wcol = piece % (K / 8);
+      *reinterpret_cast<u32x4*>(lds_w + wrow * WSTRIDE + wcol * 16) = wreg[i];
+    }
+  };
+
+  const int n_chunks = p.m_out / kChunk;
+  w_fetch(0);
+  for (int c = 0; c < n_chunks; ++c) {
+    const int c0 = c * kChunk;
+    w_commit();                                    // all waves left the previous chunk's MFMA loop (epilogue barrier)
+    __syncthreads();
+    if (c + 1 < n_chunks) w_fetch(c0 + kChunk);    // prefetch under the MFMAs
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+    }
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(lds_w + (ct * 32 + r) * WSTRIDE + (16 * s + 8 * h) * 2);
+        acc[ct] = Mfma<T>::run(a, xb[s], acc[ct]);
+      }
+    }
+
+    // ---- epilogue: lane owns data row r and output columns ct*32 + 8g + 4h + {0..3} -------------
+    unsigned char* et = lds_e + wave * 32 * ESTRIDE;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = ct * 32 + 8 * g + 4 * h;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[ct][4 * g + j] + (p.bias ? p.bias[c0 + col + j] : 0.f);
+        uint2 pk;
+        pk.x = Vec8<T>::pack(v[0], v[1]);
+        pk.y = Vec8<T>::pack(v[2], v[3]);
+        *reinterpret_cast<uint2*>(et + r * ESTRIDE + col * 2) = pk;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int er = 8 * i + (lane >> 3), piece = lane & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(et + er * ESTRIDE + piece * 16);
+      const int64_t row = row0 + er;
+      if (row < p.n_rows) *reinterpret_cast<u32x4*>(y + row * p.ldy + c0 + piece * 8) = v;
+    }
+  }
+}
+
+template <typename T>
+int launch_linear(const LinearParams& p, int k_in, hipStream_t stream) {
+  const int64_t nb = (p.n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
+  if (nb > 0x7fffffffLL) { set_error("segger_linear_fwd: too many rows"); return SEGGER_EUNSUPPORTED; }
+  dim3 grid((unsigned)nb), block(256);
+  switch (k_in) {
+    case 64:  hipLaunchKernelGGL((linear_fwd_kernel<T, 64>), grid, block, 0, stream, p); break;
+    case 128: hipLaunchKernelGGL((linear_fwd_kernel<T, 128>), grid, block, 0, stream, p); break;
+    case 256: hipLaunchKernelGGL((linear_fwd_kernel<T, 256>), grid, block, 0, stream, p); break;
+    case 384: hipLaunchKernelGGL((linear_fwd_kernel<T, 384>), grid, block, 0, stream, p); break;
+    default:
+      set_error("segger_linear_fwd: k_in=%d not supported (64, 128, 256, 384)", k_in);
+      return SEGGER_EUNSUPPORTED;
+  }
+  SEGGER_LAUNCH_CHECK("linear_fwd_kernel");
+  return SEGGER_OK;
+}
+
+}  // namespace
+}  // namespace segger
+
+using namespace segger;
+
+extern "C" int segger_linear_supported(int32_t k_in, int32_t m_out, int32_t dtype) {
+  const bool k_ok = k_in == 64 || k_in == 128 || k_in == 256 || k_in == 384;
+  return k_ok && m_out > 0 && m_out % kChunk == 0 && (dtype == SEGGER_BF16 || dtype == SEGGER_F16);
+}
+
+extern "C" int segger_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy,
+                                 int64_t n_rows, int32_t k_in, int32_t m_out, int32_t dtype, segger_stream_t stream) {
+  SEGGER_REQUIRE(n_rows >= 0 && k_in > 0 && m_out > 0, "segger_linear_fwd: bad sizes");
+  if (n_rows == 0) return SEGGER_OK;
+  if (!segger_linear_supported(k_in, m_out, dtype)) {
+    set_error("segger_linear_fwd: k_in=%d m_out=%d dtype=%d not supported (k_in in {64,128,256,384}, "
+              "m_out %% 64 == 0, bf16/f16)", k_in, m_out, dtype);
+    return SEGGER_EUNSUPPORTED;
+  }
+  SEGGER_REQUIRE(x && w && y, "segger_linear_fwd: NULL pointer");
+  SEGGER_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), "segger_linear_fwd: pointers must be 16-byte aligned");
+  SEGGER_REQUIRE(ldx >= k_in && ldy >= m_out && (ldx * 2) % 16 == 0 && (ldy * 2) % 16 == 0,
+                 "segger_linear_fwd: bad leading dimension");
+  LinearParams p{x, ldx, w, bias, y, ldy, n_rows, m_out};
+  return dtype == SEGGER_BF16 ? launch_linear<bf16_t>(p, k_in, (hipStream_t)stream)
+                              : launch_linear<f16_t>(p, k_in, (hipStream_t)stream);
+}

@@ -82,8 +82,8 @@ class Positional2dEmbedder(Module):
         freq = sinusoidal_embedding(pos.flatten(), self.frequency_embedding_size, max_period=10000)
         freq = freq.reshape(n, 2, self.frequency_embedding_size).to(dtype)
         l0, l2 = self.mlp[0], self.mlp[2]
-        h = F.silu(F.linear(freq, l0.weight.to(dtype), l0.bias.to(dtype)))
-        h = F.linear(h, l2.weight.to(dtype), l2.bias.to(dtype))
+        h = F.silu(ops.linear(freq, l0.weight, l0.bias))
+        h = ops.linear(h, l2.weight, l2.bias)
         return h.flatten(-2)
 
 
@@ -116,8 +116,8 @@ class GATv2Conv(Module):
                 return_attention_weights: bool = False):
         x_src, x_dst = x
         dt = x_src.dtype
-        xl = F.linear(x_src, self.lin_l.weight.to(dt), self.lin_l.bias.to(dt))
-        xr = F.linear(x_dst, self.lin_r.weight.to(dt), self.lin_r.bias.to(dt))
+        xl = ops.linear(x_src, self.lin_l.weight, self.lin_l.bias)
+        xr = ops.linear(x_dst, self.lin_r.weight, self.lin_r.bias)
         p = self.dropout if self.training else 0.0
         return ops.gatv2_aggregate(xl, xr, self.att, self.bias, graph, self.heads, self.out_channels,
                                    apply_gelu=apply_gelu, negative_slope=self.negative_slope,
@@ -168,10 +168,10 @@ class SkipGAT(Module):
         tt, tb = self.conv[TX_TX], self.conv[TX_BD]
         dt = x_tx.dtype
         # one fused projection for the three linear maps that read x_tx
-        w_tx = torch.cat([tt.lin_l.weight, tt.lin_r.weight, tb.lin_l.weight], 0).to(dt)
-        b_tx = torch.cat([tt.lin_l.bias, tt.lin_r.bias, tb.lin_l.bias], 0).to(dt)
-        xp_tx = F.linear(x_tx, w_tx, b_tx)
-        xp_bd = F.linear(x_bd, tb.lin_r.weight.to(dt), tb.lin_r.bias.to(dt))
+        w_tx = torch.cat([tt.lin_l.weight, tt.lin_r.weight, tb.lin_l.weight], 0)
+        b_tx = torch.cat([tt.lin_l.bias, tt.lin_r.bias, tb.lin_l.bias], 0)
+        xp_tx = ops.linear(x_tx, w_tx, b_tx)
+        xp_bd = ops.linear(x_bd, tb.lin_r.weight, tb.lin_r.bias)
         p = tt.dropout if self.training else 0.0
         y_tx, y_bd, alpha = ops.hetero_gat_layer(
             xp_tx, xp_bd, tt.att, tt.bias, tb.att, tb.bias, graphs[TX_TX], graphs[TX_BD],
@@ -199,7 +199,7 @@ class _HeteroDictLinear(Module):
         out = {}
         for k, x in x_dict.items():
             lin = self.lins[k]
-            out[k] = F.linear(x, lin.weight.to(x.dtype), lin.bias.to(x.dtype))
+            out[k] = ops.linear(x, lin.weight, lin.bias)
         return out
 
 
@@ -251,7 +251,7 @@ class ISTEncoder(Module):
         bd_lin = self.lin_first["bd"]
         x = {
             "tx": self.lin_first["tx"](x_dict["tx"].long()).to(dt),
-            "bd": F.linear(x_dict["bd"].to(dt), bd_lin.weight.to(dt), bd_lin.bias.to(dt)),
+            "bd": ops.linear(x_dict["bd"].to(dt), bd_lin.weight, bd_lin.bias),
         }
         if self.use_positional_embeddings:
             x = {k: torch.cat((v, self.pos_emb(pos_dict[k], batch_dict.get(k), num_graphs=num_graphs, dtype=dt)), -1)

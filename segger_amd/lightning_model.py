@@ -177,7 +177,7 @@ class LitISTEncoder(_Base):
         embeddings = self.forward(batch)
         tx_mask = batch['tx']['mask']
         bd_mask = batch['bd']['mask'] & (batch['bd']['cluster'] >= 0)
-        loss_tx = self.loss_tx.forward(embeddings['tx'][tx_mask], batch['tx']['cluster'][tx_mask])
+        loss_tx = self.loss_tx.forward_masked(embeddings['tx'], batch['tx']['cluster'], tx_mask)
         loss_bd = self.loss_bd.forward(embeddings['bd'][bd_mask], batch['bd']['cluster'][bd_mask])
         loss_sg = self._segmentation_loss(embeddings, batch, dst_neg)
         w_tx, w_bd, w_sg = (float(v) for v in self._scheduled_weights(self._w_start, self._w_end))
@@ -214,4 +214,6 @@ class LitISTEncoder(_Base):
         return tuple(t.cpu() for t in out)
 
     def configure_optimizers(self) -> torch.optim.Optimizer:
-        return torch.optim.Adam(self.parameters(), lr=self.learning_rate)
+        params = list(self.parameters())
+        fused = bool(params) and all(p.is_cuda for p in params)     # one multi-tensor kernel on the GPU
+        return torch.optim.Adam(params, lr=self.learning_rate, fused=fused)

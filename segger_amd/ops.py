@@ -281,15 +281,20 @@ def _triplet_args(src, pos, neg, za, zb, margin, eps):
 
 
 class _TripletEdgeLoss(torch.autograd.Function):
+    """``zb is None``: anchors, positives and negatives are rows of the same matrix ``za``
+    (loss_tx); one gradient buffer receives all three contributions."""
+
     @staticmethod
     def forward(ctx, za, zb, src, pos, neg, margin, eps):
-        _lib.require_cuda(za, zb, src)
+        same = zb is None
+        zb_ = za if same else zb
+        _lib.require_cuda(za, zb_, src)
         lib = _lib.load()
         dev = za.device
-        if za.dtype != zb.dtype or za.dtype not in DTYPE_CODE:
+        if za.dtype != zb_.dtype or za.dtype not in DTYPE_CODE:
             raise TypeError("triplet_edge_loss: z_a / z_b must share a supported dtype")
         src, pos, neg = (t.to(torch.int64).contiguous() for t in (src, pos, neg))
-        a = _triplet_args(src, pos, neg, za, zb, margin, eps)
+        a = _triplet_args(src, pos, neg, za, zb_, margin, eps)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         ws_bytes = lib.segger_triplet_workspace_bytes(a.n_edges)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -297,31 +302,34 @@ class _TripletEdgeLoss(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = lib.segger_triplet_fwd(C.byref(a), _lib.stream_ptr(dev))
         _lib.check(rc, "segger_triplet_fwd")
-        ctx.save_for_backward(za, zb, src, pos, neg)
-        ctx.cfg = (margin, eps)
+        ctx.save_for_backward(za, zb_, src, pos, neg)
+        ctx.cfg = (margin, eps, same)
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         za, zb, src, pos, neg = ctx.saved_tensors
-        margin, eps = ctx.cfg
+        margin, eps, same = ctx.cfg
         lib = _lib.load()
         dev = za.device
         a = _triplet_args(src, pos, neg, za, zb, margin, eps)
         ga = torch.zeros(za.shape, dtype=torch.float32, device=dev)
-        gb = torch.zeros(zb.shape, dtype=torch.float32, device=dev)
+        gb = ga if same else torch.zeros(zb.shape, dtype=torch.float32, device=dev)
         a.grad_a, a.grad_b = ga.data_ptr(), gb.data_ptr()
         gs = g.detach().to(torch.float32).reshape(1).contiguous()   # upstream scalar stays on the device
         a.grad_scale, a.grad_scale_dev = 1.0, gs.data_ptr()
         with torch.cuda.device(dev):
             rc = lib.segger_triplet_bwd(C.byref(a), _lib.stream_ptr(dev))
         _lib.check(rc, "segger_triplet_bwd")
-        return ga.to(za.dtype), gb.to(zb.dtype), None, None, None, None, None
+        return ga.to(za.dtype), (None if same else gb.to(zb.dtype)), None, None, None, None, None
 
 
-def triplet_edge_loss(za: Tensor, zb: Tensor, src: Tensor, pos: Tensor, neg: Tensor,
+def triplet_edge_loss(za: Tensor, zb: Optional[Tensor], src: Tensor, pos: Tensor, neg: Tensor,
                       margin: float, eps: float = 1e-6) -> Tensor:
-    """mean_e max(||za[src]-zb[pos]+eps|| - ||za[src]-zb[neg]+eps|| + margin, 0)."""
+    """mean_e max(||za[src]-zb[pos]+eps|| - ||za[src]-zb[neg]+eps|| + margin, 0).
+    Pass ``zb=None`` (or ``zb is za``) when positives / negatives index the anchor matrix itself."""
+    if zb is za:
+        zb = None
     return _TripletEdgeLoss.apply(za, zb, src, pos, neg, float(margin), float(eps))
 
 
@@ -348,3 +356,101 @@ def segment_minmax(pos: Tensor, batch: Optional[Tensor], num_graphs: int) -> Tup
                                        mins.data_ptr(), maxs.data_ptr(), _lib.stream_ptr(dev))
     _lib.check(rc, "segger_segment_minmax")
     return mins, maxs
+
+
+# --------------------------------------------------------------------------
+# Tall-skinny projection GEMM (MFMA) with autograd
+# --------------------------------------------------------------------------
+def linear_supported(k_in: int, m_out: int, dtype: torch.dtype) -> bool:
+    return dtype in (torch.bfloat16, torch.float16) and bool(
+        _lib.load().segger_linear_supported(int(k_in), int(m_out), DTYPE_CODE[dtype]))
+
+
+def linear_fwd_launch(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
+    """y = x @ w.T + bias for a [n, K] activation (row stride allowed) and contiguous [M, K] weight."""
+    _lib.require_cuda(x, w)
+    lib = _lib.load()
+    n, k = x.shape
+    m = w.shape[0]
+    if w.dtype != x.dtype or not w.is_contiguous() or w.shape[1] != k:
+        raise ValueError("linear: weight must be contiguous [M, K] in the activation dtype")
+    xp, ldx = _rows(x, k, "x")
+    y = out if out is not None else torch.empty((n, m), dtype=x.dtype, device=x.device)
+    yp, ldy = _rows(y, m, "y")
+    b = _f32_vec(bias, m, "bias")
+    with torch.cuda.device(x.device):
+        rc = lib.segger_linear_fwd(xp, ldx, w.data_ptr(), _lib.ptr(b), yp, ldy, n, k, m, DTYPE_CODE[x.dtype],
+                                   _lib.stream_ptr(x.device))
+    _lib.check(rc, "segger_linear_fwd")
+    return y
+
+
+_DW_SPLITS = 128
+
+
+def _weight_grad(gy: Tensor, x: Tensor) -> Tensor:
+    """dW[M, K] = gy^T x as a vendor GEMM.  A plain [M, n] x [n, K] product has only
+    (M/64)*(K/64) ~ 24 output tiles, i.e. 24 busy workgroups on a 256-CU chip (1.7 ms at n = 1M);
+    batching the reduction over 128 row slabs fills the chip (0.24 ms = the HBM time of reading
+    gy and x once); the slab partials are summed in fp32."""
+    n, m = gy.shape
+    k = x.shape[1]
+    s = _DW_SPLITS
+    if n < s * 256:
+        return (gy.t() @ x).float()
+    nn = n // s * s
+    gw = torch.bmm(gy[:nn].reshape(s, nn // s, m).transpose(1, 2), x[:nn].reshape(s, nn // s, k)).sum(0, dtype=torch.float32)
+    if nn < n:
+        gw += (gy[nn:].t() @ x[nn:]).float()
+    return gw
+
+
+class _Linear(torch.autograd.Function):
+    """x [n, K] (bf16/f16), weight [M, K] fp32 master, bias [M] fp32 -> [n, M].
+    Forward and the data gradient run on the hand-written MFMA kernel (x / dY read once);
+    the weight gradient (a [M, K] reduction over n rows) stays on the vendor GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w = weight.detach().to(x.dtype).contiguous()
+        y = linear_fwd_launch(x, w, bias)
+        ctx.save_for_backward(x, weight, bias if bias is not None else weight.new_empty(0))
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, bias = ctx.saved_tensors
+        dt = x.dtype
+        if gy.dtype != dt:
+            gy = gy.to(dt)
+        if gy.dim() != 2 or (gy.shape[0] > 1 and gy.stride(1) != 1):
+            gy = gy.contiguous()
+        m, k = weight.shape
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if linear_supported(m, k, dt):
+                wt = weight.detach().t().to(dt).contiguous()          # [K, M]: dX = dY @ W
+                gx = linear_fwd_launch(gy, wt, None)
+            else:
+                gx = gy @ weight.detach().to(dt)
+        if ctx.needs_input_grad[1]:
+            gw = _weight_grad(gy, x).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(0, dtype=torch.float32).to(bias.dtype)
+        return gx, gw, gb
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """``F.linear`` for node-feature matrices.  bf16/f16 activations with a covered (K, M) use the
+    MFMA kernel; fp32 activations (parity mode) and uncovered shapes use the vendor GEMM."""
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.is_cuda and linear_supported(x2.shape[1], weight.shape[0], x2.dtype) and x2.shape[0] > 0:
+        if x2.shape[0] > 1 and x2.stride(1) != 1:
+            x2 = x2.contiguous()
+        y = _Linear.apply(x2, weight, bias)
+    else:
+        _lib.require_cuda(x2)
+        y = torch.nn.functional.linear(x2, weight.to(x2.dtype), None if bias is None else bias.to(x2.dtype))
+    return y.reshape(*lead, weight.shape[0])

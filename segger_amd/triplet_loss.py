@@ -83,6 +83,20 @@ class TripletLoss(torch.nn.TripletMarginLoss):
         e = embeddings.float()
         return super().forward(e, e[pos], e[neg])
 
+    def forward_masked(self, embeddings: Tensor, labels: Tensor, mask: Tensor):
+        """``forward(embeddings[mask], labels[mask])`` (how LitISTEncoder.get_losses calls it,
+        lightning_model.py:158-161) without materialising the three gathered [n, C] matrices:
+        on the GPU the fused triplet kernel gathers anchor / positive / negative rows itself."""
+        idx = mask.nonzero(as_tuple=False).squeeze(1)
+        if idx.numel() == 0:
+            return 0.0
+        pos, neg, _, _ = self.selector.sample_triplets(labels[idx])
+        if embeddings.is_cuda:
+            from . import ops
+            return ops.triplet_edge_loss(embeddings, None, idx, idx[pos], idx[neg], self.margin, eps=self.eps)
+        e = embeddings[idx].float()
+        return super().forward(e, e[pos], e[neg])
+
 
 class MetricLoss:
     def __init__(self, cluster_similarity: Tensor):

@@ -73,3 +73,27 @@ def test_triplet_edge_loss(oracle, cuda, dtype):
     rtol, atol = (1e-5, 1e-7) if dtype == torch.float32 else (1e-2, 2e-6)
     assert torch.allclose(da.grad.cpu().double(), a.grad, rtol=rtol, atol=atol)
     assert torch.allclose(db.grad.cpu().double(), b.grad, rtol=rtol, atol=atol)
+
+
+def test_masked_tx_triplet_loss_equals_gathered_form(cuda):
+    """loss_tx through the fused kernel (anchors / positives / negatives index one matrix) equals
+    TripletLoss.forward on the gathered embeddings, values and gradients."""
+    from segger_amd.triplet_loss import TripletLoss
+    g = torch.Generator().manual_seed(9)
+    n, c, k = 5000, 64, 6
+    a = torch.randn(k, 4, generator=g); a = a / a.norm(dim=1, keepdim=True)
+    sim = a @ a.t()
+    z = torch.nn.functional.normalize(torch.randn(n, c, generator=g), dim=-1)
+    labels = torch.randint(0, k, (n,), generator=g)
+    mask = torch.rand(n, generator=g) < 0.8
+    loss_fn = TripletLoss(sim, margin=0.3)
+    zd = z.to(cuda).requires_grad_(True)
+    torch.manual_seed(77)
+    l1 = loss_fn.forward_masked(zd, labels.to(cuda), mask.to(cuda))
+    (l1 * 0.5).backward()
+    zr = z.to(cuda).requires_grad_(True)
+    torch.manual_seed(77)
+    l2 = loss_fn.forward(zr[mask.to(cuda)], labels.to(cuda)[mask.to(cuda)])
+    (l2 * 0.5).backward()
+    assert abs(l1.item() - l2.item()) < 1e-6
+    assert torch.allclose(zd.grad, zr.grad, atol=1e-7, rtol=1e-4)
