@@ -273,6 +273,37 @@ int segger_linear_supported(int32_t k_in, int32_t m_out, int32_t dtype);
 int segger_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy,
                       int64_t n_rows, int32_t k_in, int32_t m_out, int32_t dtype, segger_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Encoder front end / tail as fused row-wise kernels.
+ *
+ * segger_posfreq: Positional2dEmbedder up to the MLP input
+ *   (src/segger/models/ist_encoder.py:74 normalisation, :22-31,:51-55 sinusoid):
+ *   out[(n*2 + c), :] = [cos(p f_j) | sin(p f_j)], p = (pos[n,c] - mins[g,c]) / (maxs[g,c] - mins[g,c] + eps),
+ *   f_j = exp(-ln(max_period) * j / (freq_dim/2)), g = batch[n] (0 when batch is NULL); out is [2n, freq_dim] in `dtype`.
+ *
+ * segger_embed_gelu_fwd/bwd: x0 = gelu(cat(table[ids], pe)) (ist_encoder.py:312-320 for the 'tx' type):
+ *   table fp32 [n_rows_table, D] (nn.Embedding weight), ids int32 [n], pe [n, D] -> x0 [n, 2D].
+ *   bwd: gpe = gx0[:, D:] * gelu'(pe); gtable (optional, NULL to skip) = sum over rows of gx0[:, :D] * gelu'(table[ids]),
+ *   accumulated in per-block LDS tables (n_rows_table * 128 B <= 160 KiB), no sort and no global atomics.
+ *
+ * segger_l2norm_fwd/bwd: torch.nn.functional.normalize(dim=-1, eps) (ist_encoder.py:331-332) and its gradient;
+ *   channels in {8, 16, 32, 64, 128}.
+ * ---------------------------------------------------------------------- */
+int segger_posfreq(const float* pos, const int64_t* batch, const float* mins, const float* maxs, int64_t n,
+                   int32_t freq_dim, float eps, float max_period, void* out, int32_t dtype, segger_stream_t stream);
+int segger_embed_gelu_fwd(const float* table, const int32_t* ids, const void* pe, int64_t ld_pe, int64_t n,
+                          int32_t n_rows_table, int32_t D, void* out, int64_t ld_out, int32_t dtype,
+                          segger_stream_t stream);
+size_t segger_embed_gelu_bwd_workspace_bytes(int64_t n, int32_t n_rows_table, int32_t D);
+int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float* table, const int32_t* ids, const void* pe,
+                          int64_t ld_pe, int64_t n, int32_t n_rows_table, int32_t D, void* gpe, int64_t ld_gpe,
+                          float* gtable, void* workspace, size_t workspace_bytes, int32_t dtype,
+                          segger_stream_t stream);
+int segger_l2norm_fwd(const void* y, int64_t ld_y, int64_t n, int32_t channels, float eps, void* z, int64_t ld_z,
+                      int32_t dtype, segger_stream_t stream);
+int segger_l2norm_bwd(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, int64_t n, int32_t channels,
+                      float eps, void* gy, int64_t ld_gy, int32_t dtype, segger_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

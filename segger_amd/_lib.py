@@ -109,6 +109,13 @@ EXPORTS = {
     "segger_segment_minmax": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp, vp]),
     "segger_linear_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "segger_linear_fwd": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "segger_posfreq": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_float, C.c_float, vp, C.c_int32, vp]),
+    "segger_embed_gelu_fwd": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, C.c_int32, vp]),
+    "segger_embed_gelu_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "segger_embed_gelu_bwd": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64,
+                                        vp, vp, C.c_size_t, C.c_int32, vp]),
+    "segger_l2norm_fwd": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, C.c_float, vp, C.c_int64, C.c_int32, vp]),
+    "segger_l2norm_bwd": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_float, vp, C.c_int64, C.c_int32, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -145,45 +145,76 @@ __device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const 
   }
 }
 
-// Raw (unconverted) 8-channel fragment: keeps the U in-flight gathers in their
-// storage width (4 VGPRs for bf16/f16) until they are consumed.
+// ----------------------------------------------------------------------------
+// Arithmetic layout.  The kernels are VALU-bound (rocprofv3: VALU ~95 % busy,
+// HBM traffic 1/4 of the algorithmic bytes), so the inner loops are written for
+// instruction count:
+//  * 8 channels per lane live as 4 f32x2 pairs -> v_pk_add_f32 / v_pk_fma_f32;
+//  * leaky_relu(t) = c1*t + c2*|t| with c1=(1+slope)/2, c2=(1-slope)/2, so the
+//    logit  sum_k att_k*lrelu(t_k) = sum_k a1_k*t_k + a2_k*|t_k|  is one packed
+//    fma (a1 = att*c1*log2e) plus one fma with the free |.| source modifier
+//    (a2 = att*c2*log2e) per channel -- no multiply + max;
+//  * lrelu'(t) = c1 + c2*sgn(t) (sgn(0) = -1 as torch's `t > 0 ? 1 : slope`), so
+//    sum_e de*att*lrelu'(t) = att*(c1*sum_e de + c2*sum_e de*sgn(t)): only the
+//    sign sum is per channel; likewise grad_att = c1*sum de*t + c2*sum de*|t|.
+// ----------------------------------------------------------------------------
 template <typename T> struct Raw8 {
   u32x4 r;
-  __device__ __forceinline__ void load(const T* p) { r = *reinterpret_cast<const u32x4*>(p); }
-  __device__ __forceinline__ void zero() { r = u32x4{0u, 0u, 0u, 0u}; }
-  __device__ __forceinline__ void get(float (&f)[8]) const;
+  __device__ __forceinline__ void load(const void* p) { r = *reinterpret_cast<const u32x4*>(p); }
+  __device__ __forceinline__ void get(f32x2 (&f)[4]) const;
 };
-template <> __device__ __forceinline__ void Raw8<bf16_t>::get(float (&f)[8]) const {
-  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
-  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
-  f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
-  f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+template <> __device__ __forceinline__ void Raw8<bf16_t>::get(f32x2 (&f)[4]) const {
+  f[0] = f32x2{__uint_as_float(r.x << 16), __uint_as_float(r.x & 0xffff0000u)};
+  f[1] = f32x2{__uint_as_float(r.y << 16), __uint_as_float(r.y & 0xffff0000u)};
+  f[2] = f32x2{__uint_as_float(r.z << 16), __uint_as_float(r.z & 0xffff0000u)};
+  f[3] = f32x2{__uint_as_float(r.w << 16), __uint_as_float(r.w & 0xffff0000u)};
 }
-template <> __device__ __forceinline__ void Raw8<f16_t>::get(float (&f)[8]) const {
-  Vec8<f16_t>::unpack(r.x, f[0], f[1]); Vec8<f16_t>::unpack(r.y, f[2], f[3]);
-  Vec8<f16_t>::unpack(r.z, f[4], f[5]); Vec8<f16_t>::unpack(r.w, f[6], f[7]);
+template <> __device__ __forceinline__ void Raw8<f16_t>::get(f32x2 (&f)[4]) const {
+  float a, b;
+  Vec8<f16_t>::unpack(r.x, a, b); f[0] = f32x2{a, b};
+  Vec8<f16_t>::unpack(r.y, a, b); f[1] = f32x2{a, b};
+  Vec8<f16_t>::unpack(r.z, a, b); f[2] = f32x2{a, b};
+  Vec8<f16_t>::unpack(r.w, a, b); f[3] = f32x2{a, b};
 }
 template <> struct Raw8<float> {
   f32x4 a, b;
-  __device__ __forceinline__ void load(const float* p) {
-    a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4);
+  __device__ __forceinline__ void load(const void* p) {
+    a = *reinterpret_cast<const f32x4*>(p); b = *(reinterpret_cast<const f32x4*>(p) + 1);
   }
-  __device__ __forceinline__ void zero() { a = f32x4{0.f, 0.f, 0.f, 0.f}; b = a; }
-  __device__ __forceinline__ void get(float (&f)[8]) const {
-    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  __device__ __forceinline__ void get(f32x2 (&f)[4]) const {
+    f[0] = f32x2{a.x, a.y}; f[1] = f32x2{a.z, a.w}; f[2] = f32x2{b.x, b.y}; f[3] = f32x2{b.z, b.w};
   }
 };
 
-// attention logit (natural units) of one edge for this lane's head
-template <int LPH>
-__device__ __forceinline__ float edge_logit(const float (&v)[8], const float (&xr)[8], const float (&att)[8], float slope) {
-  float p = 0.f;
+template <typename T>
+__device__ __forceinline__ void load_pairs(const T* p, f32x2 (&f)[4]) {
+  Raw8<T> r; r.load(p); r.get(f);
+}
+template <typename T>
+__device__ __forceinline__ void store_pairs(T* p, const f32x2 (&f)[4]) {
+  const float v[8] = {f[0].x, f[0].y, f[1].x, f[1].y, f[2].x, f[2].y, f[3].x, f[3].y};
+  Vec8<T>::store(p, v);
+}
+
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat(float x) { return f32x2{x, x}; }
+
+// gathered row address: base (already offset to this lane's channels) + id * row-bytes  (one v_mad_u64_u32)
+__device__ __forceinline__ const void* row_ptr(const char* base, int id, uint32_t ld_bytes) {
+  return base + (uint64_t)(uint32_t)id * ld_bytes;
+}
+
+// sum_k a1_k*t_k + a2_k*|t_k| over this lane's 8 channels (t = v + xr), before the head reduction
+__device__ __forceinline__ float logit_partial(const f32x2 (&t)[4], const f32x2 (&a1)[4], const f32x2 (&a2)[4]) {
+  f32x2 pp = f32x2{0.f, 0.f};
+  float pa = 0.f;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const float t = v[k] + xr[k];
-    p = fmaf(att[k], fmaxf(t, slope * t), p);     // leaky_relu for 0 <= slope <= 1
+  for (int i = 0; i < 4; ++i) {
+    pp = pk_fma(a1[i], t[i], pp);
+    pa = __builtin_fmaf(a2[i].x, __builtin_fabsf(t[i].x), pa);
+    pa = __builtin_fmaf(a2[i].y, __builtin_fabsf(t[i].y), pa);
   }
-  return lane_block_sum<LPH>(p);
+  return pp.x + pp.y + pa;
 }
 
 struct LaneGeo {
@@ -201,6 +232,16 @@ __device__ __forceinline__ LaneGeo lane_geo() {
   return g;
 }
 
+// att -> (a1, a2) = att * {c1, c2} * scale
+__device__ __forceinline__ void load_att(const float* att, int ch0, float slope, float scale, f32x2 (&a1)[4], f32x2 (&a2)[4]) {
+  const float c1 = 0.5f * (1.f + slope) * scale, c2 = 0.5f * (1.f - slope) * scale;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 a = f32x2{att[ch0 + 2 * i], att[ch0 + 2 * i + 1]};
+    a1[i] = a * c1; a2[i] = a * c2;
+  }
+}
+
 // ============================================================================
 // Forward
 // ============================================================================
@@ -215,59 +256,59 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
   const bool head_leader = L.lane_on && (L.gl % LPH) == 0;
   const int64_t row = WPR ? (blk * 4 + L.wave) : ((blk * 4 + L.wave) * NG + L.grp);
   const bool row_ok = row < p.n_rows;
-  const T* __restrict__ xl = static_cast<const T*>(p.xl);
+  const char* __restrict__ xl = static_cast<const char*>(p.xl) + (size_t)ch0 * sizeof(T);
+  const uint32_t ld_xl = (uint32_t)(p.ld_xl * sizeof(T));
   const bool dropout = p.drop_thr != 0;
   const bool want_alpha = p.alpha != nullptr;
-  const float slope = p.slope;
 
-  float att[8], xr[8];
+  f32x2 a1[4], a2[4], xr[4], acc[4];
+  load_att(p.att, ch0, p.slope, kLog2e, a1, a2);      // logits come out in base-2 units
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { att[k] = p.att[ch0 + k]; xr[k] = 0.f; }
+  for (int i = 0; i < 4; ++i) { xr[i] = splat(0.f); acc[i] = splat(0.f); }
   int64_t beg = 0, end = 0;
   if (row_ok) {
     beg = p.indptr[row];
     end = p.indptr[row + 1];
-    Vec8<T>::load(static_cast<const T*>(p.xr) + row * p.ld_xr + ch0, xr);
+    load_pairs(static_cast<const T*>(p.xr) + row * p.ld_xr + ch0, xr);
   }
 
-  // online softmax state, base-2 units
-  float m = -INFINITY, s = 0.f, acc[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  float m = -INFINITY, s = 0.f;                       // online softmax state
 
   auto body = [&](const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
-    if (!valid[0]) return;
+    if (!valid[0]) return;                            // wave-per-row tail (group-uniform)
     Raw8<T> raw[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      if (valid[u]) raw[u].load(xl + (int64_t)nbr[u] * p.ld_xl + ch0);
-      else raw[u].zero();
-    }
+    for (int u = 0; u < U; ++u) raw[u].load(row_ptr(xl, nbr[u], ld_xl));   // invalid slots read row 0
     float e[U];
     float mx = m;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      float v[8];
+      f32x2 v[4], t[4];
       raw[u].get(v);
-      e[u] = valid[u] ? edge_logit<LPH>(v, xr, att, slope) * kLog2e : -INFINITY;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) t[i] = v[i] + xr[i];
+      const float pl = lane_block_sum<LPH>(logit_partial(t, a1, a2));
+      e[u] = valid[u] ? pl : -INFINITY;
       mx = fmaxf(mx, e[u]);
     }
-    const float sc = fast_exp2(m - mx);      // m = -inf -> 0 ; mx is finite because valid[0]
+    const float sc = fast_exp2(m - mx);               // m = -inf -> 0 ; mx finite because valid[0]
     s *= sc;
+    const f32x2 sc2 = splat(sc);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] *= sc;
+    for (int i = 0; i < 4; ++i) acc[i] = acc[i] * sc2;
     m = mx;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float pe = fast_exp2(e[u] - mx);  // invalid -> 0
+      const float pe = fast_exp2(e[u] - mx);          // invalid -> 0
       s += pe;
       float w = pe;
       if (dropout) w = dropout_keep((uint32_t)ed[u], H, h, p.seed_lo, p.seed_hi, p.drop_thr) ? pe * p.drop_scale : 0.f;
       if (want_alpha && valid[u] && head_leader) p.alpha[(int64_t)ed[u] * H + h] = e[u];
-      float v[8];
+      f32x2 v[4];
       raw[u].get(v);
+      const f32x2 w2 = splat(w);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] = fmaf(w, v[k], acc[k]);
+      for (int i = 0; i < 4; ++i) acc[i] = pk_fma(w2, v[i], acc[i]);
     }
   };
   if (dropout || want_alpha)
@@ -286,27 +327,30 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
       const float b = (m_o == mn) ? 1.f : fast_exp2(m_o - mn);
       s = s * a + s_o * b;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float acc_o = __shfl_xor(acc[k], off, 64);
-        acc[k] = acc[k] * a + acc_o * b;
+      for (int i = 0; i < 4; ++i) {
+        const f32x2 o = f32x2{__shfl_xor(acc[i].x, off, 64), __shfl_xor(acc[i].y, off, 64)};
+        acc[i] = acc[i] * a + o * b;
       }
       m = mn;
     }
   }
 
-  const float lse = m + fast_log2(s);          // -inf for a destination without in-edges
+  const float lse = m + fast_log2(s);                 // -inf for a destination without in-edges
   const float inv = s > 0.f ? 1.0f / s : 0.f;
   if (row_ok && L.lane_on && (!WPR || L.grp == 0)) {
-    float o[8];
+    f32x2 o[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = acc[k] * inv + (p.bias ? p.bias[ch0 + k] : 0.f);
+    for (int i = 0; i < 4; ++i) {
+      o[i] = acc[i] * inv;
+      if (p.bias) o[i] = o[i] + f32x2{p.bias[ch0 + 2 * i], p.bias[ch0 + 2 * i + 1]};
+    }
     if (p.pre && (p.pre != p.out || p.apply_gelu))
-      Vec8<T>::store(static_cast<T*>(p.pre) + row * p.ld_pre + ch0, o);
+      store_pairs(static_cast<T*>(p.pre) + row * p.ld_pre + ch0, o);
     if (p.apply_gelu) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = gelu_erf(o[k]);
+      for (int i = 0; i < 4; ++i) o[i] = f32x2{gelu_erf(o[i].x), gelu_erf(o[i].y)};
     }
-    Vec8<T>::store(static_cast<T*>(p.out) + row * p.ld_out + ch0, o);
+    store_pairs(static_cast<T*>(p.out) + row * p.ld_out + ch0, o);
     if (p.lse && head_leader) p.lse[row * H + h] = lse;
   }
 
@@ -329,8 +373,8 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
 //   g      = grad_out * gelu'(pre)                    (or grad_out)
 //   D[j,h] = sum_c g[j,h,c] * (pre[j,h,c] - bias)     = sum_i a_ij * dL/da_ij
 //   de_ij  = a_ij * (keep/(1-p) * <g_j, x_l[i]>_h - D[j,h])
-//   grad_xr[j] = sum_i de_ij * att * lrelu'(x_l[i] + x_r[j])
-//   grad_att   = sum_ij de_ij * lrelu(x_l[i] + x_r[j]) ;  grad_bias = sum_j g[j]
+//   grad_xr[j] = att * (c1 * sum_i de_ij + c2 * sum_i de_ij * sgn(t_ij))
+//   grad_att   = c1 * sum_ij de_ij * t_ij + c2 * sum_ij de_ij * |t_ij| ;  grad_bias = sum_j g[j]
 // ============================================================================
 template <typename T, int H, int LPH, bool WPR>
 __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kernel(GatParams p) {
@@ -342,14 +386,15 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
   const LaneGeo L = lane_geo<G>();
   const int h = L.h, ch0 = L.ch0;
   const bool head_leader = L.lane_on && (L.gl % LPH) == 0;
-  const T* __restrict__ xl = static_cast<const T*>(p.xl);
+  const char* __restrict__ xl = static_cast<const char*>(p.xl) + (size_t)ch0 * sizeof(T);
+  const uint32_t ld_xl = (uint32_t)(p.ld_xl * sizeof(T));
   const bool dropout = p.drop_thr != 0;
   constexpr int RPW = WPR ? 1 : NG;            // rows per wave per iteration
-  const float slope = p.slope;
 
-  float att[8], datt[8], dbias[8];
+  f32x2 a1[4], a2[4], Pt[4], Qt[4], dbias[4];
+  load_att(p.att, ch0, p.slope, kLog2e, a1, a2);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { att[k] = p.att[ch0 + k]; datt[k] = 0.f; dbias[k] = 0.f; }
+  for (int i = 0; i < 4; ++i) { Pt[i] = splat(0.f); Qt[i] = splat(0.f); dbias[i] = splat(0.f); }
 
 #pragma unroll 1
   for (int it = 0; it < p.rows_per_wave_iter; ++it) {
@@ -358,62 +403,64 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
     const int64_t row = rbase + (WPR ? 0 : L.grp);
     const bool row_ok = row < p.n_rows;
 
-    float xr[8], g[8], dxr[8];
-    float D = 0.f, lse = 0.f;
+    f32x2 xr[4], g[4], Sg[4];
+    float D = 0.f, lse = 0.f, Sde = 0.f;
     int64_t beg = 0, end = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { xr[k] = 0.f; g[k] = 0.f; dxr[k] = 0.f; }
+    for (int i = 0; i < 4; ++i) { xr[i] = splat(0.f); g[i] = splat(0.f); Sg[i] = splat(0.f); }
     if (row_ok) {
       beg = p.indptr[row]; end = p.indptr[row + 1];
-      float gy[8], pr[8];
-      Vec8<T>::load(static_cast<const T*>(p.xr) + row * p.ld_xr + ch0, xr);
-      Vec8<T>::load(static_cast<const T*>(p.gout) + row * p.ld_go + ch0, gy);
-      Vec8<T>::load(static_cast<const T*>(p.pre) + row * p.ld_pre + ch0, pr);
+      f32x2 gy[4], pr[4];
+      load_pairs(static_cast<const T*>(p.xr) + row * p.ld_xr + ch0, xr);
+      load_pairs(static_cast<const T*>(p.gout) + row * p.ld_go + ch0, gy);
+      load_pairs(static_cast<const T*>(p.pre) + row * p.ld_pre + ch0, pr);
+      f32x2 d2 = splat(0.f);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        g[k] = p.apply_gelu ? gy[k] * gelu_erf_grad(pr[k]) : gy[k];
-        D = fmaf(g[k], pr[k] - (p.bias ? p.bias[ch0 + k] : 0.f), D);
+      for (int i = 0; i < 4; ++i) {
+        g[i] = p.apply_gelu ? f32x2{gy[i].x * gelu_erf_grad(pr[i].x), gy[i].y * gelu_erf_grad(pr[i].y)} : gy[i];
+        f32x2 b = splat(0.f);
+        if (p.bias) b = f32x2{p.bias[ch0 + 2 * i], p.bias[ch0 + 2 * i + 1]};
+        d2 = pk_fma(g[i], pr[i] - b, d2);
       }
+      D = d2.x + d2.y;
       lse = p.lse[row * H + h];
     }
     D = lane_block_sum<LPH>(D);
     const bool writer = row_ok && L.lane_on && (!WPR || L.grp == 0);
     if (writer) {
-      Vec8<T>::store(static_cast<T*>(p.gpre) + row * p.ld_gp + ch0, g);
+      store_pairs(static_cast<T*>(p.gpre) + row * p.ld_gp + ch0, g);
       if (head_leader) p.dsum[row * H + h] = D;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) dbias[k] += g[k];
+      for (int i = 0; i < 4; ++i) dbias[i] = dbias[i] + g[i];
     }
 
     auto body = [&](const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
       if (!valid[0]) return;
       Raw8<T> raw[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        if (valid[u]) raw[u].load(xl + (int64_t)nbr[u] * p.ld_xl + ch0);
-        else raw[u].zero();
-      }
+      for (int u = 0; u < U; ++u) raw[u].load(row_ptr(xl, nbr[u], ld_xl));
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        float v[8];
+        f32x2 v[4], t[4];
         raw[u].get(v);
-        float pl = 0.f, da = 0.f;
+        f32x2 da2 = splat(0.f);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float t = v[k] + xr[k];
-          pl = fmaf(att[k], fmaxf(t, slope * t), pl);
-          da = fmaf(g[k], v[k], da);
-        }
-        pl = lane_block_sum<LPH>(pl);
-        da = lane_block_sum<LPH>(da);
-        const float a = valid[u] ? fast_exp2(pl * kLog2e - lse) : 0.f;
+        for (int i = 0; i < 4; ++i) { t[i] = v[i] + xr[i]; da2 = pk_fma(g[i], v[i], da2); }
+        const float pl = lane_block_sum<LPH>(logit_partial(t, a1, a2));
+        float da = lane_block_sum<LPH>(da2.x + da2.y);
+        const float a = valid[u] ? fast_exp2(pl - lse) : 0.f;
         if (dropout) da = dropout_keep((uint32_t)ed[u], H, h, p.seed_lo, p.seed_hi, p.drop_thr) ? da * p.drop_scale : 0.f;
         const float de = a * (da - D);
+        Sde += de;
+        const f32x2 de2 = splat(de);
+        const float nde = -de;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float t = v[k] + xr[k];
-          dxr[k] = fmaf(de, t > 0.f ? att[k] : att[k] * slope, dxr[k]);
-          datt[k] = fmaf(de, fmaxf(t, slope * t), datt[k]);
+        for (int i = 0; i < 4; ++i) {
+          Pt[i] = pk_fma(de2, t[i], Pt[i]);
+          Qt[i].x = __builtin_fmaf(de, __builtin_fabsf(t[i].x), Qt[i].x);
+          Qt[i].y = __builtin_fmaf(de, __builtin_fabsf(t[i].y), Qt[i].y);
+          Sg[i].x += t[i].x > 0.f ? de : nde;
+          Sg[i].y += t[i].y > 0.f ? de : nde;
         }
       }
     };
@@ -425,25 +472,42 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
     if constexpr (WPR) {
 #pragma unroll
       for (int off = GS; off < 64; off <<= 1) {
+        Sde += __shfl_xor(Sde, off, 64);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dxr[k] += __shfl_xor(dxr[k], off, 64);
+        for (int i = 0; i < 4; ++i) {
+          Sg[i].x += __shfl_xor(Sg[i].x, off, 64);
+          Sg[i].y += __shfl_xor(Sg[i].y, off, 64);
+        }
       }
     }
-    if (writer) Vec8<T>::store(static_cast<T*>(p.gxr) + row * p.ld_gxr + ch0, dxr);
+    if (writer) {
+      // a1 = att*c1*log2e, a2 = att*c2*log2e  ->  natural units via ln2
+      f32x2 dxr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dxr[i] = (a1[i] * Sde + a2[i] * Sg[i]) * kLn2;
+      store_pairs(static_cast<T*>(p.gxr) + row * p.ld_gxr + ch0, dxr);
+    }
   }
 
-  // block partials of grad_att / grad_bias -> slab[blk]
+  // grad_att = c1 * Pt + c2 * Qt ; block partials of grad_att / grad_bias -> slab[blk]
+  const float c1 = 0.5f * (1.f + p.slope), c2 = 0.5f * (1.f - p.slope);
+  float datt[8], db[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    datt[2 * i] = c1 * Pt[i].x + c2 * Qt[i].x; datt[2 * i + 1] = c1 * Pt[i].y + c2 * Qt[i].y;
+    db[2 * i] = dbias[i].x; db[2 * i + 1] = dbias[i].y;
+  }
 #pragma unroll
   for (int off = GS; off < 64; off <<= 1) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       datt[k] += __shfl_xor(datt[k], off, 64);
-      dbias[k] += __shfl_xor(dbias[k], off, 64);
+      db[k] += __shfl_xor(db[k], off, 64);
     }
   }
   if (L.grp == 0 && L.lane_on) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { red[L.wave][0][ch0 + k] = datt[k]; red[L.wave][1][ch0 + k] = dbias[k]; }
+    for (int k = 0; k < 8; ++k) { red[L.wave][0][ch0 + k] = datt[k]; red[L.wave][1][ch0 + k] = db[k]; }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * HC; i += 256) {
@@ -454,7 +518,7 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
 
 // ============================================================================
 // Backward, source side:  grad_xl   (rows = sources, col = destinations)
-//   grad_xl[i] = sum_j  keep/(1-p) * a_ij * g[j]  +  de_ij * att * lrelu'(x_l[i] + x_r[j])
+//   grad_xl[i] = sum_j keep/(1-p) * a_ij * g[j]  +  att * (c1 * sum_j de_ij + c2 * sum_j de_ij * sgn(t_ij))
 // ============================================================================
 template <typename T, int H, int LPH, bool WPR>
 __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kernel(GatParams p) {
@@ -466,18 +530,20 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
   const int h = L.h, ch0 = L.ch0;
   const int64_t row = WPR ? (blk * 4 + L.wave) : ((blk * 4 + L.wave) * NG + L.grp);
   const bool row_ok = row < p.n_rows;
-  const T* __restrict__ xr_base = static_cast<const T*>(p.xr);
-  const T* __restrict__ g_base = static_cast<const T*>(p.gpre);
+  const char* __restrict__ xr_base = static_cast<const char*>(p.xr) + (size_t)ch0 * sizeof(T);
+  const char* __restrict__ g_base = static_cast<const char*>(p.gpre) + (size_t)ch0 * sizeof(T);
+  const uint32_t ld_xr = (uint32_t)(p.ld_xr * sizeof(T)), ld_gp = (uint32_t)(p.ld_gp * sizeof(T));
   const bool dropout = p.drop_thr != 0;
-  const float slope = p.slope;
 
-  float att[8], v[8], acc[8];
+  f32x2 a1[4], a2[4], v[4], acc[4], Sg[4];
+  load_att(p.att, ch0, p.slope, kLog2e, a1, a2);
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { att[k] = p.att[ch0 + k]; acc[k] = 0.f; v[k] = 0.f; }
+  for (int i = 0; i < 4; ++i) { v[i] = splat(0.f); acc[i] = splat(0.f); Sg[i] = splat(0.f); }
+  float Sde = 0.f;
   int64_t beg = 0, end = 0;
   if (row_ok) {
     beg = p.indptr[row]; end = p.indptr[row + 1];
-    Vec8<T>::load(static_cast<const T*>(p.xl) + row * p.ld_xl + ch0, v);
+    load_pairs(static_cast<const T*>(p.xl) + row * p.ld_xl + ch0, v);
   }
 
   auto body = [&](const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
@@ -486,30 +552,22 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
     float lse[U], D[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      if (valid[u]) {
-        rxr[u].load(xr_base + (int64_t)nbr[u] * p.ld_xr + ch0);
-        rg[u].load(g_base + (int64_t)nbr[u] * p.ld_gp + ch0);
-        lse[u] = p.lse[(int64_t)nbr[u] * H + h];
-        D[u] = p.dsum[(int64_t)nbr[u] * H + h];
-      } else {
-        rxr[u].zero(); rg[u].zero(); lse[u] = 0.f; D[u] = 0.f;
-      }
+      rxr[u].load(row_ptr(xr_base, nbr[u], ld_xr));
+      rg[u].load(row_ptr(g_base, nbr[u], ld_gp));
+      lse[u] = p.lse[(int64_t)nbr[u] * H + h];
+      D[u] = p.dsum[(int64_t)nbr[u] * H + h];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      float xr[8], g[8];
+      f32x2 xr[4], g[4], t[4];
       rxr[u].get(xr);
       rg[u].get(g);
-      float pl = 0.f, da = 0.f;
+      f32x2 da2 = splat(0.f);
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float t = v[k] + xr[k];
-        pl = fmaf(att[k], fmaxf(t, slope * t), pl);
-        da = fmaf(g[k], v[k], da);
-      }
-      pl = lane_block_sum<LPH>(pl);
-      da = lane_block_sum<LPH>(da);
-      const float a = valid[u] ? fast_exp2(pl * kLog2e - lse[u]) : 0.f;
+      for (int i = 0; i < 4; ++i) { t[i] = v[i] + xr[i]; da2 = pk_fma(g[i], v[i], da2); }
+      const float pl = lane_block_sum<LPH>(logit_partial(t, a1, a2));
+      float da = lane_block_sum<LPH>(da2.x + da2.y);
+      const float a = valid[u] ? fast_exp2(pl - lse[u]) : 0.f;
       float a_eff = a;
       if (dropout) {
         const bool keep = dropout_keep((uint32_t)ed[u], H, h, p.seed_lo, p.seed_hi, p.drop_thr);
@@ -517,11 +575,14 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
         a_eff = keep ? a * p.drop_scale : 0.f;
       }
       const float de = a * (da - D[u]);
+      Sde += de;
+      const f32x2 ae2 = splat(a_eff);
+      const float nde = -de;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float t = v[k] + xr[k];
-        acc[k] = fmaf(a_eff, g[k], acc[k]);
-        acc[k] = fmaf(de, t > 0.f ? att[k] : att[k] * slope, acc[k]);
+      for (int i = 0; i < 4; ++i) {
+        acc[i] = pk_fma(ae2, g[i], acc[i]);
+        Sg[i].x += t[i].x > 0.f ? de : nde;
+        Sg[i].y += t[i].y > 0.f ? de : nde;
       }
     }
   };
@@ -530,15 +591,20 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
   else
     walk_row<GS, WPR, false>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
 
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = acc[i] + (a1[i] * Sde + a2[i] * Sg[i]) * kLn2;
   if constexpr (WPR) {
 #pragma unroll
     for (int off = GS; off < 64; off <<= 1) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) acc[k] += __shfl_xor(acc[k], off, 64);
+      for (int i = 0; i < 4; ++i) {
+        acc[i].x += __shfl_xor(acc[i].x, off, 64);
+        acc[i].y += __shfl_xor(acc[i].y, off, 64);
+      }
     }
   }
   if (row_ok && L.lane_on && (!WPR || L.grp == 0))
-    Vec8<T>::store(static_cast<T*>(p.gxl) + row * p.ld_gxl + ch0, acc);
+    store_pairs(static_cast<T*>(p.gxl) + row * p.ld_gxl + ch0, acc);
 }
 
 }  // namespace segger

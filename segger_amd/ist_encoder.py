@@ -77,10 +77,17 @@ class Positional2dEmbedder(Module):
 
     def forward(self, pos: Tensor, batch: Optional[Tensor] = None, *, num_graphs: Optional[int] = None,
                 dtype: torch.dtype = torch.float32) -> Tensor:
-        pos = self.normalize(pos, batch, num_graphs)
         n = pos.shape[0]
-        freq = sinusoidal_embedding(pos.flatten(), self.frequency_embedding_size, max_period=10000)
-        freq = freq.reshape(n, 2, self.frequency_embedding_size).to(dtype)
+        fd = self.frequency_embedding_size
+        if batch is not None and fd % 16 == 0:
+            # fused: per-graph min/max (one pass) -> normalise + sinusoid written straight in `dtype`
+            if num_graphs is None:
+                num_graphs = int(batch.max()) + 1 if batch.numel() else 0
+            mins, maxs = ops.segment_minmax(pos, batch, num_graphs)
+            freq = ops.posfreq(pos, batch, mins, maxs, fd, dtype, eps=1e-8, max_period=10000.0)
+        else:
+            pos = self.normalize(pos, batch, num_graphs)
+            freq = sinusoidal_embedding(pos.flatten(), fd, max_period=10000).reshape(n, 2, fd).to(dtype)
         l0, l2 = self.mlp[0], self.mlp[2]
         h = F.silu(ops.linear(freq, l0.weight, l0.bias))
         h = ops.linear(h, l2.weight, l2.bias)
@@ -249,14 +256,19 @@ class ISTEncoder(Module):
         dt = self.compute_dtype
         self._materialize_bd(x_dict["bd"].shape[-1], x_dict["bd"].device)
         bd_lin = self.lin_first["bd"]
-        x = {
-            "tx": self.lin_first["tx"](x_dict["tx"].long()).to(dt),
-            "bd": ops.linear(x_dict["bd"].to(dt), bd_lin.weight, bd_lin.bias),
-        }
+        emb = self.lin_first["tx"]
+        pe = (lambda k: self.pos_emb(pos_dict[k], batch_dict.get(k), num_graphs=num_graphs, dtype=dt))
+        x_bd = ops.linear(x_dict["bd"].to(dt), bd_lin.weight, bd_lin.bias)
         if self.use_positional_embeddings:
-            x = {k: torch.cat((v, self.pos_emb(pos_dict[k], batch_dict.get(k), num_graphs=num_graphs, dtype=dt)), -1)
-                 for k, v in x.items()}
-        x = {k: F.gelu(v) for k, v in x.items()}
+            x_bd = F.gelu(torch.cat((x_bd, pe("bd")), -1))
+            if self.in_channels % 32 == 0 and emb.weight.dtype == torch.float32:
+                x_tx = ops.embed_gelu(emb.weight, x_dict["tx"], pe("tx"))      # gather + concat + GELU, one kernel
+            else:
+                x_tx = F.gelu(torch.cat((emb(x_dict["tx"].long()).to(dt), pe("tx")), -1))
+        else:
+            x_bd = F.gelu(x_bd)
+            x_tx = F.gelu(emb(x_dict["tx"].long()).to(dt))
+        x = {"tx": x_tx, "bd": x_bd}
 
         graphs = {et: edge_graph(cache, et, edge_index_dict[et], x[et[0]].shape[0], x[et[2]].shape[0])
                   for et in (TX_TX, TX_BD) if et in edge_index_dict}
@@ -268,5 +280,5 @@ class ISTEncoder(Module):
 
         x = self.lin_last(x)
         if self.normalize_embeddings:
-            x = {k: F.normalize(v.float(), dim=-1).to(dt) for k, v in x.items()}
+            x = {k: ops.l2_normalize(v) for k, v in x.items()}
         return x

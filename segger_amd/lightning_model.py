@@ -177,7 +177,7 @@ class LitISTEncoder(_Base):
         embeddings = self.forward(batch)
         tx_mask = batch['tx']['mask']
         bd_mask = batch['bd']['mask'] & (batch['bd']['cluster'] >= 0)
-        loss_tx = self.loss_tx.forward_masked(embeddings['tx'], batch['tx']['cluster'], tx_mask)
+        loss_tx = self.loss_tx.forward_masked(embeddings['tx'], batch['tx']['cluster'], tx_mask, batch_cache(batch))
         loss_bd = self.loss_bd.forward(embeddings['bd'][bd_mask], batch['bd']['cluster'][bd_mask])
         loss_sg = self._segmentation_loss(embeddings, batch, dst_neg)
         w_tx, w_bd, w_sg = (float(v) for v in self._scheduled_weights(self._w_start, self._w_end))

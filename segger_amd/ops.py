@@ -454,3 +454,119 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
         _lib.require_cuda(x2)
         y = torch.nn.functional.linear(x2, weight.to(x2.dtype), None if bias is None else bias.to(x2.dtype))
     return y.reshape(*lead, weight.shape[0])
+
+
+# --------------------------------------------------------------------------
+# Encoder front end / tail (fused row-wise kernels)
+# --------------------------------------------------------------------------
+@torch.no_grad()
+def posfreq(pos: Tensor, batch: Optional[Tensor], mins: Tensor, maxs: Tensor, freq_dim: int, dtype: torch.dtype,
+            eps: float = 1e-8, max_period: float = 10000.0) -> Tensor:
+    """[n, 2] positions -> [n, 2, freq_dim] sinusoid of the per-graph normalised coordinates."""
+    _lib.require_cuda(pos)
+    lib = _lib.load()
+    dev = pos.device
+    pos = pos.to(torch.float32).contiguous()
+    n = int(pos.shape[0])
+    if batch is not None:
+        batch = batch.to(device=dev, dtype=torch.int64).contiguous()
+    out = torch.empty((n, 2, freq_dim), dtype=dtype, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.segger_posfreq(pos.data_ptr(), _lib.ptr(batch), mins.data_ptr(), maxs.data_ptr(), n, freq_dim,
+                                eps, max_period, out.data_ptr(), DTYPE_CODE[dtype], _lib.stream_ptr(dev))
+    _lib.check(rc, "segger_posfreq")
+    return out
+
+
+class _EmbedGelu(torch.autograd.Function):
+    """gelu(cat(table[ids], pe)): table fp32 [G, D] (embedding weight), ids int32 [n], pe [n, D] -> [n, 2D]."""
+
+    @staticmethod
+    def forward(ctx, table, ids, pe):
+        _lib.require_cuda(table, ids, pe)
+        lib = _lib.load()
+        n, d = pe.shape
+        g = table.shape[0]
+        out = torch.empty((n, 2 * d), dtype=pe.dtype, device=pe.device)
+        pp, ldp = _rows(pe, d, "pe")
+        with torch.cuda.device(pe.device):
+            rc = lib.segger_embed_gelu_fwd(table.data_ptr(), ids.data_ptr(), pp, ldp, n, g, d, out.data_ptr(), 2 * d,
+                                           DTYPE_CODE[pe.dtype], _lib.stream_ptr(pe.device))
+        _lib.check(rc, "segger_embed_gelu_fwd")
+        ctx.save_for_backward(table, ids, pe)
+        return out
+
+    @staticmethod
+    def backward(ctx, gx0):
+        table, ids, pe = ctx.saved_tensors
+        lib = _lib.load()
+        dev = pe.device
+        n, d = pe.shape
+        g = table.shape[0]
+        if gx0.dtype != pe.dtype:
+            gx0 = gx0.to(pe.dtype)
+        if gx0.stride(-1) != 1:
+            gx0 = gx0.contiguous()
+        gp, ldg = _rows(gx0, 2 * d, "gx0")
+        pp, ldp = _rows(pe, d, "pe")
+        gpe = torch.empty_like(pe)
+        want_table = ctx.needs_input_grad[0]
+        gtable = torch.empty_like(table) if want_table else None
+        ws_bytes = lib.segger_embed_gelu_bwd_workspace_bytes(n, g, d) if want_table else 0
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.segger_embed_gelu_bwd(gp, ldg, table.data_ptr(), ids.data_ptr(), pp, ldp, n, g, d,
+                                           gpe.data_ptr(), d, _lib.ptr(gtable), ws.data_ptr(), ws_bytes,
+                                           DTYPE_CODE[pe.dtype], _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_embed_gelu_bwd")
+        return gtable, None, gpe
+
+
+def embed_gelu(table: Tensor, ids: Tensor, pe: Tensor) -> Tensor:
+    if table.dtype != torch.float32 or not table.is_contiguous():
+        raise TypeError("embed_gelu: the embedding table must be contiguous fp32")
+    if pe.shape[1] != table.shape[1] or pe.shape[1] % 32:
+        raise ValueError("embed_gelu: pe width must equal the embedding width and be a multiple of 32")
+    return _EmbedGelu.apply(table, ids.to(torch.int32).contiguous(), pe.contiguous())
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, eps):
+        _lib.require_cuda(y)
+        lib = _lib.load()
+        n, c = y.shape
+        z = torch.empty((n, c), dtype=y.dtype, device=y.device)
+        yp, ldy = _rows(y, c, "y")
+        with torch.cuda.device(y.device):
+            rc = lib.segger_l2norm_fwd(yp, ldy, n, c, eps, z.data_ptr(), c, DTYPE_CODE[y.dtype], _lib.stream_ptr(y.device))
+        _lib.check(rc, "segger_l2norm_fwd")
+        ctx.save_for_backward(y)
+        ctx.eps = eps
+        return z
+
+    @staticmethod
+    def backward(ctx, gz):
+        (y,) = ctx.saved_tensors
+        lib = _lib.load()
+        n, c = y.shape
+        if gz.dtype != y.dtype:
+            gz = gz.to(y.dtype)
+        if gz.stride(-1) != 1 or gz.dim() != 2:
+            gz = gz.contiguous()
+        gy = torch.empty((n, c), dtype=y.dtype, device=y.device)
+        yp, ldy = _rows(y, c, "y")
+        gp, ldg = _rows(gz, c, "gz")
+        with torch.cuda.device(y.device):
+            rc = lib.segger_l2norm_bwd(yp, ldy, gp, ldg, n, c, ctx.eps, gy.data_ptr(), c, DTYPE_CODE[y.dtype],
+                                       _lib.stream_ptr(y.device))
+        _lib.check(rc, "segger_l2norm_bwd")
+        return gy, None
+
+
+def l2_normalize(y: Tensor, eps: float = 1e-12) -> Tensor:
+    """F.normalize(y, dim=-1) for [n, C] with C in {8,16,32,64,128}; other widths use torch."""
+    if y.dim() == 2 and y.shape[1] in (8, 16, 32, 64, 128) and y.dtype in DTYPE_CODE:
+        return _L2Norm.apply(y, float(eps))
+    _lib.require_cuda(y)
+    return torch.nn.functional.normalize(y.float(), dim=-1, eps=eps).to(y.dtype)

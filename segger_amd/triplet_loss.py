@@ -34,12 +34,11 @@ class FastTripletSelector:
         return c
 
     @torch.no_grad()
-    def sample_triplets(self, labels: Tensor, uniforms: Optional[Tuple[Tensor, Tensor, Tensor, Tensor]] = None):
-        """-> positives, negatives, dists_pos, dists_neg (all [N]).  ``uniforms`` overrides the
-        four U[0,1) draws (positive cluster, positive member, negative cluster, negative member)."""
+    def build_index(self, labels: Tensor) -> dict:
+        """Everything ``sample_triplets`` derives from the labels alone (reference ``_build_index``,
+        triplet_loss.py:27-80).  Labels of a batch do not change between steps, so callers may cache it."""
         dev = labels.device
         labels = labels.long()
-        n = labels.numel()
         sim, dis = self.similarity.to(dev), self.dissimilarity.to(dev)
         n_clusters = sim.shape[0]
         counts = torch.bincount(labels, minlength=n_clusters)
@@ -51,23 +50,34 @@ class FastTripletSelector:
         slot_of = torch.full((n_clusters,), -1, dtype=torch.long, device=dev)
         slot_of[present] = torch.arange(present.numel(), device=dev)
         row = slot_of[labels]
-        cdf_pos = self._cdf(sim[present][:, present])
-        cdf_neg = self._cdf(dis[present][:, present])
+        return dict(labels=labels, counts=counts, offsets=offsets, members=members, present=present,
+                    cdf_pos=self._cdf(sim[present][:, present])[row], cdf_neg=self._cdf(dis[present][:, present])[row],
+                    dists=1.0 - sim)
+
+    @torch.no_grad()
+    def sample_triplets(self, labels: Tensor, uniforms: Optional[Tuple[Tensor, Tensor, Tensor, Tensor]] = None,
+                        index: Optional[dict] = None):
+        """-> positives, negatives, dists_pos, dists_neg (all [N]).  ``uniforms`` overrides the
+        four U[0,1) draws (positive cluster, positive member, negative cluster, negative member)."""
+        ix = index if index is not None else self.build_index(labels)
+        dev = ix["labels"].device
+        n = ix["labels"].numel()
         if uniforms is None:
             u = [torch.rand(n, device=dev) for _ in range(4)]
             # reference draw order: cluster(pos), member(pos), cluster(neg), member(neg)
         else:
             u = [t.to(dev) for t in uniforms]
+        counts, offsets, members, present = ix["counts"], ix["offsets"], ix["members"], ix["present"]
 
-        def draw(cdf: Tensor, u_cluster: Tensor, u_member: Tensor) -> Tensor:
-            k = torch.searchsorted(cdf[row], u_cluster.unsqueeze(-1)).squeeze(-1)
+        def draw(cdf_rows: Tensor, u_cluster: Tensor, u_member: Tensor) -> Tensor:
+            k = torch.searchsorted(cdf_rows, u_cluster.unsqueeze(-1)).squeeze(-1)
             cl = present[k]
             within = (u_member * counts[cl].float()).floor().long()
             return members[offsets[cl] + within]
 
-        positives = draw(cdf_pos, u[0], u[1])
-        negatives = draw(cdf_neg, u[2], u[3])
-        dists = 1.0 - sim
+        positives = draw(ix["cdf_pos"], u[0], u[1])
+        negatives = draw(ix["cdf_neg"], u[2], u[3])
+        labels, dists = ix["labels"], ix["dists"]
         return positives, negatives, dists[labels, labels[positives]], dists[labels, labels[negatives]]
 
 
@@ -83,14 +93,23 @@ class TripletLoss(torch.nn.TripletMarginLoss):
         e = embeddings.float()
         return super().forward(e, e[pos], e[neg])
 
-    def forward_masked(self, embeddings: Tensor, labels: Tensor, mask: Tensor):
+    def forward_masked(self, embeddings: Tensor, labels: Tensor, mask: Tensor, cache: Optional[dict] = None):
         """``forward(embeddings[mask], labels[mask])`` (how LitISTEncoder.get_losses calls it,
         lightning_model.py:158-161) without materialising the three gathered [n, C] matrices:
-        on the GPU the fused triplet kernel gathers anchor / positive / negative rows itself."""
-        idx = mask.nonzero(as_tuple=False).squeeze(1)
+        on the GPU the fused triplet kernel gathers anchor / positive / negative rows itself.
+        ``cache`` (per batch) keeps the mask's index list and the selector's label index across steps."""
+        key = ("tx_triplet_index", mask.data_ptr(), labels.data_ptr(), int(mask.numel()))
+        hit = cache.get(key) if cache is not None else None
+        if hit is None:
+            idx = mask.nonzero(as_tuple=False).squeeze(1)
+            index = self.selector.build_index(labels[idx]) if idx.numel() else None
+            hit = (idx, index)
+            if cache is not None:
+                cache[key] = hit
+        idx, index = hit
         if idx.numel() == 0:
             return 0.0
-        pos, neg, _, _ = self.selector.sample_triplets(labels[idx])
+        pos, neg, _, _ = self.selector.sample_triplets(labels[idx] if index is None else index["labels"], index=index)
         if embeddings.is_cuda:
             from . import ops
             return ops.triplet_edge_loss(embeddings, None, idx, idx[pos], idx[neg], self.margin, eps=self.eps)

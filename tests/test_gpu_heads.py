@@ -97,3 +97,56 @@ def test_masked_tx_triplet_loss_equals_gathered_form(cuda):
     (l2 * 0.5).backward()
     assert abs(l1.item() - l2.item()) < 1e-6
     assert torch.allclose(zd.grad, zr.grad, atol=1e-7, rtol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_posfreq_matches_reference_formula(oracle, cuda, dtype):
+    from segger_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n = 3000
+    pos = torch.rand(n, 2, generator=g) * 500 + 10
+    batch = torch.sort(torch.randint(0, 5, (n,), generator=g)).values
+    mins, maxs = ops.segment_minmax(pos.to(cuda), batch.to(cuda), 6)
+    for b in range(5):
+        m = batch == b
+        assert torch.equal(mins[b].cpu(), pos[m].min(0).values) and torch.equal(maxs[b].cpu(), pos[m].max(0).values)
+    assert (mins[5] == 0).all() and (maxs[5] == 0).all()                       # graph without nodes
+    out = ops.posfreq(pos.to(cuda), batch.to(cuda), mins, maxs, 256, dtype)
+    p = oracle.normalize_positions(pos.double(), batch)
+    ref = oracle.sinusoidal_embedding(p.flatten(), 256, 10000).reshape(n, 2, 256)
+    tol = 2e-6 if dtype == torch.float32 else 4e-3
+    assert (out.double().cpu() - ref).abs().max() < tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_embed_gelu_and_l2norm_autograd(cuda, dtype):
+    from segger_amd import ops
+    g = torch.Generator().manual_seed(4)
+    n, G, D = 5000, 37, 64
+    table = torch.randn(G, D, generator=g)
+    ids = torch.randint(0, G - 2, (n,), generator=g)                           # two genes never occur
+    pe = torch.randn(n, D, generator=g).to(dtype)
+    gx = torch.randn(n, 2 * D, generator=g).to(dtype)
+    t_d, pe_d = table.to(cuda).requires_grad_(True), pe.to(cuda).requires_grad_(True)
+    x0 = ops.embed_gelu(t_d, ids.to(cuda), pe_d)
+    x0.backward(gx.to(cuda))
+    t_r, pe_r = table.double().requires_grad_(True), pe.double().requires_grad_(True)
+    ref = torch.nn.functional.gelu(torch.cat((t_r[ids], pe_r), -1))
+    ref.backward(gx.double())
+    rt = 1e-5 if dtype == torch.float32 else 1e-2
+    assert torch.allclose(x0.double().cpu(), ref, rtol=rt, atol=rt)
+    assert torch.allclose(pe_d.grad.double().cpu(), pe_r.grad, rtol=rt, atol=rt)
+    assert torch.allclose(t_d.grad.double().cpu(), t_r.grad, rtol=1e-4, atol=1e-3 if dtype == torch.float32 else 5e-2)
+    assert (t_d.grad[G - 2:] == 0).all()
+    # L2 normalisation
+    y = torch.randn(n, 64, generator=g).to(dtype); y[7] = 0                      # a zero row stays zero
+    gz = torch.randn(n, 64, generator=g).to(dtype)
+    y_d = y.to(cuda).requires_grad_(True)
+    z = ops.l2_normalize(y_d)
+    z.backward(gz.to(cuda))
+    y_r = y.double().requires_grad_(True)
+    z_r = torch.nn.functional.normalize(y_r, dim=-1)
+    z_r.backward(gz.double())
+    assert torch.allclose(z.double().cpu(), z_r, rtol=rt, atol=rt)
+    ok = torch.ones(n, dtype=torch.bool); ok[7] = False                          # torch: grad at the clamp is gz/eps
+    assert torch.allclose(y_d.grad.double().cpu()[ok], y_r.grad[ok], rtol=rt, atol=rt * 3)
