@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -129,11 +130,15 @@ def main():
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_id = local_rank % torch.cuda.device_count()      # == local_rank on a real N-GPU launch
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from segger_amd import LitISTEncoder, TX_TX, TX_BD, TX_NB_BD, ops
     from segger_amd.dp import FlatGradBucket, broadcast_parameters

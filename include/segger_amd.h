@@ -104,9 +104,9 @@ int segger_csr_from_coo(const int64_t* row, const int64_t* colv, int64_t n_edges
  *   out        = apply_gelu ? gelu_erf(pre) : pre
  *
  * A destination without in-edges gets pre = bias.
- * Dropout (ist_encoder.py:116,123; training only): keep(e,h) =
- *   (mix32(mix32((eid*H+h) ^ seed_lo) + seed_hi) >> 8) >= floor(p * 2^24),
- *   mix32(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16.
+ * Dropout (ist_encoder.py:116,123; training only), with (lo, hi) = halves of splitmix64(seed):
+ *   x = (eid*H + h) ^ lo;  x *= 0x85ebca6b; x ^= x>>13; x *= 0xc2b2ae35; x ^= x>>16; x ^= hi;
+ *   keep(e,h) = (x >> 8) >= floor(p * 2^24)      (uint32 arithmetic).
  * ---------------------------------------------------------------------- */
 typedef struct segger_gatv2_fwd_args {
   segger_csr by_dst;      /* rows = destination nodes, col = source ids */

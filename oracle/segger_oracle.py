@@ -356,23 +356,29 @@ def bd_metric_loss(z, positives, negatives, dists_pos, dists_neg):
 # checked with an explicit mask.  Not part of the reference (its F.dropout
 # stream cannot be reproduced by any other implementation).
 # --------------------------------------------------------------------------
+def _splitmix64(z: int) -> int:
+    m = 0xFFFFFFFFFFFFFFFF
+    z = (z + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
 def dropout_keep_mask(seed: int, n_edges: int, heads: int, p: float) -> Tensor:
-    """keep[e,h] for ORIGINAL (COO) edge id e:  c = e*H + h (mod 2^32);
-    x = mix32(mix32(c ^ seed_lo) + seed_hi);  keep = (x >> 8) >= floor(p * 2^24).
-    mix32 = x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16."""
+    """keep[e,h] for ORIGINAL (COO) edge id e, as include/segger_amd.h defines it:
+    (lo, hi) = halves of splitmix64(seed); x = (e*H + h) ^ lo; x *= 0x85ebca6b; x ^= x>>13;
+    x *= 0xc2b2ae35; x ^= x>>16; x ^= hi; keep = (x >> 8) >= floor(p * 2^24)   (uint32)."""
     import numpy as np
-    def mix32(x):
-        x = x ^ (x >> np.uint32(16))
-        x = x * np.uint32(0x7FEB352D)
-        x = x ^ (x >> np.uint32(15))
-        x = x * np.uint32(0x846CA68B)
-        x = x ^ (x >> np.uint32(16))
-        return x
-    lo = np.uint32(seed & 0xFFFFFFFF)
-    hi = np.uint32((seed >> 32) & 0xFFFFFFFF)
+    s = _splitmix64(seed & 0xFFFFFFFFFFFFFFFF)
+    lo, hi = np.uint32(s & 0xFFFFFFFF), np.uint32(s >> 32)
     c = np.arange(n_edges * heads, dtype=np.uint64).astype(np.uint32)
     with np.errstate(over="ignore"):
-        x = mix32(mix32(c ^ lo) + hi)
+        x = c ^ lo
+        x = x * np.uint32(0x85EBCA6B)
+        x = x ^ (x >> np.uint32(13))
+        x = x * np.uint32(0xC2B2AE35)
+        x = x ^ (x >> np.uint32(16))
+        x = x ^ hi
     thr = np.uint32(int(p * float(1 << 24)))
     return torch.from_numpy(((x >> np.uint32(8)) >= thr).reshape(n_edges, heads))
 

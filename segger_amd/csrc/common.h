@@ -156,15 +156,19 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
   return cdf + x * pdf;
 }
 
-// counter-based attention-dropout mask (include/segger_amd.h)
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return x;
-}
+// counter-based attention-dropout mask (include/segger_amd.h): one murmur3-style finaliser per
+// (edge, head); seed_lo / seed_hi are the halves of splitmix64(seed), mixed on the host
 __device__ __forceinline__ bool dropout_keep(uint32_t eid, uint32_t heads, uint32_t h,
                                              uint32_t seed_lo, uint32_t seed_hi, uint32_t thr) {
-  const uint32_t c = eid * heads + h;
-  return (mix32(mix32(c ^ seed_lo) + seed_hi) >> 8) >= thr;
+  uint32_t x = (eid * heads + h) ^ seed_lo;
+  x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16; x ^= seed_hi;
+  return (x >> 8) >= thr;
+}
+static inline uint64_t splitmix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
 }
 
 // XCD-aware block remap: consecutive logical blocks land on the same XCD (blocks

@@ -73,8 +73,9 @@ void set_dropout(GatParams& p, float dropout_p, uint64_t seed) {
     p.drop_thr = (uint32_t)((double)dropout_p * 16777216.0);
     p.drop_scale = 1.0f / (1.0f - dropout_p);
   }
-  p.seed_lo = (uint32_t)(seed & 0xffffffffu);
-  p.seed_hi = (uint32_t)(seed >> 32);
+  const uint64_t mixed = splitmix64(seed);
+  p.seed_lo = (uint32_t)(mixed & 0xffffffffu);
+  p.seed_hi = (uint32_t)(mixed >> 32);
 }
 
 bool use_wave_per_row(const segger_csr& g) {

@@ -19,7 +19,16 @@
 
 namespace segger {
 
-constexpr int kEdgeUnroll = 4;   // neighbour rows in flight per lane
+// neighbour rows in flight per lane, per kernel
+#ifndef SEGGER_FWD_UNROLL
+#define SEGGER_FWD_UNROLL 4
+#endif
+#ifndef SEGGER_DST_UNROLL
+#define SEGGER_DST_UNROLL 2
+#endif
+#ifndef SEGGER_SRC_UNROLL
+#define SEGGER_SRC_UNROLL 4
+#endif
 
 // minimum resident waves per SIMD the register allocator must leave room for
 // (second __launch_bounds__ argument: 512 VGPRs / waves, granule 8)
@@ -27,7 +36,7 @@ constexpr int kEdgeUnroll = 4;   // neighbour rows in flight per lane
 #define SEGGER_FWD_WAVES 4
 #endif
 #ifndef SEGGER_BWD_DST_WAVES
-#define SEGGER_BWD_DST_WAVES 2
+#define SEGGER_BWD_DST_WAVES 3
 #endif
 #ifndef SEGGER_BWD_SRC_WAVES
 #define SEGGER_BWD_SRC_WAVES 3
@@ -100,10 +109,9 @@ constexpr int kDppRowRor0 = 0x120;   // row_ror:n
 // for successive batches of U edges of this group's share of row [beg,end).
 // All lanes of a group see identical arguments.  In wave-per-row mode the loop
 // is wave-uniform and a group may be handed a batch with valid[0] == false.
-template <int GS, bool WPR, bool NEED_EID, typename Body>
+template <int GS, bool WPR, bool NEED_EID, int U, typename Body>
 __device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
                                          int64_t beg, int64_t end, int lane, int grp, int gl, Body&& body) {
-  constexpr int U = kEdgeUnroll;
   constexpr int NG = 64 / GS;
   constexpr int CHUNK = WPR ? 64 : GS;      // ids fetched per coalesced load (per wave / per group)
   constexpr bool kDpp = !WPR && GS == 16;
@@ -248,7 +256,7 @@ __device__ __forceinline__ void load_att(const float* att, int ch0, float slope,
 template <typename T, int H, int LPH, bool WPR>
 __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatParams p) {
   using G = Geo<H, LPH>;
-  constexpr int GS = G::GS, NG = G::NG, U = kEdgeUnroll;
+  constexpr int GS = G::GS, NG = G::NG, U = SEGGER_FWD_UNROLL;
   const int64_t blk = xcd_remap(blockIdx.x, p.nblocks_padded, p.nblocks);
   if (blk < 0) return;
   const LaneGeo L = lane_geo<G>();
@@ -312,9 +320,9 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
     }
   };
   if (dropout || want_alpha)
-    walk_row<GS, WPR, true>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+    walk_row<GS, WPR, true, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
   else
-    walk_row<GS, WPR, false>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+    walk_row<GS, WPR, false, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
 
   if constexpr (WPR) {
     // merge the NG groups' online-softmax states
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
 template <typename T, int H, int LPH, bool WPR>
 __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kernel(GatParams p) {
   using G = Geo<H, LPH>;
-  constexpr int GS = G::GS, NG = G::NG, U = kEdgeUnroll, HC = G::HC;
+  constexpr int GS = G::GS, NG = G::NG, U = SEGGER_DST_UNROLL, HC = G::HC;
   __shared__ float red[4][2][HC];
   const int64_t blk = xcd_remap(blockIdx.x, p.nblocks_padded, p.nblocks);
   if (blk < 0) return;
@@ -465,9 +473,9 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
       }
     };
     if (dropout)
-      walk_row<GS, WPR, true>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+      walk_row<GS, WPR, true, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
     else
-      walk_row<GS, WPR, false>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+      walk_row<GS, WPR, false, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
 
     if constexpr (WPR) {
 #pragma unroll
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
 template <typename T, int H, int LPH, bool WPR>
 __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kernel(GatParams p) {
   using G = Geo<H, LPH>;
-  constexpr int GS = G::GS, NG = G::NG, U = kEdgeUnroll;
+  constexpr int GS = G::GS, NG = G::NG, U = SEGGER_SRC_UNROLL;
   const int64_t blk = xcd_remap(blockIdx.x, p.nblocks_padded, p.nblocks);
   if (blk < 0) return;
   const LaneGeo L = lane_geo<G>();
@@ -587,9 +595,9 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
     }
   };
   if (dropout)
-    walk_row<GS, WPR, true>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+    walk_row<GS, WPR, true, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
   else
-    walk_row<GS, WPR, false>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+    walk_row<GS, WPR, false, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
 
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = acc[i] + (a1[i] * Sde + a2[i] * Sg[i]) * kLn2;
