@@ -66,7 +66,7 @@ def host_threads():
     return max(1, min(n, 16))           # the GPU box gives 16 cores per GPU
 
 
-def cpu_baseline(sample_tx=10_000, sample_bd=100, k=15, budget_s=25.0):
+def cpu_baseline(sample_tx=50_000, sample_bd=500, k=15, budget_s=25.0):
     """The oracle (pure-torch CPU restatement of the PyG path, fp32) timed on the
     host cores over a bounded sample of the same workload: fwd + seg loss + bwd."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))

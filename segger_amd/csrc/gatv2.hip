@@ -38,7 +38,13 @@ namespace {
 // average-degree threshold above which the NG groups of a wave split ONE row
 constexpr double kWavePerRowDegree = 32.0;
 
-int launch(Pass pass, GatParams& p, int dtype, int heads, int channels, bool wpr, hipStream_t stream) {
+// set per call by the extern "C" entry points: generic kernels write grad_att / grad_bias themselves
+struct GenericOut { float* grad_att = nullptr; float* grad_bias = nullptr; };
+
+int launch(Pass pass, GatParams& p, int dtype, int heads, int channels, bool wpr, hipStream_t stream,
+           const GenericOut& gen = GenericOut()) {
+  if (!gatv2_has_specialised(heads, channels))
+    return gatv2_launch_generic((int)pass, p, dtype, heads, channels, gen.grad_att, gen.grad_bias, stream);
   typedef int (*fn_t)(GatParams&, int, int, bool, hipStream_t);
   static const fn_t table[3][3] = {
       {gatv2_launch_fwd_f32, gatv2_launch_fwd_bf16, gatv2_launch_fwd_f16},
@@ -50,11 +56,17 @@ int launch(Pass pass, GatParams& p, int dtype, int heads, int channels, bool wpr
 
 size_t elem_size(int dtype) { return dtype == SEGGER_F32 ? 4 : 2; }
 
+// vectorised (specialised) kernels need 16-byte aligned rows; the generic kernels load element-wise
+thread_local bool g_need_align = true;
+
 int check_rows(const char* name, const void* ptr, int64_t ld, int dtype, int hc) {
   SEGGER_REQUIRE(ptr != nullptr, "gatv2: %s is NULL", name);
-  SEGGER_REQUIRE(aligned16(ptr), "gatv2: %s is not 16-byte aligned", name);
   SEGGER_REQUIRE(ld >= hc, "gatv2: ld of %s (%lld) < heads*channels (%d)", name, (long long)ld, hc);
-  SEGGER_REQUIRE((ld * (int64_t)elem_size(dtype)) % 16 == 0, "gatv2: row stride of %s is not a multiple of 16 bytes", name);
+  SEGGER_REQUIRE(ld * (int64_t)elem_size(dtype) < 0xffffffffLL, "gatv2: row stride of %s exceeds 4 GiB", name);
+  if (g_need_align) {
+    SEGGER_REQUIRE(aligned16(ptr), "gatv2: %s is not 16-byte aligned", name);
+    SEGGER_REQUIRE((ld * (int64_t)elem_size(dtype)) % 16 == 0, "gatv2: row stride of %s is not a multiple of 16 bytes", name);
+  }
   return SEGGER_OK;
 }
 
@@ -93,6 +105,7 @@ extern "C" int segger_gatv2_fwd(const segger_gatv2_fwd_args* a, segger_stream_t 
   SEGGER_REQUIRE(a != nullptr, "segger_gatv2_fwd: args is NULL");
   SEGGER_REQUIRE(a->heads > 0 && a->channels > 0, "segger_gatv2_fwd: heads/channels must be positive");
   const int hc = a->heads * a->channels;
+  g_need_align = gatv2_has_specialised(a->heads, a->channels);
   CHECK_RC(check_csr("by_dst", a->by_dst));
   SEGGER_REQUIRE(a->att != nullptr, "segger_gatv2_fwd: att is NULL");
   SEGGER_REQUIRE(a->negative_slope >= 0.f && a->negative_slope <= 1.f, "segger_gatv2_fwd: negative_slope must be in [0,1]");
@@ -131,6 +144,8 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
   SEGGER_REQUIRE(a != nullptr, "segger_gatv2_bwd: args is NULL");
   SEGGER_REQUIRE(a->heads > 0 && a->channels > 0, "segger_gatv2_bwd: heads/channels must be positive");
   const int hc = a->heads * a->channels;
+  const bool specialised = gatv2_has_specialised(a->heads, a->channels);
+  g_need_align = specialised;
   CHECK_RC(check_csr("by_dst", a->by_dst));
   CHECK_RC(check_csr("by_src", a->by_src));
   SEGGER_REQUIRE(a->by_dst.n_edges == a->by_src.n_edges && a->by_dst.n_rows == a->by_src.n_cols &&
@@ -173,7 +188,9 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
   p.indptr = a->by_dst.indptr; p.col = a->by_dst.col; p.eid = a->by_dst.eid;
   p.n_rows = n_dst; p.n_edges = n_edges; p.rows_per_wave_iter = kBwdRowIters;
   if (n_dst > 0) {
-    CHECK_RC(launch(Pass::BwdDst, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), stream));
+    GenericOut gen; gen.grad_att = a->grad_att; gen.grad_bias = a->grad_bias;
+    CHECK_RC(launch(Pass::BwdDst, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), stream, gen));
+    if (specialised) {
     const int width = 2 * hc;
     float* part = p.slab + p.nblocks * width;          // behind the per-block slabs
     hipLaunchKernelGGL(slab_reduce_stage1, dim3((width + 63) / 64, kSlabSplits), dim3(256), 0, stream,
@@ -181,6 +198,7 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
     hipLaunchKernelGGL(slab_reduce_stage2, dim3((width + 255) / 256), dim3(256), 0, stream,
                        part, width, hc, a->grad_att, a->grad_bias);
     SEGGER_LAUNCH_CHECK("slab_reduce kernels");
+    }
   } else {
     SEGGER_HIP(hipMemsetAsync(a->grad_att, 0, hc * sizeof(float), stream));
     if (a->grad_bias) SEGGER_HIP(hipMemsetAsync(a->grad_bias, 0, hc * sizeof(float), stream));

@@ -30,4 +30,9 @@ SEGGER_DECL_LAUNCH(gatv2_launch_bwd_src_bf16)
 SEGGER_DECL_LAUNCH(gatv2_launch_bwd_src_f16)
 #undef SEGGER_DECL_LAUNCH
 
+// any other (heads, channels <= 512): one wave per row, element loads (gatv2_generic.hip)
+bool gatv2_has_specialised(int heads, int channels);
+int gatv2_launch_generic(int pass, GatParams& p, int dtype, int heads, int channels, float* grad_att, float* grad_bias,
+                         hipStream_t stream);
+
 }  // namespace segger

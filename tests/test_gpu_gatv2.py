@@ -51,6 +51,13 @@ CASES = [
     (4, 32, 64, 3, 600),
     (3, 64, 33, 40, 200),
     (2, 32, 80, 64, 0),
+    # no specialised geometry -> generic one-wave-per-row kernels (any H, C <= 512, unaligned rows)
+    (5, 16, 70, 40, 500),
+    (1, 40, 50, 9, 700),
+    (2, 128, 60, 30, 400),
+    (6, 24, 40, 25, 300),
+    (1, 5, 30, 12, 100),
+    (3, 200, 20, 8, 90),
 ]
 
 
@@ -176,8 +183,9 @@ def test_rejects_bad_arguments(cuda):
     with pytest.raises(IndexError):
         build_edge_graph(ei.to(cuda), 2, 2)
     graph = build_edge_graph(torch.tensor([[0, 1], [0, 1]]).to(cuda), 2, 2)
+    x = torch.randn(2, 600, device=cuda)
+    with pytest.raises(_lib.SeggerAmdError, match="exceeds the generic kernel's limit"):
+        ops.gatv2_aggregate(x, x, torch.randn(600, device=cuda), None, graph, 1, 600)
     x = torch.randn(2, 40, device=cuda)
-    with pytest.raises(_lib.SeggerAmdError, match="no specialised kernel"):
-        ops.gatv2_aggregate(x, x, torch.randn(40, device=cuda), None, graph, 1, 40)
     with pytest.raises(_lib.SeggerAmdError, match="no CPU fallback"):
         ops.gatv2_aggregate(x.cpu(), x.cpu(), torch.randn(40), None, graph, 1, 40)

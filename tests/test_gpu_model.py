@@ -31,7 +31,7 @@ def build(spec, dev, dtype=torch.float32, heads=2, hidden=64, in_channels=128, *
 
 
 @pytest.mark.parametrize("n_graphs", [1, 4])
-@pytest.mark.parametrize("heads,hidden", [(2, 64), (3, 32)])
+@pytest.mark.parametrize("heads,hidden", [(2, 64), (3, 32), (5, 24)])      # (5, 24): generic kernels
 def test_encoder_matches_oracle_fp32(oracle, cuda, n_graphs, heads, hidden):
     from segger_amd.synthetic import SyntheticSpec
     spec = SyntheticSpec(n_tx=1000, n_bd=100, k_tx=5, n_graphs=n_graphs, seed=3)
