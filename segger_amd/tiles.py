@@ -1,0 +1,375 @@
+"""Device-resident tile batcher: what feeds the hot path.
+
+Restates, with tensors that can live in HBM for the whole run,
+
+* ``SquareTiling``           reference ``src/segger/data/tiling.py:238-300`` (+ ``label`` / ``mask``
+                             semantics of ``Tiling``, ``:152-196``, for point geometries)
+* ``TilePartition``          ``data/partition/dataset.py:340-579`` as used by ``TileFitDataset``
+                             (``data/tile_dataset.py:13-153``): nodes permuted so every tile is a
+                             contiguous slice, inter-tile edges dropped, O(1) tile slicing, margin ``mask``
+* ``best_fit_decreasing`` / ``harmonic_k`` / ``first_fit_decreasing_bucketed`` / ``TileBatchSampler``
+                             ``data/partition/sampler.py:11-405`` (batches of tiles up to ``edges_per_batch``)
+* ``PredictTiles``           ``data/tile_dataset.py:156-264`` (bbox + margin subgraph, ``predict_mask``)
+
+The reference slices on the host inside DataLoader workers and ships every batch over PCIe; here the
+partitioned graph stays on the device and a batch is assembled by index arithmetic on device tensors
+(``TilePartition.batch``), so 8 ranks are not limited by Python ``__getitem__`` + collate.
+Everything is plain torch (works on CPU tensors too, which is how the unit tests run it).
+"""
+from __future__ import annotations
+
+import math
+import random
+from typing import Dict, Iterator, List, Optional, Sequence
+
+import torch
+from torch import Tensor
+
+from .hetero import EdgeType, HeteroBatch
+
+NODE_SKIP = ("batch", "num_nodes")
+
+
+# ------------------------------------------------------------------------------------------ tiling
+class SquareTiling:
+    """Uniform square grid over the extent of ``positions`` (edge tiles are clipped to the extent)."""
+
+    def __init__(self, positions: Tensor, side_length: float):
+        if side_length <= 0:
+            raise ValueError(f"side_length must be positive, but got {side_length}.")
+        if positions.dim() != 2 or positions.shape[-1] != 2:
+            raise ValueError(f"positions must be a tensor of shape (N, 2), but got {positions.shape}.")
+        if len(positions) == 0:
+            raise ValueError("positions cannot be empty.")
+        self.min_x, self.max_x = positions[:, 0].min().item(), positions[:, 0].max().item()
+        self.min_y, self.max_y = positions[:, 1].min().item(), positions[:, 1].max().item()
+        self.side_length = float(side_length)
+        self.nx = max(1, math.ceil((self.max_x - self.min_x) / self.side_length))
+        self.ny = max(1, math.ceil((self.max_y - self.min_y) / self.side_length))
+
+    def __len__(self) -> int:
+        return self.nx * self.ny
+
+    @property
+    def tiles(self) -> Tensor:
+        """[T, 4] boxes (x0, y0, x1, y1); tile id = ix * ny + iy (meshgrid 'ij' order of the reference)."""
+        ix = torch.arange(self.nx, dtype=torch.float64).repeat_interleave(self.ny)
+        iy = torch.arange(self.ny, dtype=torch.float64).repeat(self.nx)
+        x0 = self.min_x + ix * self.side_length
+        y0 = self.min_y + iy * self.side_length
+        x1 = torch.minimum(x0 + self.side_length, torch.tensor(self.max_x, dtype=torch.float64))
+        y1 = torch.minimum(y0 + self.side_length, torch.tensor(self.max_y, dtype=torch.float64))
+        return torch.stack([x0, y0, x1, y1], 1)
+
+    def _cell(self, pos: Tensor):
+        fx = (pos[:, 0].double() - self.min_x) / self.side_length
+        fy = (pos[:, 1].double() - self.min_y) / self.side_length
+        ix = fx.floor().long().clamp_(0, self.nx - 1)
+        iy = fy.floor().long().clamp_(0, self.ny - 1)
+        return ix, iy
+
+    def label(self, pos: Tensor) -> Tensor:
+        """Tile index of every point ('intersects': boundaries included; a point on a shared edge goes to
+        the upper tile, points on the extent's max edge to the last tile); -1 outside the extent."""
+        ix, iy = self._cell(pos)
+        lab = ix * self.ny + iy
+        inside = ((pos[:, 0] >= self.min_x) & (pos[:, 0] <= self.max_x) &
+                  (pos[:, 1] >= self.min_y) & (pos[:, 1] <= self.max_y))
+        return torch.where(inside, lab, torch.full_like(lab, -1))
+
+    def mask(self, pos: Tensor, margin: float) -> Tensor:
+        """True where the point lies strictly inside its tile shrunk by ``margin`` ('contains').  A margin
+        that would make a tile vanish is halved until every tile survives (tiling.py:103-127)."""
+        if margin < 0:
+            raise ValueError(f"The margin must be non-negative, but got {margin}.")
+        t = self.tiles
+        w = torch.minimum(t[:, 2] - t[:, 0], t[:, 3] - t[:, 1]).min().item()
+        eff = float(margin)
+        while eff > 0 and 2 * eff >= w:
+            eff = eff / 2 if eff > 1e-6 else 0.0
+        ix, iy = self._cell(pos)
+        tid = ix * self.ny + iy
+        box = t.to(pos.device)[tid]
+        x, y = pos[:, 0].double(), pos[:, 1].double()
+        return ((x > box[:, 0] + eff) & (x < box[:, 2] - eff) & (y > box[:, 1] + eff) & (y < box[:, 3] - eff))
+
+
+# --------------------------------------------------------------------------------------- partition
+class TilePartition:
+    """A full-slide graph re-ordered so that tile ``t`` owns nodes ``node_indptr[type][t:t+2]`` and edges
+    ``edge_indptr[etype][t:t+2]``; edges whose endpoints lie in different tiles are dropped (the reference
+    does the same, partition/dataset.py:480-494).  ``labels`` maps node type -> tile id per node."""
+
+    def __init__(self, data: HeteroBatch, labels: Dict[str, Tensor], num_tiles: int):
+        self.num_tiles = int(num_tiles)
+        self.node_perm: Dict[str, Tensor] = {}
+        self.node_indptr: Dict[str, Tensor] = {}
+        self.node_sizes: Dict[str, Tensor] = {}
+        self.edge_indptr: Dict[EdgeType, Tensor] = {}
+        self.edge_sizes: Dict[EdgeType, Tensor] = {}
+        self.data = HeteroBatch(num_graphs=1)
+        inv: Dict[str, Tensor] = {}
+        sorted_labels: Dict[str, Tensor] = {}
+        for nt in data.node_types:
+            lab = labels[nt].long()
+            if lab.numel() and (int(lab.min()) < 0 or int(lab.max()) >= self.num_tiles):
+                raise ValueError(f"node type '{nt}': tile labels must lie in [0, {self.num_tiles})")
+            perm = torch.argsort(lab, stable=True)
+            sizes = torch.bincount(lab, minlength=self.num_tiles)
+            self.node_perm[nt] = perm
+            self.node_sizes[nt] = sizes
+            self.node_indptr[nt] = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)])
+            for a, v in data[nt].items():
+                if a in NODE_SKIP:
+                    continue
+                self.data[nt][a] = v.index_select(0, perm) if isinstance(v, Tensor) else v
+            i = torch.empty_like(perm)
+            i[perm] = torch.arange(perm.numel(), device=perm.device)
+            inv[nt] = i
+            sorted_labels[nt] = lab[perm]
+        for et in data.edge_types:
+            s, _, d = et
+            ei = data[et].edge_index.long()
+            src, dst = inv[s][ei[0]], inv[d][ei[1]]
+            ls, ld = sorted_labels[s][src], sorted_labels[d][dst]
+            keep = ls == ld
+            order = torch.argsort(ls[keep], stable=True)
+            src, dst, lab = src[keep][order], dst[keep][order], ls[keep][order]
+            sizes = torch.bincount(lab, minlength=self.num_tiles)
+            self.data[et]["edge_index"] = torch.stack([src, dst])
+            self.edge_sizes[et] = sizes
+            self.edge_indptr[et] = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)])
+        # host copies of the pointers: batch assembly computes offsets without device syncs
+        self._nptr = {k: v.tolist() for k, v in self.node_indptr.items()}
+        self._eptr = {k: v.tolist() for k, v in self.edge_indptr.items()}
+
+    def __len__(self) -> int:
+        return self.num_tiles
+
+    def add_node_attr(self, node_type: str, name: str, value: Tensor, permuted: bool = False) -> None:
+        self.data[node_type][name] = value if permuted else value.index_select(0, self.node_perm[node_type])
+
+    def weights(self, mode: str = "edge") -> List[int]:
+        """Per-tile packing weight: total edges (all edge types) or total nodes (sampler.py:56-64)."""
+        src = self.edge_sizes if mode == "edge" else self.node_sizes
+        return torch.stack([v.cpu() for v in src.values()]).sum(0).tolist()
+
+    def tile(self, index: int) -> HeteroBatch:
+        return self.batch([index])
+
+    def batch(self, tile_ids: Sequence[int]) -> HeteroBatch:
+        """The collated batch of the given tiles (== PyG ``Batch.from_data_list([tile(i) ...])`` for the
+        fields of the contract): node slices concatenated, edge ids rebased, ``batch`` = graph id."""
+        tile_ids = [int(t) + (self.num_tiles if t < 0 else 0) for t in tile_ids]
+        for t in tile_ids:
+            if not 0 <= t < self.num_tiles:
+                raise IndexError(f"Index {t} is out of range for dataset with {self.num_tiles} partitions.")
+        out = HeteroBatch(num_graphs=len(tile_ids))
+        base: Dict[str, List[int]] = {}
+        for nt, store in self.data._nodes.items():
+            ptr = self._nptr[nt]
+            dev = self.node_perm[nt].device
+            offs, sizes, run = [], [], 0
+            for t in tile_ids:
+                offs.append(run)
+                sizes.append(ptr[t + 1] - ptr[t])
+                run += sizes[-1]
+            base[nt] = offs
+            for a, v in store.items():
+                if isinstance(v, Tensor):
+                    out[nt][a] = torch.cat([v[ptr[t]:ptr[t + 1]] for t in tile_ids], 0) if tile_ids else v[:0]
+                else:
+                    out[nt][a] = v
+            out[nt]["batch"] = torch.repeat_interleave(
+                torch.arange(len(tile_ids), device=dev), torch.tensor(sizes, device=dev, dtype=torch.long))
+        for et, store in self.data._edges.items():
+            s, _, d = et
+            ptr = self._eptr[et]
+            ei = store["edge_index"]
+            parts = []
+            for k, t in enumerate(tile_ids):
+                e = ei[:, ptr[t]:ptr[t + 1]]
+                shift = torch.tensor([[base[s][k] - self._nptr[s][t]], [base[d][k] - self._nptr[d][t]]],
+                                     device=ei.device, dtype=ei.dtype)
+                parts.append(e + shift)
+            out[et]["edge_index"] = torch.cat(parts, 1) if parts else ei[:, :0]
+        return out
+
+
+def partition_by_tiling(data: HeteroBatch, tiling: SquareTiling, margin: float, pos_key: str = "pos") -> TilePartition:
+    """``TileFitDataset``: label nodes by tile, partition, add the margin ``mask`` (tile_dataset.py:37-60,128-144)."""
+    for nt in data.node_types:
+        if "mask" in data[nt]:
+            raise KeyError(f"Node type '{nt}' in the 'data' object must not contain an attribute 'mask'.")
+    labels = {nt: tiling.label(data[nt][pos_key]) for nt in data.node_types}
+    part = TilePartition(data, labels, len(tiling))
+    for nt in data.node_types:
+        part.add_node_attr(nt, "mask", tiling.mask(part.data[nt][pos_key], margin), permuted=True)
+    return part
+
+
+# ------------------------------------------------------------------------------------- bin packing
+def _indexed(items: Sequence[float], cap: float, skip_too_big: bool):
+    if skip_too_big:
+        return [(v, i) for i, v in enumerate(items) if 0 < v <= cap]
+    if not all(0 < v <= cap for v in items):
+        raise ValueError("All items must be > 0 and <= bin_capacity.")
+    return [(v, i) for i, v in enumerate(items)]
+
+
+def best_fit_decreasing(items: Sequence[float], bin_capacity: float, skip_too_big: bool = False) -> List[List[int]]:
+    """Largest first; each item into the open bin it fills most tightly (sampler.py:11-84)."""
+    todo = sorted(_indexed(items, bin_capacity, skip_too_big), key=lambda x: x[0], reverse=True)
+    bins: List[List[int]] = []
+    room: List[float] = []
+    for v, i in todo:
+        best, slack = -1, float("inf")
+        for b, r in enumerate(room):
+            if r >= v and r - v < slack:
+                best, slack = b, r - v
+        if best < 0:
+            bins.append([i]); room.append(bin_capacity - v)
+        else:
+            bins[best].append(i); room[best] -= v
+    return bins
+
+
+def harmonic_k(items: Sequence[float], bin_capacity: float, k: int = 6, skip_too_big: bool = False) -> List[List[int]]:
+    """Online Harmonic-k: an item of scaled size in (1/(j+1), 1/j] shares a bin with j-1 peers of its
+    class; items <= 1/k are packed first-fit (sampler.py:87-178)."""
+    if k < 2:
+        raise ValueError("Parameter k must be an integer >= 2.")
+    todo = _indexed(items, bin_capacity, skip_too_big)
+    done: List[List[int]] = []
+    open_class: Dict[int, List[int]] = {}
+    small: List[List[int]] = []
+    small_room: List[float] = []
+    for v, i in todo:
+        scaled = v / bin_capacity
+        if scaled > 1 / k:
+            j = math.floor(1 / scaled)
+            open_class.setdefault(j, []).append(i)
+            if len(open_class[j]) == j:
+                done.append(open_class[j]); open_class[j] = []
+        else:
+            for b, r in enumerate(small_room):
+                if v <= r:
+                    small[b].append(i); small_room[b] -= v
+                    break
+            else:
+                small.append([i]); small_room.append(bin_capacity - v)
+    done.extend(b for b in open_class.values() if b)
+    done.extend(small)
+    return done
+
+
+def first_fit_decreasing_bucketed(items: Sequence[float], bin_capacity: float, skip_too_big: bool = False,
+                                  n_buckets: Optional[int] = 1, rng: Optional[random.Random] = None) -> List[List[int]]:
+    """First-fit over a descending order that is shuffled inside ``n_buckets`` value buckets
+    (None / >= n: plain FFD; 1: fully random first-fit), sampler.py:181-289."""
+    rng = rng or random
+    todo = sorted(_indexed(items, bin_capacity, skip_too_big), key=lambda x: x[0], reverse=True)
+    n = len(todo)
+    if n == 0:
+        return []
+    if n_buckets is not None and 1 <= n_buckets < n:
+        if n_buckets == 1:
+            rng.shuffle(todo)
+        else:
+            gaps = sorted(((todo[i - 1][0] - todo[i][0], i) for i in range(1, n)), reverse=True)
+            cuts = sorted({pos for _, pos in gaps[:n_buckets - 1]} | {n})
+            start = 0
+            for c in cuts:
+                seg = todo[start:c]
+                rng.shuffle(seg)            # NB: the reference shuffles a slice COPY (a no-op); we shuffle in place
+                todo[start:c] = seg
+                start = c
+    bins: List[List[int]] = []
+    room: List[float] = []
+    for v, i in todo:
+        for b, r in enumerate(room):
+            if r >= v:
+                bins[b].append(i); room[b] -= v
+                break
+        else:
+            bins.append([i]); room.append(bin_capacity - v)
+    return bins
+
+
+class TileBatchSampler:
+    """Batches of tile ids whose summed weight stays within ``max_num`` (PartitionSampler, sampler.py:292-405):
+    shuffle -> random order + bucketed first-fit, re-packed every epoch; otherwise best-fit-decreasing once."""
+
+    def __init__(self, partition: TilePartition, max_num: int, mode: str = "edge", shuffle: bool = False,
+                 skip_too_big: bool = False, seed: Optional[int] = None):
+        if mode not in ("node", "edge"):
+            raise ValueError("mode must be 'node' or 'edge'")
+        self.weights = partition.weights(mode)
+        self.max_num, self.shuffle, self.skip_too_big = max_num, shuffle, skip_too_big
+        self._rng = random.Random(seed)
+        self._batches: List[List[int]] = []
+        self._generate()
+
+    def _generate(self) -> None:
+        idx = list(range(len(self.weights)))
+        if self.shuffle:
+            self._rng.shuffle(idx)
+        w = [self.weights[i] for i in idx]
+        if self.shuffle:
+            bins = first_fit_decreasing_bucketed(w, self.max_num, self.skip_too_big, rng=self._rng)
+        else:
+            bins = best_fit_decreasing(w, self.max_num, self.skip_too_big)
+        self._batches = [[idx[j] for j in b] for b in bins]
+
+    def __iter__(self) -> Iterator[List[int]]:
+        yield from self._batches
+        if self.shuffle:
+            self._generate()
+
+    def __len__(self) -> int:
+        return len(self._batches)
+
+
+# ---------------------------------------------------------------------------------- predict tiles
+class PredictTiles:
+    """Overlapping prediction tiles: the subgraph of all nodes inside ``tile.buffer(margin)`` with a
+    ``predict_mask`` marking nodes inside the tile proper (tile_dataset.py:218-246).  Boxes follow the
+    reference's half-open outer test (``>= lo`` and ``< hi``) and closed inner test (``>=`` and ``<=``)."""
+
+    def __init__(self, data: HeteroBatch, tiles: Tensor, margin: float = 0.0):
+        missing = [nt for nt in data.node_types if "pos" not in data[nt]]
+        if missing:
+            raise ValueError(f"Missing 'pos' attribute for node type: {', '.join(missing)}")
+        self.data, self.tiles, self.margin = data, tiles, float(margin)
+
+    def __len__(self) -> int:
+        return int(self.tiles.shape[0])
+
+    def __getitem__(self, idx: int) -> HeteroBatch:
+        if idx < 0 or idx >= len(self):
+            raise IndexError(f"Requested {idx}, but tiling only contains {len(self)} tiles.")
+        x0, y0, x1, y1 = (float(v) for v in self.tiles[idx])
+        m = self.margin
+        out = HeteroBatch(num_graphs=1)
+        new_id: Dict[str, Tensor] = {}
+        for nt, store in self.data._nodes.items():
+            pos = store["pos"]
+            keep = (pos[:, 0] >= x0 - m) & (pos[:, 0] < x1 + m) & (pos[:, 1] >= y0 - m) & (pos[:, 1] < y1 + m)
+            sub = keep.nonzero(as_tuple=False).squeeze(1)
+            for a, v in store.items():
+                if a in NODE_SKIP:
+                    continue
+                out[nt][a] = v.index_select(0, sub) if isinstance(v, Tensor) else v
+            p = out[nt]["pos"]
+            out[nt]["predict_mask"] = (p[:, 0] >= x0) & (p[:, 0] <= x1) & (p[:, 1] >= y0) & (p[:, 1] <= y1)
+            out[nt]["batch"] = torch.zeros(sub.numel(), dtype=torch.long, device=pos.device)
+            nid = torch.full((pos.shape[0],), -1, dtype=torch.long, device=pos.device)
+            nid[sub] = torch.arange(sub.numel(), device=pos.device)
+            new_id[nt] = nid
+        for et, store in self.data._edges.items():
+            s, _, d = et
+            ei = store["edge_index"].long()
+            a, b = new_id[s][ei[0]], new_id[d][ei[1]]
+            ok = (a >= 0) & (b >= 0)
+            out[et]["edge_index"] = torch.stack([a[ok], b[ok]])
+        return out

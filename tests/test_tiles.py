@@ -1,0 +1,151 @@
+"""Tile batcher (host / torch logic; CPU): partition, O(1) tile slicing, collation, bin packing, predict tiles."""
+import random
+
+import pytest
+import torch
+
+from segger_amd.hetero import TX_BD, TX_NB_BD, TX_TX, collate
+from segger_amd.synthetic import SyntheticSpec, make_graph
+from segger_amd import tiles as T
+
+
+@pytest.fixture(scope="module")
+def graph():
+    g = make_graph(SyntheticSpec(n_tx=3000, n_bd=90, k_tx=6, seed=4))
+    for nt in ("tx", "bd"):
+        del g[nt]["mask"]                       # the fit mask is what the tile partition adds
+    return g
+
+
+def all_pos(g):
+    return torch.cat([g["tx"].pos, g["bd"].pos])
+
+
+def test_square_tiling_label_and_mask():
+    pos = torch.tensor([[0.0, 0.0], [10.0, 10.0], [4.9, 5.1], [5.0, 5.0], [9.99, 0.01], [2.5, 2.5]])
+    t = T.SquareTiling(pos, 5.0)
+    assert len(t) == 4 and t.tiles.shape == (4, 4)
+    lab = t.label(pos)
+    assert lab.tolist() == [0, 3, 1, 3, 2, 0]                 # id = ix * ny + iy; shared edges go to the upper tile
+    assert t.label(torch.tensor([[-1.0, 0.0], [11.0, 3.0]])).tolist() == [-1, -1]
+    m = t.mask(pos, 1.0)
+    assert m.tolist() == [False, False, False, False, False, True]
+    assert t.mask(pos, 0.0).tolist() == [False, False, True, False, True, True]     # strict interior
+    with pytest.raises(ValueError):
+        t.mask(pos, -1.0)
+    assert t.mask(pos, 100.0).dtype == torch.bool              # oversize margin is halved until tiles survive
+    with pytest.raises(ValueError):
+        T.SquareTiling(pos, 0.0)
+
+
+def test_partition_matches_naive_and_collate(graph):
+    tiling = T.SquareTiling(all_pos(graph), 40.0)
+    part = T.partition_by_tiling(graph, tiling, margin=3.0)
+    labels = {nt: tiling.label(graph[nt].pos) for nt in ("tx", "bd")}
+    n_t = len(tiling)
+    assert len(part) == n_t and sum(part.node_sizes["tx"].tolist()) == 3000
+    total_edges = {et: 0 for et in (TX_TX, TX_BD, TX_NB_BD)}
+    for t in range(n_t):
+        tile = part.tile(t)
+        for nt in ("tx", "bd"):
+            ids = (labels[nt] == t).nonzero().squeeze(1)                     # stable order inside a tile
+            assert torch.equal(tile[nt].index if nt == "tx" else tile[nt].index.long(), graph[nt].index[ids].long())
+            assert torch.equal(tile[nt].pos, graph[nt].pos[ids])
+            assert torch.equal(tile[nt]["mask"], tiling.mask(graph[nt].pos[ids], 3.0))
+            assert (tile[nt]["batch"] == 0).all()
+        for et in (TX_TX, TX_BD, TX_NB_BD):
+            s, _, d = et
+            ei = graph[et].edge_index
+            keep = (labels[s][ei[0]] == t) & (labels[d][ei[1]] == t)         # intra-tile edges only
+            want = {(int(graph[s].index[a]), int(graph[d].index[b])) for a, b in ei[:, keep].t().tolist()}
+            got_ei = tile[et].edge_index
+            got = {(int(tile[s].index[a]), int(tile[d].index[b])) for a, b in got_ei.t().tolist()}
+            assert got == want and got_ei.shape[1] == int(keep.sum())
+            total_edges[et] += got_ei.shape[1]
+    assert total_edges[TX_TX] < graph[TX_TX].edge_index.shape[1]             # inter-tile edges were dropped
+    # a batch assembled on the partition == PyG-style collation of the individual tiles
+    ids = [3, 0, n_t - 1]
+    b1, b2 = part.batch(ids), collate([part.tile(i) for i in ids])
+    assert b1.num_graphs == 3
+    for nt in ("tx", "bd"):
+        for a in ("x", "pos", "index", "mask", "cluster", "batch"):
+            assert torch.equal(b1[nt][a], b2[nt][a]), (nt, a)
+    for et in (TX_TX, TX_BD, TX_NB_BD):
+        assert torch.equal(b1[et].edge_index, b2[et].edge_index)
+    assert part.batch([-1])["tx"].num_nodes == part.tile(n_t - 1)["tx"].num_nodes
+    with pytest.raises(IndexError):
+        part.batch([n_t])
+    with pytest.raises(ValueError):
+        T.TilePartition(graph, {"tx": labels["tx"] - 1, "bd": labels["bd"]}, n_t)
+
+
+def check_bins(bins, items, cap):
+    flat = sorted(i for b in bins for i in b)
+    assert flat == list(range(len(items)))
+    assert all(sum(items[i] for i in b) <= cap + 1e-9 for b in bins)
+
+
+def test_bin_packing_algorithms():
+    items = [7, 5, 5, 4, 4, 3, 2, 2, 1, 1]
+    bfd = T.best_fit_decreasing(items, 10)
+    check_bins(bfd, items, 10)
+    assert len(bfd) == 4 and bfd[0] == [0, 5]                               # 7 + 3 fills the first bin exactly
+    hk = T.harmonic_k([6, 6, 4, 4, 4, 3, 1, 1], 10, k=3)
+    # classes: 0.6 -> j=1 (own bin each); 0.4 -> j=2 (pairs); 0.3, 0.1 -> small items, first-fit together
+    assert hk == [[0], [1], [2, 3], [4], [5, 6, 7]]
+    rng = random.Random(0)
+    ffd = T.first_fit_decreasing_bucketed(items, 10, n_buckets=None)
+    check_bins(ffd, items, 10)
+    assert ffd[0] == [0, 5]
+    check_bins(T.first_fit_decreasing_bucketed(items, 10, n_buckets=1, rng=rng), items, 10)
+    check_bins(T.first_fit_decreasing_bucketed(items, 10, n_buckets=3, rng=rng), items, 10)
+    with pytest.raises(ValueError):
+        T.best_fit_decreasing([11], 10)
+    assert T.best_fit_decreasing([11, 0, 3], 10, skip_too_big=True) == [[2]]
+    with pytest.raises(ValueError):
+        T.harmonic_k([1], 10, k=1)
+    assert T.first_fit_decreasing_bucketed([], 10) == []
+
+
+def test_tile_batch_sampler(graph):
+    part = T.partition_by_tiling(graph, T.SquareTiling(all_pos(graph), 25.0), margin=2.0)
+    w = part.weights("edge")
+    cap = max(w) * 3
+    s = T.TileBatchSampler(part, cap, mode="edge", skip_too_big=True)
+    batches = list(s)
+    used = sorted(i for b in batches for i in b)
+    assert used == [i for i, v in enumerate(w) if v > 0] and len(s) == len(batches)
+    assert all(sum(w[i] for i in b) <= cap for b in batches)
+    assert list(s) == batches                                                # deterministic without shuffle
+    sh = T.TileBatchSampler(part, cap, shuffle=True, skip_too_big=True, seed=1)
+    e1, e2 = list(sh), list(sh)
+    assert sorted(i for b in e1 for i in b) == used and e1 != e2             # re-packed every epoch
+    assert T.TileBatchSampler(part, max(part.weights("node")) * 2, mode="node", skip_too_big=True)
+    with pytest.raises(ValueError):
+        T.TileBatchSampler(part, 1, skip_too_big=False)
+
+
+def test_predict_tiles_subgraph(graph):
+    tiling = T.SquareTiling(all_pos(graph), 30.0)
+    ds = T.PredictTiles(graph, tiling.tiles, margin=4.0)
+    assert len(ds) == len(tiling)
+    seen = torch.zeros(3000, dtype=torch.long)
+    for i in range(len(ds)):
+        x0, y0, x1, y1 = ds.tiles[i].tolist()
+        t = ds[i]
+        pos = graph["tx"].pos
+        outer = (pos[:, 0] >= x0 - 4) & (pos[:, 0] < x1 + 4) & (pos[:, 1] >= y0 - 4) & (pos[:, 1] < y1 + 4)
+        assert torch.equal(t["tx"].index, graph["tx"].index[outer])
+        inner = (t["tx"].pos[:, 0] >= x0) & (t["tx"].pos[:, 0] <= x1) & (t["tx"].pos[:, 1] >= y0) & (t["tx"].pos[:, 1] <= y1)
+        assert torch.equal(t["tx"].predict_mask, inner)
+        seen[t["tx"].index[t["tx"].predict_mask]] += 1
+        ei = t[TX_NB_BD].edge_index
+        g_ei = graph[TX_NB_BD].edge_index
+        bd_outer = ((graph["bd"].pos[:, 0] >= x0 - 4) & (graph["bd"].pos[:, 0] < x1 + 4) &
+                    (graph["bd"].pos[:, 1] >= y0 - 4) & (graph["bd"].pos[:, 1] < y1 + 4))
+        want = {(a, b) for a, b in g_ei[:, outer[g_ei[0]] & bd_outer[g_ei[1]]].t().tolist()}
+        got = {(int(t["tx"].index[a]), int(t["bd"].index[b])) for a, b in ei.t().tolist()}
+        assert got == want
+    assert (seen >= 1).all()                    # every transcript is predicted by at least one tile
+    with pytest.raises(IndexError):
+        ds[len(ds)]
