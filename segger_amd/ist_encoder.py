@@ -252,7 +252,8 @@ class ISTEncoder(Module):
 
     def forward(self, x_dict: Dict[str, Tensor], edge_index_dict: Dict[EdgeType, Tensor],
                 pos_dict: Dict[str, Tensor], batch_dict: Dict[str, Tensor], *,
-                num_graphs: Optional[int] = None, cache: Optional[dict] = None) -> Dict[str, Tensor]:
+                num_graphs: Optional[int] = None, cache: Optional[dict] = None,
+                graphs: Optional[Dict[EdgeType, EdgeGraph]] = None) -> Dict[str, Tensor]:
         dt = self.compute_dtype
         self._materialize_bd(x_dict["bd"].shape[-1], x_dict["bd"].device)
         bd_lin = self.lin_first["bd"]
@@ -270,8 +271,9 @@ class ISTEncoder(Module):
             x_tx = F.gelu(emb(x_dict["tx"].long()).to(dt))
         x = {"tx": x_tx, "bd": x_bd}
 
-        graphs = {et: edge_graph(cache, et, edge_index_dict[et], x[et[0]].shape[0], x[et[2]].shape[0])
-                  for et in (TX_TX, TX_BD) if et in edge_index_dict}
+        if graphs is None:       # sorted views of the edge stores: built once per batch, shared by all layers
+            graphs = {et: edge_graph(cache, et, edge_index_dict[et], x[et[0]].shape[0], x[et[2]].shape[0])
+                      for et in (TX_TX, TX_BD) if et in edge_index_dict}
         if self.training:
             self._step += 1
         for li, layer in enumerate(self.conv_layers):

@@ -243,3 +243,35 @@ def test_tile_batches_are_independent_graphs(cuda):
 def batch_with_predict_mask(batch):
     batch["tx"]["predict_mask"] = torch.ones(batch["tx"].num_nodes, dtype=torch.bool, device=batch["tx"].pos.device)
     return batch
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_graphed_predictor_matches_eager_predict_step(cuda, dtype):
+    """hipGraph replay over bucket-padded batches == eager predict_step, for several tiles of different
+    sizes that share one bucket (config 5: inference-only edge scoring, fp16)."""
+    from segger_amd import tiles as T
+    from segger_amd.inference import GraphedPredictor, bucket_sizes
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=9000, n_bd=220, k_tx=8, seed=31)
+    m, _, b, _ = build(spec, cuda, dtype=dtype)
+    m.eval()
+    bg = b.to(cuda)
+    tiling = T.SquareTiling(torch.cat([b["tx"].pos, b["bd"].pos]), 50.0)
+    ds = T.PredictTiles(bg, tiling.tiles.to(cuda), margin=5.0)
+    tiles = [ds[i] for i in range(len(ds))]
+    tiles = [t for t in tiles if t["bd"].num_nodes > 1 and t["tx"].num_nodes > 100]
+    sizes = {}
+    for t in tiles:                                    # one bucket that fits every tile
+        for k, v in bucket_sizes(t, floor=256).items():
+            sizes[k] = max(sizes.get(k, 0), v)
+    gp = GraphedPredictor(m, sizes, bd_dim=spec.bd_dim)
+    n_checked = 0
+    for t in tiles[:6]:
+        want = m.predict_step(t, 0)
+        got = gp.predict(t)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[3], want[3])
+        tol = 1e-5 if dtype == torch.float32 else 2e-3
+        assert torch.allclose(got[2], want[2], atol=tol)
+        assert (got[1] == want[1]).float().mean() > (0.999 if dtype == torch.float32 else 0.98)
+        n_checked += 1
+    assert n_checked >= 3 and gp.graph is not None
