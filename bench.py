@@ -169,11 +169,10 @@ def main():
     bucket = FlatGradBucket(model.parameters())
 
     def step():
-        bucket.zero_()
+        opt.zero_grad(set_to_none=True)
         loss = model.training_step(batch, 0)
         loss.backward()
-        bucket.reattach()
-        bucket.all_reduce_mean()
+        bucket.all_reduce_mean()           # one flat RCCL all-reduce (no-op for a single rank)
         opt.step()
         return loss
 

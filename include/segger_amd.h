@@ -304,6 +304,21 @@ int segger_l2norm_fwd(const void* y, int64_t ld_y, int64_t n, int32_t channels, 
 int segger_l2norm_bwd(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, int64_t n, int32_t channels,
                       float eps, void* gy, int64_t ld_gy, int32_t dtype, segger_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Exact 2-D k-nearest neighbours on a uniform grid: the step BEFORE the hot path
+ * (graph construction).  Replaces scipy.spatial.KDTree(points).query(queries, k,
+ * distance_upper_bound=max_dist, workers=-1) in src/segger/data/utils/neighbors.py:122-163.
+ *   points [n,2] fp32; queries [m,2] fp32 or NULL (= points, then m must equal n);
+ *   grid: origin (x0,y0), square cells of side `cell`, nx x ny cells (points outside are
+ *   clamped into the border cells, so any grid is valid; the host picks ~2 points per cell);
+ *   nbr [m,k] int32: neighbour ids sorted by distance, padded with n (scipy's convention);
+ *   dist [m,k] fp32 or NULL: distances, +inf for padding;  1 <= k <= 64; max_dist may be +inf.
+ * ---------------------------------------------------------------------- */
+size_t segger_knn_workspace_bytes(int64_t n_points, int32_t nx, int32_t ny);
+int segger_knn_grid(const float* points, int64_t n_points, const float* queries, int64_t n_queries, int32_t k,
+                    float max_dist, float x0, float y0, float cell, int32_t nx, int32_t ny,
+                    int32_t* nbr, float* dist, void* workspace, size_t workspace_bytes, segger_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

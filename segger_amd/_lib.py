@@ -116,6 +116,9 @@ EXPORTS = {
                                         vp, vp, C.c_size_t, C.c_int32, vp]),
     "segger_l2norm_fwd": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, C.c_float, vp, C.c_int64, C.c_int32, vp]),
     "segger_l2norm_bwd": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_float, vp, C.c_int64, C.c_int32, vp]),
+    "segger_knn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "segger_knn_grid": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_int32, C.c_int32, vp, vp, vp, C.c_size_t, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -94,29 +94,37 @@ __global__ __launch_bounds__(256) void embed_gelu_bwd_pe_kernel(const T* __restr
 // Block (bx, by) owns a 32-channel slice `by` and a contiguous row range `bx`; it sums
 // sum_n gx0[n, c] per gene in an LDS table [G][32] (ds_add_f32), then writes the table to
 // partial[bx][G][D]; gelu'(table) is applied once per table entry by the reduce kernel.
-constexpr int kEmbSlice = 32;
+constexpr int kEmbSlice = 32;      // D must be a multiple of this
+// Block (bx, by) owns the channel slice [by*S, by*S+S) (S = 64 when the LDS table fits, else 32) and a
+// contiguous row range; a thread loads 8 channels of one row (16 B, a full 128-B line per row at S=64)
+// and adds them into the block's LDS table [G][S+1] (the +1 skews genes over banks).
 template <typename T>
 __global__ __launch_bounds__(256) void embed_grad_partial_kernel(const T* __restrict__ gx0, int64_t ld_g, const int32_t* __restrict__ ids,
-                                                                int64_t n, int G, int D, int64_t rows_per_block,
+                                                                int64_t n, int G, int D, int S, int64_t rows_per_block,
                                                                 float* __restrict__ partial) {
-  extern __shared__ float tab[];                         // [G][32]
-  for (int i = threadIdx.x; i < G * kEmbSlice; i += 256) tab[i] = 0.f;
+  extern __shared__ float tab[];                         // [G][S + 1]
+  const int stride = S + 1;
+  for (int i = threadIdx.x; i < G * stride; i += 256) tab[i] = 0.f;
   __syncthreads();
-  const int c = threadIdx.x & (kEmbSlice - 1);
-  const int rl = threadIdx.x / kEmbSlice;                // 8 rows per block iteration
-  const int c0 = blockIdx.y * kEmbSlice;
+  const int tpr = S / 8;                                 // threads per row
+  const int c8 = (threadIdx.x % tpr) * 8;
+  const int rl = threadIdx.x / tpr;
+  const int c0 = blockIdx.y * S;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
-  for (int64_t row = r0 + rl; row < r1; row += 256 / kEmbSlice) {
+  for (int64_t row = r0 + rl; row < r1; row += 256 / tpr) {
     const int g = ids[row];
-    const float v = ld1(gx0 + row * ld_g + c0 + c);
-    atomicAdd(&tab[g * kEmbSlice + c], v);               // LDS atomic
+    float v[8];
+    Vec8<T>::load(gx0 + row * ld_g + c0 + c8, v);
+    float* t = tab + g * stride + c8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) atomicAdd(t + k, v[k]);  // LDS atomics
   }
   __syncthreads();
   float* dst = partial + (int64_t)blockIdx.x * G * D;
-  for (int i = threadIdx.x; i < G * kEmbSlice; i += 256) {
-    const int g = i / kEmbSlice, cc = i % kEmbSlice;
-    dst[(int64_t)g * D + c0 + cc] = tab[i];
+  for (int i = threadIdx.x; i < G * S; i += 256) {
+    const int g = i / S, cc = i % S;
+    dst[(int64_t)g * D + c0 + cc] = tab[g * stride + cc];
   }
 }
 
@@ -268,7 +276,9 @@ extern "C" int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float*
   }
   SEGGER_REQUIRE(gx0 && pe && gpe, "segger_embed_gelu_bwd: NULL pointer");
   SEGGER_REQUIRE(aligned16(gx0) && aligned16(pe) && aligned16(gpe), "segger_embed_gelu_bwd: 16-byte alignment required");
-  const size_t lds_bytes = (size_t)n_rows_table * kEmbSlice * sizeof(float);
+  // widest channel slice whose [G][S+1] fp32 table fits the 160 KiB LDS
+  const int S = (D % 64 == 0 && (size_t)n_rows_table * 65 * sizeof(float) <= 160 * 1024) ? 64 : kEmbSlice;
+  const size_t lds_bytes = (size_t)n_rows_table * (S + 1) * sizeof(float);
   {
     const int64_t items = n * (D / 8);
     const int64_t nb = (items + 255) / 256;
@@ -290,12 +300,12 @@ extern "C" int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float*
     }
     const int64_t rpb = (n + nparts - 1) / nparts;
     float* partial = static_cast<float*>(workspace);
-    dim3 grid((unsigned)nparts, (unsigned)(D / kEmbSlice));
+    dim3 grid((unsigned)nparts, (unsigned)(D / S));
 #define GO(T)                                                                                                         \
   do {                                                                                                                \
     if (lds_bytes > 64 * 1024)                                                                                        \
       (void)hipFuncSetAttribute((const void*)embed_grad_partial_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-    hipLaunchKernelGGL((embed_grad_partial_kernel<T>), grid, dim3(256), lds_bytes, stream, (const T*)gx0, ld_g, ids, n, n_rows_table, D, rpb, partial); \
+    hipLaunchKernelGGL((embed_grad_partial_kernel<T>), grid, dim3(256), lds_bytes, stream, (const T*)gx0, ld_g, ids, n, n_rows_table, D, S, rpb, partial); \
   } while (0)
     DISPATCH_DTYPE(dtype, GO(float), GO(bf16_t), GO(f16_t))
 #undef GO

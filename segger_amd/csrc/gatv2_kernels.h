@@ -544,15 +544,19 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
   const bool dropout = p.drop_thr != 0;
 
   f32x2 a1[4], a2[4], v[4], acc[4], Sg[4];
-  load_att(p.att, ch0, p.slope, kLog2e, a1, a2);
 #pragma unroll
   for (int i = 0; i < 4; ++i) { v[i] = splat(0.f); acc[i] = splat(0.f); Sg[i] = splat(0.f); }
   float Sde = 0.f;
   int64_t beg = 0, end = 0;
-  if (row_ok) {
-    beg = p.indptr[row]; end = p.indptr[row + 1];
-    load_pairs(static_cast<const T*>(p.xl) + row * p.ld_xl + ch0, v);
+  if (row_ok) { beg = p.indptr[row]; end = p.indptr[row + 1]; }
+  // tx-belongs-bd by source: most transcripts have no out-edge; such waves only write zeros
+  if (__all(beg == end)) {
+    if (row_ok && L.lane_on && (!WPR || L.grp == 0))
+      store_pairs(static_cast<T*>(p.gxl) + row * p.ld_gxl + ch0, acc);
+    return;
   }
+  load_att(p.att, ch0, p.slope, kLog2e, a1, a2);
+  if (row_ok) load_pairs(static_cast<const T*>(p.xl) + row * p.ld_xl + ch0, v);
 
   auto body = [&](const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
     if (!valid[0]) return;

@@ -18,37 +18,23 @@ from torch import Tensor
 
 
 class FlatGradBucket:
-    """Owns one contiguous fp32 buffer that every parameter's ``.grad`` is a view of,
-    so ``all_reduce`` needs no pack/unpack copies."""
+    """One flat fp32 gradient exchange per optimizer step.
+
+    Autograd leaves every parameter its own ``.grad`` tensor (with ``zero_grad(set_to_none=True)`` the
+    accumulation step is a pointer hand-over, not an add kernel per parameter).  ``all_reduce_mean`` packs
+    those ~50 tensors into ONE contiguous buffer (a single ``cat``), runs ONE collective on it, and scatters
+    the averaged slices back with one multi-tensor copy -- three launches instead of one collective per
+    parameter.  With a single rank it does nothing at all."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
-        dev = self.params[0].device
-        n = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
-        off = 0
         for p in self.params:
             if p.dtype != torch.float32:
                 raise TypeError("parameters are kept in fp32")
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-
-    def zero_(self) -> None:
-        self.flat.zero_()
-
-    def reattach(self) -> None:
-        """Re-point ``.grad`` at the bucket (after ``zero_grad(set_to_none=True)``)."""
-        off = 0
-        for p in self.params:
-            v = self.flat[off:off + p.numel()].view_as(p)
-            if p.grad is None:
-                p.grad = v
-            elif p.grad.data_ptr() != v.data_ptr():
-                v.copy_(p.grad)
-                p.grad = v
-            off += p.numel()
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat: torch.Tensor = torch.empty(0)
 
     def all_reduce_mean(self, group=None) -> None:
         if not (dist.is_available() and dist.is_initialized()):
@@ -56,8 +42,19 @@ class FlatGradBucket:
         world = dist.get_world_size(group)
         if world == 1:
             return
+        grads = []
+        for p in self.params:                      # a rank whose tile never touched a parameter sends zeros
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            grads.append(p.grad)
+        self.flat = torch.cat([g.reshape(-1) for g in grads])
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         self.flat.div_(world)
+        views, off = [], 0
+        for g in grads:
+            views.append(self.flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
+        torch._foreach_copy_(grads, views)
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:
