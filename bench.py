@@ -239,6 +239,16 @@ def main():
                                      "algorithmic_bytes_per_launch": b_bwd, "ms_per_launch": ms_bwd}}
         log(f"[bench] gatv2 fwd {ms_fwd:.3f} ms ({ach:.0f} GB/s alg.), bwd {ms_bwd:.3f} ms ({ach_b:.0f} GB/s alg.)")
 
+    # ---- secondary figure: inference-only edge scoring (predict_step) on the same tile ----------------
+    predict = None
+    if rank == 0:
+        model.eval()
+        with torch.no_grad():
+            ms_pred = time_kernel(lambda: model.predict_step(batch, 0), iters=5, warm=2)
+        predict = {"ms_per_batch": ms_pred, "edges_scored_per_s": ep / (ms_pred * 1e-3),
+                   "note": "predict_step incl. mask + D2H of the 4-tuple, eager (no hipGraph), same dtype"}
+        log(f"[bench] predict_step {ms_pred:.2f} ms -> {ep / (ms_pred * 1e-3):.3e} tx->cell edges/s")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -262,7 +272,7 @@ def main():
                        "tiles_per_step": world, "parallelism": f"dp{world}"},
             "mp_edges_per_s": n_layers * (ett_all + etb_all) * args.steps / dt,
             "loss": loss_val,
-            "roofline": roof, "roofline_other": extra, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_other": extra, "cpu_baseline": cpu, "predict": predict,
         }
         print(json.dumps(res), flush=True)
     if world > 1:
