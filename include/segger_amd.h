@@ -104,7 +104,7 @@ int segger_csr_from_coo(const int64_t* row, const int64_t* colv, int64_t n_edges
  *   out        = apply_gelu ? gelu_erf(pre) : pre
  *
  * A destination without in-edges gets pre = bias.
- * Dropout (ist_encoder.py:116,123; training only), with (lo, hi) = halves of splitmix64(seed):
+ * Dropout (ist_encoder.py:116,123; training only), with (lo, hi) = halves of splitmix64(seed + *seed_dev):
  *   x = (eid*H + h) ^ lo;  x *= 0x85ebca6b; x ^= x>>13; x *= 0xc2b2ae35; x ^= x>>16; x ^= hi;
  *   keep(e,h) = (x >> 8) >= floor(p * 2^24)      (uint32 arithmetic).
  * ---------------------------------------------------------------------- */
@@ -123,6 +123,8 @@ typedef struct segger_gatv2_fwd_args {
   float negative_slope;   /* 0.2 in GATv2Conv */
   float dropout_p;        /* 0 = eval */
   uint64_t seed;
+  const uint64_t* seed_dev; /* optional DEVICE word: the effective seed is seed + *seed_dev, read when the kernel
+                               runs (a captured hipGraph draws a fresh mask every replay); NULL = seed alone */
   void* out;              /* [n_dst, H*C] */
   int64_t ld_out;
   void* pre;              /* [n_dst, H*C] pre-activation for backward; NULL = skip
@@ -159,6 +161,7 @@ typedef struct segger_gatv2_bwd_args {
   float negative_slope;
   float dropout_p;
   uint64_t seed;
+  const uint64_t* seed_dev; /* as in forward; must hold the value the forward saw */
   const void* grad_out;   /* [n_dst, H*C] dL/d out */
   int64_t ld_go;
   const void* pre;        /* [n_dst, H*C] from forward */

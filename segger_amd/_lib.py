@@ -41,7 +41,7 @@ class GatFwdArgs(C.Structure):
         ("x_r", vp), ("ld_xr", C.c_int64),
         ("att", vp), ("bias", vp),
         ("heads", C.c_int32), ("channels", C.c_int32), ("dtype", C.c_int32), ("apply_gelu", C.c_int32),
-        ("negative_slope", C.c_float), ("dropout_p", C.c_float), ("seed", C.c_uint64),
+        ("negative_slope", C.c_float), ("dropout_p", C.c_float), ("seed", C.c_uint64), ("seed_dev", vp),
         ("out", vp), ("ld_out", C.c_int64),
         ("pre", vp), ("ld_pre", C.c_int64),
         ("lse", vp), ("alpha", vp),
@@ -55,7 +55,7 @@ class GatBwdArgs(C.Structure):
         ("x_r", vp), ("ld_xr", C.c_int64),
         ("att", vp), ("bias", vp),
         ("heads", C.c_int32), ("channels", C.c_int32), ("dtype", C.c_int32), ("apply_gelu", C.c_int32),
-        ("negative_slope", C.c_float), ("dropout_p", C.c_float), ("seed", C.c_uint64),
+        ("negative_slope", C.c_float), ("dropout_p", C.c_float), ("seed", C.c_uint64), ("seed_dev", vp),
         ("grad_out", vp), ("ld_go", C.c_int64),
         ("pre", vp), ("ld_pre", C.c_int64),
         ("lse", vp),

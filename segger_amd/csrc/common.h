@@ -164,7 +164,7 @@ __device__ __forceinline__ bool dropout_keep(uint32_t eid, uint32_t heads, uint3
   x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16; x ^= seed_hi;
   return (x >> 8) >= thr;
 }
-static inline uint64_t splitmix64(uint64_t z) {
+__host__ __device__ static inline uint64_t splitmix64(uint64_t z) {
   z += 0x9e3779b97f4a7c15ull;
   z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
   z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;

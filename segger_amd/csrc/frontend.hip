@@ -277,7 +277,9 @@ extern "C" int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float*
   SEGGER_REQUIRE(gx0 && pe && gpe, "segger_embed_gelu_bwd: NULL pointer");
   SEGGER_REQUIRE(aligned16(gx0) && aligned16(pe) && aligned16(gpe), "segger_embed_gelu_bwd: 16-byte alignment required");
   // widest channel slice whose [G][S+1] fp32 table fits the 160 KiB LDS
-  const int S = (D % 64 == 0 && (size_t)n_rows_table * 65 * sizeof(float) <= 160 * 1024) ? 64 : kEmbSlice;
+  // (64-wide slices only while the table stays within the default 64 KiB dynamic-LDS limit: larger requests
+  //  need hipFuncSetAttribute, and hipGraph instantiation of such kernel nodes crashed on ROCm 7.0/7.2)
+  const int S = (D % 64 == 0 && (size_t)n_rows_table * 65 * sizeof(float) <= 64 * 1024) ? 64 : kEmbSlice;
   const size_t lds_bytes = (size_t)n_rows_table * (S + 1) * sizeof(float);
   {
     const int64_t items = n * (D / 8);
@@ -303,8 +305,11 @@ extern "C" int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float*
     dim3 grid((unsigned)nparts, (unsigned)(D / S));
 #define GO(T)                                                                                                         \
   do {                                                                                                                \
-    if (lds_bytes > 64 * 1024)                                                                                        \
-      (void)hipFuncSetAttribute((const void*)embed_grad_partial_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+    static bool attr_set = false;   /* once per type: not a stream operation, keep it out of graph captures */   \
+    if (!attr_set) {                                                                                                  \
+      (void)hipFuncSetAttribute((const void*)embed_grad_partial_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      attr_set = true;                                                                                                \
+    }                                                                                                                 \
     hipLaunchKernelGGL((embed_grad_partial_kernel<T>), grid, dim3(256), lds_bytes, stream, (const T*)gx0, ld_g, ids, n, n_rows_table, D, S, rpb, partial); \
   } while (0)
     DISPATCH_DTYPE(dtype, GO(float), GO(bf16_t), GO(f16_t))

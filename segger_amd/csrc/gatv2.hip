@@ -79,7 +79,7 @@ int check_csr(const char* name, const segger_csr& g) {
   return SEGGER_OK;
 }
 
-void set_dropout(GatParams& p, float dropout_p, uint64_t seed) {
+void set_dropout(GatParams& p, float dropout_p, uint64_t seed, const uint64_t* seed_dev) {
   p.drop_thr = 0; p.drop_scale = 1.f;
   if (dropout_p > 0.f) {
     p.drop_thr = (uint32_t)((double)dropout_p * 16777216.0);
@@ -88,6 +88,8 @@ void set_dropout(GatParams& p, float dropout_p, uint64_t seed) {
   const uint64_t mixed = splitmix64(seed);
   p.seed_lo = (uint32_t)(mixed & 0xffffffffu);
   p.seed_hi = (uint32_t)(mixed >> 32);
+  p.seed_raw = seed;
+  p.seed_dev = seed_dev;
 }
 
 bool use_wave_per_row(const segger_csr& g) {
@@ -128,14 +130,15 @@ extern "C" int segger_gatv2_fwd(const segger_gatv2_fwd_args* a, segger_stream_t 
   p.out = a->out; p.ld_out = a->ld_out; p.pre = a->pre; p.ld_pre = a->ld_pre;
   p.lse = a->lse; p.alpha = a->alpha;
   p.slope = a->negative_slope; p.apply_gelu = a->apply_gelu; p.rows_per_wave_iter = 1;
-  set_dropout(p, a->dropout_p, a->seed);
+  set_dropout(p, a->dropout_p, a->seed, a->seed_dev);
   return launch(Pass::Fwd, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), (hipStream_t)stream);
 }
 
 extern "C" size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads, int32_t channels) {
   if (n_dst <= 0 || heads <= 0 || channels <= 0) return 16;
   // upper bound over both modes: wave-per-row has the most blocks (4 rows per block-iteration)
-  const int64_t blocks = (n_dst + 4 * kBwdRowIters - 1) / (4 * kBwdRowIters) + kNumXcd;
+  const int64_t per = 4 * (int64_t)bwd_row_iters(n_dst);
+  const int64_t blocks = (n_dst + per - 1) / per + kNumXcd;
   return (size_t)(blocks + kSlabSplits) * 2 * heads * channels * sizeof(float);
 }
 
@@ -182,11 +185,11 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
   p.gxl = a->grad_xl; p.ld_gxl = a->ld_gxl; p.gxr = a->grad_xr; p.ld_gxr = a->ld_gxr;
   p.slab = static_cast<float*>(a->workspace);
   p.slope = a->negative_slope; p.apply_gelu = a->apply_gelu;
-  set_dropout(p, a->dropout_p, a->seed);
+  set_dropout(p, a->dropout_p, a->seed, a->seed_dev);
 
   // ---- destination side ------------------------------------------------------
   p.indptr = a->by_dst.indptr; p.col = a->by_dst.col; p.eid = a->by_dst.eid;
-  p.n_rows = n_dst; p.n_edges = n_edges; p.rows_per_wave_iter = kBwdRowIters;
+  p.n_rows = n_dst; p.n_edges = n_edges; p.rows_per_wave_iter = bwd_row_iters(n_dst);
   if (n_dst > 0) {
     GenericOut gen; gen.grad_att = a->grad_att; gen.grad_bias = a->grad_bias;
     CHECK_RC(launch(Pass::BwdDst, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), stream, gen));

@@ -41,6 +41,11 @@ __global__ __launch_bounds__(256) void gen_fwd_kernel(GenParams q) {
   const T* xr = static_cast<const T*>(p.xr);
   const int64_t beg = p.indptr[row], end = p.indptr[row + 1];
   const bool dropout = p.drop_thr != 0;
+  uint32_t seed_lo = p.seed_lo, seed_hi = p.seed_hi;
+  if (dropout && p.seed_dev) {
+    const uint64_t mixed = splitmix64(p.seed_raw + *p.seed_dev);
+    seed_lo = (uint32_t)mixed; seed_hi = (uint32_t)(mixed >> 32);
+  }
   for (int h = 0; h < H; ++h) {
     float xr_c[kMaxCPL], att_c[kMaxCPL], acc[kMaxCPL];
 #pragma unroll
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(256) void gen_fwd_kernel(GenParams q) {
       s = s * sc + pe;
       float w = pe;
       const int64_t id = p.eid ? (int64_t)p.eid[e] : e;
-      if (dropout) w = dropout_keep((uint32_t)id, H, h, p.seed_lo, p.seed_hi, p.drop_thr) ? pe * p.drop_scale : 0.f;
+      if (dropout) w = dropout_keep((uint32_t)id, H, h, seed_lo, seed_hi, p.drop_thr) ? pe * p.drop_scale : 0.f;
       if (p.alpha && lane == 0) p.alpha[id * H + h] = e2;
 #pragma unroll
       for (int k = 0; k < kMaxCPL; ++k) acc[k] = acc[k] * sc + w * v[k];
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256) void gen_fwd_kernel(GenParams q) {
       for (int64_t e = beg; e < end; ++e) {
         const int64_t id = p.eid ? (int64_t)p.eid[e] : e;
         float a = fast_exp2(p.alpha[id * H + h] - lse);
-        if (dropout) a = dropout_keep((uint32_t)id, H, h, p.seed_lo, p.seed_hi, p.drop_thr) ? a * p.drop_scale : 0.f;
+        if (dropout) a = dropout_keep((uint32_t)id, H, h, seed_lo, seed_hi, p.drop_thr) ? a * p.drop_scale : 0.f;
         p.alpha[id * H + h] = a;
       }
     }
@@ -107,6 +112,11 @@ __global__ __launch_bounds__(256) void gen_bwd_dst_kernel(GenParams q) {
   const T* xr = static_cast<const T*>(p.xr);
   const int64_t beg = p.indptr[row], end = p.indptr[row + 1];
   const bool dropout = p.drop_thr != 0;
+  uint32_t seed_lo = p.seed_lo, seed_hi = p.seed_hi;
+  if (dropout && p.seed_dev) {
+    const uint64_t mixed = splitmix64(p.seed_raw + *p.seed_dev);
+    seed_lo = (uint32_t)mixed; seed_hi = (uint32_t)(mixed >> 32);
+  }
   for (int h = 0; h < H; ++h) {
     float xr_c[kMaxCPL], att_c[kMaxCPL], g[kMaxCPL], dxr[kMaxCPL], datt[kMaxCPL];
     float D = 0.f;
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256) void gen_bwd_dst_kernel(GenParams q) {
       pl = wave_sum(pl); da = wave_sum(da);
       const float a = fast_exp2(pl * kLog2e - lse);
       const int64_t id = p.eid ? (int64_t)p.eid[e] : e;
-      if (dropout) da = dropout_keep((uint32_t)id, H, h, p.seed_lo, p.seed_hi, p.drop_thr) ? da * p.drop_scale : 0.f;
+      if (dropout) da = dropout_keep((uint32_t)id, H, h, seed_lo, seed_hi, p.drop_thr) ? da * p.drop_scale : 0.f;
       const float de = a * (da - D);
 #pragma unroll
       for (int k = 0; k < kMaxCPL; ++k) {
@@ -174,6 +184,11 @@ __global__ __launch_bounds__(256) void gen_bwd_src_kernel(GenParams q) {
   const T* gp = static_cast<const T*>(p.gpre);
   const int64_t beg = p.indptr[row], end = p.indptr[row + 1];
   const bool dropout = p.drop_thr != 0;
+  uint32_t seed_lo = p.seed_lo, seed_hi = p.seed_hi;
+  if (dropout && p.seed_dev) {
+    const uint64_t mixed = splitmix64(p.seed_raw + *p.seed_dev);
+    seed_lo = (uint32_t)mixed; seed_hi = (uint32_t)(mixed >> 32);
+  }
   for (int h = 0; h < H; ++h) {
     float v[kMaxCPL], att_c[kMaxCPL], acc[kMaxCPL];
 #pragma unroll
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(256) void gen_bwd_src_kernel(GenParams q) {
       float a_eff = a;
       const int64_t id = p.eid ? (int64_t)p.eid[e] : e;
       if (dropout) {
-        const bool keep = dropout_keep((uint32_t)id, H, h, p.seed_lo, p.seed_hi, p.drop_thr);
+        const bool keep = dropout_keep((uint32_t)id, H, h, seed_lo, seed_hi, p.drop_thr);
         da = keep ? da * p.drop_scale : 0.f;
         a_eff = keep ? a * p.drop_scale : 0.f;
       }

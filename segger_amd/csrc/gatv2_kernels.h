@@ -82,7 +82,9 @@ struct GatParams {
   float slope;
   float drop_scale;              // 1/(1-p)
   uint32_t drop_thr;             // floor(p * 2^24); 0 = no dropout
-  uint32_t seed_lo, seed_hi;
+  uint32_t seed_lo, seed_hi;      // halves of splitmix64(seed) when seed_dev is NULL
+  const uint64_t* seed_dev;       // optional device word added to seed_raw before mixing (hipGraph replays)
+  uint64_t seed_raw;
   int32_t apply_gelu;
   int32_t rows_per_wave_iter;    // dst pass: row batches each wave walks
   int64_t nblocks, nblocks_padded;
@@ -267,6 +269,11 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
   const char* __restrict__ xl = static_cast<const char*>(p.xl) + (size_t)ch0 * sizeof(T);
   const uint32_t ld_xl = (uint32_t)(p.ld_xl * sizeof(T));
   const bool dropout = p.drop_thr != 0;
+  uint32_t seed_lo = p.seed_lo, seed_hi = p.seed_hi;
+  if (dropout && p.seed_dev) {
+    const uint64_t mixed = splitmix64(p.seed_raw + *p.seed_dev);
+    seed_lo = (uint32_t)mixed; seed_hi = (uint32_t)(mixed >> 32);
+  }
   const bool want_alpha = p.alpha != nullptr;
 
   f32x2 a1[4], a2[4], xr[4], acc[4];
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
       const float pe = fast_exp2(e[u] - mx);          // invalid -> 0
       s += pe;
       float w = pe;
-      if (dropout) w = dropout_keep((uint32_t)ed[u], H, h, p.seed_lo, p.seed_hi, p.drop_thr) ? pe * p.drop_scale : 0.f;
+      if (dropout) w = dropout_keep((uint32_t)ed[u], H, h, seed_lo, seed_hi, p.drop_thr) ? pe * p.drop_scale : 0.f;
       if (want_alpha && valid[u] && head_leader) p.alpha[(int64_t)ed[u] * H + h] = e[u];
       f32x2 v[4];
       raw[u].get(v);
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
     for (int64_t e = beg + (WPR ? L.grp : 0); e < end; e += step) {
       const int64_t id = p.eid[e];
       float a = fast_exp2(p.alpha[id * H + h] - lse);
-      if (dropout) a = dropout_keep((uint32_t)id, H, h, p.seed_lo, p.seed_hi, p.drop_thr) ? a * p.drop_scale : 0.f;
+      if (dropout) a = dropout_keep((uint32_t)id, H, h, seed_lo, seed_hi, p.drop_thr) ? a * p.drop_scale : 0.f;
       p.alpha[id * H + h] = a;
     }
   }
@@ -397,6 +404,11 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
   const char* __restrict__ xl = static_cast<const char*>(p.xl) + (size_t)ch0 * sizeof(T);
   const uint32_t ld_xl = (uint32_t)(p.ld_xl * sizeof(T));
   const bool dropout = p.drop_thr != 0;
+  uint32_t seed_lo = p.seed_lo, seed_hi = p.seed_hi;
+  if (dropout && p.seed_dev) {
+    const uint64_t mixed = splitmix64(p.seed_raw + *p.seed_dev);
+    seed_lo = (uint32_t)mixed; seed_hi = (uint32_t)(mixed >> 32);
+  }
   constexpr int RPW = WPR ? 1 : NG;            // rows per wave per iteration
 
   f32x2 a1[4], a2[4], Pt[4], Qt[4], dbias[4];
@@ -457,7 +469,7 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
         const float pl = lane_block_sum<LPH>(logit_partial(t, a1, a2));
         float da = lane_block_sum<LPH>(da2.x + da2.y);
         const float a = valid[u] ? fast_exp2(pl - lse) : 0.f;
-        if (dropout) da = dropout_keep((uint32_t)ed[u], H, h, p.seed_lo, p.seed_hi, p.drop_thr) ? da * p.drop_scale : 0.f;
+        if (dropout) da = dropout_keep((uint32_t)ed[u], H, h, seed_lo, seed_hi, p.drop_thr) ? da * p.drop_scale : 0.f;
         const float de = a * (da - D);
         Sde += de;
         const f32x2 de2 = splat(de);
@@ -542,6 +554,11 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
   const char* __restrict__ g_base = static_cast<const char*>(p.gpre) + (size_t)ch0 * sizeof(T);
   const uint32_t ld_xr = (uint32_t)(p.ld_xr * sizeof(T)), ld_gp = (uint32_t)(p.ld_gp * sizeof(T));
   const bool dropout = p.drop_thr != 0;
+  uint32_t seed_lo = p.seed_lo, seed_hi = p.seed_hi;
+  if (dropout && p.seed_dev) {
+    const uint64_t mixed = splitmix64(p.seed_raw + *p.seed_dev);
+    seed_lo = (uint32_t)mixed; seed_hi = (uint32_t)(mixed >> 32);
+  }
 
   f32x2 a1[4], a2[4], v[4], acc[4], Sg[4];
 #pragma unroll
@@ -582,7 +599,7 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
       const float a = valid[u] ? fast_exp2(pl - lse[u]) : 0.f;
       float a_eff = a;
       if (dropout) {
-        const bool keep = dropout_keep((uint32_t)ed[u], H, h, p.seed_lo, p.seed_hi, p.drop_thr);
+        const bool keep = dropout_keep((uint32_t)ed[u], H, h, seed_lo, seed_hi, p.drop_thr);
         da = keep ? da * p.drop_scale : 0.f;
         a_eff = keep ? a * p.drop_scale : 0.f;
       }

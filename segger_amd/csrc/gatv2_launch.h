@@ -11,6 +11,12 @@ enum class Pass : int { Fwd = 0, BwdDst = 1, BwdSrc = 2 };
 // destination rows walked per wave in the dst-side backward (amortises the
 // per-block grad_att / grad_bias partial slab)
 constexpr int kBwdRowIters = 8;
+// ... but small graphs (tile batches of ~50 k nodes) keep one row batch per wave so the grid still has
+// thousands of blocks: iterations grow with the row count, 1 below 32 k rows, 8 from 256 k rows up
+static inline int bwd_row_iters(int64_t n_rows) {
+  const int64_t it = n_rows / 32768;
+  return (int)(it < 1 ? 1 : (it > kBwdRowIters ? kBwdRowIters : it));
+}
 
 // (heads, channels/8) combinations with a specialised kernel
 #define SEGGER_GEOMETRIES(X) \

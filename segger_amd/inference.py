@@ -43,7 +43,7 @@ def bucket_sizes(batch, granularity: float = 1.25, floor: int = 1024) -> Dict[st
 def pad_batch(batch, sizes: Dict[str, int]) -> HeteroBatch:
     """Pad to ``sizes``: dummy nodes copy node 0's attributes (positions included, so per-graph min/max
     are unchanged), get ``predict_mask`` False, and padding edges connect the LAST dummy tx to the last dummy
-    tx / bd only."""
+    tx / bd only (spread round-robin over the dummies)."""
     out = HeteroBatch(num_graphs=getattr(batch, "num_graphs", 1))
     n = {}
     for nt in ("tx", "bd"):
@@ -66,7 +66,11 @@ def pad_batch(batch, sizes: Dict[str, int]) -> HeteroBatch:
         pad = tgt - ei.shape[1]
         if pad <= 0:
             raise ValueError(f"bucket for {et} ({tgt}) must exceed the edge count ({ei.shape[1]})")
-        fill = torch.tensor([[n[s] - 1], [n[d] - 1]], device=ei.device, dtype=ei.dtype).expand(2, pad)
+        # spread the padding edges round-robin over the dummy nodes: one dummy hub with ~25 % of all edges
+        # would serialise a whole kernel on a single row
+        k = torch.arange(pad, device=ei.device, dtype=ei.dtype)
+        n_ds, n_dd = n[s] - batch[s].num_nodes, n[d] - batch[d].num_nodes
+        fill = torch.stack([batch[s].num_nodes + k % n_ds, batch[d].num_nodes + k % n_dd])
         out[et]["edge_index"] = torch.cat([ei, fill], 1)
     return out
 

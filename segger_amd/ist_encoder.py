@@ -34,6 +34,13 @@ GAT_DROPOUT = 0.2          # ist_encoder.py:116,123
 NEGATIVE_SLOPE = 0.2       # GATv2Conv default
 
 
+def _layer_seed(seed, which: int):
+    """(2*layer + edge-type slot) with the optional device counter carried along."""
+    if isinstance(seed, tuple):
+        return (2 * int(seed[0]) + which, seed[1])
+    return 2 * int(seed) + which
+
+
 def pyg_key(edge_type: EdgeType) -> str:
     """torch_geometric's ModuleDict key for a tuple (state-dict compatibility)."""
     return "<" + "___".join(edge_type) + ">"
@@ -163,7 +170,7 @@ class SkipGAT(Module):
 
     def forward(self, x_dict: Dict[str, Tensor], edge_index_dict: Dict[EdgeType, Tensor], *,
                 graphs: Optional[Dict[EdgeType, EdgeGraph]] = None, apply_gelu: bool = False,
-                seed: int = 0) -> Dict[str, Tensor]:
+                seed=0) -> Dict[str, Tensor]:
         for et in (TX_TX, TX_BD):
             if et not in edge_index_dict:
                 raise KeyError(f"edge type {et} missing from edge_index_dict: segger's HeteroConv would "
@@ -183,7 +190,7 @@ class SkipGAT(Module):
         y_tx, y_bd, alpha = ops.hetero_gat_layer(
             xp_tx, xp_bd, tt.att, tt.bias, tb.att, tb.bias, graphs[TX_TX], graphs[TX_BD],
             self.n_heads, self.out_channels, apply_gelu=apply_gelu, negative_slope=tt.negative_slope,
-            dropout_p=p, seed_tt=2 * seed, seed_tb=2 * seed + 1, return_alpha=self.store_attention)
+            dropout_p=p, seed_tt=_layer_seed(seed, 0), seed_tb=_layer_seed(seed, 1), return_alpha=self.store_attention)
         if self.store_attention:
             self._attn_weights[TX_TX] = alpha
         return {"tx": y_tx, "bd": y_bd}
@@ -244,7 +251,9 @@ class ISTEncoder(Module):
         last_in = hidden_channels * n_heads
         self.conv_layers.append(SkipGAT((last_in, last_in), out_channels, n_heads))
         self.lin_last = _HeteroDictLinear(out_channels * n_heads, out_channels, types=("tx", "bd"))
-        self._step = 0          # advances the dropout seed every training forward
+        # dropout stream: effective seed of (layer, edge type, step) = 2*layer + type + *_step_dev; the counter
+        # lives on the device and advances by 256 per training forward, so captured graphs see fresh masks
+        self.register_buffer("_step_dev", torch.zeros(1, dtype=torch.int64), persistent=False)
 
     def _materialize_bd(self, d_in: int, device) -> None:
         if "bd" not in self.lin_first:
@@ -275,10 +284,9 @@ class ISTEncoder(Module):
             graphs = {et: edge_graph(cache, et, edge_index_dict[et], x[et[0]].shape[0], x[et[2]].shape[0])
                       for et in (TX_TX, TX_BD) if et in edge_index_dict}
         if self.training:
-            self._step += 1
+            self._step_dev.add_(256)
         for li, layer in enumerate(self.conv_layers):
-            seed = (self._step << 8) + li
-            x = layer(x, edge_index_dict, graphs=graphs, apply_gelu=True, seed=seed)   # conv + GELU (:324-325)
+            x = layer(x, edge_index_dict, graphs=graphs, apply_gelu=True, seed=(li, self._step_dev))   # conv + GELU (:324-325)
 
         x = self.lin_last(x)
         if self.normalize_embeddings:

@@ -51,7 +51,9 @@ except Exception:  # noqa: BLE001
             self.hparams = args
 
         def log(self, name, value, **kw):
-            self.logged[name] = value
+            # detached, like Lightning's: a logged loss must not keep the step's autograd graph alive
+            # (a live graph from an earlier step also breaks a later hipGraph capture of the backward)
+            self.logged[name] = value.detach() if isinstance(value, torch.Tensor) else value
 
         @property
         def device(self):
@@ -170,11 +172,13 @@ class LitISTEncoder(_Base):
         labels = torch.cat([torch.ones(n, device=logits.device), torch.zeros(n, device=logits.device)])
         return BCEWithLogitsLoss()(logits, labels)
 
-    def get_losses(self, batch, dst_neg: Optional[Tensor] = None):
-        """(loss_tx, loss_bd, loss_sg, loss), lightning_model.py:151-213."""
+    def get_losses(self, batch, dst_neg: Optional[Tensor] = None, embeddings: Optional[dict] = None):
+        """(loss_tx, loss_bd, loss_sg, loss), lightning_model.py:151-213.  ``embeddings`` lets a caller supply
+        the encoder output it already has (e.g. from a hipGraph replay, ``train_graph.GraphedEncoder``)."""
         if self.loss_tx is None or self.loss_bd is None:
             raise RuntimeError("call setup() (or set_similarities) before computing losses")
-        embeddings = self.forward(batch)
+        if embeddings is None:
+            embeddings = self.forward(batch)
         tx_mask = batch['tx']['mask']
         bd_mask = batch['bd']['mask'] & (batch['bd']['cluster'] >= 0)
         loss_tx = self.loss_tx.forward_masked(embeddings['tx'], batch['tx']['cluster'], tx_mask, batch_cache(batch))

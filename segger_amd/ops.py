@@ -30,6 +30,15 @@ def _rows(t: Tensor, width: int, name: str) -> Tuple[int, int]:
     return t.data_ptr(), int(ld)
 
 
+def _seed_parts(seed):
+    """``seed`` is an int, or ``(int, device int64 tensor)``: the kernels then use ``int + *tensor`` read at
+    run time, so a captured hipGraph draws a new dropout mask on every replay."""
+    if isinstance(seed, tuple):
+        value, dev = seed
+        return int(value) & 0xFFFFFFFFFFFFFFFF, (None if dev is None else dev.data_ptr())
+    return int(seed) & 0xFFFFFFFFFFFFFFFF, None
+
+
 def _f32_vec(t: Optional[Tensor], n: int, name: str) -> Optional[Tensor]:
     if t is None:
         return None
@@ -61,7 +70,8 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
     keep = (_f32_vec(att, hc, "att"), _f32_vec(bias, hc, "bias"))
     a.att, a.bias = keep[0].data_ptr(), _lib.ptr(keep[1])
     a.heads, a.channels, a.dtype, a.apply_gelu = heads, channels, DTYPE_CODE[xl.dtype], int(apply_gelu)
-    a.negative_slope, a.dropout_p, a.seed = negative_slope, dropout_p, seed & 0xFFFFFFFFFFFFFFFF
+    a.negative_slope, a.dropout_p = negative_slope, dropout_p
+    a.seed, a.seed_dev = _seed_parts(seed)
     a.out, a.ld_out = _rows(out, hc, "out")
     if pre is not None:
         a.pre, a.ld_pre = _rows(pre, hc, "pre")
@@ -88,7 +98,8 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
     keep = (_f32_vec(att, hc, "att"), _f32_vec(bias, hc, "bias"))
     a.att, a.bias = keep[0].data_ptr(), _lib.ptr(keep[1])
     a.heads, a.channels, a.dtype, a.apply_gelu = heads, channels, DTYPE_CODE[dt], int(apply_gelu)
-    a.negative_slope, a.dropout_p, a.seed = negative_slope, dropout_p, seed & 0xFFFFFFFFFFFFFFFF
+    a.negative_slope, a.dropout_p = negative_slope, dropout_p
+    a.seed, a.seed_dev = _seed_parts(seed)
     if grad_out.dtype != dt:
         grad_out = grad_out.to(dt)
     if grad_out.dim() == 2 and grad_out.shape[0] > 1 and grad_out.stride(1) != 1:
