@@ -230,8 +230,12 @@ def main():
         tr = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tr):
             try:
-                roof["traffic"] = json.load(open(tr)).get("gatv2_fwd_bytes_per_launch")
-                roof["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc, separate run)"
+                meas = json.load(open(tr))
+                w = meas.get("workload", {})
+                # the PMC passes were taken on one workload; the figure means nothing for another size
+                if (w.get("n_tx"), w.get("k"), w.get("dtype")) == (args.n_tx, args.k, args.dtype):
+                    roof["traffic"] = meas.get("gatv2_fwd_bytes_per_launch")
+                    roof["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc, separate run)"
             except Exception:  # noqa: BLE001
                 pass
         ach_b = b_bwd / (ms_bwd * 1e-3) / 1e9

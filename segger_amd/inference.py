@@ -78,7 +78,8 @@ def pad_batch(batch, sizes: Dict[str, int]) -> HeteroBatch:
 class GraphedPredictor:
     """Replays ``model.predict_step`` for batches of ONE bucket shape through a captured HIP graph."""
 
-    def __init__(self, model, sizes: Dict[str, int], bd_dim: int, min_similarity: Optional[float] = None):
+    def __init__(self, model, sizes: Dict[str, int], bd_dim: int, min_similarity: Optional[float] = None,
+                 max_graphs: int = 64):
         self.model, self.sizes, self.min_similarity = model, dict(sizes), min_similarity
         dev = next(model.parameters()).device
         nt, nb = sizes["tx"], sizes["bd"]
@@ -93,7 +94,9 @@ class GraphedPredictor:
         self._csr_buffers: Dict = {}
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out: Dict[str, Tensor] = {}
-        self.num_graphs = 1
+        # the per-graph min / max tables are sized for max_graphs, so one captured graph serves batches of any
+        # number of tiles up to that (graphs without nodes are never read)
+        self.num_graphs = int(max_graphs)
 
     # -- staging ------------------------------------------------------------------------------
     def _stage(self, pb) -> None:
@@ -133,8 +136,9 @@ class GraphedPredictor:
         """-> (tx_index, seg_idx, max_sim, gene_id) on the CPU, exactly like ``predict_step``."""
         if self.model.training:
             raise RuntimeError("GraphedPredictor needs model.eval()")
+        if getattr(batch, "num_graphs", 1) > self.num_graphs:
+            raise ValueError(f"batch holds {batch.num_graphs} graphs, predictor was built for <= {self.num_graphs}")
         pb = pad_batch(batch, self.sizes)
-        self.num_graphs = getattr(batch, "num_graphs", 1)
         self._stage(pb)
         if self.graph is None:
             s = torch.cuda.Stream()
@@ -142,12 +146,9 @@ class GraphedPredictor:
             with torch.cuda.stream(s):
                 self._run()                              # warm-up on a side stream (lazy inits, allocator)
             torch.cuda.current_stream().wait_stream(s)
-            self._captured_graphs = self.num_graphs
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self._run()
-        elif self.num_graphs != self._captured_graphs:
-            raise ValueError("the number of graphs per batch is part of the captured shape")
         self.graph.replay()
         n = batch["tx"].num_nodes
         mask = batch["tx"]["predict_mask"]

@@ -59,6 +59,97 @@ def _morton(xy: np.ndarray, lo: float, hi: float) -> np.ndarray:
     return spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1))
 
 
+def _morton_torch(xy: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
+    q = ((xy - lo) / (hi - lo) * 65535.0).clamp_(0, 65535).long()
+
+    def spread(v):
+        v = (v | (v << 8)) & 0x00FF00FF
+        v = (v | (v << 4)) & 0x0F0F0F0F
+        v = (v | (v << 2)) & 0x33333333
+        v = (v | (v << 1)) & 0x55555555
+        return v
+    return spread(q[:, 0]) | (spread(q[:, 1]) << 1)
+
+
+def make_fov(spec: SyntheticSpec, device, return_aux: bool = False):
+    """The same generative model as :func:`make_graph`, built ON THE DEVICE for full-FOV sizes (BASELINE
+    configs 3 / 5: 50-100 M transcripts): torch RNG instead of numpy's, and the three edge stores come from the
+    HIP grid kNN (``segger_knn_grid``) instead of a host KD-tree.  Adds ``tx.cell`` (index of the true nucleus),
+    so the label of a candidate edge is ``bd.index[dst] == tx.cell[src]`` in any tile batch."""
+    from .neighbors import knn_grid, knn_to_edge_index
+
+    dev = torch.device(device)
+    gen = torch.Generator(device=dev).manual_seed(spec.seed)
+    Nt, Nb, T, G = spec.n_tx, spec.n_bd, spec.n_types, spec.n_genes
+    L = 10.0 * float(np.sqrt(Nb))
+    lo, hi = -4 * spec.sigma, L + 4 * spec.sigma
+
+    def rand(*s):
+        return torch.rand(*s, device=dev, generator=gen)
+
+    def randn(*s):
+        return torch.randn(*s, device=dev, generator=gen)
+
+    centres = rand(Nb, 2) * L
+    centres = centres[torch.argsort(_morton_torch(centres, lo, hi), stable=True)]
+    bd_type = torch.randint(0, T, (Nb,), device=dev, generator=gen)
+    profiles = torch.from_numpy(np.random.default_rng(spec.seed).dirichlet(np.full(G, 0.3), size=T)).to(dev)
+    type_mean = randn(T, spec.bd_dim)
+    bd_x = type_mean[bd_type] + 0.5 * randn(Nb, spec.bd_dim)
+
+    cell = torch.randint(0, Nb, (Nt,), device=dev, generator=gen)
+    pos = centres[cell] + spec.sigma * randn(Nt, 2)
+    order = torch.argsort(_morton_torch(pos, lo, hi), stable=True)
+    cell, pos = cell[order], pos[order].contiguous()
+    del order
+    # gene ~ Categorical(profile[type(cell)]): one searchsorted over the row-offset CDFs
+    cdf = profiles.cumsum(1)
+    cdf[:, -1] = 1.0
+    flat = (cdf + torch.arange(T, device=dev, dtype=cdf.dtype)[:, None]).reshape(-1)
+    ttype = bd_type[cell]
+    u = torch.rand(Nt, device=dev, generator=gen, dtype=torch.float64) * (1.0 - 1e-12)
+    gene = (torch.searchsorted(flat, u + ttype.to(torch.float64), right=True) - ttype * G).clamp_(0, G - 1)
+    del u, flat
+    gene_cluster = profiles.argmax(0)
+
+    k = min(spec.k_tx, Nt)
+    nbr, _ = knn_grid(pos, k)
+    ett, _ = knn_to_edge_index(nbr, padding_value=Nt)
+    del nbr
+    d_own = (pos - centres[cell]).norm(dim=1)
+    inside = (d_own < spec.belongs_radius).nonzero(as_tuple=False).squeeze(1)
+    etb = torch.stack([inside, cell[inside]])
+    del d_own, inside
+    pk = min(spec.pred_k, Nb)
+    cnb, _ = knn_grid(centres, pk, spec.pred_radius, query=pos)
+    ep, _ = knn_to_edge_index(cnb, padding_value=Nb)
+    del cnb
+
+    b = HeteroBatch(num_graphs=1)
+    tx, bd = b["tx"], b["bd"]
+    tx["x"] = gene.to(torch.int32)
+    tx["pos"] = pos.to(torch.float32)
+    tx["batch"] = torch.zeros(Nt, dtype=torch.long, device=dev)
+    tx["cluster"] = gene_cluster[gene]
+    tx["index"] = torch.arange(Nt, dtype=torch.int64, device=dev)
+    tx["cell"] = cell
+    bd["x"] = bd_x.to(torch.float32)
+    bd["pos"] = centres.to(torch.float32)
+    bd["batch"] = torch.zeros(Nb, dtype=torch.long, device=dev)
+    bd["cluster"] = bd_type.to(torch.int32)
+    bd["index"] = torch.arange(Nb, dtype=torch.int32, device=dev)
+    b[TX_TX]["edge_index"] = ett
+    b[TX_BD]["edge_index"] = etb
+    b[TX_NB_BD]["edge_index"] = ep
+    if not return_aux:
+        return b
+    pn = profiles - profiles.mean(1, keepdim=True)
+    pn = pn / pn.norm(dim=1, keepdim=True)
+    tn = type_mean.double() / type_mean.double().norm(dim=1, keepdim=True)
+    aux = {"tx_similarity": (pn @ pn.T).to(torch.float32), "bd_similarity": (tn @ tn.T).to(torch.float32)}
+    return b, aux
+
+
 def make_graph(spec: SyntheticSpec = C1, return_aux: bool = False):
     from scipy.spatial import cKDTree
 

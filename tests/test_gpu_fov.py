@@ -1,0 +1,99 @@
+"""BASELINE.json config 3 at test scale: a FOV generated on the device, partitioned into resident tiles,
+streamed as packed batches -- the HIP path against the CPU oracle on sample batches of that stream
+(identical weights, after a few training steps), and the device AUROC against the oracle's.
+
+Tolerances: fp32 cosine scores atol 5e-5; bf16 / fp16 scores atol 3e-2 (four stacked low-precision layers,
+tests/test_gpu_model.py) and |dAUROC| <= 1e-3 (BASELINE.json north_star)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fov(cuda):
+    from segger_amd import LitISTEncoder
+    from segger_amd.synthetic import SyntheticSpec, make_fov
+    from segger_amd.tiles import SquareTiling, TileBatchSampler, partition_by_tiling
+    spec = SyntheticSpec(n_tx=120_000, n_bd=1_200, k_tx=8, seed=11)
+    data, aux = make_fov(spec, cuda, return_aux=True)
+    L = 10.0 * math.sqrt(spec.n_bd)
+    tiling = SquareTiling(data["tx"]["pos"], L / 4.0)
+    part = partition_by_tiling(data, tiling, margin=5.0)
+    batches = list(TileBatchSampler(part, 200_000, mode="edge", skip_too_big=True))
+    torch.manual_seed(0)
+    m = LitISTEncoder(n_genes=spec.n_genes, in_channels=128)
+    m.model._materialize_bd(spec.bd_dim, "cpu")
+    m = m.to(cuda)
+    m.set_similarities(aux["tx_similarity"].to(cuda), aux["bd_similarity"].to(cuda))
+    m._max_epochs_override, m.current_epoch = 20, 10
+    opt = m.configure_optimizers()
+    m.train()
+    for i, ids in enumerate(batches[:6]):                    # a few steps so the weights are not the init
+        opt.zero_grad(set_to_none=True)
+        loss = m.training_step(part.batch(ids), i)
+        assert torch.isfinite(loss)
+        loss.backward()
+        opt.step()
+    m.eval()
+    return spec, data, part, batches, m
+
+
+def test_fov_generator_contract(fov):
+    spec, data, part, batches, _ = fov
+    from segger_amd import TX_BD, TX_NB_BD, TX_TX
+    nt, nb = spec.n_tx, spec.n_bd
+    ett, etb, ep = (data[e].edge_index for e in (TX_TX, TX_BD, TX_NB_BD))
+    assert ett.shape == (2, nt * spec.k_tx)
+    assert bool((ett[0].view(nt, spec.k_tx) == torch.arange(nt, device=ett.device)[:, None]).all())   # src = query
+    assert bool((ett[1].view(nt, spec.k_tx)[:, 0] == torch.arange(nt, device=ett.device)).all())      # self first
+    # belongs edges point at the transcript's own nucleus and lie within the radius
+    assert bool((etb[1] == data["tx"]["cell"][etb[0]]).all())
+    d = (data["tx"]["pos"][etb[0]] - data["bd"]["pos"][etb[1]]).norm(dim=1)
+    assert float(d.max()) < spec.belongs_radius + 1e-4
+    frac = etb.shape[1] / nt
+    assert 0.3 < frac < 0.5                                  # 1 - exp(-r^2 / 2 sigma^2) = 0.39
+    dp = (data["tx"]["pos"][ep[0]] - data["bd"]["pos"][ep[1]]).norm(dim=1)
+    assert float(dp.max()) <= spec.pred_radius + 1e-4 and int(ep[1].max()) < nb
+    # tiles: every node in exactly one tile, inter-tile edges dropped, batches within budget
+    assert int(part.node_sizes["tx"].sum()) == nt and int(part.node_sizes["bd"].sum()) == nb
+    assert int(part.edge_sizes[TX_TX].sum()) < ett.shape[1]
+    w = part.weights("edge")
+    assert all(sum(w[t] for t in ids) <= 200_000 for ids in batches)
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float32, 5e-5), (torch.bfloat16, 3e-2), (torch.float16, 3e-2)])
+def test_streamed_batches_match_oracle_and_auroc(oracle, fov, dtype, atol):
+    from segger_amd import TX_NB_BD, ops
+    from segger_amd.graph import batch_cache, edge_graph
+    from segger_amd.metrics import auroc
+    spec, _, part, batches, m = fov
+    sd = {k: v.detach().double().cpu() for k, v in m.state_dict().items()}
+    m.model.compute_dtype = dtype
+    sims, refs, labs = [], [], []
+    for ids in (batches[0], batches[len(batches) // 2]):
+        b = part.batch(ids)
+        with torch.no_grad():
+            z = m.forward(b)
+        ei = b[TX_NB_BD].edge_index
+        g = edge_graph(batch_cache(b), TX_NB_BD, ei, b["tx"].num_nodes, b["bd"].num_nodes, need_by_dst=False)
+        _, _, seg, sim = ops.edge_cos_argmax(g.by_src, z["tx"], z["bd"], dst_index=b["bd"]["index"], return_sim=True)
+        bc = b.to("cpu")
+        z_ref = oracle.ist_encoder_forward(sd, bc.x_dict, bc.edge_index_dict, bc.pos_dict, bc.batch_dict, n_heads=2)
+        eic = bc[TX_NB_BD].edge_index
+        ref = oracle.edge_scores(z_ref["tx"], z_ref["bd"], eic)
+        assert (sim.double().cpu() - ref).abs().max().item() < atol
+        if dtype == torch.float32:                           # assignments: identical wherever the margin is clear
+            seg_ref, _ = oracle.predict_assign(z_ref["tx"], z_ref["bd"], eic, bc["bd"]["index"])
+            # (near-ties within the fp32 error may legitimately flip)
+            assert (seg.cpu() == seg_ref).double().mean().item() > 0.999
+        sims.append(sim.cpu()); refs.append(ref); labs.append((bc["bd"]["index"][eic[1]].long() == bc["tx"]["cell"][eic[0]]))
+    sim, ref, lab = torch.cat(sims), torch.cat(refs), torch.cat(labs)
+    a_dev = auroc(sim.cuda(), lab.cuda())
+    a_ref = oracle.auroc(ref, lab)
+    assert 0.5 < a_ref < 1.0
+    assert abs(a_dev - a_ref) <= 1e-3, (a_dev, a_ref)
+    # the device AUROC routine itself against the oracle's on identical scores
+    assert abs(auroc(ref.float().cuda(), lab.cuda()) - oracle.auroc(ref.float().double(), lab)) < 1e-9

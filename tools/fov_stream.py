@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Full-FOV streaming run (BASELINE.json configs 3 and 5) on ONE MI355X.
+
+Builds a synthetic Xenium-scale field of view on the device (``synthetic.make_fov``: N transcripts, grid kNN
+edges), partitions it into square tiles that stay resident in HBM (``tiles.partition_by_tiling``), packs the
+tiles into batches of <= ``--edges-per-batch`` edges (``TileBatchSampler``; segger's ``edges_per_batch``,
+reference ``data/data_module.py:158``) and
+
+1. trains over the batch stream (fwd + bwd + Adam)               -> tx->cell edges scored / s,
+2. scores every ``tx-neighbors-bd`` candidate edge of the FOV with the SAME weights in each requested dtype
+   -> edge-AUROC per dtype (label: the candidate is the transcript's true nucleus) and |dAUROC| vs fp32,
+3. (``--graphed``) repeats the scoring pass through the hipGraph-captured predictor, one graph per shape
+   bucket (config 5: inference only, fp16).
+
+Prints one JSON object; progress goes to stderr.  This is a driver around the product path: it never touches
+``oracle/`` (the oracle comparison at tile scale lives in tests/test_gpu_fov.py).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+class Phase:
+    def __init__(self, name, out):
+        self.name, self.out = name, out
+
+    def __enter__(self):
+        torch.cuda.synchronize()
+        self.t = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        self.out[self.name] = time.perf_counter() - self.t
+        log(f"[fov] {self.name}: {self.out[self.name]:.2f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n-tx", type=int, default=50_000_000)
+    ap.add_argument("--n-bd", type=int, default=500_000)
+    ap.add_argument("--k", type=int, default=15)
+    ap.add_argument("--tile-nodes", type=int, default=50_000, help="target transcripts per tile (data_module.py:155)")
+    ap.add_argument("--edges-per-batch", type=int, default=1_000_000)
+    ap.add_argument("--margin", type=float, default=10.0, help="tile margin excluded from the losses (um)")
+    ap.add_argument("--train-batches", type=int, default=0, help="0 = one full epoch")
+    ap.add_argument("--train-dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--score-dtypes", default="f32,bf16,f16")
+    ap.add_argument("--graphed", action="store_true", help="also run the hipGraph-captured predictor (fp16)")
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out", default=None, help="also write the JSON here")
+    args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise SystemExit("fov_stream.py needs an MI355X: there is no CPU fallback")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+
+    from segger_amd import LitISTEncoder, TX_BD, TX_NB_BD, TX_TX, ops
+    from segger_amd.graph import batch_cache, edge_graph
+    from segger_amd.inference import GraphedPredictor, bucket_sizes
+    from segger_amd.metrics import assignment_accuracy, auroc
+    from segger_amd.synthetic import SyntheticSpec, make_fov
+    from segger_amd.tiles import SquareTiling, TileBatchSampler, partition_by_tiling
+
+    DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+    times: dict = {}
+    spec = SyntheticSpec(n_tx=args.n_tx, n_bd=args.n_bd, k_tx=args.k, seed=args.seed)
+    with Phase("build_fov_s", times):
+        data, aux = make_fov(spec, dev, return_aux=True)
+    n_edges = {"__".join(et): int(data[et].edge_index.shape[1]) for et in (TX_TX, TX_BD, TX_NB_BD)}
+    log(f"[fov] {args.n_tx} tx, {args.n_bd} nuclei, edges {n_edges}")
+
+    with Phase("partition_s", times):
+        L = 10.0 * math.sqrt(args.n_bd)
+        side = math.sqrt(args.tile_nodes / (args.n_tx / (L * L)))
+        tiling = SquareTiling(data["tx"]["pos"], side)
+        part = partition_by_tiling(data, tiling, margin=args.margin)
+        part.add_node_attr("tx", "predict_mask", torch.ones(args.n_tx, dtype=torch.bool, device=dev), permuted=True)
+        del data
+        sampler = TileBatchSampler(part, args.edges_per_batch, mode="edge", skip_too_big=True)
+        batches = list(sampler)
+    kept = {"__".join(et): int(v.sum()) for et, v in part.edge_sizes.items()}
+    log(f"[fov] {len(tiling)} tiles of side {side:.1f} um -> {len(batches)} batches; intra-tile edges {kept}")
+    torch.cuda.empty_cache()
+
+    torch.manual_seed(0)
+    model = LitISTEncoder(n_genes=spec.n_genes, in_channels=128)
+    model.model._materialize_bd(spec.bd_dim, "cpu")
+    model = model.to(dev)
+    model.set_similarities(aux["tx_similarity"].to(dev), aux["bd_similarity"].to(dev))
+    model._max_epochs_override = 20
+    model.current_epoch = 10
+    opt = model.configure_optimizers()
+
+    # ---- 1. training over the batch stream -----------------------------------------------------------
+    model.model.compute_dtype = DT[args.train_dtype]
+    model.train()
+    todo = batches if args.train_batches <= 0 else batches[: args.train_batches]
+    for ids in todo[:3]:                                     # warm-up: lazy inits, allocator
+        b = part.batch(ids)
+        opt.zero_grad(set_to_none=True)
+        model.training_step(b, 0).backward()
+        opt.step()
+    etb_seen = ett_seen = 0
+    loss = None
+    with Phase("train_s", times):
+        for i, ids in enumerate(todo):
+            b = part.batch(ids)
+            opt.zero_grad(set_to_none=True)
+            loss = model.training_step(b, i)
+            loss.backward()
+            opt.step()
+            etb_seen += int(b[TX_BD].edge_index.shape[1])
+            ett_seen += int(b[TX_TX].edge_index.shape[1])
+            if i % 200 == 0:
+                log(f"[fov] train batch {i}/{len(todo)} loss {float(loss.detach()):.4f}")
+    train = {
+        "batches": len(todo), "dtype": args.train_dtype, "seconds": times["train_s"],
+        "ms_per_batch": times["train_s"] / len(todo) * 1e3,
+        "edges_scored_per_s": 2.0 * etb_seen / times["train_s"],
+        "mp_edges_per_s": 4.0 * (ett_seen + etb_seen) / times["train_s"],
+        "final_loss": float(loss.detach()),
+    }
+
+    # ---- 2. score every candidate edge, one pass per dtype, identical weights ------------------------
+    model.eval()
+    ep_sizes = part.edge_sizes[TX_NB_BD].tolist()
+    ep_total = sum(ep_sizes[t] for ids in batches for t in ids)      # tiles over the batch budget are skipped
+    labels = torch.empty(ep_total, dtype=torch.bool, device=dev)
+    scoring = {}
+    ref_scores = None
+    for name in [s for s in args.score_dtypes.split(",") if s]:
+        model.model.compute_dtype = DT[name]
+        scores = torch.empty(ep_total, dtype=torch.float32, device=dev)
+        hit = tot = 0.0
+        with torch.no_grad(), Phase(f"score_{name}_s", times):
+            o = 0
+            for ids in batches:
+                b = part.batch(ids)
+                z = model.forward(b)
+                ei = b[TX_NB_BD].edge_index
+                g = edge_graph(batch_cache(b), TX_NB_BD, ei, b["tx"].num_nodes, b["bd"].num_nodes, need_by_dst=False)
+                _, _, seg, sim = ops.edge_cos_argmax(g.by_src, z["tx"], z["bd"], dst_index=b["bd"]["index"],
+                                                     return_sim=True)
+                e = int(ei.shape[1])
+                scores[o:o + e] = sim
+                lab = b["bd"]["index"][ei[1]].long() == b["tx"]["cell"][ei[0]]
+                labels[o:o + e] = lab
+                has = torch.zeros(b["tx"].num_nodes, dtype=torch.bool, device=dev)
+                has[ei[0][lab]] = True
+                hit += float(((seg == b["tx"]["cell"]) & has).sum())
+                tot += float(has.sum())
+                o += e
+        a = auroc(scores, labels)
+        scoring[name] = {"auroc": a, "assignment_accuracy": hit / max(tot, 1.0), "seconds": times[f"score_{name}_s"],
+                         "edges_scored_per_s": ep_total / times[f"score_{name}_s"]}
+        if name == "f32":
+            ref_scores = scores
+        elif ref_scores is not None:
+            scoring[name]["max_abs_score_diff_vs_f32"] = float((scores - ref_scores).abs().max())
+            scoring[name]["auroc_diff_vs_f32"] = abs(a - scoring["f32"]["auroc"])
+        log(f"[fov] {name}: {scoring[name]}")
+    del ref_scores
+
+    # ---- 3. hipGraph-captured predictor (config 5) ---------------------------------------------------
+    graphed = None
+    if args.graphed:
+        model.model.compute_dtype = torch.float16
+        preds: dict = {}
+        n_out = 0
+        for warm in (True, False):                           # first sweep captures one graph per bucket
+            with Phase("graphed_capture_s" if warm else "graphed_predict_s", times):
+                n_out = 0
+                for ids in batches:
+                    b = part.batch(ids)
+                    sizes = bucket_sizes(b)
+                    key = tuple(sorted(sizes.items()))
+                    if key not in preds:
+                        preds[key] = GraphedPredictor(model, sizes, bd_dim=spec.bd_dim)
+                    out = preds[key].predict(b)
+                    n_out += int(out[0].numel())
+        graphed = {"dtype": "f16", "buckets": len(preds), "capture_sweep_s": times["graphed_capture_s"],
+                   "seconds": times["graphed_predict_s"], "transcripts_out": n_out,
+                   "edges_scored_per_s": ep_total / times["graphed_predict_s"],
+                   "note": "predict() incl. padding, CSR rebuild, graph replay, mask + D2H of the 4-tuple"}
+        log(f"[fov] graphed: {graphed}")
+
+    res = {
+        "workload": f"synthetic FOV: {args.n_tx} tx, {args.n_bd} nuclei, k={args.k}; {len(tiling)} square tiles "
+                    f"(~{args.tile_nodes} tx), {len(batches)} batches of <= {args.edges_per_batch} edges",
+        "edges_total": n_edges, "edges_intra_tile": kept, "phases_s": times,
+        "train": train, "scoring": scoring, "graphed_predict": graphed,
+        "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
+    }
+    s = json.dumps(res)
+    print(s, flush=True)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, "w") as f:
+            f.write(s + "\n")
+
+
+if __name__ == "__main__":
+    main()
