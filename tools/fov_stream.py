@@ -183,9 +183,11 @@ def main():
         model.model.compute_dtype = torch.float16
         preds: dict = {}
         n_out = 0
+        outs = []
         for warm in (True, False):                           # first sweep captures one graph per bucket
             with Phase("graphed_capture_s" if warm else "graphed_predict_s", times):
                 n_out = 0
+                outs = []
                 for ids in batches:
                     b = part.batch(ids)
                     sizes = bucket_sizes(b)
@@ -194,10 +196,22 @@ def main():
                         preds[key] = GraphedPredictor(model, sizes, bd_dim=spec.bd_dim)
                     out = preds[key].predict(b)
                     n_out += int(out[0].numel())
+                    outs.append(out)
         graphed = {"dtype": "f16", "buckets": len(preds), "capture_sweep_s": times["graphed_capture_s"],
                    "seconds": times["graphed_predict_s"], "transcripts_out": n_out,
                    "edges_scored_per_s": ep_total / times["graphed_predict_s"],
                    "note": "predict() incl. padding, CSR rebuild, graph replay, mask + D2H of the 4-tuple"}
+        # the step after the path: best row per transcript + per-gene Yen / Li thresholds, on the device
+        from segger_amd.postprocess import assign_transcripts_to_cells
+        with Phase("postprocess_s", times):
+            seg = assign_transcripts_to_cells(outs, device=dev)
+        thr = seg["similarity_threshold"]
+        graphed["postprocess"] = {
+            "seconds": times["postprocess_s"], "rows": int(seg["row_index"].numel()),
+            "assigned": int((seg["cell_encoding"] >= 0).sum()),
+            "above_threshold": int(((seg["cell_encoding"] >= 0) & (seg["similarity"].double() >= thr)).sum()),
+            "global_threshold": seg["global_threshold"], "failed_genes": int(seg["failed_genes"].numel())}
+        del outs, seg
         log(f"[fov] graphed: {graphed}")
 
     res = {
