@@ -373,3 +373,75 @@ class PredictTiles:
             ok = (a >= 0) & (b >= 0)
             out[et]["edge_index"] = torch.stack([a[ok], b[ok]])
         return out
+
+
+class PredictTileIndex(PredictTiles):
+    """``PredictTiles`` over the tiles of a :class:`SquareTiling` with work per tile proportional to the tile's
+    3 x 3 neighbourhood instead of the whole slide: nodes are binned by tile once (one stable sort), edges by the
+    tile of their source, and a prediction tile only looks at the 9 slices around it.  Returns exactly what
+    ``PredictTiles.__getitem__`` returns (same node and edge order).  Needs ``margin <= side_length``."""
+
+    def __init__(self, data: HeteroBatch, tiling: SquareTiling, margin: float = 0.0):
+        super().__init__(data, tiling.tiles, margin)
+        if margin > tiling.side_length:
+            raise ValueError(f"margin ({margin}) must not exceed the tile side ({tiling.side_length})")
+        self.nx, self.ny = tiling.nx, tiling.ny
+        T = len(tiling)
+        self._nperm: Dict[str, Tensor] = {}
+        self._nptr: Dict[str, List[int]] = {}
+        self._new_id: Dict[str, Tensor] = {}
+        tile_of: Dict[str, Tensor] = {}
+        for nt, store in data._nodes.items():
+            ix, iy = tiling._cell(store["pos"])            # clamped: nodes outside the extent go to a border tile
+            lab = ix * tiling.ny + iy
+            tile_of[nt] = lab
+            self._nperm[nt] = torch.argsort(lab, stable=True)
+            sizes = torch.bincount(lab, minlength=T)
+            self._nptr[nt] = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)]).tolist()
+            self._new_id[nt] = torch.full((store["pos"].shape[0],), -1, dtype=torch.long, device=store["pos"].device)
+        self._edges: Dict[EdgeType, Tensor] = {}
+        self._eptr: Dict[EdgeType, List[int]] = {}
+        for et, store in data._edges.items():
+            ei = store["edge_index"].long()
+            lab = tile_of[et[0]][ei[0]]
+            order = torch.argsort(lab, stable=True)
+            self._edges[et] = torch.cat([ei[:, order], order[None]], 0)      # rows: src, dst, original edge id
+            sizes = torch.bincount(lab, minlength=T)
+            self._eptr[et] = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)]).tolist()
+
+    def __getitem__(self, idx: int) -> HeteroBatch:
+        if idx < 0 or idx >= len(self):
+            raise IndexError(f"Requested {idx}, but tiling only contains {len(self)} tiles.")
+        x0, y0, x1, y1 = (float(v) for v in self.tiles[idx])
+        m = self.margin
+        ix, iy = idx // self.ny, idx % self.ny
+        neigh = [jx * self.ny + jy for jx in range(max(ix - 1, 0), min(ix + 2, self.nx))
+                 for jy in range(max(iy - 1, 0), min(iy + 2, self.ny))]
+        out = HeteroBatch(num_graphs=1)
+        subs: Dict[str, Tensor] = {}
+        for nt, store in self.data._nodes.items():
+            ptr, perm = self._nptr[nt], self._nperm[nt]
+            cand = torch.cat([perm[ptr[t]:ptr[t + 1]] for t in neigh])
+            pos = store["pos"].index_select(0, cand)
+            keep = (pos[:, 0] >= x0 - m) & (pos[:, 0] < x1 + m) & (pos[:, 1] >= y0 - m) & (pos[:, 1] < y1 + m)
+            sub = cand[keep].sort().values                  # ascending original id, like a boolean-mask subgraph
+            subs[nt] = sub
+            for a, v in store.items():
+                if a in NODE_SKIP:
+                    continue
+                out[nt][a] = v.index_select(0, sub) if isinstance(v, Tensor) else v
+            p = out[nt]["pos"]
+            out[nt]["predict_mask"] = (p[:, 0] >= x0) & (p[:, 0] <= x1) & (p[:, 1] >= y0) & (p[:, 1] <= y1)
+            out[nt]["batch"] = torch.zeros(sub.numel(), dtype=torch.long, device=pos.device)
+            self._new_id[nt][sub] = torch.arange(sub.numel(), device=pos.device)
+        for et in self.data._edges:
+            s, _, d = et
+            ptr, tab = self._eptr[et], self._edges[et]
+            e = torch.cat([tab[:, ptr[t]:ptr[t + 1]] for t in neigh], 1)
+            a, b = self._new_id[s][e[0]], self._new_id[d][e[1]]
+            ok = (a >= 0) & (b >= 0)
+            order = torch.argsort(e[2][ok])                 # back to the original edge order
+            out[et]["edge_index"] = torch.stack([a[ok][order], b[ok][order]])
+        for nt, sub in subs.items():
+            self._new_id[nt][sub] = -1
+        return out

@@ -149,3 +149,24 @@ def test_predict_tiles_subgraph(graph):
     assert (seen >= 1).all()                    # every transcript is predicted by at least one tile
     with pytest.raises(IndexError):
         ds[len(ds)]
+
+
+@pytest.mark.parametrize("side,margin", [(30.0, 4.0), (17.0, 17.0), (1000.0, 5.0)])
+def test_predict_tile_index_equals_predict_tiles(graph, side, margin):
+    """The 3 x 3-neighbourhood index returns exactly the whole-slide subgraph of PredictTiles."""
+    tiling = T.SquareTiling(all_pos(graph), side)
+    slow = T.PredictTiles(graph, tiling.tiles, margin=margin)
+    fast = T.PredictTileIndex(graph, tiling, margin=margin)
+    assert len(fast) == len(slow)
+    for i in range(len(slow)):
+        a, b = slow[i], fast[i]
+        for nt in ("tx", "bd"):
+            assert set(a[nt].keys()) == set(b[nt].keys())
+            for k, v in a[nt].items():
+                if isinstance(v, torch.Tensor):
+                    assert torch.equal(v, b[nt][k]), (i, nt, k)
+        for et in a.edge_types:
+            assert torch.equal(a[et].edge_index, b[et].edge_index), (i, et)
+    assert all(bool((v == -1).all()) for v in fast._new_id.values())       # scratch map restored
+    with pytest.raises(ValueError):
+        T.PredictTileIndex(graph, tiling, margin=side * 1.5)

@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--train-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--score-dtypes", default="f32,bf16,f16")
     ap.add_argument("--graphed", action="store_true", help="also run the hipGraph-captured predictor (fp16)")
+    ap.add_argument("--overlap-predict", action="store_true",
+                    help="also run segger's real predict pipeline: overlapping tiles (bbox + margin, predict_mask), "
+                         "predict_step per tile, dedup + per-gene thresholds")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None, help="also write the JSON here")
     args = ap.parse_args()
@@ -75,7 +78,7 @@ def main():
     from segger_amd.inference import GraphedPredictor, bucket_sizes
     from segger_amd.metrics import assignment_accuracy, auroc
     from segger_amd.synthetic import SyntheticSpec, make_fov
-    from segger_amd.tiles import SquareTiling, TileBatchSampler, partition_by_tiling
+    from segger_amd.tiles import PredictTileIndex, SquareTiling, TileBatchSampler, partition_by_tiling
 
     DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
     times: dict = {}
@@ -91,6 +94,7 @@ def main():
         tiling = SquareTiling(data["tx"]["pos"], side)
         part = partition_by_tiling(data, tiling, margin=args.margin)
         part.add_node_attr("tx", "predict_mask", torch.ones(args.n_tx, dtype=torch.bool, device=dev), permuted=True)
+        pti = PredictTileIndex(data, tiling, margin=args.margin) if args.overlap_predict else None
         del data
         sampler = TileBatchSampler(part, args.edges_per_batch, mode="edge", skip_too_big=True)
         batches = list(sampler)
@@ -214,11 +218,31 @@ def main():
         del outs, seg
         log(f"[fov] graphed: {graphed}")
 
+    # ---- 4. overlapping prediction tiles -> predict_step -> dedup + thresholds ---------------------------
+    overlap = None
+    if pti is not None:
+        from segger_amd.postprocess import assign_transcripts_to_cells
+        model.model.compute_dtype = torch.float16
+        outs = []
+        with Phase("overlap_predict_s", times):
+            for i in range(len(pti)):
+                outs.append(model.predict_step(pti[i], i))
+        rows = sum(int(o[0].numel()) for o in outs)
+        with Phase("overlap_postprocess_s", times):
+            seg = assign_transcripts_to_cells(outs, device=dev)
+        overlap = {"tiles": len(pti), "margin_um": args.margin, "dtype": "f16", "predict_seconds": times["overlap_predict_s"],
+                   "rows_from_tiles": rows, "transcripts": int(seg["row_index"].numel()),
+                   "assigned": int((seg["cell_encoding"] >= 0).sum()),
+                   "postprocess_seconds": times["overlap_postprocess_s"], "global_threshold": seg["global_threshold"],
+                   "transcripts_per_s": int(seg["row_index"].numel()) / times["overlap_predict_s"]}
+        del outs, seg
+        log(f"[fov] overlap predict: {overlap}")
+
     res = {
         "workload": f"synthetic FOV: {args.n_tx} tx, {args.n_bd} nuclei, k={args.k}; {len(tiling)} square tiles "
                     f"(~{args.tile_nodes} tx), {len(batches)} batches of <= {args.edges_per_batch} edges",
         "edges_total": n_edges, "edges_intra_tile": kept, "phases_s": times,
-        "train": train, "scoring": scoring, "graphed_predict": graphed,
+        "train": train, "scoring": scoring, "graphed_predict": graphed, "overlap_predict": overlap,
         "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
     }
     s = json.dumps(res)
