@@ -286,11 +286,17 @@ int segger_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bi
  *
  * segger_embed_gelu_fwd/bwd: x0 = gelu(cat(table[ids], pe)) (ist_encoder.py:312-320 for the 'tx' type):
  *   table fp32 [n_rows_table, D] (nn.Embedding weight), ids int32 [n], pe [n, D] -> x0 [n, 2D].
- *   bwd: gpe = gx0[:, D:] * gelu'(pe); gtable (optional, NULL to skip) = sum over rows of gx0[:, :D] * gelu'(table[ids]),
- *   accumulated in per-block LDS tables (n_rows_table * 128 B <= 160 KiB), no sort and no global atomics.
+ *   bwd: gpe = gx0[:, D:] * gelu'(pe); gtable (optional, NULL to skip) = gelu'(table) * sum over the rows of each
+ *   id of gx0[:, :D].  The rows come GROUPED BY ID: gene_ptr int64 [n_rows_table + 1] / gene_rows int32 [n] are the
+ *   indptr / col arrays of segger_csr_from_coo(row = ids, col = 0..n-1) (one sort per batch); the sum is a
+ *   deterministic two-stage segmented reduction (no atomics).  D % 8 == 0, D <= 2048.
  *
  * segger_l2norm_fwd/bwd: torch.nn.functional.normalize(dim=-1, eps) (ist_encoder.py:331-332) and its gradient;
  *   channels in {8, 16, 32, 64, 128}.
+ *
+ * segger_colsum: out[c] = sum_n x[n, c] in fp32 -- the bias gradient of every nn.Linear / PyG Linear on the path
+ *   (lin_l / lin_r of GATv2Conv, ist_encoder.py:111-124; pos-embedding MLP :45-49; lin_last :282-286), which autograd
+ *   computes as grad_output.sum(0).  cols % 8 == 0, cols <= 2048; deterministic (two-stage, no atomics).
  * ---------------------------------------------------------------------- */
 int segger_posfreq(const float* pos, const int64_t* batch, const float* mins, const float* maxs, int64_t n,
                    int32_t freq_dim, float eps, float max_period, void* out, int32_t dtype, segger_stream_t stream);
@@ -298,14 +304,17 @@ int segger_embed_gelu_fwd(const float* table, const int32_t* ids, const void* pe
                           int32_t n_rows_table, int32_t D, void* out, int64_t ld_out, int32_t dtype,
                           segger_stream_t stream);
 size_t segger_embed_gelu_bwd_workspace_bytes(int64_t n, int32_t n_rows_table, int32_t D);
-int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float* table, const int32_t* ids, const void* pe,
-                          int64_t ld_pe, int64_t n, int32_t n_rows_table, int32_t D, void* gpe, int64_t ld_gpe,
-                          float* gtable, void* workspace, size_t workspace_bytes, int32_t dtype,
-                          segger_stream_t stream);
+int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float* table, const void* pe, int64_t ld_pe,
+                          int64_t n, int32_t n_rows_table, int32_t D, void* gpe, int64_t ld_gpe, float* gtable,
+                          const int64_t* gene_ptr, const int32_t* gene_rows, void* workspace, size_t workspace_bytes,
+                          int32_t dtype, segger_stream_t stream);
 int segger_l2norm_fwd(const void* y, int64_t ld_y, int64_t n, int32_t channels, float eps, void* z, int64_t ld_z,
                       int32_t dtype, segger_stream_t stream);
 int segger_l2norm_bwd(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, int64_t n, int32_t channels,
                       float eps, void* gy, int64_t ld_gy, int32_t dtype, segger_stream_t stream);
+size_t segger_colsum_workspace_bytes(int64_t n, int32_t cols);
+int segger_colsum(const void* x, int64_t ld, int64_t n, int32_t cols, int32_t dtype, float* out,
+                  void* workspace, size_t workspace_bytes, segger_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Exact 2-D k-nearest neighbours on a uniform grid: the step BEFORE the hot path

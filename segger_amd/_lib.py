@@ -112,10 +112,12 @@ EXPORTS = {
     "segger_posfreq": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_float, C.c_float, vp, C.c_int32, vp]),
     "segger_embed_gelu_fwd": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, C.c_int32, vp]),
     "segger_embed_gelu_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
-    "segger_embed_gelu_bwd": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64,
-                                        vp, vp, C.c_size_t, C.c_int32, vp]),
+    "segger_embed_gelu_bwd": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64,
+                                        vp, vp, vp, vp, C.c_size_t, C.c_int32, vp]),
     "segger_l2norm_fwd": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, C.c_float, vp, C.c_int64, C.c_int32, vp]),
     "segger_l2norm_bwd": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_float, vp, C.c_int64, C.c_int32, vp]),
+    "segger_colsum_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "segger_colsum": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_size_t, vp]),
     "segger_knn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "segger_knn_grid": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_int32, C.c_int32, vp, vp, vp, C.c_size_t, vp]),

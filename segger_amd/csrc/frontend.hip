@@ -90,50 +90,103 @@ __global__ __launch_bounds__(256) void embed_gelu_bwd_pe_kernel(const T* __restr
   Vec8<T>::store(gpe + row * ld_gpe + c0, g);
 }
 
-// backward, embedding table: gtable[g, c] = sum_{n: ids[n]=g} gx0[n, c] * gelu'(table[g, c]).
-// Block (bx, by) owns a 32-channel slice `by` and a contiguous row range `bx`; it sums
-// sum_n gx0[n, c] per gene in an LDS table [G][32] (ds_add_f32), then writes the table to
-// partial[bx][G][D]; gelu'(table) is applied once per table entry by the reduce kernel.
-constexpr int kEmbSlice = 32;      // D must be a multiple of this
-// Block (bx, by) owns the channel slice [by*S, by*S+S) (S = 64 when the LDS table fits, else 32) and a
-// contiguous row range; a thread loads 8 channels of one row (16 B, a full 128-B line per row at S=64)
-// and adds them into the block's LDS table [G][S+1] (the +1 skews genes over banks).
-template <typename T>
-__global__ __launch_bounds__(256) void embed_grad_partial_kernel(const T* __restrict__ gx0, int64_t ld_g, const int32_t* __restrict__ ids,
-                                                                int64_t n, int G, int D, int S, int64_t rows_per_block,
-                                                                float* __restrict__ partial) {
-  extern __shared__ float tab[];                         // [G][S + 1]
-  const int stride = S + 1;
-  for (int i = threadIdx.x; i < G * stride; i += 256) tab[i] = 0.f;
+// backward, embedding table: gtable[g, c] = gelu'(table[g, c]) * sum_{n: ids[n] = g} gx0[n, c].
+// LDS float atomics (ds_add_f32) retire about one lane every three clocks per CU on gfx950 -- a per-block LDS
+// table took 0.66 ms for 1 M rows whatever the id distribution -- so the sum runs over the rows GROUPED BY GENE
+// (gene_ptr / gene_rows: the CSR of ids, one radix sort per batch, shared by every step on that batch):
+//   1. emb_plan_kernel: per gene, the number of chunks (<= kEmbMaxChunks, >= kEmbChunk rows each) and their
+//      exclusive prefix -> chunk_ptr[G + 1];
+//   2. emb_gather_kernel: block b finds its (gene, chunk) by binary search, every thread sums ITS 8 channels
+//      over the chunk's rows in registers (full 16-B loads, 4 in flight), the row-lanes meet in LDS -> partial[b];
+//   3. emb_finish_kernel: per gene, the <= kEmbMaxChunks partial rows in order, times gelu'(table).
+// Deterministic, no atomics.
+constexpr int kEmbChunk = 256;
+constexpr int kEmbMaxChunks = 32;
+
+__device__ __forceinline__ int emb_chunks_of(int64_t len) {
+  if (len <= 0) return 0;
+  const int64_t c = (len + kEmbChunk - 1) / kEmbChunk;
+  return c > kEmbMaxChunks ? kEmbMaxChunks : (int)c;
+}
+
+__global__ __launch_bounds__(256) void emb_plan_kernel(const int64_t* __restrict__ gene_ptr, int G, int* __restrict__ chunk_ptr) {
+  __shared__ int scan[256];
+  __shared__ int carry;
+  if (threadIdx.x == 0) { carry = 0; chunk_ptr[0] = 0; }
   __syncthreads();
-  const int tpr = S / 8;                                 // threads per row
-  const int c8 = (threadIdx.x % tpr) * 8;
-  const int rl = threadIdx.x / tpr;
-  const int c0 = blockIdx.y * S;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
-  for (int64_t row = r0 + rl; row < r1; row += 256 / tpr) {
-    const int g = ids[row];
-    float v[8];
-    Vec8<T>::load(gx0 + row * ld_g + c0 + c8, v);
-    float* t = tab + g * stride + c8;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) atomicAdd(t + k, v[k]);  // LDS atomics
-  }
-  __syncthreads();
-  float* dst = partial + (int64_t)blockIdx.x * G * D;
-  for (int i = threadIdx.x; i < G * S; i += 256) {
-    const int g = i / S, cc = i % S;
-    dst[(int64_t)g * D + c0 + cc] = tab[g * stride + cc];
+  for (int g0 = 0; g0 < G; g0 += 256) {
+    const int g = g0 + threadIdx.x;
+    int v = g < G ? emb_chunks_of(gene_ptr[g + 1] - gene_ptr[g]) : 0;
+    scan[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      const int t = threadIdx.x >= d ? scan[threadIdx.x - d] : 0;
+      __syncthreads();
+      scan[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (g < G) chunk_ptr[g + 1] = carry + scan[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 255) carry += scan[255];
+    __syncthreads();
   }
 }
 
-__global__ __launch_bounds__(256) void embed_grad_reduce_kernel(const float* __restrict__ partial, int nparts, const float* __restrict__ table,
-                                                               int64_t gd, float* __restrict__ gtable) {
+template <typename T>
+__global__ __launch_bounds__(256) void emb_gather_kernel(const T* __restrict__ gx0, int64_t ld_g, const int64_t* __restrict__ gene_ptr,
+                                                        const int32_t* __restrict__ gene_rows, const int* __restrict__ chunk_ptr,
+                                                        int G, int D, float* __restrict__ partial) {
+  extern __shared__ float red[];                        // [R][D]
+  const int b = blockIdx.x;
+  if (b >= chunk_ptr[G]) return;                         // uniform per block
+  int lo = 0, hi = G;                                    // last gene with chunk_ptr[g] <= b
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_ptr[mid] <= b) lo = mid; else hi = mid;
+  }
+  const int g = lo;
+  const int64_t beg = gene_ptr[g], len = gene_ptr[g + 1] - beg;
+  const int nch = chunk_ptr[g + 1] - chunk_ptr[g], j = b - chunk_ptr[g];
+  const int64_t per = (len + nch - 1) / nch;
+  const int64_t p0 = beg + j * per, p1 = (p0 + per < beg + len) ? p0 + per : beg + len;
+  const int P = D / 8, R = blockDim.x / P;
+  const int q = threadIdx.x % P, rl = threadIdx.x / P;
+  const T* base = gx0 + q * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  int64_t p = p0 + rl;
+  for (; p + 3 * (int64_t)R < p1; p += 4 * (int64_t)R) {
+    const int64_t r0 = gene_rows[p], r1 = gene_rows[p + R], r2 = gene_rows[p + 2 * R], r3 = gene_rows[p + 3 * R];
+    float v0[8], v1[8], v2[8], v3[8];
+    Vec8<T>::load(base + r0 * ld_g, v0);
+    Vec8<T>::load(base + r1 * ld_g, v1);
+    Vec8<T>::load(base + r2 * ld_g, v2);
+    Vec8<T>::load(base + r3 * ld_g, v3);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += (v0[k] + v1[k]) + (v2[k] + v3[k]);
+  }
+  for (; p < p1; p += R) {
+    float v[8];
+    Vec8<T>::load(base + (int64_t)gene_rows[p] * ld_g, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[rl * D + q * 8 + k] = acc[k];
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float sum = 0.f;
+    for (int r = 0; r < R; ++r) sum += red[r * D + c];
+    partial[(int64_t)b * D + c] = sum;
+  }
+}
+
+__global__ __launch_bounds__(256) void emb_finish_kernel(const float* __restrict__ partial, const int* __restrict__ chunk_ptr,
+                                                        const float* __restrict__ table, int G, int D, float* __restrict__ gtable) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= gd) return;
+  if (i >= (int64_t)G * D) return;
+  const int g = (int)(i / D), c = (int)(i % D);
   float s = 0.f;
-  for (int p = 0; p < nparts; ++p) s += partial[(int64_t)p * gd + i];
+  for (int b = chunk_ptr[g]; b < chunk_ptr[g + 1]; ++b) s += partial[(int64_t)b * D + c];
   gtable[i] = s * gelu_erf_grad(table[i]);
 }
 
@@ -199,6 +252,84 @@ int launch_l2norm(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, in
 
 size_t esize(int dtype) { return dtype == SEGGER_F32 ? 4 : 2; }
 
+
+// ---------------------------------------------------------------------------------------------
+// Column sums of a tall matrix: out[c] = sum_n x[n, c]  (bias gradients of the projections).
+// P = cols/8 lanes cover one row with 16-byte loads; a block of P * R threads (R = 256 / P rows per
+// sweep) walks a contiguous row range, every thread accumulating ITS 8 columns in fp32 registers
+// (4 independent loads in flight), then the R row-lanes of a column group are summed through LDS and
+// the block writes one partial row; a second kernel sums the partial rows.  Deterministic, no atomics.
+// ---------------------------------------------------------------------------------------------
+constexpr int kColsumMaxBlocks = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, int64_t ld, int64_t n, int cols,
+                                                            int64_t rows_per_block, float* __restrict__ partial) {
+  extern __shared__ float red[];                        // [R][cols]
+  const int P = cols / 8, R = blockDim.x / P;
+  const int q = threadIdx.x % P, rl = threadIdx.x / P;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const T* base = x + q * 8;
+  int64_t row = r0 + rl;
+  for (; row + 3 * (int64_t)R < r1; row += 4 * (int64_t)R) {
+    float v0[8], v1[8], v2[8], v3[8];
+    Vec8<T>::load(base + row * ld, v0);
+    Vec8<T>::load(base + (row + R) * ld, v1);
+    Vec8<T>::load(base + (row + 2 * R) * ld, v2);
+    Vec8<T>::load(base + (row + 3 * R) * ld, v3);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += (v0[k] + v1[k]) + (v2[k] + v3[k]);
+  }
+  for (; row < r1; row += R) {
+    float v[8];
+    Vec8<T>::load(base + row * ld, v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += v[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[rl * cols + q * 8 + k] = acc[k];
+  __syncthreads();
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += red[r * cols + c];
+    partial[(int64_t)blockIdx.x * cols + c] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ partial, int nparts, int cols,
+                                                           float* __restrict__ out) {
+  // a block owns 16 columns; 16 threads per column stride over the partial rows, then meet in LDS
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, sub = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < cols) {
+    int p = sub;
+    for (; p + 16 < nparts; p += 32) {
+      s0 += partial[(int64_t)p * cols + c];
+      s1 += partial[(int64_t)(p + 16) * cols + c];
+    }
+    if (p < nparts) s0 += partial[(int64_t)p * cols + c];
+  }
+  red[sub][cl] = s0 + s1;
+  __syncthreads();
+  if (sub == 0 && c < cols) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += red[r][cl];
+    out[c] = s;
+  }
+}
+
+static int colsum_blocks(int64_t n) {
+  int64_t b = (n + 255) / 256;                           // >= 256 rows per block
+  if (b > kColsumMaxBlocks) b = kColsumMaxBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
 }  // namespace
 }  // namespace segger
 
@@ -251,23 +382,23 @@ extern "C" int segger_embed_gelu_fwd(const float* table, const int32_t* ids, con
   return SEGGER_OK;
 }
 
-static int emb_row_blocks(int64_t n) {
-  int64_t b = (n + 4095) / 4096;          // >= 4096 rows per block
-  if (b > 256) b = 256;
-  if (b < 1) b = 1;
-  return (int)b;
+static int64_t emb_max_chunks(int64_t n, int32_t G) {
+  const int64_t by_rows = (n + kEmbChunk - 1) / kEmbChunk + G;          // every gene adds at most one ragged chunk
+  const int64_t by_genes = (int64_t)G * kEmbMaxChunks;
+  return by_rows < by_genes ? by_rows : by_genes;
 }
 
 extern "C" size_t segger_embed_gelu_bwd_workspace_bytes(int64_t n, int32_t n_rows_table, int32_t D) {
-  return (size_t)emb_row_blocks(n) * (size_t)n_rows_table * (size_t)D * sizeof(float) + 16;
+  if (n < 0 || n_rows_table <= 0 || D <= 0) return 16;
+  return (size_t)emb_max_chunks(n, n_rows_table) * (size_t)D * sizeof(float) + ((size_t)n_rows_table + 1) * sizeof(int) + 32;
 }
 
-extern "C" int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float* table, const int32_t* ids, const void* pe,
-                                     int64_t ld_pe, int64_t n, int32_t n_rows_table, int32_t D, void* gpe, int64_t ld_gpe,
-                                     float* gtable, void* workspace, size_t workspace_bytes, int32_t dtype,
-                                     segger_stream_t stream_) {
+extern "C" int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float* table, const void* pe, int64_t ld_pe,
+                                     int64_t n, int32_t n_rows_table, int32_t D, void* gpe, int64_t ld_gpe, float* gtable,
+                                     const int64_t* gene_ptr, const int32_t* gene_rows, void* workspace,
+                                     size_t workspace_bytes, int32_t dtype, segger_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  SEGGER_REQUIRE(n >= 0 && D > 0 && D % kEmbSlice == 0, "segger_embed_gelu_bwd: D must be a positive multiple of 32");
+  SEGGER_REQUIRE(n >= 0 && D > 0 && D % 8 == 0 && D <= 2048, "segger_embed_gelu_bwd: D must be a multiple of 8, <= 2048");
   SEGGER_REQUIRE(n_rows_table > 0, "segger_embed_gelu_bwd: empty table");
   const int64_t gd = (int64_t)n_rows_table * D;
   if (n == 0) {
@@ -276,47 +407,68 @@ extern "C" int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float*
   }
   SEGGER_REQUIRE(gx0 && pe && gpe, "segger_embed_gelu_bwd: NULL pointer");
   SEGGER_REQUIRE(aligned16(gx0) && aligned16(pe) && aligned16(gpe), "segger_embed_gelu_bwd: 16-byte alignment required");
-  // widest channel slice whose [G][S+1] fp32 table fits the 160 KiB LDS
-  // (64-wide slices only while the table stays within the default 64 KiB dynamic-LDS limit: larger requests
-  //  need hipFuncSetAttribute, and hipGraph instantiation of such kernel nodes crashed on ROCm 7.0/7.2)
-  const int S = (D % 64 == 0 && (size_t)n_rows_table * 65 * sizeof(float) <= 64 * 1024) ? 64 : kEmbSlice;
-  const size_t lds_bytes = (size_t)n_rows_table * (S + 1) * sizeof(float);
+  SEGGER_REQUIRE((ld_g * esize(dtype)) % 16 == 0 && ld_g >= 2 * D, "segger_embed_gelu_bwd: bad leading dimension of gx0");
   {
     const int64_t items = n * (D / 8);
     const int64_t nb = (items + 255) / 256;
+    SEGGER_REQUIRE(nb < 0x7fffffffLL, "segger_embed_gelu_bwd: too many rows");
 #define GO(T) hipLaunchKernelGGL((embed_gelu_bwd_pe_kernel<T>), dim3((unsigned)nb), dim3(256), 0, stream, (const T*)gx0, ld_g, (const T*)pe, ld_pe, n, D, (T*)gpe, ld_gpe)
     DISPATCH_DTYPE(dtype, GO(float), GO(bf16_t), GO(f16_t))
 #undef GO
   }
   if (gtable) {
-    SEGGER_REQUIRE(table && ids, "segger_embed_gelu_bwd: table / ids required for the table gradient");
-    if (lds_bytes > 160 * 1024) {
-      set_error("segger_embed_gelu_bwd: %d table rows need %zu B of LDS (> 160 KiB)", n_rows_table, lds_bytes);
-      return SEGGER_EUNSUPPORTED;
-    }
-    const int nparts = emb_row_blocks(n);
+    SEGGER_REQUIRE(table && gene_ptr && gene_rows, "segger_embed_gelu_bwd: table / gene_ptr / gene_rows required for the table gradient");
     const size_t need = segger_embed_gelu_bwd_workspace_bytes(n, n_rows_table, D);
     if (!workspace || workspace_bytes < need) {
       set_error("segger_embed_gelu_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
       return SEGGER_EWORKSPACE;
     }
-    const int64_t rpb = (n + nparts - 1) / nparts;
+    const int64_t max_chunks = emb_max_chunks(n, n_rows_table);
+    SEGGER_REQUIRE(max_chunks < 0x7fffffffLL, "segger_embed_gelu_bwd: too many rows");
     float* partial = static_cast<float*>(workspace);
-    dim3 grid((unsigned)nparts, (unsigned)(D / S));
-#define GO(T)                                                                                                         \
-  do {                                                                                                                \
-    static bool attr_set = false;   /* once per type: not a stream operation, keep it out of graph captures */   \
-    if (!attr_set) {                                                                                                  \
-      (void)hipFuncSetAttribute((const void*)embed_grad_partial_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      attr_set = true;                                                                                                \
-    }                                                                                                                 \
-    hipLaunchKernelGGL((embed_grad_partial_kernel<T>), grid, dim3(256), lds_bytes, stream, (const T*)gx0, ld_g, ids, n, n_rows_table, D, S, rpb, partial); \
-  } while (0)
+    int* chunk_ptr = reinterpret_cast<int*>(static_cast<char*>(workspace) + (((size_t)max_chunks * D * sizeof(float) + 15) & ~(size_t)15));
+    hipLaunchKernelGGL(emb_plan_kernel, dim3(1), dim3(256), 0, stream, gene_ptr, (int)n_rows_table, chunk_ptr);
+    const int P = D / 8, R = 256 / P > 0 ? 256 / P : 1;
+    const size_t lds = (size_t)R * D * sizeof(float);
+#define GO(T) hipLaunchKernelGGL((emb_gather_kernel<T>), dim3((unsigned)max_chunks), dim3((unsigned)(P * R)), lds, stream, (const T*)gx0, ld_g, gene_ptr, gene_rows, chunk_ptr, (int)n_rows_table, D, partial)
     DISPATCH_DTYPE(dtype, GO(float), GO(bf16_t), GO(f16_t))
 #undef GO
-    hipLaunchKernelGGL(embed_grad_reduce_kernel, dim3((unsigned)((gd + 255) / 256)), dim3(256), 0, stream, partial, nparts, table, gd, gtable);
+    hipLaunchKernelGGL(emb_finish_kernel, dim3((unsigned)((gd + 255) / 256)), dim3(256), 0, stream, partial, chunk_ptr, table, (int)n_rows_table, D, gtable);
   }
   SEGGER_LAUNCH_CHECK("embed_gelu_bwd kernels");
+  return SEGGER_OK;
+}
+
+extern "C" size_t segger_colsum_workspace_bytes(int64_t n, int32_t cols) {
+  return (size_t)colsum_blocks(n) * (size_t)(cols > 0 ? cols : 0) * sizeof(float) + 16;
+}
+
+extern "C" int segger_colsum(const void* x, int64_t ld, int64_t n, int32_t cols, int32_t dtype, float* out,
+                             void* workspace, size_t workspace_bytes, segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGGER_REQUIRE(n >= 0 && cols > 0 && cols % 8 == 0 && cols <= 2048, "segger_colsum: cols must be a multiple of 8, <= 2048");
+  SEGGER_REQUIRE(out, "segger_colsum: NULL output");
+  if (n == 0) {
+    SEGGER_HIP(hipMemsetAsync(out, 0, (size_t)cols * sizeof(float), stream));
+    return SEGGER_OK;
+  }
+  SEGGER_REQUIRE(x && aligned16(x) && ld >= cols && (ld * esize(dtype)) % 16 == 0, "segger_colsum: bad pointer / leading dimension");
+  const size_t need = segger_colsum_workspace_bytes(n, cols);
+  if (!workspace || workspace_bytes < need) {
+    set_error("segger_colsum: workspace %zu < %zu bytes", workspace_bytes, need);
+    return SEGGER_EWORKSPACE;
+  }
+  const int nparts = colsum_blocks(n);
+  const int64_t rpb = (n + nparts - 1) / nparts;
+  const int P = cols / 8, R = 256 / P > 0 ? 256 / P : 1;
+  SEGGER_REQUIRE(P <= 256, "segger_colsum: cols must be <= 2048");
+  const size_t lds = (size_t)R * cols * sizeof(float);    // <= 256/P * P*8 * 4 = 8 KiB
+  float* partial = static_cast<float*>(workspace);
+#define GO(T) hipLaunchKernelGGL((colsum_partial_kernel<T>), dim3((unsigned)nparts), dim3((unsigned)(P * R)), lds, stream, (const T*)x, ld, n, cols, rpb, partial)
+  DISPATCH_DTYPE(dtype, GO(float), GO(bf16_t), GO(f16_t))
+#undef GO
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((unsigned)((cols + 15) / 16)), dim3(256), 0, stream, partial, nparts, cols, out);
+  SEGGER_LAUNCH_CHECK("colsum kernels");
   return SEGGER_OK;
 }
 

@@ -272,7 +272,18 @@ class ISTEncoder(Module):
         if self.use_positional_embeddings:
             x_bd = F.gelu(torch.cat((x_bd, pe("bd")), -1))
             if self.in_channels % 32 == 0 and emb.weight.dtype == torch.float32:
-                x_tx = ops.embed_gelu(emb.weight, x_dict["tx"], pe("tx"))      # gather + concat + GELU, one kernel
+                # gather + concat + GELU in one kernel; its table gradient sums over rows grouped by gene id: one
+                # sort per batch (not needed without grad), cached with the batch or supplied with `graphs`
+                ids = x_dict["tx"]
+                by_gene = graphs.get("tx_by_gene") if graphs is not None else None
+                if by_gene is None and torch.is_grad_enabled() and emb.weight.requires_grad:
+                    key = ("by_gene", ids.data_ptr(), int(ids.shape[0]))
+                    by_gene = cache.get(key) if cache is not None else None
+                    if by_gene is None:
+                        by_gene = ops.rows_by_id(ids, emb.weight.shape[0])
+                        if cache is not None:
+                            cache[key] = by_gene
+                x_tx = ops.embed_gelu(emb.weight, ids, pe("tx"), by_gene)
             else:
                 x_tx = F.gelu(torch.cat((emb(x_dict["tx"].long()).to(dt), pe("tx")), -1))
         else:

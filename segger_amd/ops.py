@@ -396,6 +396,24 @@ def linear_fwd_launch(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Optiona
     return y
 
 
+def colsum(x: Tensor) -> Tensor:
+    """fp32 column sums of a [n, cols] matrix (row stride allowed): the bias gradient ``grad_out.sum(0)``."""
+    _lib.require_cuda(x)
+    lib = _lib.load()
+    n, cols = x.shape
+    if x.dtype not in DTYPE_CODE or cols % 8 != 0 or cols > 2048:
+        return x.sum(0, dtype=torch.float32)
+    xp, ld = _rows(x, cols, "x")
+    out = torch.empty(cols, dtype=torch.float32, device=x.device)
+    ws_bytes = lib.segger_colsum_workspace_bytes(n, cols)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.segger_colsum(xp, ld, n, cols, DTYPE_CODE[x.dtype], out.data_ptr(), ws.data_ptr(), ws_bytes,
+                               _lib.stream_ptr(x.device))
+    _lib.check(rc, "segger_colsum")
+    return out
+
+
 _DW_SPLITS = 128
 
 
@@ -448,7 +466,7 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = _weight_grad(gy, x).to(weight.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum(0, dtype=torch.float32).to(bias.dtype)
+            gb = colsum(gy).to(bias.dtype)
         return gx, gw, gb
 
 
@@ -493,7 +511,7 @@ class _EmbedGelu(torch.autograd.Function):
     """gelu(cat(table[ids], pe)): table fp32 [G, D] (embedding weight), ids int32 [n], pe [n, D] -> [n, 2D]."""
 
     @staticmethod
-    def forward(ctx, table, ids, pe):
+    def forward(ctx, table, ids, pe, by_gene):
         _lib.require_cuda(table, ids, pe)
         lib = _lib.load()
         n, d = pe.shape
@@ -505,6 +523,7 @@ class _EmbedGelu(torch.autograd.Function):
                                            DTYPE_CODE[pe.dtype], _lib.stream_ptr(pe.device))
         _lib.check(rc, "segger_embed_gelu_fwd")
         ctx.save_for_backward(table, ids, pe)
+        ctx.by_gene = by_gene
         return out
 
     @staticmethod
@@ -525,20 +544,33 @@ class _EmbedGelu(torch.autograd.Function):
         gtable = torch.empty_like(table) if want_table else None
         ws_bytes = lib.segger_embed_gelu_bwd_workspace_bytes(n, g, d) if want_table else 0
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        by_gene = ctx.by_gene
+        if want_table and by_gene is None:
+            by_gene = rows_by_id(ids, g)
         with torch.cuda.device(dev):
-            rc = lib.segger_embed_gelu_bwd(gp, ldg, table.data_ptr(), ids.data_ptr(), pp, ldp, n, g, d,
-                                           gpe.data_ptr(), d, _lib.ptr(gtable), ws.data_ptr(), ws_bytes,
-                                           DTYPE_CODE[pe.dtype], _lib.stream_ptr(dev))
+            rc = lib.segger_embed_gelu_bwd(gp, ldg, table.data_ptr(), pp, ldp, n, g, d, gpe.data_ptr(), d, _lib.ptr(gtable),
+                                           by_gene.indptr.data_ptr() if want_table else None,
+                                           (by_gene.col.data_ptr() if n else None) if want_table else None,
+                                           ws.data_ptr(), ws_bytes, DTYPE_CODE[pe.dtype], _lib.stream_ptr(dev))
         _lib.check(rc, "segger_embed_gelu_bwd")
-        return gtable, None, gpe
+        return gtable, None, gpe, None
 
 
-def embed_gelu(table: Tensor, ids: Tensor, pe: Tensor) -> Tensor:
+def rows_by_id(ids: Tensor, n_ids: int) -> EdgeCSR:
+    """Rows grouped by id (``indptr`` over ids, ``col`` = row numbers, ascending inside an id): what the
+    embedding-table gradient sums over.  One radix sort; cache it per batch (``ISTEncoder`` does)."""
+    from .graph import csr_from_coo
+    n = int(ids.shape[0])
+    return csr_from_coo(ids.long(), torch.arange(n, device=ids.device), int(n_ids), max(n, 1), validate=False)
+
+
+def embed_gelu(table: Tensor, ids: Tensor, pe: Tensor, by_gene: Optional[EdgeCSR] = None) -> Tensor:
+    """``by_gene`` = :func:`rows_by_id` of ``ids`` when the caller has it cached (built in backward otherwise)."""
     if table.dtype != torch.float32 or not table.is_contiguous():
         raise TypeError("embed_gelu: the embedding table must be contiguous fp32")
     if pe.shape[1] != table.shape[1] or pe.shape[1] % 32:
         raise ValueError("embed_gelu: pe width must equal the embedding width and be a multiple of 32")
-    return _EmbedGelu.apply(table, ids.to(torch.int32).contiguous(), pe.contiguous())
+    return _EmbedGelu.apply(table, ids.to(torch.int32).contiguous(), pe.contiguous(), by_gene)
 
 
 class _L2Norm(torch.autograd.Function):

@@ -22,6 +22,7 @@ from typing import Dict, Optional
 import torch
 from torch import Tensor
 
+from . import ops
 from .graph import EdgeGraph, build_edge_graph
 from .hetero import TX_BD, TX_TX
 from .inference import bucket_sizes, pad_batch  # noqa: F401  (re-exported for callers)
@@ -76,6 +77,14 @@ class GraphedEncoder:
                 for side in ("by_dst", "by_src"):
                     cur, new = getattr(self.graphs[et], side), getattr(g, side)
                     cur.indptr.copy_(new.indptr); cur.col.copy_(new.col); cur.eid.copy_(new.eid)
+        # rows grouped by gene id for the embedding-table gradient
+        emb = self.lit.model.lin_first["tx"]
+        bg = ops.rows_by_id(self.inp[0], emb.weight.shape[0])
+        if "tx_by_gene" not in self.graphs:
+            self.graphs["tx_by_gene"] = bg
+        else:
+            cur = self.graphs["tx_by_gene"]
+            cur.indptr.copy_(bg.indptr); cur.col.copy_(bg.col)
 
     def __call__(self, batch) -> Dict[str, Tensor]:
         if getattr(batch, "num_graphs", 1) > self.max_graphs:

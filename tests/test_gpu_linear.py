@@ -69,3 +69,34 @@ def test_unsupported_shapes_use_vendor_gemm(cuda):
     x = torch.randn(10, 100, device=cuda).to(torch.bfloat16)
     w = torch.randn(96, 100, device=cuda)
     assert ops.linear(x, w, None).shape == (10, 96)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n,cols", [(1, 64), (255, 8), (4097, 384), (100_003, 128), (70_001, 2048), (600_000, 64)])
+def test_colsum_matches_fp64_sum(cuda, dtype, n, cols):
+    """Bias-gradient reduction: fp32 accumulation of <= 6e5 values of magnitude ~1 -> rtol 1e-5 of sum |x|."""
+    from segger_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(n + cols)
+    x = (torch.randn(n, cols, device=cuda, generator=g) + 0.25).to(dtype)
+    got = ops.colsum(x)
+    ref = x.double().sum(0)
+    bound = 1e-5 * x.double().abs().sum(0) + 1e-6
+    assert got.dtype == torch.float32 and got.shape == (cols,)
+    assert bool(((got.double() - ref).abs() <= bound).all())
+    # a column window of a wider matrix (row stride != cols), as the fused projection gradient is laid out
+    if cols >= 16:
+        view = x[:, cols // 2:]
+        assert bool(((ops.colsum(view).double() - ref[cols // 2:]).abs() <= bound[cols // 2:]).all())
+    assert torch.equal(ops.colsum(x), got)                  # deterministic
+
+
+def test_colsum_empty_and_errors(cuda):
+    from segger_amd import _lib, ops
+    assert torch.equal(ops.colsum(torch.empty(0, 64, device=cuda)), torch.zeros(64, device=cuda))
+    lib = _lib.load()
+    x = torch.zeros(10, 64, device=cuda)
+    out = torch.zeros(64, device=cuda)
+    rc = lib.segger_colsum(x.data_ptr(), 64, 10, 64, 0, out.data_ptr(), None, 0, _lib.stream_ptr(cuda))
+    assert rc != 0 and b"workspace" in lib.segger_last_error()
+    rc = lib.segger_colsum(x.data_ptr(), 64, 10, 60, 0, out.data_ptr(), None, 0, _lib.stream_ptr(cuda))
+    assert rc != 0
