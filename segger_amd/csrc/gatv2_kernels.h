@@ -258,7 +258,7 @@ __device__ __forceinline__ void load_att(const float* att, int ch0, float slope,
 template <typename T, int H, int LPH, bool WPR>
 __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatParams p) {
   using G = Geo<H, LPH>;
-  constexpr int GS = G::GS, NG = G::NG, U = SEGGER_FWD_UNROLL;
+  constexpr int GS = G::GS, NG = G::NG, U = SEGGER_FWD_UNROLL < GS ? SEGGER_FWD_UNROLL : GS;
   const int64_t blk = xcd_remap(blockIdx.x, p.nblocks_padded, p.nblocks);
   if (blk < 0) return;
   const LaneGeo L = lane_geo<G>();
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
 template <typename T, int H, int LPH, bool WPR>
 __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kernel(GatParams p) {
   using G = Geo<H, LPH>;
-  constexpr int GS = G::GS, NG = G::NG, U = SEGGER_DST_UNROLL, HC = G::HC;
+  constexpr int GS = G::GS, NG = G::NG, U = SEGGER_DST_UNROLL < GS ? SEGGER_DST_UNROLL : GS, HC = G::HC;
   __shared__ float red[4][2][HC];
   const int64_t blk = xcd_remap(blockIdx.x, p.nblocks_padded, p.nblocks);
   if (blk < 0) return;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
 template <typename T, int H, int LPH, bool WPR>
 __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kernel(GatParams p) {
   using G = Geo<H, LPH>;
-  constexpr int GS = G::GS, NG = G::NG, U = SEGGER_SRC_UNROLL;
+  constexpr int GS = G::GS, NG = G::NG, U = SEGGER_SRC_UNROLL < GS ? SEGGER_SRC_UNROLL : GS;
   const int64_t blk = xcd_remap(blockIdx.x, p.nblocks_padded, p.nblocks);
   if (blk < 0) return;
   const LaneGeo L = lane_geo<G>();
