@@ -213,18 +213,21 @@ def main():
         out = torch.empty(n_tx, hc, dtype=dtype, device=dev)
         pre = torch.empty_like(out)
         lse = torch.empty(n_tx, H, device=dev)
+        # same configuration as inside the step (attention dropout on unless --no-dropout), so the rocprofv3
+        # average over ALL launches of this kernel in a profiled run is the figure reported here
+        drop = 0.0 if args.no_dropout else 0.2
         fwd = lambda: ops.gatv2_fwd_launch(g_tt.by_dst, xp[:, :hc], xp[:, hc:2 * hc], att, bias, H, C, out,
-                                           pre=pre, lse=lse, apply_gelu=True)
+                                           pre=pre, lse=lse, apply_gelu=True, dropout_p=drop, seed=11)
         ms_fwd = time_kernel(fwd)
         gy = torch.randn(n_tx, hc, device=dev, generator=gen).to(dtype)
         gxp = torch.empty_like(xp)
         bwd = lambda: ops.gatv2_bwd_launch(g_tt, xp[:, :hc], xp[:, hc:2 * hc], att, bias, H, C, gy, pre, lse,
-                                           gxp[:, :hc], gxp[:, hc:2 * hc], apply_gelu=True)
+                                           gxp[:, :hc], gxp[:, hc:2 * hc], apply_gelu=True, dropout_p=drop, seed=11)
         ms_bwd = time_kernel(bwd)
         b_fwd = gat_fwd_algorithmic_bytes(ett, n_tx, hc, elem)
         b_bwd = gat_bwd_algorithmic_bytes(ett, n_tx, n_tx, hc, H, elem)
         ach = b_fwd / (ms_fwd * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "gatv2_fwd_kernel<bf16,H=2,C=64> (tx-neighbors-tx aggregation)",
+        roof = {"bound": "hbm", "kernel": f"gatv2_fwd_kernel<{args.dtype},H=2,C=64> (tx-neighbors-tx aggregation, dropout {drop})",
                 "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": None, "algorithmic_bytes_per_launch": b_fwd, "ms_per_launch": ms_fwd}
         tr = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -233,14 +236,21 @@ def main():
                 meas = json.load(open(tr))
                 w = meas.get("workload", {})
                 # the PMC passes were taken on one workload; the figure means nothing for another size
-                if (w.get("n_tx"), w.get("k"), w.get("dtype")) == (args.n_tx, args.k, args.dtype):
+                if (w.get("n_tx"), w.get("k"), w.get("dtype"), w.get("dropout")) == (args.n_tx, args.k, args.dtype, drop):
                     roof["traffic"] = meas.get("gatv2_fwd_bytes_per_launch")
                     roof["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc, separate run)"
             except Exception:  # noqa: BLE001
                 pass
         ach_b = b_bwd / (ms_bwd * 1e-3) / 1e9
         extra = {"gatv2_bwd_tx_tx": {"achieved": ach_b, "frac": ach_b / HBM_PEAK_GBS, "unit": "GB/s",
-                                     "algorithmic_bytes_per_launch": b_bwd, "ms_per_launch": ms_bwd}}
+                                     "algorithmic_bytes_per_launch": b_bwd, "ms_per_launch": ms_bwd,
+                                     "note": "bwd_dst + bwd_src kernel pair of one layer, same dropout as the step"}}
+        if drop > 0:        # the same forward kernel as prediction runs it (no dropout, no edge-id stream)
+            ms_eval = time_kernel(lambda: ops.gatv2_fwd_launch(g_tt.by_dst, xp[:, :hc], xp[:, hc:2 * hc], att, bias, H, C,
+                                                               out, pre=pre, lse=lse, apply_gelu=True))
+            ach_e = b_fwd / (ms_eval * 1e-3) / 1e9
+            extra["gatv2_fwd_tx_tx_eval"] = {"achieved": ach_e, "frac": ach_e / HBM_PEAK_GBS, "unit": "GB/s",
+                                             "algorithmic_bytes_per_launch": b_fwd, "ms_per_launch": ms_eval}
         log(f"[bench] gatv2 fwd {ms_fwd:.3f} ms ({ach:.0f} GB/s alg.), bwd {ms_bwd:.3f} ms ({ach_b:.0f} GB/s alg.)")
 
     # ---- secondary figure: inference-only edge scoring (predict_step) on the same tile ----------------
