@@ -10,7 +10,7 @@ all-reduce is latency-bound, so it is ONE collective on one contiguous buffer.
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Sequence
+from typing import Iterable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -82,3 +82,23 @@ def assign_tiles(weights: Sequence[float], world_size: int) -> List[List[int]]:
         out[r].append(i)
         loads[r] += weights[i]
     return out
+
+
+def rank_schedule(batch_weights: Sequence[float], world_size: int) -> List[List[Optional[int]]]:
+    """Per-rank list of batch ids for one epoch: batches go to ranks by :func:`assign_tiles` (balanced edge
+    counts), each rank runs its heaviest batch first, and shorter lists are padded with ``None`` so every rank
+    takes the same number of optimizer steps.  On a ``None`` step a rank skips forward / backward and still
+    calls ``FlatGradBucket.all_reduce_mean`` (it contributes zeros; the mean is over the world size, as DDP's
+    join does), so the collective never deadlocks on uneven batch counts."""
+    per_rank = assign_tiles(batch_weights, world_size)
+    steps = max((len(r) for r in per_rank), default=0)
+    return [list(r) + [None] * (steps - len(r)) for r in per_rank]
+
+
+def seed_rank(base_seed: int, rank: int, encoder=None) -> None:
+    """Rank-offset RNG streams: torch's generators (negative sampling, triplet sampling) and, when the encoder
+    is given, its device-side attention-dropout counter -- replicas must not draw identical masks."""
+    torch.manual_seed(int(base_seed) + 7919 * int(rank))
+    if encoder is not None and hasattr(encoder, "_step_dev"):
+        with torch.no_grad():
+            encoder._step_dev.fill_(int(rank) << 40)

@@ -69,3 +69,62 @@ def test_single_process_is_a_noop():
     before = [p.grad.clone() for p in lin.parameters()]
     b.all_reduce_mean()                                  # no process group: nothing happens
     assert all(torch.equal(x, p.grad) for x, p in zip(before, lin.parameters())) and b.flat.numel() == 0
+
+
+def _uneven_worker(rank, world, port, out):
+    """5 batches over 2 ranks -> 3 steps; the rank that runs out takes an EMPTY step (zeros into the all-reduce)."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from segger_amd.dp import FlatGradBucket, broadcast_parameters, rank_schedule, seed_rank
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(4, 3)
+    broadcast_parameters(lin)
+    seed_rank(123, rank)
+    draw = torch.rand(1).item()                             # rank-offset RNG stream
+    data = [torch.full((2, 4), float(i + 1)) for i in range(5)]
+    weights = [10, 9, 8, 7, 6]
+    sched = rank_schedule(weights, world)
+    bucket = FlatGradBucket(lin.parameters())
+    opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+    for b in sched[rank]:
+        opt.zero_grad(set_to_none=True)
+        if b is not None:
+            lin(data[b]).sum().backward()
+        bucket.all_reduce_mean()
+        opt.step()
+    w = torch.cat([p.detach().reshape(-1) for p in lin.parameters()])
+    gathered = [torch.empty_like(w) for _ in range(world)]
+    dist.all_gather(gathered, w)
+    draws = [None] * world
+    dist.all_gather_object(draws, draw)
+    if rank == 0:
+        out.put((sched, torch.equal(gathered[0], gathered[1]), w.clone(), draws))
+    dist.destroy_process_group()
+
+
+def test_uneven_batch_counts_take_empty_steps_world2():
+    from segger_amd.dp import rank_schedule
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    sched, in_sync, w, draws = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sched == [[0, 3, 4], [1, 2, None]] == rank_schedule([10, 9, 8, 7, 6], 2)
+    assert in_sync and draws[0] != draws[1]
+    # single-process replay of the same 3 averaged steps
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(4, 3)
+    opt = torch.optim.SGD(lin.parameters(), lr=0.1)
+    data = [torch.full((2, 4), float(i + 1)) for i in range(5)]
+    for pair in zip(*sched):
+        opt.zero_grad()
+        for b in pair:
+            if b is not None:
+                (lin(data[b]).sum() / 2).backward()          # mean over the world size, empty rank = zeros
+        opt.step()
+    assert torch.allclose(w, torch.cat([p.detach().reshape(-1) for p in lin.parameters()]), atol=1e-6)

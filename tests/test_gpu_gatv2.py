@@ -61,7 +61,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("H,C,n_src,n_dst,E", CASES)
 @pytest.mark.parametrize("gelu", [False, True])
 def test_gatv2_forward_backward(oracle, cuda, dtype, H, C, n_src, n_dst, E, gelu):

@@ -12,6 +12,12 @@ reference ``data/data_module.py:158``) and
 3. (``--graphed``) repeats the scoring pass through the hipGraph-captured predictor, one graph per shape
    bucket (config 5: inference only, fp16).
 
+Under ``python -m torch.distributed.run --nproc-per-node N … tools/fov_stream.py`` the training epoch is data
+parallel over the packed batches (BASELINE config 4): every rank builds the same FOV from the seed (0.4 s; no data
+path collective), takes its share of the batches (``dp.rank_schedule``: balanced edge counts, empty steps where a
+rank runs out), one flat RCCL all-reduce per step; scoring / prediction stay on rank 0 (inference needs no
+collective -- tiles would simply be split).
+
 Prints one JSON object; progress goes to stderr.  This is a driver around the product path: it never touches
 ``oracle/`` (the oracle comparison at tile scale lives in tests/test_gpu_fov.py).
 """
@@ -64,16 +70,27 @@ def main():
     ap.add_argument("--overlap-predict", action="store_true",
                     help="also run segger's real predict pipeline: overlapping tiles (bbox + margin, predict_mask), "
                          "predict_step per tile, dedup + per-gene thresholds")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None, help="also write the JSON here")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
         raise SystemExit("fov_stream.py needs an MI355X: there is no CPU fallback")
-    dev = torch.device("cuda", 0)
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from segger_amd import LitISTEncoder, TX_BD, TX_NB_BD, TX_TX, ops
+    from segger_amd.dp import FlatGradBucket, broadcast_parameters, rank_schedule, seed_rank
     from segger_amd.graph import batch_cache, edge_graph
     from segger_amd.inference import GraphedPredictor, bucket_sizes
     from segger_amd.metrics import assignment_accuracy, auroc
@@ -110,36 +127,61 @@ def main():
     model._max_epochs_override = 20
     model.current_epoch = 10
     opt = model.configure_optimizers()
+    broadcast_parameters(model)
+    seed_rank(args.seed, rank, model.model)
+    bucket = FlatGradBucket(model.parameters())
 
-    # ---- 1. training over the batch stream -----------------------------------------------------------
+    # ---- 1. training over the batch stream (data parallel over the packed batches when world > 1) ------
     model.model.compute_dtype = DT[args.train_dtype]
     model.train()
     todo = batches if args.train_batches <= 0 else batches[: args.train_batches]
-    for ids in todo[:3]:                                     # warm-up: lazy inits, allocator
-        b = part.batch(ids)
+    w_all = part.weights("edge")
+    sched = rank_schedule([sum(w_all[t] for t in ids) for ids in todo], world)[rank]
+
+    def train_step(k, i):
         opt.zero_grad(set_to_none=True)
-        model.training_step(b, 0).backward()
-        opt.step()
-    etb_seen = ett_seen = 0
-    loss = None
-    with Phase("train_s", times):
-        for i, ids in enumerate(todo):
-            b = part.batch(ids)
-            opt.zero_grad(set_to_none=True)
-            loss = model.training_step(b, i)
+        loss = None
+        if k is not None:                                    # None: this rank ran out of batches (empty step)
+            loss = model.training_step(part.batch(todo[k]), i)
             loss.backward()
-            opt.step()
-            etb_seen += int(b[TX_BD].edge_index.shape[1])
-            ett_seen += int(b[TX_TX].edge_index.shape[1])
-            if i % 200 == 0:
-                log(f"[fov] train batch {i}/{len(todo)} loss {float(loss.detach()):.4f}")
+        bucket.all_reduce_mean()
+        opt.step()
+        return loss
+
+    for k in sched[:3]:                                      # warm-up: lazy inits, allocator
+        train_step(k, 0)
+    etb_seen = ett_seen = 0
+    eptr_tb, eptr_tt = part.edge_sizes[TX_BD].tolist(), part.edge_sizes[TX_TX].tolist()
+    loss = None
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    with Phase("train_s", times):
+        for i, k in enumerate(sched):
+            l = train_step(k, i)
+            if k is not None:
+                loss = l
+                etb_seen += sum(eptr_tb[t] for t in todo[k])
+                ett_seen += sum(eptr_tt[t] for t in todo[k])
+            if i % 200 == 0 and loss is not None:
+                log(f"[fov r{rank}] train step {i}/{len(sched)} loss {float(loss.detach()):.4f}")
+        if world > 1:
+            dist.barrier()
+    stats = torch.tensor([times["train_s"], float(etb_seen), float(ett_seen)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = stats[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        sums = stats[1:].clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        times["train_s"], etb_seen, ett_seen = float(tmax[0]), float(sums[0]), float(sums[1])
     train = {
-        "batches": len(todo), "dtype": args.train_dtype, "seconds": times["train_s"],
-        "ms_per_batch": times["train_s"] / len(todo) * 1e3,
+        "batches": len(todo), "steps_per_rank": len(sched), "n_gpus": world, "dtype": args.train_dtype,
+        "seconds": times["train_s"], "ms_per_step": times["train_s"] / max(len(sched), 1) * 1e3,
         "edges_scored_per_s": 2.0 * etb_seen / times["train_s"],
         "mp_edges_per_s": 4.0 * (ett_seen + etb_seen) / times["train_s"],
-        "final_loss": float(loss.detach()),
+        "final_loss": float(loss.detach()) if loss is not None else None,
     }
+    if rank != 0:                                            # scoring / prediction: rank 0 only
+        dist.destroy_process_group()
+        return
 
     # ---- 2. score every candidate edge, one pass per dtype, identical weights ------------------------
     model.eval()
@@ -245,6 +287,8 @@ def main():
         "train": train, "scoring": scoring, "graphed_predict": graphed, "overlap_predict": overlap,
         "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30,
     }
+    if world > 1:
+        dist.destroy_process_group()
     s = json.dumps(res)
     print(s, flush=True)
     if args.out:
