@@ -227,6 +227,21 @@ __device__ __forceinline__ float logit_partial(const f32x2 (&t)[4], const f32x2 
   return pp.x + pp.y + pa;
 }
 
+// ---- sign algebra of the backward passes ------------------------------------
+// Both passes carry nt = -(x_l + x_r) instead of t, formed as (-a) - b with every zero of the PER-ROW operand a
+// canonicalised to -0: then nt is +0 whenever t is +-0 and sign(nt) == (t > 0) exactly (torch's leaky_relu
+// derivative is `t > 0 ? 1 : slope`, so sgn(+-0) = -1).  de * sgn(t) is then one bit operation,
+//   s = bits(-de) ^ (bits(nt) & 0x80000000)                     (v_bitop3_b32),
+// which also yields de * |t| = s * t without a compare / select per channel.
+__device__ __forceinline__ f32x2 neg_canon_zero(f32x2 a) {          // -a, with +-0 -> +0
+  return f32x2{a.x == 0.f ? 0.f : -a.x, a.y == 0.f ? 0.f : -a.y};
+}
+__device__ __forceinline__ float sign_mul(float nde, float nt) {     // de * sgn(t) given -de and nt
+  // a ^ (b & c) as one v_bitop3_b32 (truth table 0xF0 ^ (0xCC & 0xAA) = 0x78); the compiler does not fold the
+  // and + xor pair by itself
+  return __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(nde), __float_as_uint(nt), 0x80000000u, 0x78));
+}
+
 struct LaneGeo {
   int lane, wave, grp, gl, h, ch0;
   bool lane_on;
@@ -411,10 +426,10 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
   }
   constexpr int RPW = WPR ? 1 : NG;            // rows per wave per iteration
 
-  f32x2 a1[4], a2[4], Pt[4], Qt[4], dbias[4];
+  f32x2 a1[4], na1[4], a2[4], Pt[4], Qt[4], dbias[4];
   load_att(p.att, ch0, p.slope, kLog2e, a1, a2);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { Pt[i] = splat(0.f); Qt[i] = splat(0.f); dbias[i] = splat(0.f); }
+  for (int i = 0; i < 4; ++i) { na1[i] = -a1[i]; Pt[i] = splat(0.f); Qt[i] = splat(0.f); dbias[i] = splat(0.f); }
 
 #pragma unroll 1
   for (int it = 0; it < p.rows_per_wave_iter; ++it) {
@@ -423,15 +438,17 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
     const int64_t row = rbase + (WPR ? 0 : L.grp);
     const bool row_ok = row < p.n_rows;
 
-    f32x2 xr[4], g[4], Sg[4];
+    f32x2 nxr[4], g[4], Sg[4];
     float D = 0.f, lse = 0.f, Sde = 0.f;
     int64_t beg = 0, end = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { xr[i] = splat(0.f); g[i] = splat(0.f); Sg[i] = splat(0.f); }
+    for (int i = 0; i < 4; ++i) { nxr[i] = splat(0.f); g[i] = splat(0.f); Sg[i] = splat(0.f); }
     if (row_ok) {
       beg = p.indptr[row]; end = p.indptr[row + 1];
-      f32x2 gy[4], pr[4];
+      f32x2 gy[4], pr[4], xr[4];
       load_pairs(static_cast<const T*>(p.xr) + row * p.ld_xr + ch0, xr);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nxr[i] = neg_canon_zero(xr[i]);
       load_pairs(static_cast<const T*>(p.gout) + row * p.ld_go + ch0, gy);
       load_pairs(static_cast<const T*>(p.pre) + row * p.ld_pre + ch0, pr);
       f32x2 d2 = splat(0.f);
@@ -461,26 +478,25 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
       for (int u = 0; u < U; ++u) raw[u].load(row_ptr(xl, nbr[u], ld_xl));
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        f32x2 v[4], t[4];
+        f32x2 v[4], nt[4];
         raw[u].get(v);
         f32x2 da2 = splat(0.f);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { t[i] = v[i] + xr[i]; da2 = pk_fma(g[i], v[i], da2); }
-        const float pl = lane_block_sum<LPH>(logit_partial(t, a1, a2));
+        for (int i = 0; i < 4; ++i) { nt[i] = nxr[i] - v[i]; da2 = pk_fma(g[i], v[i], da2); }
+        const float pl = lane_block_sum<LPH>(logit_partial(nt, na1, a2));
         float da = lane_block_sum<LPH>(da2.x + da2.y);
         const float a = valid[u] ? fast_exp2(pl - lse) : 0.f;
         if (dropout) da = dropout_keep((uint32_t)ed[u], H, h, seed_lo, seed_hi, p.drop_thr) ? da * p.drop_scale : 0.f;
         const float de = a * (da - D);
         Sde += de;
-        const f32x2 de2 = splat(de);
         const float nde = -de;
+        const f32x2 nde2 = splat(nde);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          Pt[i] = pk_fma(de2, t[i], Pt[i]);
-          Qt[i].x = __builtin_fmaf(de, __builtin_fabsf(t[i].x), Qt[i].x);
-          Qt[i].y = __builtin_fmaf(de, __builtin_fabsf(t[i].y), Qt[i].y);
-          Sg[i].x += t[i].x > 0.f ? de : nde;
-          Sg[i].y += t[i].y > 0.f ? de : nde;
+          const f32x2 sg = f32x2{sign_mul(nde, nt[i].x), sign_mul(nde, nt[i].y)};    // de * sgn(t)
+          Pt[i] = pk_fma(nde2, nt[i], Pt[i]);                                        // de * t
+          Qt[i] = pk_fma(-sg, nt[i], Qt[i]);                                         // de * |t|
+          Sg[i] = Sg[i] + sg;
         }
       }
     };
@@ -560,9 +576,9 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
     seed_lo = (uint32_t)mixed; seed_hi = (uint32_t)(mixed >> 32);
   }
 
-  f32x2 a1[4], a2[4], v[4], acc[4], Sg[4];
+  f32x2 a1[4], na1[4], a2[4], nv[4], acc[4], Sg[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { v[i] = splat(0.f); acc[i] = splat(0.f); Sg[i] = splat(0.f); }
+  for (int i = 0; i < 4; ++i) { nv[i] = splat(0.f); acc[i] = splat(0.f); Sg[i] = splat(0.f); }
   float Sde = 0.f;
   int64_t beg = 0, end = 0;
   if (row_ok) { beg = p.indptr[row]; end = p.indptr[row + 1]; }
@@ -573,7 +589,14 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
     return;
   }
   load_att(p.att, ch0, p.slope, kLog2e, a1, a2);
-  if (row_ok) load_pairs(static_cast<const T*>(p.xl) + row * p.ld_xl + ch0, v);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) na1[i] = -a1[i];
+  if (row_ok) {
+    f32x2 v[4];
+    load_pairs(static_cast<const T*>(p.xl) + row * p.ld_xl + ch0, v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nv[i] = neg_canon_zero(v[i]);
+  }
 
   auto body = [&](const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
     if (!valid[0]) return;
@@ -588,14 +611,14 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      f32x2 xr[4], g[4], t[4];
+      f32x2 xr[4], g[4], nt[4];
       rxr[u].get(xr);
       rg[u].get(g);
-      f32x2 da2 = splat(0.f);
+      f32x2 nda2 = splat(0.f);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { t[i] = v[i] + xr[i]; da2 = pk_fma(g[i], v[i], da2); }
-      const float pl = lane_block_sum<LPH>(logit_partial(t, a1, a2));
-      float da = lane_block_sum<LPH>(da2.x + da2.y);
+      for (int i = 0; i < 4; ++i) { nt[i] = nv[i] - xr[i]; nda2 = pk_fma(g[i], nv[i], nda2); }
+      const float pl = lane_block_sum<LPH>(logit_partial(nt, na1, a2));
+      float da = -lane_block_sum<LPH>(nda2.x + nda2.y);
       const float a = valid[u] ? fast_exp2(pl - lse[u]) : 0.f;
       float a_eff = a;
       if (dropout) {
@@ -610,8 +633,7 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         acc[i] = pk_fma(ae2, g[i], acc[i]);
-        Sg[i].x += t[i].x > 0.f ? de : nde;
-        Sg[i].y += t[i].y > 0.f ? de : nde;
+        Sg[i] = Sg[i] + f32x2{sign_mul(nde, nt[i].x), sign_mul(nde, nt[i].y)};
       }
     }
   };
