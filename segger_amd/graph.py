@@ -104,6 +104,10 @@ def edge_graph(cache: Optional[dict], key, edge_index: Tensor, n_src: int, n_dst
          kw.get("need_by_dst", True), kw.get("need_by_src", True))
     g = cache.get(k)
     if g is None:
-        g = build_edge_graph(edge_index, n_src, n_dst, **kw)
+        factory = cache.get("graph_factory")         # tiles.TilePartition: views sliced from a once-per-slide sort
+        if factory is not None:
+            g = factory(key, edge_index, n_src, n_dst, kw.get("need_by_dst", True), kw.get("need_by_src", True))
+        if g is None:
+            g = build_edge_graph(edge_index, n_src, n_dst, **kw)
         cache[k] = g
     return g

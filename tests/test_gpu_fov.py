@@ -97,3 +97,38 @@ def test_streamed_batches_match_oracle_and_auroc(oracle, fov, dtype, atol):
     assert abs(a_dev - a_ref) <= 1e-3, (a_dev, a_ref)
     # the device AUROC routine itself against the oracle's on identical scores
     assert abs(auroc(ref.float().cuda(), lab.cuda()) - oracle.auroc(ref.float().double(), lab)) < 1e-9
+
+
+def test_slide_csr_views_equal_per_batch_sorts(fov):
+    """TilePartition.build_csr: the views sliced from the once-per-slide sort are exactly what sorting the
+    batch's own edge_index gives (same stable order), for single tiles and multi-tile batches."""
+    from segger_amd import TX_BD, TX_NB_BD, TX_TX
+    from segger_amd.graph import batch_cache, build_edge_graph, edge_graph
+    spec, data, part, batches, m = fov
+    try:
+        part.build_csr()
+        part.csr_max_tiles = 64                              # exercise the multi-tile assembly too
+        todo = [[0], [len(part) - 1], batches[0], batches[-1], [3, 1, 7]]
+        for ids in todo:
+            b = part.batch(ids)
+            for et in (TX_TX, TX_BD, TX_NB_BD):
+                ei = b[et].edge_index
+                ns, nd = b[et[0]].num_nodes, b[et[2]].num_nodes
+                got = edge_graph(batch_cache(b), et, ei, ns, nd)
+                ref = build_edge_graph(ei, ns, nd)
+                assert got is not ref and got.n_edges == ref.n_edges
+                for side in ("by_dst", "by_src"):
+                    g, r = getattr(got, side), getattr(ref, side)
+                    assert (g.n_rows, g.n_cols) == (r.n_rows, r.n_cols)
+                    assert torch.equal(g.indptr, r.indptr) and torch.equal(g.col, r.col) and torch.equal(g.eid, r.eid)
+        # and the model output is unchanged
+        b1 = part.batch(batches[1])
+        with torch.no_grad():
+            z1 = m.forward(b1)
+        part._csr = None
+        b2 = part.batch(batches[1])
+        with torch.no_grad():
+            z2 = m.forward(b2)
+        assert torch.equal(z1["tx"], z2["tx"]) and torch.equal(z1["bd"], z2["bd"])
+    finally:
+        part._csr = None

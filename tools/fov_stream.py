@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--overlap-predict", action="store_true",
                     help="also run segger's real predict pipeline: overlapping tiles (bbox + margin, predict_mask), "
                          "predict_step per tile, dedup + per-gene thresholds")
+    ap.add_argument("--no-slide-csr", action="store_true",
+                    help="sort the edges of every batch (5 radix sorts) instead of slicing the once-per-slide CSR views")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None, help="also write the JSON here")
@@ -113,6 +115,8 @@ def main():
         part.add_node_attr("tx", "predict_mask", torch.ones(args.n_tx, dtype=torch.bool, device=dev), permuted=True)
         pti = PredictTileIndex(data, tiling, margin=args.margin) if args.overlap_predict else None
         del data
+        if not args.no_slide_csr:
+            part.build_csr()
         sampler = TileBatchSampler(part, args.edges_per_batch, mode="edge", skip_too_big=True)
         batches = list(sampler)
     kept = {"__".join(et): int(v.sum()) for et, v in part.edge_sizes.items()}
