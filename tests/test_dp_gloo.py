@@ -98,7 +98,7 @@ def _uneven_worker(rank, world, port, out):
     draws = [None] * world
     dist.all_gather_object(draws, draw)
     if rank == 0:
-        out.put((sched, torch.equal(gathered[0], gathered[1]), w.clone(), draws))
+        out.put((sched, torch.equal(gathered[0], gathered[1]), w.tolist(), draws))   # plain lists: no fd hand-over
     dist.destroy_process_group()
 
 
@@ -127,4 +127,4 @@ def test_uneven_batch_counts_take_empty_steps_world2():
             if b is not None:
                 (lin(data[b]).sum() / 2).backward()          # mean over the world size, empty rank = zeros
         opt.step()
-    assert torch.allclose(w, torch.cat([p.detach().reshape(-1) for p in lin.parameters()]), atol=1e-6)
+    assert torch.allclose(torch.tensor(w), torch.cat([p.detach().reshape(-1) for p in lin.parameters()]), atol=1e-6)
