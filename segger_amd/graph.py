@@ -40,8 +40,56 @@ class EdgeCSR:
                         self.n_rows, self.n_cols, self.n_edges)
 
 
-def csr_from_coo(row: Tensor, col: Tensor, n_rows: int, n_cols: int, validate: bool = True) -> EdgeCSR:
-    """Stable sort of COO edges by ``row`` on the device (rows/cols as in ``edge_index``)."""
+# ---- deferred validation -------------------------------------------------------------------------------
+# segger_csr_from_coo counts edges whose node ids fall outside the graph and CLAMPS them (no kernel ever reads out
+# of bounds), so the check needs no host sync in the middle of a step: the counter is copied to pinned memory
+# asynchronously and examined when a later call (or flush_validation) finds the copy complete.
+_PIN_SLOTS = 256
+_pin: Optional[Tensor] = None
+_pin_next = 0
+_pending: list = []            # (event, slot, message)
+
+
+def _poll_validation(block: bool = False) -> None:
+    global _pending
+    keep = []
+    for ev, slot, msg in _pending:
+        if block:
+            ev.synchronize()
+        if ev.query():
+            n_bad = int(_pin[slot])
+            if n_bad:
+                _pending = []
+                raise IndexError(msg.format(n=n_bad))
+        else:
+            keep.append((ev, slot, msg))
+    _pending = keep
+
+
+def flush_validation() -> None:
+    """Wait for every outstanding deferred edge-index check and raise IndexError if one failed."""
+    _poll_validation(block=True)
+
+
+def _defer_validation(bad: Tensor, msg: str) -> None:
+    global _pin, _pin_next
+    if _pin is None:
+        _pin = torch.zeros(_PIN_SLOTS, dtype=torch.int32).pin_memory()
+    if len(_pending) >= _PIN_SLOTS - 1:
+        _poll_validation(block=True)
+    slot = _pin_next
+    _pin_next = (_pin_next + 1) % _PIN_SLOTS
+    _pin[slot:slot + 1].copy_(bad, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(bad.device))
+    _pending.append((ev, slot, msg))
+    _poll_validation()
+
+
+def csr_from_coo(row: Tensor, col: Tensor, n_rows: int, n_cols: int, validate=True) -> EdgeCSR:
+    """Stable sort of COO edges by ``row`` on the device (rows/cols as in ``edge_index``).
+    ``validate``: True = check the node ids now (one host sync), ``"deferred"`` = check without a sync (raises
+    from a later call or from :func:`flush_validation`; out-of-range ids are clamped meanwhile), False = never."""
     _lib.require_cuda(row, col)
     lib = _lib.load()
     dev = row.device
@@ -51,19 +99,22 @@ def csr_from_coo(row: Tensor, col: Tensor, n_rows: int, n_cols: int, validate: b
     indptr = torch.empty(n_rows + 1, dtype=torch.int64, device=dev)
     ccol = torch.empty(E, dtype=torch.int32, device=dev)
     eid = torch.empty(E, dtype=torch.int32, device=dev)
-    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev) if validate else None
     ws_bytes = lib.segger_csr_from_coo_workspace_bytes(E, n_rows)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         rc = lib.segger_csr_from_coo(row.data_ptr(), col.data_ptr(), E, n_rows, n_cols,
-                                     indptr.data_ptr(), ccol.data_ptr(), eid.data_ptr(), bad.data_ptr(),
+                                     indptr.data_ptr(), ccol.data_ptr(), eid.data_ptr(), _lib.ptr(bad),
                                      ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
     _lib.check(rc, "segger_csr_from_coo")
-    if validate:
+    msg = f"edge_index holds {{n}} edge(s) with node ids outside [0,{n_rows}) x [0,{n_cols})"
+    if validate == "deferred":
+        with torch.cuda.device(dev):
+            _defer_validation(bad, msg)
+    elif validate:
         n_bad = int(bad.item())          # one host sync per edge type per batch
         if n_bad:
-            raise IndexError(f"edge_index holds {n_bad} edge(s) with node ids outside "
-                             f"[0,{n_rows}) x [0,{n_cols})")
+            raise IndexError(msg.format(n=n_bad))
     return EdgeCSR(indptr, ccol, eid, n_rows, n_cols)
 
 
@@ -78,10 +129,11 @@ class EdgeGraph:
 
 
 def build_edge_graph(edge_index: Tensor, n_src: int, n_dst: int, *, need_by_dst: bool = True,
-                     need_by_src: bool = True, validate: bool = True) -> EdgeGraph:
+                     need_by_src: bool = True, validate=True) -> EdgeGraph:
     src, dst = edge_index[0], edge_index[1]
     by_dst = csr_from_coo(dst, src, n_dst, n_src, validate) if need_by_dst else None
-    by_src = csr_from_coo(src, dst, n_src, n_dst, validate and not need_by_dst) if need_by_src else None
+    # both views hold the same edges: one check is enough
+    by_src = csr_from_coo(src, dst, n_src, n_dst, False if need_by_dst else validate) if need_by_src else None
     return EdgeGraph(by_dst, by_src, n_src, n_dst, int(edge_index.shape[1]))
 
 

@@ -177,7 +177,8 @@ class SkipGAT(Module):
                                f"drop node type '{et[2]}' and fail in the next layer")
         x_tx, x_bd = x_dict["tx"], x_dict["bd"]
         if graphs is None:
-            graphs = {et: edge_graph(None, et, edge_index_dict[et], x_dict[et[0]].shape[0], x_dict[et[2]].shape[0])
+            graphs = {et: edge_graph(None, et, edge_index_dict[et], x_dict[et[0]].shape[0], x_dict[et[2]].shape[0],
+                                     validate="deferred")
                       for et in (TX_TX, TX_BD)}
         tt, tb = self.conv[TX_TX], self.conv[TX_BD]
         dt = x_tx.dtype
@@ -292,7 +293,8 @@ class ISTEncoder(Module):
         x = {"tx": x_tx, "bd": x_bd}
 
         if graphs is None:       # sorted views of the edge stores: built once per batch, shared by all layers
-            graphs = {et: edge_graph(cache, et, edge_index_dict[et], x[et[0]].shape[0], x[et[2]].shape[0])
+            graphs = {et: edge_graph(cache, et, edge_index_dict[et], x[et[0]].shape[0], x[et[2]].shape[0],
+                                     validate="deferred")     # checked without a host sync (graph.py)
                       for et in (TX_TX, TX_BD) if et in edge_index_dict}
         if self.training:
             self._step_dev.add_(256)

@@ -23,7 +23,7 @@ from torch import Tensor
 from torch.nn import BCEWithLogitsLoss
 
 from . import ops
-from .graph import batch_cache, edge_graph
+from .graph import batch_cache, edge_graph, flush_validation
 from .hetero import TX_BD, TX_NB_BD
 from .ist_encoder import ISTEncoder
 from .triplet_loss import MetricLoss, TripletLoss
@@ -210,12 +210,14 @@ class LitISTEncoder(_Base):
         z_tx, z_bd = embeddings['tx'], embeddings['bd']
         ei = batch[TX_NB_BD].edge_index
         n_tx = batch['tx'].num_nodes
-        g = edge_graph(batch_cache(batch), TX_NB_BD, ei, n_tx, z_bd.shape[0], need_by_dst=False)
+        g = edge_graph(batch_cache(batch), TX_NB_BD, ei, n_tx, z_bd.shape[0], need_by_dst=False, validate="deferred")
         max_sim, _, seg_idx, _ = ops.edge_cos_argmax(
             g.by_src, z_tx, z_bd, dst_index=batch['bd']['index'], min_similarity=min_similarity)
         mask = batch['tx']['predict_mask']
         out = (batch['tx']['index'][mask], seg_idx[mask], max_sim[mask], batch['tx']['x'][mask])
-        return tuple(t.cpu() for t in out)
+        out = tuple(t.cpu() for t in out)
+        flush_validation()                 # the copies above synchronised: surface a bad edge_index of this batch now
+        return out
 
     def configure_optimizers(self) -> torch.optim.Optimizer:
         params = list(self.parameters())

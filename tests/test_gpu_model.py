@@ -318,3 +318,35 @@ def test_graphed_encoder_matches_eager_forward_and_backward(cuda):
     z1 = ge(tiles[0])["tx"].detach().clone()
     z2 = ge(tiles[0])["tx"].detach().clone()
     assert torch.isfinite(z1).all() and (z1 - z2).abs().max() > 1e-4
+
+
+def test_bad_edge_index_is_reported_without_a_mid_step_sync(cuda):
+    """Deferred validation: a model forward over an edge_index with out-of-range node ids does not fault (ids are
+    clamped) and the IndexError surfaces from a later graph build, flush_validation() or predict_step."""
+    from segger_amd import TX_TX
+    from segger_amd.graph import build_edge_graph, flush_validation
+    from segger_amd.synthetic import SyntheticSpec
+    flush_validation()
+    spec = SyntheticSpec(n_tx=500, n_bd=40, k_tx=4, seed=2)
+    m, _, b, _ = build(spec, cuda)
+    m.eval()
+    bad = b.to(cuda)
+    ei = bad[TX_TX].edge_index.clone()
+    ei[1, 7] = spec.n_tx + 3                                 # destination outside the graph
+    bad[TX_TX]["edge_index"] = ei
+    with pytest.raises(IndexError, match="outside"):
+        with torch.no_grad():
+            m(bad)                                           # ids are clamped: no fault; the error surfaces from a later
+        flush_validation()                                   # graph build of this forward or, at the latest, from here
+    flush_validation()                                       # the queue is clean again
+    g = build_edge_graph(b.to(cuda)[TX_TX].edge_index, spec.n_tx, spec.n_tx, validate="deferred")
+    flush_validation()
+    assert g.n_edges == b[TX_TX].edge_index.shape[1]
+    from segger_amd import TX_NB_BD
+    bad2 = b.to(cuda)                                        # a fresh batch (no cached graphs) with a bad candidate edge
+    bad2["tx"]["predict_mask"] = torch.ones(spec.n_tx, dtype=torch.bool, device=cuda)
+    ep = bad2[TX_NB_BD].edge_index.clone()
+    ep[1, 0] = spec.n_bd + 1
+    bad2[TX_NB_BD]["edge_index"] = ep
+    with pytest.raises(IndexError):
+        m.predict_step(bad2, 0)                              # predict_step flushes after its own D2H copies
