@@ -293,7 +293,9 @@ class ISTEncoder(Module):
         x = {"tx": x_tx, "bd": x_bd}
 
         if graphs is None:       # sorted views of the edge stores: built once per batch, shared by all layers
+            # the by-source view only serves the backward: inference sorts each edge store once, not twice
             graphs = {et: edge_graph(cache, et, edge_index_dict[et], x[et[0]].shape[0], x[et[2]].shape[0],
+                                     need_by_src=torch.is_grad_enabled(),
                                      validate="deferred")     # checked without a host sync (graph.py)
                       for et in (TX_TX, TX_BD) if et in edge_index_dict}
         if self.training:
