@@ -75,6 +75,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default=None, help="also write the JSON here")
+    ap.add_argument("--segmentation-parquet", default=None,
+                    help="with --overlap-predict: write the transcript -> cell table (row_index, segger_cell_id, "
+                         "segger_similarity, similarity_threshold), the columns of segger_segmentation.parquet")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -281,6 +284,11 @@ def main():
                    "assigned": int((seg["cell_encoding"] >= 0).sum()),
                    "postprocess_seconds": times["overlap_postprocess_s"], "global_threshold": seg["global_threshold"],
                    "transcripts_per_s": int(seg["row_index"].numel()) / times["overlap_predict_s"]}
+        if args.segmentation_parquet:
+            from segger_amd.postprocess import to_frame
+            with Phase("write_parquet_s", times):
+                to_frame(seg).to_parquet(args.segmentation_parquet, index=False)
+            overlap["parquet"] = args.segmentation_parquet
         del outs, seg
         log(f"[fov] overlap predict: {overlap}")
 
