@@ -101,8 +101,15 @@ def cpu_baseline(sample_tx=50_000, sample_bd=500, k=15, budget_s=25.0):
     dt = sorted(ts)[len(ts) // 2]
     etb = int(ei.shape[1])
     mp_edges = 4 * (int(b[O.TX_TX].edge_index.shape[1]) + etb)
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
     return {
         "value": 2 * etb / dt, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
+        "host": {"cpu": cpu_model, "os_cpu_count": os.cpu_count(), "threads_used": torch.get_num_threads()},
         "sample": f"oracle fp32 fwd+seg-loss+bwd on a {sample_tx}-tx/{sample_bd}-bd k={k} tile "
                   f"(Etb={etb}), median of {reps} after 1 warm-up, {dt:.2f} s/step",
         "mp_edges_per_s": mp_edges / dt,
