@@ -102,6 +102,8 @@ int segger_csr_from_coo(const int64_t* row, const int64_t* colv, int64_t n_edges
  *   a[i->j,h]  = softmax over the in-edges of j ;  a *= keep/(1-p) (dropout)
  *   pre[j,h,c] = sum_i a[i->j,h] * x_l[i,h,c] + bias[h,c]
  *   out        = apply_gelu ? gelu_erf(pre) : pre
+ *                (exact-erf GELU, torch approximate='none'; evaluated through a polynomial erfc with
+ *                |error| <= 4e-7 in fp32, see csrc/common.h::normal_cdf)
  *
  * A destination without in-edges gets pre = bias.
  * Dropout (ist_encoder.py:116,123; training only), with (lo, hi) = halves of splitmix64(seed + *seed_dev):
