@@ -350,3 +350,44 @@ def test_bad_edge_index_is_reported_without_a_mid_step_sync(cuda):
     bad2[TX_NB_BD]["edge_index"] = ep
     with pytest.raises(IndexError):
         m.predict_step(bad2, 0)                              # predict_step flushes after its own D2H copies
+
+
+def test_c2_scale_backward_properties(cuda):
+    """BASELINE C2-sized layer (1M nodes, 15M edges, bf16), backward: with att = 0 every in-edge weighs 1/deg, so
+    forward and grad_xl reduce to plain gather / scatter means that torch index ops reproduce at full size, and
+    grad_xr vanishes; doubling grad_out doubles every gradient bit-exactly (powers of two commute with rounding)."""
+    from segger_amd import ops
+    from segger_amd.graph import build_edge_graph
+    n, k, H, C = 1_000_000, 15, 2, 64
+    hc = H * C
+    g = torch.Generator(device=cuda).manual_seed(1)
+    src = torch.arange(n, device=cuda).repeat_interleave(k)
+    dst = (src + torch.randint(-3000, 3000, (n * k,), device=cuda, generator=g)).clamp_(0, n - 1)
+    graph = build_edge_graph(torch.stack([src, dst]), n, n)
+    xl = torch.randn(n, hc, device=cuda, generator=g).to(torch.bfloat16)
+    xr = torch.randn(n, hc, device=cuda, generator=g).to(torch.bfloat16)
+    gy = torch.randn(n, hc, device=cuda, generator=g).to(torch.bfloat16)
+    att0 = torch.zeros(hc, device=cuda)
+    out, pre, lse = torch.empty_like(xl), torch.empty_like(xl), torch.empty(n, H, device=cuda)
+    ops.gatv2_fwd_launch(graph.by_dst, xl, xr, att0, None, H, C, out, pre=pre, lse=lse)
+    deg = torch.zeros(n, device=cuda).index_add_(0, dst, torch.ones(n * k, device=cuda))
+    mean = torch.zeros(n, hc, device=cuda).index_add_(0, dst, xl.float()[src]) / deg.clamp(min=1)[:, None]
+    assert (out.float() - mean).abs().max() < 2e-2
+    gxl, gxr = torch.empty_like(xl), torch.empty_like(xr)
+    ga, gb = ops.gatv2_bwd_launch(graph, xl, xr, att0, None, H, C, gy, out, lse, gxl, gxr, apply_gelu=False)
+    w = (gy.float() / deg.clamp(min=1)[:, None])
+    ref_gxl = torch.zeros(n, hc, device=cuda).index_add_(0, src, w[dst])
+    assert (gxl.float() - ref_gxl).abs().max() < 4e-2 * max(1.0, float(ref_gxl.abs().max()))
+    assert (gxr == 0).all()
+    assert torch.allclose(gb, gy.float().sum(0), rtol=1e-3, atol=1.0)        # grad_bias = column sums of grad_out
+    # linearity in grad_out, bit-exact under a power-of-two scale (general att)
+    att = torch.randn(hc, device=cuda, generator=g) * 0.3
+    ops.gatv2_fwd_launch(graph.by_dst, xl, xr, att, None, H, C, out, pre=pre, lse=lse, apply_gelu=True)
+    res = []
+    for scale in (1.0, 2.0):
+        a, b = torch.empty_like(xl), torch.empty_like(xr)
+        ga, gb = ops.gatv2_bwd_launch(graph, xl, xr, att, None, H, C, (gy.float() * scale).to(torch.bfloat16), pre, lse,
+                                      a, b, apply_gelu=True)
+        res.append((a.float(), b.float(), ga.clone(), gb.clone()))
+    for one, two in zip(*res):
+        assert torch.equal(one * 2.0, two)
