@@ -220,7 +220,7 @@ int segger_edge_cos_argmax(const segger_edge_argmax_args* args, segger_stream_t 
  * and its autograd.
  *   loss = mean_e max(||a-p+eps|| - ||a-n+eps|| + margin, 0)
  * fwd writes partial sums; `loss` receives the mean.  bwd accumulates
- * (fp32 atomics) into grad_a / grad_b, which the caller zero-fills.
+ * (atomics: fp32, or packed 16-bit pairs, see grad_*_packed) into grad_a / grad_b, which the caller zero-fills.
  * ---------------------------------------------------------------------- */
 typedef struct segger_triplet_args {
   const int64_t* src;     /* [n_edges] anchor rows of z_a */
@@ -240,8 +240,15 @@ typedef struct segger_triplet_args {
   float* loss;            /* [1] */
   float grad_scale;       /* bwd: dL/dloss (the 1/n_edges is applied inside) */
   const float* grad_scale_dev; /* bwd: optional DEVICE scalar multiplied into grad_scale (avoids a host sync) */
-  float* grad_a;          /* [n_a, C] fp32, bwd only */
-  float* grad_b;          /* [n_b, C] fp32, bwd only */
+  void* grad_a;           /* [n_a, C] bwd only: fp32, or `dtype` when grad_a_packed */
+  void* grad_b;           /* [n_b, C] bwd only: fp32, or `dtype` when grad_b_packed */
+  int32_t grad_a_packed;  /* 1: accumulate with packed 2-channel atomics in the embeddings' 16-bit dtype (half the
+                             atomics, no fp32 staging + cast); meant for matrices whose rows collect a handful of
+                             terms (transcripts); needs a 16-bit dtype and even C */
+  int32_t grad_b_packed;
+  float* contrib;         /* bwd, optional: [n_edges, 2, C] fp32.  When given, the z_b side uses NO atomics: triplet e
+                             leaves (-dL/d z_b[pos_e], +dL/d z_b[neg_e]) in rows 2e, 2e+1 (zeros when inactive) and the
+                             caller sums the rows grouped by boundary with segger_segment_rowsum; grad_b is ignored */
   void* workspace;
   size_t workspace_bytes;
 } segger_triplet_args;
@@ -314,6 +321,14 @@ int segger_l2norm_fwd(const void* y, int64_t ld_y, int64_t n, int32_t channels, 
                       int32_t dtype, segger_stream_t stream);
 int segger_l2norm_bwd(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, int64_t n, int32_t channels,
                       float eps, void* gy, int64_t ld_gy, int32_t dtype, segger_stream_t stream);
+/* out[s, :] = sum of the rows x[seg_rows[seg_ptr[s] : seg_ptr[s+1]], :] in fp32 (deterministic, no atomics): the
+ * scatter-add of per-edge rows into a small table, e.g. the boundary-side gradient of the triplet loss
+ * (lightning_model.py:182-187 autograd).  seg_ptr / seg_rows = indptr / col of segger_csr_from_coo(row = segment id of
+ * every x row, col = 0..n-1).  D % 8 == 0, D <= 2048. */
+size_t segger_segment_rowsum_workspace_bytes(int64_t n, int32_t n_segments, int32_t D);
+int segger_segment_rowsum(const void* x, int64_t ld, int64_t n, int32_t D, int32_t dtype, const int64_t* seg_ptr,
+                          const int32_t* seg_rows, int32_t n_segments, float* out, void* workspace,
+                          size_t workspace_bytes, segger_stream_t stream);
 size_t segger_colsum_workspace_bytes(int64_t n, int32_t cols);
 int segger_colsum(const void* x, int64_t ld, int64_t n, int32_t cols, int32_t dtype, float* out,
                   void* workspace, size_t workspace_bytes, segger_stream_t stream);

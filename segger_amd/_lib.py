@@ -88,7 +88,8 @@ class TripletArgs(C.Structure):
         ("channels", C.c_int32), ("dtype", C.c_int32),
         ("margin", C.c_float), ("eps", C.c_float),
         ("loss", vp), ("grad_scale", C.c_float), ("grad_scale_dev", vp),
-        ("grad_a", vp), ("grad_b", vp),
+        ("grad_a", vp), ("grad_b", vp), ("grad_a_packed", C.c_int32), ("grad_b_packed", C.c_int32),
+        ("contrib", vp),
         ("workspace", vp), ("workspace_bytes", C.c_size_t),
     ]
 
@@ -116,6 +117,9 @@ EXPORTS = {
                                         vp, vp, vp, vp, C.c_size_t, C.c_int32, vp]),
     "segger_l2norm_fwd": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, C.c_float, vp, C.c_int64, C.c_int32, vp]),
     "segger_l2norm_bwd": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_float, vp, C.c_int64, C.c_int32, vp]),
+    "segger_segment_rowsum_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "segger_segment_rowsum": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, vp,
+                                        C.c_size_t, vp]),
     "segger_colsum_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "segger_colsum": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_size_t, vp]),
     "segger_knn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void emb_finish_kernel(const float* __restrict
   const int g = (int)(i / D), c = (int)(i % D);
   float s = 0.f;
   for (int b = chunk_ptr[g]; b < chunk_ptr[g + 1]; ++b) s += partial[(int64_t)b * D + c];
-  gtable[i] = s * gelu_erf_grad(table[i]);
+  gtable[i] = table ? s * gelu_erf_grad(table[i]) : s;        // table == NULL: plain segmented row sum
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -436,6 +436,44 @@ extern "C" int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float*
     hipLaunchKernelGGL(emb_finish_kernel, dim3((unsigned)((gd + 255) / 256)), dim3(256), 0, stream, partial, chunk_ptr, table, (int)n_rows_table, D, gtable);
   }
   SEGGER_LAUNCH_CHECK("embed_gelu_bwd kernels");
+  return SEGGER_OK;
+}
+
+extern "C" size_t segger_segment_rowsum_workspace_bytes(int64_t n, int32_t n_segments, int32_t D) {
+  return segger_embed_gelu_bwd_workspace_bytes(n, n_segments, D);
+}
+
+extern "C" int segger_segment_rowsum(const void* x, int64_t ld, int64_t n, int32_t D, int32_t dtype, const int64_t* seg_ptr,
+                                     const int32_t* seg_rows, int32_t n_segments, float* out, void* workspace,
+                                     size_t workspace_bytes, segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGGER_REQUIRE(n >= 0 && n_segments > 0 && D > 0 && D % 8 == 0 && D <= 2048, "segger_segment_rowsum: D must be a multiple of 8, <= 2048");
+  SEGGER_REQUIRE(out, "segger_segment_rowsum: NULL output");
+  const int64_t gd = (int64_t)n_segments * D;
+  if (n == 0) {
+    SEGGER_HIP(hipMemsetAsync(out, 0, gd * sizeof(float), stream));
+    return SEGGER_OK;
+  }
+  SEGGER_REQUIRE(x && seg_ptr && seg_rows, "segger_segment_rowsum: NULL pointer");
+  SEGGER_REQUIRE(aligned16(x) && ld >= D && (ld * esize(dtype)) % 16 == 0, "segger_segment_rowsum: bad pointer / leading dimension");
+  const size_t need = segger_segment_rowsum_workspace_bytes(n, n_segments, D);
+  if (!workspace || workspace_bytes < need) {
+    set_error("segger_segment_rowsum: workspace %zu < %zu bytes", workspace_bytes, need);
+    return SEGGER_EWORKSPACE;
+  }
+  const int64_t max_chunks = emb_max_chunks(n, n_segments);
+  SEGGER_REQUIRE(max_chunks < 0x7fffffffLL, "segger_segment_rowsum: too many rows");
+  float* partial = static_cast<float*>(workspace);
+  int* chunk_ptr = reinterpret_cast<int*>(static_cast<char*>(workspace) + (((size_t)max_chunks * D * sizeof(float) + 15) & ~(size_t)15));
+  hipLaunchKernelGGL(emb_plan_kernel, dim3(1), dim3(256), 0, stream, seg_ptr, (int)n_segments, chunk_ptr);
+  const int P = D / 8, R = 256 / P > 0 ? 256 / P : 1;
+  const size_t lds = (size_t)R * D * sizeof(float);
+#define GO(T) hipLaunchKernelGGL((emb_gather_kernel<T>), dim3((unsigned)max_chunks), dim3((unsigned)(P * R)), lds, stream, (const T*)x, ld, seg_ptr, seg_rows, chunk_ptr, (int)n_segments, D, partial)
+  DISPATCH_DTYPE(dtype, GO(float), GO(bf16_t), GO(f16_t))
+#undef GO
+  hipLaunchKernelGGL(emb_finish_kernel, dim3((unsigned)((gd + 255) / 256)), dim3(256), 0, stream, partial, chunk_ptr,
+                     (const float*)nullptr, (int)n_segments, D, out);
+  SEGGER_LAUNCH_CHECK("segment_rowsum kernels");
   return SEGGER_OK;
 }
 

@@ -7,6 +7,7 @@ There is no CPU path (see ``_lib.require_cuda``).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -291,6 +292,10 @@ def _triplet_args(src, pos, neg, za, zb, margin, eps):
     return a
 
 
+_CONTRIB_MIN_EDGES = 131072
+_PACKED_ATOMICS = os.environ.get("SEGGER_TRIPLET_PACKED", "1") != "0"      # A/B switch (scratch experiments)
+
+
 class _TripletEdgeLoss(torch.autograd.Function):
     """``zb is None``: anchors, positives and negatives are rows of the same matrix ``za``
     (loss_tx); one gradient buffer receives all three contributions."""
@@ -324,14 +329,34 @@ class _TripletEdgeLoss(torch.autograd.Function):
         lib = _lib.load()
         dev = za.device
         a = _triplet_args(src, pos, neg, za, zb, margin, eps)
-        ga = torch.zeros(za.shape, dtype=torch.float32, device=dev)
-        gb = ga if same else torch.zeros(zb.shape, dtype=torch.float32, device=dev)
-        a.grad_a, a.grad_b = ga.data_ptr(), gb.data_ptr()
+        # anchor-matrix rows collect a handful of terms: packed 16-bit atomics straight into a gradient of the
+        # embeddings' dtype; a separate (boundary) matrix sums dozens of terms per row and stays fp32
+        packed = (za.dtype in (torch.bfloat16, torch.float16) and za.shape[1] % 2 == 0 and _PACKED_ATOMICS
+                  and src.numel() >= _CONTRIB_MIN_EDGES)     # small batches measured no gain from either variant
+        ga = torch.zeros(za.shape, dtype=za.dtype if packed else torch.float32, device=dev)
+        a.grad_a, a.grad_a_packed, a.grad_b_packed = ga.data_ptr(), int(packed), int(packed and same)
+        contrib = None
+        if same:
+            gb = ga
+            a.grad_b = ga.data_ptr()
+        elif za.shape[1] % 8 == 0 and src.numel() >= _CONTRIB_MIN_EDGES:
+            # boundary side without atomics: a 10^4-row matrix under 8 * 10^5 x C fp32 atomic adds made this the
+            # slowest kernel of the loss backward (0.58 ms; 0.14 ms + a sort and a segmented sum this way).  Small
+            # batches keep the atomics: the sort's ~25 launches cost more than they save there.
+            contrib = torch.empty((2 * int(src.numel()), za.shape[1]), dtype=torch.float32, device=dev)
+            a.contrib, a.grad_b = contrib.data_ptr(), None
+            gb = None
+        else:
+            gb = torch.zeros(zb.shape, dtype=torch.float32, device=dev)
+            a.grad_b = gb.data_ptr()
         gs = g.detach().to(torch.float32).reshape(1).contiguous()   # upstream scalar stays on the device
         a.grad_scale, a.grad_scale_dev = 1.0, gs.data_ptr()
         with torch.cuda.device(dev):
             rc = lib.segger_triplet_bwd(C.byref(a), _lib.stream_ptr(dev))
         _lib.check(rc, "segger_triplet_bwd")
+        if contrib is not None:
+            ids = torch.stack([pos, neg], 1).reshape(-1)                 # row 2e -> pos[e], row 2e + 1 -> neg[e]
+            gb = segment_rowsum(contrib, rows_by_id(ids, int(zb.shape[0])))
         return ga.to(za.dtype), (None if same else gb.to(zb.dtype)), None, None, None, None, None
 
 
@@ -411,6 +436,24 @@ def colsum(x: Tensor) -> Tensor:
         rc = lib.segger_colsum(xp, ld, n, cols, DTYPE_CODE[x.dtype], out.data_ptr(), ws.data_ptr(), ws_bytes,
                                _lib.stream_ptr(x.device))
     _lib.check(rc, "segger_colsum")
+    return out
+
+
+def segment_rowsum(x: Tensor, by_id: EdgeCSR) -> Tensor:
+    """fp32 [n_ids, D]: sum of the rows of ``x`` grouped by id (``by_id`` = :func:`rows_by_id` of the row ids)."""
+    _lib.require_cuda(x)
+    lib = _lib.load()
+    n, d = x.shape
+    n_seg = by_id.n_rows
+    xp, ld = _rows(x, d, "x")
+    out = torch.empty((n_seg, d), dtype=torch.float32, device=x.device)
+    ws_bytes = lib.segger_segment_rowsum_workspace_bytes(n, n_seg, d)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.segger_segment_rowsum(xp, ld, n, d, DTYPE_CODE[x.dtype], by_id.indptr.data_ptr(),
+                                       by_id.col.data_ptr() if n else None, n_seg, out.data_ptr(), ws.data_ptr(),
+                                       ws_bytes, _lib.stream_ptr(x.device))
+    _lib.check(rc, "segger_segment_rowsum")
     return out
 
 
