@@ -189,3 +189,20 @@ def test_rejects_bad_arguments(cuda):
     x = torch.randn(2, 40, device=cuda)
     with pytest.raises(_lib.SeggerAmdError, match="no CPU fallback"):
         ops.gatv2_aggregate(x.cpu(), x.cpu(), torch.randn(40), None, graph, 1, 40)
+
+
+def test_dropout_mask_known_answer_on_device(cuda):
+    """The kernels' dropout stream against the literal bits of tests/test_oracle.py (seed 5, H = 2, p = 0.2): the
+    attention output is exactly zero where, and only where, the pinned mask drops the edge."""
+    from segger_amd import ops
+    from segger_amd.graph import build_edge_graph
+    want = "11111011111111110110110001010111111010111110001100010011001111011101111111111111"
+    keep = torch.tensor([int(c) for c in want], dtype=torch.bool).reshape(40, 2)
+    H, C, n = 2, 64, 12
+    g = torch.Generator().manual_seed(0)
+    ei = torch.stack([torch.randint(0, n, (40,), generator=g), torch.randint(0, n, (40,), generator=g)])
+    graph = build_edge_graph(ei.to(cuda), n, n)
+    x = torch.randn(n, H * C, generator=g).to(cuda)
+    att = (torch.randn(H * C, generator=g) * 0.3).to(cuda)
+    _, alpha = ops.gatv2_aggregate(x, x, att, None, graph, H, C, dropout_p=0.2, seed=5, return_alpha=True)
+    assert torch.equal((alpha != 0).cpu(), keep)

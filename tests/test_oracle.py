@@ -168,3 +168,15 @@ def test_oracle_selector_matches_reference_vectors(oracle):
     lt = oracle.tx_triplet_loss(emb, pos, neg, float(z["margin"]))
     lm = oracle.bd_metric_loss(emb, pos, neg, dp, dn)
     assert abs(lt.item() - float(z["triplet_loss"])) < 1e-6 and abs(lm.item() - float(z["metric_loss"])) < 1e-6
+
+
+def test_dropout_mask_known_answer(oracle):
+    """The counter-based dropout stream of include/segger_amd.h, pinned by literal bits worked out with plain Python
+    integers (splitmix64(5) = 0x63033b0ca389c35a): a change of the hash in the oracle or the kernels must show here."""
+    assert oracle._splitmix64(5) == 0x63033B0CA389C35A
+    want = "11111011111111110110110001010111111010111110001100010011001111011101111111111111"
+    got = "".join(str(int(v)) for v in oracle.dropout_keep_mask(5, 40, 2, 0.2).reshape(-1).tolist())
+    assert got == want
+    want3 = "101010110101001001010001111111101010100010111111001100111111011110001110"
+    got3 = "".join(str(int(v)) for v in oracle.dropout_keep_mask(2 ** 40 + 17, 24, 3, 0.5).reshape(-1).tolist())
+    assert got3 == want3
