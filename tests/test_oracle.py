@@ -180,3 +180,18 @@ def test_dropout_mask_known_answer(oracle):
     want3 = "101010110101001001010001111111101010100010111111001100111111011110001110"
     got3 = "".join(str(int(v)) for v in oracle.dropout_keep_mask(2 ** 40 + 17, 24, 3, 0.5).reshape(-1).tolist())
     assert got3 == want3
+
+
+def test_sinusoidal_embedding_known_answer(oracle):
+    """ist_encoder.py:22-31 by hand: x = 0 -> cos block all ones, sin block all zeros; x = 1 -> entry j is
+    cos / sin of max_period^(-j/half); an odd dim appends one zero column."""
+    import math
+    e = oracle.sinusoidal_embedding(torch.tensor([0.0, 1.0], dtype=torch.float64), 256, max_period=10000)
+    assert e.shape == (2, 256)
+    assert torch.equal(e[0, :128], torch.ones(128, dtype=torch.float64)) and torch.equal(e[0, 128:], torch.zeros(128, dtype=torch.float64))
+    for j in (0, 1, 64, 127):
+        f = math.exp(-math.log(10000.0) * j / 128)
+        assert abs(e[1, j].item() - math.cos(f)) < 1e-6 and abs(e[1, 128 + j].item() - math.sin(f)) < 1e-6
+    assert abs(e[1, 0].item() - math.cos(1.0)) < 1e-12 and abs(e[1, 128].item() - math.sin(1.0)) < 1e-12
+    odd = oracle.sinusoidal_embedding(torch.tensor([0.5], dtype=torch.float64), 7, max_period=1000)
+    assert odd.shape == (1, 7) and odd[0, 6] == 0
