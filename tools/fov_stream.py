@@ -287,8 +287,16 @@ def main():
         if args.segmentation_parquet:
             from segger_amd.postprocess import to_frame
             with Phase("write_parquet_s", times):
-                to_frame(seg).to_parquet(args.segmentation_parquet, index=False)
-            overlap["parquet"] = args.segmentation_parquet
+                df = to_frame(seg)
+                try:
+                    df.to_parquet(args.segmentation_parquet, index=False)
+                    overlap["parquet"] = args.segmentation_parquet
+                except ImportError as e:                      # no pyarrow / fastparquet on this host
+                    alt = os.path.splitext(args.segmentation_parquet)[0] + ".npz"
+                    import numpy as np
+                    np.savez(alt, **{c: df[c].to_numpy(dtype="float64" if c == "segger_cell_id" else None, na_value=np.nan)
+                                     if c == "segger_cell_id" else df[c].to_numpy() for c in df.columns})
+                    overlap["parquet"] = f"{alt} (no parquet engine: {type(e).__name__})"
         del outs, seg
         log(f"[fov] overlap predict: {overlap}")
 
