@@ -488,6 +488,7 @@ class _Linear(torch.autograd.Function):
         y = linear_fwd_launch(x, w, bias)
         ctx.save_for_backward(x, weight, bias if bias is not None else weight.new_empty(0))
         ctx.has_bias = bias is not None
+        ctx.w_cast = w                       # the backward transposes this copy instead of casting again
         return y
 
     @staticmethod
@@ -502,7 +503,7 @@ class _Linear(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if linear_supported(m, k, dt):
-                wt = weight.detach().t().to(dt).contiguous()          # [K, M]: dX = dY @ W
+                wt = ctx.w_cast.t().contiguous()                      # [K, M]: dX = dY @ W
                 gx = linear_fwd_launch(gy, wt, None)
             else:
                 gx = gy @ weight.detach().to(dt)
