@@ -7,7 +7,6 @@ There is no CPU path (see ``_lib.require_cuda``).
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Optional, Tuple
 
 import torch
@@ -293,7 +292,6 @@ def _triplet_args(src, pos, neg, za, zb, margin, eps):
 
 
 _CONTRIB_MIN_EDGES = 131072
-_PACKED_ATOMICS = os.environ.get("SEGGER_TRIPLET_PACKED", "1") != "0"      # A/B switch (scratch experiments)
 
 
 class _TripletEdgeLoss(torch.autograd.Function):
@@ -331,8 +329,9 @@ class _TripletEdgeLoss(torch.autograd.Function):
         a = _triplet_args(src, pos, neg, za, zb, margin, eps)
         # anchor-matrix rows collect a handful of terms: packed 16-bit atomics straight into a gradient of the
         # embeddings' dtype; a separate (boundary) matrix sums dozens of terms per row and stays fp32
-        packed = (za.dtype in (torch.bfloat16, torch.float16) and za.shape[1] % 2 == 0 and _PACKED_ATOMICS
-                  and src.numel() >= _CONTRIB_MIN_EDGES)     # small batches measured no gain from either variant
+        # (small batches measured no gain from either variant: they keep fp32 atomics on both sides)
+        packed = (za.dtype in (torch.bfloat16, torch.float16) and za.shape[1] % 2 == 0
+                  and src.numel() >= _CONTRIB_MIN_EDGES)
         ga = torch.zeros(za.shape, dtype=za.dtype if packed else torch.float32, device=dev)
         a.grad_a, a.grad_a_packed, a.grad_b_packed = ga.data_ptr(), int(packed), int(packed and same)
         contrib = None
