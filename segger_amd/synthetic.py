@@ -181,9 +181,17 @@ def make_graph(spec: SyntheticSpec = C1, return_aux: bool = False):
     gene_cluster = profiles.argmax(0)            # cluster of a gene = its dominant type
 
     # --- edges ---------------------------------------------------------------
+    # host KD-tree threads: all cores for a single process, a fair share when N ranks build their tiles at once
+    import os
+    world = max(1, int(os.environ.get("WORLD_SIZE", "1")))
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    workers = -1 if world == 1 else max(1, cores // world)
     tree = cKDTree(pos, leafsize=64)
     k = min(spec.k_tx, Nt)
-    _, nbr = tree.query(pos, k=k, workers=-1)
+    _, nbr = tree.query(pos, k=k, workers=workers)
     nbr = nbr.reshape(Nt, k)
     ett = np.stack([np.repeat(np.arange(Nt), k), nbr.reshape(-1)])       # src = query, dst = neighbour
 
@@ -193,7 +201,7 @@ def make_graph(spec: SyntheticSpec = C1, return_aux: bool = False):
 
     ctree = cKDTree(centres, leafsize=32)
     pk = min(spec.pred_k, Nb)
-    dist, cidx = ctree.query(pos, k=pk, distance_upper_bound=spec.pred_radius, workers=-1)
+    dist, cidx = ctree.query(pos, k=pk, distance_upper_bound=spec.pred_radius, workers=workers)
     dist, cidx = dist.reshape(Nt, pk), cidx.reshape(Nt, pk)
     ok = np.isfinite(dist)
     ep = np.stack([np.repeat(np.arange(Nt), pk)[ok.reshape(-1)], cidx[ok]])
