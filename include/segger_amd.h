@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEGGER_ABI_VERSION 1
+#define SEGGER_ABI_VERSION 2
 
 enum segger_status {
   SEGGER_OK = 0,

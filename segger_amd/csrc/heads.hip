@@ -137,6 +137,7 @@ int launch_argmax(const ArgmaxParams& p, hipStream_t stream) {
 struct TripletParams {
   const int64_t* src; const int64_t* pos; const int64_t* neg; int64_t n_edges;
   const void* za; int64_t ld_za; const void* zb; int64_t ld_zb;
+  int64_t n_a, n_b;      // rows of za / zb: a triplet naming a row outside them is skipped (never dereferenced)
   int channels; float margin, eps;
   float* partial;        // [nblocks]
   float scale;           // bwd: grad_scale / n_edges
@@ -196,8 +197,13 @@ __global__ __launch_bounds__(256) void triplet_kernel(TripletParams p) {
 #pragma unroll 1
   for (int i = wave * 4 + grp; i < kTripletEdgesPerBlock; i += 16) {
     const int64_t e = e_base + i;
-    const bool ok = e < p.n_edges;                    // group-uniform
-    const int64_t ia = ok ? p.src[e] : 0, ip = ok ? p.pos[e] : 0, in = ok ? p.neg[e] : 0;
+    bool ok = e < p.n_edges;                          // group-uniform
+    int64_t ia = ok ? p.src[e] : 0, ip = ok ? p.pos[e] : 0, in = ok ? p.neg[e] : 0;
+    // ids outside the matrices (a malformed edge_index the deferred validation has not reported yet): the triplet
+    // contributes nothing and no row is touched; the mean keeps dividing by n_edges
+    if ((uint64_t)ia >= (uint64_t)p.n_a || (uint64_t)ip >= (uint64_t)p.n_b || (uint64_t)in >= (uint64_t)p.n_b) {
+      ok = false; ia = ip = in = 0;
+    }
     float sp = 0.f, sn = 0.f;
     if (ok)
       for (int c = gl; c < C; c += 16) {
@@ -215,8 +221,8 @@ __global__ __launch_bounds__(256) void triplet_kernel(TripletParams p) {
     } else if (p.contrib != nullptr && (C & 1) == 0) {
       // z_b side without atomics: every triplet leaves its two rows (zeros when inactive); the caller sums them
       // grouped by boundary (segger_segment_rowsum).  The anchor side keeps its (packed) atomics.
-      if (ok) {
-        const bool active = l > 0.f;
+      if (e < p.n_edges) {                             // a skipped (bad-id) triplet still zeroes its two rows
+        const bool active = ok && l > 0.f;
         const float sc = p.scale_dev ? p.scale * p.scale_dev[0] : p.scale;
         const float ip_ = active && dap > 0.f ? sc / dap : 0.f;
         const float in_ = active && dan > 0.f ? sc / dan : 0.f;
@@ -301,8 +307,13 @@ __global__ __launch_bounds__(256) void triplet_c64_kernel(TripletParams p) {
 #pragma unroll 1
   for (int i = wave * 4 + grp; i < kTripletEdgesPerBlock; i += 16) {
     const int64_t e = e_base + i;
-    const bool ok = e < p.n_edges;                    // group-uniform
-    const int64_t ia = ok ? p.src[e] : 0, ip = ok ? p.pos[e] : 0, in = ok ? p.neg[e] : 0;
+    bool ok = e < p.n_edges;                          // group-uniform
+    int64_t ia = ok ? p.src[e] : 0, ip = ok ? p.pos[e] : 0, in = ok ? p.neg[e] : 0;
+    // ids outside the matrices (a malformed edge_index the deferred validation has not reported yet): the triplet
+    // contributes nothing and no row is touched; the mean keeps dividing by n_edges
+    if ((uint64_t)ia >= (uint64_t)p.n_a || (uint64_t)ip >= (uint64_t)p.n_b || (uint64_t)in >= (uint64_t)p.n_b) {
+      ok = false; ia = ip = in = 0;
+    }
     float a[4], pp[4], nn[4], dp[4], dn[4];
     load4(za + ia * p.ld_za + c0, a);
     load4(zb + ip * p.ld_zb + c0, pp);
@@ -397,8 +408,9 @@ static int triplet_common(const segger_triplet_args* a, bool bwd, hipStream_t st
   }
   SEGGER_REQUIRE(a->src && a->pos && a->neg && a->z_a && a->z_b, "segger_triplet: NULL input");
   SEGGER_REQUIRE(a->ld_za >= a->channels && a->ld_zb >= a->channels, "segger_triplet: ld < channels");
+  SEGGER_REQUIRE(a->n_a > 0 && a->n_b > 0, "segger_triplet: n_a / n_b (rows of z_a / z_b) must be positive");
   const int64_t nb = triplet_blocks(a->n_edges);
-  TripletParams p{a->src, a->pos, a->neg, a->n_edges, a->z_a, a->ld_za, a->z_b, a->ld_zb, a->channels, a->margin, a->eps,
+  TripletParams p{a->src, a->pos, a->neg, a->n_edges, a->z_a, a->ld_za, a->z_b, a->ld_zb, a->n_a, a->n_b, a->channels, a->margin, a->eps,
                   static_cast<float*>(a->workspace), 0.f, nullptr, a->grad_a, a->grad_b,
                   a->grad_a_packed, a->grad_b_packed, bwd ? a->contrib : nullptr};
   if (!bwd) {

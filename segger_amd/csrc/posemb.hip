@@ -7,11 +7,14 @@ namespace segger {
 namespace {
 
 // order-preserving float atomics on plain global words initialised to +inf / -inf
+// (-0.0f compares >= 0 but its bit pattern is INT_MIN: canonicalise it to +0 before choosing the integer view)
 __device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
+  v += 0.f;
   if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
   else          atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+  v += 0.f;
   if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
   else          atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }

@@ -255,6 +255,21 @@ class ISTEncoder(Module):
         # dropout stream: effective seed of (layer, edge type, step) = 2*layer + type + *_step_dev; the counter
         # lives on the device and advances by 256 per training forward, so captured graphs see fresh masks
         self.register_buffer("_step_dev", torch.zeros(1, dtype=torch.int64), persistent=False)
+        self.register_load_state_dict_pre_hook(ISTEncoder._adopt_reference_state_dict)
+
+    @staticmethod
+    def _adopt_reference_state_dict(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                    error_msgs) -> None:
+        """Makes a reference checkpoint load with ``strict=True``: the reference's lazy ``Linear(-1, in)`` for
+        boundaries (ist_encoder.py:261) is materialised from the shape of the incoming ``lin_first.bd.weight``
+        (instead of being fabricated at random by the first forward), and the entries of the never-initialised
+        ``('bd','contains','tx')`` conv (lazy placeholders, no trained values) are dropped."""
+        w = state_dict.get(prefix + "lin_first.bd.weight")
+        if w is not None and "bd" not in module.lin_first and getattr(w, "dim", lambda: 0)() == 2:
+            ref = module.lin_first["tx"].weight
+            module.lin_first["bd"] = Linear(int(w.shape[1]), int(w.shape[0])).to(device=ref.device)
+        for k in [k for k in state_dict if k.startswith(prefix) and "<bd___contains___tx>" in k]:
+            del state_dict[k]
 
     def _materialize_bd(self, d_in: int, device) -> None:
         if "bd" not in self.lin_first:
@@ -298,10 +313,15 @@ class ISTEncoder(Module):
                                      need_by_src=torch.is_grad_enabled(),
                                      validate="deferred")     # checked without a host sync (graph.py)
                       for et in (TX_TX, TX_BD) if et in edge_index_dict}
+        step = self._step_dev
         if self.training:
+            # every training forward gets its own snapshot of the advanced counter: its backward re-reads THAT word,
+            # so a second forward before the first backward (two views, checkpointing, a logging pass) cannot change
+            # the masks the first backward regenerates.  Capture-safe: the clone lives in the graph's pool.
             self._step_dev.add_(256)
+            step = self._step_dev.clone()
         for li, layer in enumerate(self.conv_layers):
-            x = layer(x, edge_index_dict, graphs=graphs, apply_gelu=True, seed=(li, self._step_dev))   # conv + GELU (:324-325)
+            x = layer(x, edge_index_dict, graphs=graphs, apply_gelu=True, seed=(li, step))   # conv + GELU (:324-325)
 
         x = self.lin_last(x)
         if self.normalize_embeddings:

@@ -44,7 +44,8 @@ class FastTripletSelector:
         counts = torch.bincount(labels, minlength=n_clusters)
         offsets = counts.cumsum(0) - counts
         # default (unstable) argsort, the very call the reference makes (triplet_loss.py:41): the order of
-        # equal labels is implementation-defined and decides WHICH member of the drawn cluster is returned
+        # equal labels is implementation-defined (torch's CPU and GPU sorts differ) and decides WHICH member of
+        # the drawn cluster is returned; pass a ready-made ``index`` to pin it
         members = torch.argsort(labels)
         present = torch.nonzero(counts > 0).flatten()
         slot_of = torch.full((n_clusters,), -1, dtype=torch.long, device=dev)
@@ -86,14 +87,20 @@ class TripletLoss(torch.nn.TripletMarginLoss):
         super().__init__(margin=margin, **kwargs)
         self.selector = FastTripletSelector(cluster_similarity)
 
-    def forward(self, embeddings: Tensor, labels: Tensor):  # type: ignore[override]
+    def forward(self, embeddings: Tensor, labels: Tensor, uniforms=None):  # type: ignore[override]
+        """``uniforms`` (not in the reference): the four U[0,1) draws of the selector, for replaying given vectors."""
         if labels.numel() == 0:
             return 0.0
-        pos, neg, _, _ = self.selector.sample_triplets(labels)
+        pos, neg, _, _ = self.selector.sample_triplets(labels, uniforms)
+        if embeddings.is_cuda:
+            from . import ops
+            idx = torch.arange(labels.numel(), device=embeddings.device)
+            return ops.triplet_edge_loss(embeddings, None, idx, pos, neg, self.margin, eps=self.eps)
         e = embeddings.float()
         return super().forward(e, e[pos], e[neg])
 
-    def forward_masked(self, embeddings: Tensor, labels: Tensor, mask: Tensor, cache: Optional[dict] = None):
+    def forward_masked(self, embeddings: Tensor, labels: Tensor, mask: Tensor, cache: Optional[dict] = None,
+                       uniforms=None):
         """``forward(embeddings[mask], labels[mask])`` (how LitISTEncoder.get_losses calls it,
         lightning_model.py:158-161) without materialising the three gathered [n, C] matrices:
         on the GPU the fused triplet kernel gathers anchor / positive / negative rows itself.
@@ -109,7 +116,8 @@ class TripletLoss(torch.nn.TripletMarginLoss):
         idx, index = hit
         if idx.numel() == 0:
             return 0.0
-        pos, neg, _, _ = self.selector.sample_triplets(labels[idx] if index is None else index["labels"], index=index)
+        pos, neg, _, _ = self.selector.sample_triplets(labels[idx] if index is None else index["labels"], uniforms,
+                                                       index=index)
         if embeddings.is_cuda:
             from . import ops
             return ops.triplet_edge_loss(embeddings, None, idx, idx[pos], idx[neg], self.margin, eps=self.eps)
@@ -121,10 +129,10 @@ class MetricLoss:
     def __init__(self, cluster_similarity: Tensor):
         self.selector = FastTripletSelector(cluster_similarity)
 
-    def forward(self, embeddings: Tensor, labels: Tensor):
+    def forward(self, embeddings: Tensor, labels: Tensor, uniforms=None):
         if labels.numel() == 0:
             return 0.0
-        pos, neg, d_pos, d_neg = self.selector.sample_triplets(labels)
+        pos, neg, d_pos, d_neg = self.selector.sample_triplets(labels, uniforms)
         e = embeddings.float()
         cos_pos = torch.cosine_similarity(e, e[pos])
         cos_neg = torch.cosine_similarity(e, e[neg])

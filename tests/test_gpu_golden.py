@@ -1,0 +1,191 @@
+"""The committed golden fixtures replayed ON THE GPU (through the C ABI), so that a drift of the oracle and a drift
+of the kernels in the same direction cannot pass unnoticed:
+
+* ``encoder_small.npz``  -- inputs, weights under the reference's state-dict names and STORED float64 answers
+  (embeddings, layer-0 attention, predict 4-tuple, segmentation loss, parameter gradients); the oracle is not
+  run here at all.  Tolerances as in test_gpu_model.py: fp32 5e-5 on unit-norm embeddings, bf16 3e-2.
+* ``triplet_selector.npz`` -- genuine outputs of the reference's own ``models/triplet_loss.py`` (made by
+  tests/golden/make_golden.py): the device selector must reproduce positives / negatives bit-exactly from the same
+  four uniform draws, ``loss_tx`` (through ``segger_triplet_*``) and ``loss_bd`` within 1e-6
+  (reference ``triplet_loss.py:83-125,144-160,176-204``).
+* prediction post-processing on the device against the numpy oracle (reference ``data/writer.py:186-241``).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load_encoder_golden():
+    from segger_amd.hetero import HeteroBatch
+    z = np.load(os.path.join(GOLD, "encoder_small.npz"))
+    sd = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w::")}
+    b = HeteroBatch(num_graphs=4)
+    for k in z.files:
+        if k.startswith("in::edge::"):
+            b[tuple(k[len("in::edge::"):].split("__"))]["edge_index"] = torch.from_numpy(z[k])
+        elif k.startswith("in::tx::") or k.startswith("in::bd::"):
+            _, nt, a = k.split("::")
+            b[nt][a] = torch.from_numpy(z[k])
+    return z, sd, b
+
+
+def golden_model(sd, dev, dtype):
+    from segger_amd import LitISTEncoder
+    n_genes, d = sd["model.lin_first.tx.weight"].shape
+    hid = sd["model.lin_last.lins.tx.weight"].shape[0]
+    m = LitISTEncoder(n_genes=n_genes, in_channels=d, hidden_channels=hid, out_channels=hid, n_mid_layers=2, n_heads=2)
+    # reference-shaped checkpoint, strict: the boundary projection is materialised from the incoming weight
+    m.load_state_dict(sd, strict=True)
+    m.model.compute_dtype = dtype
+    return m.to(dev)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_encoder_golden_embeddings_attention_and_predict(cuda, dtype):
+    from segger_amd import TX_TX
+    z, sd, b = load_encoder_golden()
+    m = golden_model(sd, cuda, dtype).eval()
+    m.model.conv_layers[0].store_attention = True
+    bg = b.to(cuda)
+    with torch.no_grad():
+        out = m(bg)
+    tol = 5e-5 if dtype == torch.float32 else 3e-2
+    for k in ("tx", "bd"):
+        err = np.abs(out[k].double().cpu().numpy() - z[f"out::z_{k}"]).max()
+        assert err < tol, f"z_{k}: {err}"
+    alpha = m.model.conv_layers[0].attention_weights[TX_TX].double().cpu().numpy()
+    assert alpha.shape == z["out::alpha0_tx_tx"].shape
+    assert np.abs(alpha - z["out::alpha0_tx_tx"]).max() < (2e-5 if dtype == torch.float32 else 2e-2)
+    pred = m.predict_step(bg, 0)
+    assert np.array_equal(pred[0].numpy(), z["out::pred_tx_index"])
+    assert np.array_equal(pred[3].numpy(), z["out::pred_gene"])
+    assert np.abs(pred[2].double().numpy() - z["out::pred_sim"]).max() < tol
+    agree = (pred[1].numpy() == z["out::pred_seg"]).mean()
+    # an assignment can only differ where the two best candidates are within rounding of each other
+    assert agree > (0.995 if dtype == torch.float32 else 0.95), agree
+    if dtype == torch.float32:
+        diff = pred[1].numpy() != z["out::pred_seg"]
+        assert np.abs(pred[2].double().numpy() - z["out::pred_sim"])[diff].max(initial=0.0) < 5e-5
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_encoder_golden_loss_and_parameter_gradients(cuda, dtype):
+    from segger_amd import TX_BD
+    z, sd, b = load_encoder_golden()
+    m = golden_model(sd, cuda, dtype).eval()              # dropout off, gradients flow
+    bg = b.to(cuda)
+    emb = m(bg)
+    loss = m._segmentation_loss(emb, bg, torch.from_numpy(z["in::neg"]).to(cuda))
+    loss.backward()
+    ref_loss = float(z["out::loss_sg"])
+    assert abs(loss.item() - ref_loss) < (2e-5 if dtype == torch.float32 else 2e-2)
+    named = dict(m.named_parameters())
+    checked = 0
+    rel = 2e-3 if dtype == torch.float32 else 0.12
+    for k in sd:
+        ref = z[f"grad::{k}"].astype(np.float64)
+        if k not in named or named[k].grad is None:
+            assert not np.any(ref), k
+            continue
+        got = named[k].grad.double().cpu().numpy()
+        scale = max(np.abs(ref).max(), 1e-8)
+        err = np.abs(got - ref).max()
+        assert err < rel * scale + 1e-7, f"{k}: grad err {err} (scale {scale})"
+        checked += 1
+    assert checked >= 40
+    assert bg[TX_BD].edge_index.shape[1] == z["in::neg"].shape[0]
+
+
+def test_reference_triplet_vectors_on_device(cuda):
+    """N1: FastTripletSelector / TripletLoss / MetricLoss on the MI355X against outputs of the reference's own file."""
+    from segger_amd.triplet_loss import FastTripletSelector, MetricLoss, TripletLoss
+    from segger_amd import ops
+    z = np.load(os.path.join(GOLD, "triplet_selector.npz"))
+    sim, labels = torch.from_numpy(z["similarity"]), torch.from_numpy(z["labels"])
+    emb = torch.from_numpy(z["embeddings"])
+    n = labels.numel()
+    torch.manual_seed(int(z["seed"]))
+    u = tuple(torch.rand(n) for _ in range(4))            # the reference's four CPU draws, in its order
+    ud = tuple(t.to(cuda) for t in u)
+    sel = FastTripletSelector(sim.to(cuda))
+    # (i) everything on the device, its own sort: the reference's default argsort leaves the order of equal labels
+    # implementation-defined (triplet_loss.py:41), so WHICH member of the drawn cluster comes back may differ from the
+    # CPU-made vectors; the drawn clusters and hence the distances must not
+    p_d, n_d, dp, dn = sel.sample_triplets(labels.to(cuda), uniforms=ud)
+    assert p_d.is_cuda and n_d.is_cuda
+    assert np.array_equal(labels[p_d.cpu()].numpy(), labels.numpy()[z["positives"]])
+    assert np.array_equal(labels[n_d.cpu()].numpy(), labels.numpy()[z["negatives"]])
+    assert np.array_equal(dp.cpu().numpy(), z["dists_pos"]) and np.array_equal(dn.cpu().numpy(), z["dists_neg"])
+    # (ii) with the member order of the CPU sort (the one the vectors were made with) handed to the device: bit-exact
+    cpu_index = FastTripletSelector(sim).build_index(labels)
+    index = sel.build_index(labels.to(cuda))
+    index["members"] = cpu_index["members"].to(cuda)
+    pos, neg, dp, dn = sel.sample_triplets(labels.to(cuda), uniforms=ud, index=index)
+    assert np.array_equal(pos.cpu().numpy(), z["positives"]) and np.array_equal(neg.cpu().numpy(), z["negatives"])
+    assert np.array_equal(dp.cpu().numpy(), z["dists_pos"]) and np.array_equal(dn.cpu().numpy(), z["dists_neg"])
+
+    # loss_tx: the fused HIP triplet kernel over the sampled triplets (fp32 embeddings)
+    e = emb.to(cuda)
+    idx = torch.arange(n, device=cuda)
+    lt = ops.triplet_edge_loss(e, None, idx, pos, neg, float(z["margin"]), eps=1e-6)
+    assert abs(lt.item() - float(z["triplet_loss"])) < 1e-6
+    # ... and through the module, with torch's device RNG replaced by the reference's draws
+    tl = TripletLoss(sim.to(cuda), margin=float(z["margin"]))
+    ml = MetricLoss(sim.to(cuda))
+    tl.selector.build_index = ml.selector.build_index = lambda labels_: index
+    assert abs(float(tl.forward(e, labels.to(cuda), uniforms=ud)) - float(z["triplet_loss"])) < 1e-6
+    mask = torch.ones(n, dtype=torch.bool, device=cuda)
+    assert abs(float(tl.forward_masked(e, labels.to(cuda), mask, {}, uniforms=ud)) - float(z["triplet_loss"])) < 1e-6
+    assert abs(float(ml.forward(e, labels.to(cuda), uniforms=ud)) - float(z["metric_loss"])) < 1e-6
+
+    # gradient of loss_tx through segger_triplet_bwd == autograd through torch's TripletMarginLoss on the same triplets
+    e1 = e.clone().requires_grad_(True)
+    ops.triplet_edge_loss(e1, None, idx, pos, neg, float(z["margin"]), eps=1e-6).backward()
+    e2 = e.clone().requires_grad_(True)
+    torch.nn.TripletMarginLoss(margin=float(z["margin"]))(e2, e2[pos], e2[neg]).backward()
+    assert torch.allclose(e1.grad, e2.grad, atol=1e-6)
+
+
+@pytest.mark.parametrize("seed", [0, 3])
+def test_postprocess_on_device_matches_numpy_oracle(cuda, seed):
+    """N4: the writer's dedup + per-gene Yen/Li thresholds computed on the MI355X (what consumes predict_step)."""
+    import postprocess_oracle as po
+    from segger_amd import postprocess as pp
+    from test_postprocess import fake_predictions
+    preds = fake_predictions(seed, n_tx=20000, n_genes=24, n_batches=6)
+    got = pp.assign_transcripts_to_cells([[t.to(cuda) for t in p] for p in preds])
+    assert got["row_index"].is_cuda and got["similarity_threshold"].is_cuda
+    got2 = pp.assign_transcripts_to_cells(preds, device="cuda")            # CPU tuples (predict_step's output), device run
+    ref = po.assign_transcripts_to_cells([[t.numpy() for t in p] for p in preds])
+    for g in (got, got2):
+        assert np.array_equal(g["row_index"].cpu().numpy(), ref["row_index"])
+        assert np.array_equal(g["cell_encoding"].cpu().numpy(), ref["cell_encoding"])
+        assert np.array_equal(g["similarity"].cpu().numpy(), ref["similarity"])
+        assert np.array_equal(g["gene"].cpu().numpy(), ref["gene"])
+        assert np.allclose(g["similarity_threshold"].cpu().numpy(), ref["similarity_threshold"], atol=1e-9, equal_nan=True)
+        assert abs(g["global_threshold"] - ref["global_threshold"]) < 1e-9
+        assert np.array_equal(g["failed_genes"].cpu().numpy(), ref["failed_genes"])
+
+
+def test_postprocess_consumes_predict_step_output(cuda):
+    """predict_step 4-tuples of overlapping prediction tiles -> device post-processing == oracle post-processing."""
+    import postprocess_oracle as po
+    from segger_amd import postprocess as pp
+    z, sd, b = load_encoder_golden()
+    m = golden_model(sd, cuda, torch.float32).eval()
+    bg = b.to(cuda)
+    outs = []
+    g = torch.Generator().manual_seed(5)
+    for _ in range(3):                                    # three overlapping "tiles": different predict masks
+        bg["tx"]["predict_mask"] = (torch.rand(b["tx"].num_nodes, generator=g) < 0.6).to(cuda)
+        outs.append(m.predict_step(bg, 0))
+    got = pp.assign_transcripts_to_cells(outs, device="cuda")
+    ref = po.assign_transcripts_to_cells([[t.numpy() for t in p] for p in outs])
+    assert np.array_equal(got["row_index"].cpu().numpy(), ref["row_index"])
+    assert np.array_equal(got["cell_encoding"].cpu().numpy(), ref["cell_encoding"])
+    assert np.allclose(got["similarity_threshold"].cpu().numpy(), ref["similarity_threshold"], atol=1e-9, equal_nan=True)

@@ -164,6 +164,36 @@ def test_training_mode_dropout_matches_oracle_with_same_mask(oracle, cuda):
     assert (z2["tx"] - z["tx"]).abs().max() > 1e-4
 
 
+def test_backward_uses_its_own_forwards_dropout_mask(cuda):
+    """forward A, forward B, backward A: the gradients equal those of a lone forward A + backward A at the same
+    counter value (each training forward snapshots the device dropout counter; the backward re-reads its snapshot)."""
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=1500, n_bd=80, k_tx=6, seed=41)
+    m, _, b, _ = build(spec, cuda)
+    m.train()
+    bg = b.to(cuda)
+    w = torch.randn(spec.n_tx, 64, device=cuda)
+
+    def grads():
+        return {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m.model._step_dev.fill_(1024)
+    m.zero_grad(set_to_none=True)
+    za = m(bg)
+    (za["tx"] * w).sum().backward()
+    lone = grads()
+    m.model._step_dev.fill_(1024)
+    m.zero_grad(set_to_none=True)
+    za2 = m(bg)
+    with torch.no_grad():
+        zb = m(bg)                                   # e.g. a logging pass in train mode: advances the counter
+    assert torch.equal(za2["tx"], za["tx"]) and not torch.equal(zb["tx"], za["tx"])
+    (za2["tx"] * w).sum().backward()
+    both = grads()
+    assert lone.keys() == both.keys() and len(lone) > 40
+    for k in lone:
+        assert torch.equal(lone[k], both[k]), k
+
+
 def test_full_training_step_runs_and_learns(cuda):
     from segger_amd.synthetic import SyntheticSpec
     spec = SyntheticSpec(n_tx=4000, n_bd=150, k_tx=8, seed=23)

@@ -18,6 +18,11 @@ def header_functions():
     return sorted(set(re.findall(r"\b(segger_[a-z0-9_]+)\s*\(", src)))
 
 
+def header_abi_version():
+    src = open(os.path.join(ROOT, "include", "segger_amd.h")).read()
+    return int(re.search(r"#define\s+SEGGER_ABI_VERSION\s+(\d+)", src).group(1))
+
+
 def test_library_exports_every_declared_symbol():
     from segger_amd import _lib
     lib = _lib.load()                      # loads without a GPU; no compute call is made
@@ -27,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
         assert hasattr(raw, n), f"{n} declared in include/segger_amd.h but not exported"
-    assert lib.segger_abi_version() == 1
+    assert lib.segger_abi_version() == _lib.ABI_VERSION == header_abi_version()
     assert lib.segger_csr_from_coo_workspace_bytes(0, 10) > 0
     assert lib.segger_gatv2_bwd_workspace_bytes(1000, 2, 64) >= 1000 // 32 * 2 * 128 * 4
     assert lib.segger_triplet_workspace_bytes(1000) >= 16 * 4
@@ -99,6 +104,32 @@ def test_state_dict_keys_follow_the_reference():
     with pytest.raises(ValueError, match="Unrecognized segmentation loss"):
         LitISTEncoder(n_genes=3, in_channels=8, sg_loss_type="hinge")
     assert isinstance(m.configure_optimizers(), torch.optim.Adam)
+
+
+def test_reference_checkpoint_loads_strictly():
+    """A reference-shaped state dict (trained ``lin_first.bd`` of the reference's lazy Linear + the never-initialised
+    ``<bd___contains___tx>`` placeholders) loads with strict=True into a fresh module and keeps the
+    boundary projection's trained values (no random re-materialisation on the first forward)."""
+    from segger_amd import LitISTEncoder
+    kw = dict(n_genes=10, in_channels=16, hidden_channels=8, out_channels=8, n_mid_layers=2, n_heads=2)
+    src = LitISTEncoder(**kw)
+    src.model._materialize_bd(5, "cpu")
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    for li in range(4):                                     # what PyG saves for an uninitialised lazy conv
+        p = f"model.conv_layers.{li}.conv.convs.<bd___contains___tx>."
+        for name in ("lin_l.weight", "lin_r.weight", "att", "bias", "lin_l.bias", "lin_r.bias"):
+            sd[p + name] = torch.empty(0)
+    m = LitISTEncoder(**kw)
+    assert "bd" not in m.model.lin_first
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert torch.equal(m.model.lin_first["bd"].weight, src.model.lin_first["bd"].weight)
+    assert m.model.lin_first["bd"].in_features == 5
+    m.model._materialize_bd(5, "cpu")                        # what the first forward calls: must keep the loaded weights
+    assert torch.equal(m.model.lin_first["bd"].bias, src.model.lin_first["bd"].bias)
+    assert set(m.state_dict()) == set(src.state_dict())
+    with pytest.raises(RuntimeError):                        # a genuinely foreign key is still an error
+        LitISTEncoder(**kw).load_state_dict({**sd, "model.foo.weight": torch.zeros(1)}, strict=True)
 
 
 def test_setup_requires_datamodule_similarities():
