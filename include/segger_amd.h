@@ -67,6 +67,8 @@ typedef struct segger_csr {
   int64_t n_rows;
   int64_t n_cols;
   int64_t n_edges;
+  const int32_t* row_order; /* [n_rows] or NULL: the order in which kernels visit the rows (a permutation of
+                               0..n_rows-1 from segger_csr_row_order); results never depend on it */
 } segger_csr;
 
 /*
@@ -88,6 +90,17 @@ int segger_csr_from_coo(const int64_t* row, const int64_t* colv, int64_t n_edges
                         int32_t* n_invalid,
                         void* workspace, size_t workspace_bytes,
                         segger_stream_t stream);
+
+/*
+ * segger_csr_row_order: a visiting order for the rows of a CSR that balances the lanes of a wavefront.
+ * The aggregation kernels give each 16-lane group of a wave its own row; a wave is busy until its
+ * longest row is done, so rows of unequal degree (kNN in-degrees: mean k, spread ~ sqrt(k)) idle lanes.
+ * Inside every window of `window` consecutive rows (a power of two <= 64, so neighbouring rows still
+ * share an L2) the rows are ordered by descending degree: the 4 rows of a wave then have near-equal
+ * length.  order_out[n_rows] is a permutation of 0..n_rows-1.
+ */
+int segger_csr_row_order(const int64_t* indptr, int64_t n_rows, int32_t window,
+                         int32_t* order_out, segger_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * GATv2 attention aggregation (the roofline kernel).
@@ -284,6 +297,23 @@ int segger_segment_minmax(const float* pos, const int64_t* batch, int64_t n, int
 int segger_linear_supported(int32_t k_in, int32_t m_out, int32_t dtype);
 int segger_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy,
                       int64_t n_rows, int32_t k_in, int32_t m_out, int32_t dtype, segger_stream_t stream);
+
+/*
+ * segger_linear_wgrad: the parameter gradients of the same projections,
+ *     grad_w[M, K] = dY[n, M]^T * X[n, K]      grad_b[M] = sum_n dY[n, :]       (fp32 outputs)
+ * i.e. what torch autograd computes for nn.Linear / PyG Linear (lin_l, lin_r, lin_last, the positional MLP;
+ * src/segger/models/ist_encoder.py:44-48,111-124,261,282-286) as `grad.t() @ x` and `grad.sum(0)`.
+ * One pass over dY and X on the matrix cores: row slabs per workgroup, the whole [M, K] accumulator in
+ * registers, transposed operand reads from LDS (ds_read_b64_tr_b16), deterministic slab-order reduction.
+ *   dy [n_rows, m_out] row stride ld_dy, x [n_rows, k_in] row stride ld_x (elements; 16-byte aligned rows)
+ *   covered: m_out in {64,128,192,384}, k_in in {64,128,256}, bf16 / f16 (segger_linear_wgrad_supported)
+ *   grad_b may be NULL; workspace >= segger_linear_wgrad_workspace_bytes(n_rows, m_out, k_in)
+ */
+int segger_linear_wgrad_supported(int32_t m_out, int32_t k_in, int32_t dtype);
+size_t segger_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t m_out, int32_t k_in);
+int segger_linear_wgrad(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, int64_t n_rows,
+                        int32_t m_out, int32_t k_in, int32_t dtype, float* grad_w, float* grad_b,
+                        void* workspace, size_t workspace_bytes, segger_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Encoder front end / tail as fused row-wise kernels.

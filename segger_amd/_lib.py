@@ -31,7 +31,7 @@ vp = C.c_void_p
 
 class Csr(C.Structure):
     _fields_ = [("indptr", vp), ("col", vp), ("eid", vp),
-                ("n_rows", C.c_int64), ("n_cols", C.c_int64), ("n_edges", C.c_int64)]
+                ("n_rows", C.c_int64), ("n_cols", C.c_int64), ("n_edges", C.c_int64), ("row_order", vp)]
 
 
 class GatFwdArgs(C.Structure):
@@ -100,6 +100,7 @@ EXPORTS = {
     "segger_last_error": (C.c_char_p, []),
     "segger_csr_from_coo_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "segger_csr_from_coo": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, C.c_size_t, vp]),
+    "segger_csr_row_order": (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp]),
     "segger_gatv2_fwd": (C.c_int, [C.POINTER(GatFwdArgs), vp]),
     "segger_gatv2_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "segger_gatv2_bwd": (C.c_int, [C.POINTER(GatBwdArgs), vp]),
@@ -110,6 +111,10 @@ EXPORTS = {
     "segger_segment_minmax": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp, vp]),
     "segger_linear_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "segger_linear_fwd": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "segger_linear_wgrad_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "segger_linear_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
+    "segger_linear_wgrad": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp, vp,
+                                      vp, C.c_size_t, vp]),
     "segger_posfreq": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_float, C.c_float, vp, C.c_int32, vp]),
     "segger_embed_gelu_fwd": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, C.c_int32, vp]),
     "segger_embed_gelu_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),

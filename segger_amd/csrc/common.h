@@ -41,7 +41,21 @@ constexpr int kNumXcd = 8;
 struct bf16_t { uint16_t v; };
 struct f16_t  { uint16_t v; };
 
+// A pair of fp32 channels.  As an ext vector hipcc selects v_pk_add/mul/fma_f32 for its arithmetic; measured on
+// gfx950 (tools/valu_probe.hip, >= 2 waves per SIMD) one v_pk_*_f32 costs 6.1 cycles against 2 x 2.3-2.6 for the
+// two scalar instructions it replaces, so the kernels can also be built on a plain struct (SEGGER_SCALAR_PAIRS).
+#ifdef SEGGER_SCALAR_PAIRS
+struct f32x2 {
+  float x, y;
+};
+__device__ __forceinline__ f32x2 operator+(f32x2 a, f32x2 b) { return f32x2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f32x2 operator-(f32x2 a, f32x2 b) { return f32x2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f32x2 operator*(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f32x2 operator*(f32x2 a, float b) { return f32x2{a.x * b, a.y * b}; }
+__device__ __forceinline__ f32x2 operator-(f32x2 a) { return f32x2{-a.x, -a.y}; }
+#else
 typedef float    f32x2 __attribute__((ext_vector_type(2)));
+#endif
 typedef float    f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
@@ -75,7 +89,8 @@ template <> struct Vec8<bf16_t> {
   }
   static __device__ __forceinline__ uint32_t pack(float a, float b) {
     // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
-    f32x2 v = {a, b};
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f v = {a, b};
     b16x2 h = __builtin_convertvector(v, b16x2);
     return __builtin_bit_cast(uint32_t, h);
   }

@@ -39,6 +39,27 @@ __global__ __launch_bounds__(256) void csr_finalize_kernel(const uint32_t* __res
     for (int64_t r = k + 1; r <= n_rows; ++r) indptr[r] = n_edges;
 }
 
+// one wave per window of W <= 64 rows: rank = number of rows of the window that come first
+// (larger degree, ties by row id); order[base + rank] = row
+__global__ __launch_bounds__(256) void csr_row_order_kernel(const int64_t* __restrict__ indptr, int64_t n_rows, int window,
+                                                           int32_t* __restrict__ order) {
+  const int lane = threadIdx.x & 63;
+  const int per_wave = 64 / window;                       // windows handled by one wave
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t base = (wave_id * per_wave + lane / window) * window;   // first row of this lane's window
+  const int wl = lane % window;
+  const int64_t row = base + wl;
+  int deg = -1;
+  if (row < n_rows) deg = (int)(indptr[row + 1] - indptr[row]);
+  int rank = 0;
+  const int w0 = lane - wl;                               // first lane of the window
+  for (int j = 0; j < window; ++j) {
+    const int dj = __shfl(deg, w0 + j, 64);
+    rank += (dj > deg) || (dj == deg && j < wl);
+  }
+  if (row < n_rows) order[base + rank] = (int32_t)row;    // rows past the end rank last: ranks of real rows stay < count
+}
+
 int key_bits(int64_t n_rows) {
   int b = 1;
   while (b < 32 && (1LL << b) < n_rows) ++b;
@@ -102,5 +123,19 @@ extern "C" int segger_csr_from_coo(const int64_t* row, const int64_t* colv, int6
   hipLaunchKernelGGL(csr_finalize_kernel, dim3(nblk), dim3(256), 0, stream, keys_out, eid, colv, n_edges, n_rows, n_cols,
                      indptr, col);
   SEGGER_LAUNCH_CHECK("csr_finalize_kernel");
+  return SEGGER_OK;
+}
+
+extern "C" int segger_csr_row_order(const int64_t* indptr, int64_t n_rows, int32_t window, int32_t* order_out,
+                                    segger_stream_t stream) {
+  SEGGER_REQUIRE(n_rows >= 0 && n_rows < 0x7fffffffLL, "segger_csr_row_order: bad n_rows");
+  SEGGER_REQUIRE(window >= 1 && window <= 64 && (window & (window - 1)) == 0,
+                 "segger_csr_row_order: window must be a power of two <= 64");
+  if (n_rows == 0) return SEGGER_OK;
+  SEGGER_REQUIRE(indptr && order_out, "segger_csr_row_order: NULL pointer");
+  const int64_t waves = (n_rows + 63) / 64;
+  hipLaunchKernelGGL(csr_row_order_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     indptr, n_rows, (int)window, order_out);
+  SEGGER_LAUNCH_CHECK("csr_row_order_kernel");
   return SEGGER_OK;
 }

@@ -123,7 +123,7 @@ extern "C" int segger_gatv2_fwd(const segger_gatv2_fwd_args* a, segger_stream_t 
   SEGGER_REQUIRE(!(a->dropout_p > 0.f || a->alpha) || a->by_dst.n_edges == 0 || a->by_dst.eid != nullptr,
                  "segger_gatv2_fwd: by_dst.eid is required for dropout / alpha output");
   GatParams p{};
-  p.indptr = a->by_dst.indptr; p.col = a->by_dst.col; p.eid = a->by_dst.eid;
+  p.indptr = a->by_dst.indptr; p.col = a->by_dst.col; p.eid = a->by_dst.eid; p.order = a->by_dst.row_order;
   p.n_rows = a->by_dst.n_rows; p.n_edges = a->by_dst.n_edges;
   p.xl = a->x_l; p.ld_xl = a->ld_xl; p.xr = a->x_r; p.ld_xr = a->ld_xr;
   p.att = a->att; p.bias = a->bias;
@@ -188,7 +188,7 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
   set_dropout(p, a->dropout_p, a->seed, a->seed_dev);
 
   // ---- destination side ------------------------------------------------------
-  p.indptr = a->by_dst.indptr; p.col = a->by_dst.col; p.eid = a->by_dst.eid;
+  p.indptr = a->by_dst.indptr; p.col = a->by_dst.col; p.eid = a->by_dst.eid; p.order = a->by_dst.row_order;
   p.n_rows = n_dst; p.n_edges = n_edges; p.rows_per_wave_iter = bwd_row_iters(n_dst);
   if (n_dst > 0) {
     GenericOut gen; gen.grad_att = a->grad_att; gen.grad_bias = a->grad_bias;
@@ -207,7 +207,7 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
     if (a->grad_bias) SEGGER_HIP(hipMemsetAsync(a->grad_bias, 0, hc * sizeof(float), stream));
   }
   // ---- source side -----------------------------------------------------------
-  p.indptr = a->by_src.indptr; p.col = a->by_src.col; p.eid = a->by_src.eid;
+  p.indptr = a->by_src.indptr; p.col = a->by_src.col; p.eid = a->by_src.eid; p.order = a->by_src.row_order;
   p.n_rows = n_src; p.rows_per_wave_iter = 1;
   if (n_src > 0) CHECK_RC(launch(Pass::BwdSrc, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_src), stream));
   return SEGGER_OK;

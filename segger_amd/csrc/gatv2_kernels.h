@@ -59,6 +59,7 @@ struct GatParams {
   const int64_t* indptr;
   const int32_t* col;
   const int32_t* eid;
+  const int32_t* order;          // nullable: position -> row (degree-balanced visiting order, group-per-row mode)
   int64_t n_rows;
   int64_t n_edges;
   // features
@@ -206,7 +207,13 @@ __device__ __forceinline__ void store_pairs(T* p, const f32x2 (&f)[4]) {
   Vec8<T>::store(p, v);
 }
 
+#ifdef SEGGER_SCALAR_PAIRS
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+  return f32x2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)};
+}
+#else
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
 __device__ __forceinline__ f32x2 splat(float x) { return f32x2{x, x}; }
 
 // gathered row address: base (already offset to this lane's channels) + id * row-bytes  (one v_mad_u64_u32)
@@ -240,6 +247,13 @@ __device__ __forceinline__ float sign_mul(float nde, float nt) {     // de * sgn
   // a ^ (b & c) as one v_bitop3_b32 (truth table 0xF0 ^ (0xCC & 0xAA) = 0x78); the compiler does not fold the
   // and + xor pair by itself
   return __uint_as_float(__builtin_amdgcn_bitop3_b32(__float_as_uint(nde), __float_as_uint(nt), 0x80000000u, 0x78));
+}
+
+// position -> row through the optional degree-balanced order (include/segger_amd.h: segger_csr_row_order)
+template <bool WPR>
+__device__ __forceinline__ int64_t visit_row(const int32_t* __restrict__ order, int64_t pos, bool ok) {
+  if constexpr (WPR) return pos;
+  return (order != nullptr && ok) ? (int64_t)order[pos] : pos;
 }
 
 struct LaneGeo {
@@ -279,8 +293,9 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
   const LaneGeo L = lane_geo<G>();
   const int h = L.h, ch0 = L.ch0;
   const bool head_leader = L.lane_on && (L.gl % LPH) == 0;
-  const int64_t row = WPR ? (blk * 4 + L.wave) : ((blk * 4 + L.wave) * NG + L.grp);
-  const bool row_ok = row < p.n_rows;
+  const int64_t pos = WPR ? (blk * 4 + L.wave) : ((blk * 4 + L.wave) * NG + L.grp);
+  const bool row_ok = pos < p.n_rows;
+  const int64_t row = visit_row<WPR>(p.order, pos, row_ok);
   const char* __restrict__ xl = static_cast<const char*>(p.xl) + (size_t)ch0 * sizeof(T);
   const uint32_t ld_xl = (uint32_t)(p.ld_xl * sizeof(T));
   const bool dropout = p.drop_thr != 0;
@@ -435,8 +450,9 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
   for (int it = 0; it < p.rows_per_wave_iter; ++it) {
     const int64_t rbase = ((blk * 4 + L.wave) * (int64_t)p.rows_per_wave_iter + it) * RPW;
     if (rbase >= p.n_rows) break;              // wave-uniform
-    const int64_t row = rbase + (WPR ? 0 : L.grp);
-    const bool row_ok = row < p.n_rows;
+    const int64_t pos = rbase + (WPR ? 0 : L.grp);
+    const bool row_ok = pos < p.n_rows;
+    const int64_t row = visit_row<WPR>(p.order, pos, row_ok);
 
     f32x2 nxr[4], g[4], Sg[4];
     float D = 0.f, lse = 0.f, Sde = 0.f;
@@ -564,8 +580,9 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
   if (blk < 0) return;
   const LaneGeo L = lane_geo<G>();
   const int h = L.h, ch0 = L.ch0;
-  const int64_t row = WPR ? (blk * 4 + L.wave) : ((blk * 4 + L.wave) * NG + L.grp);
-  const bool row_ok = row < p.n_rows;
+  const int64_t pos = WPR ? (blk * 4 + L.wave) : ((blk * 4 + L.wave) * NG + L.grp);
+  const bool row_ok = pos < p.n_rows;
+  const int64_t row = visit_row<WPR>(p.order, pos, row_ok);
   const char* __restrict__ xr_base = static_cast<const char*>(p.xr) + (size_t)ch0 * sizeof(T);
   const char* __restrict__ g_base = static_cast<const char*>(p.gpre) + (size_t)ch0 * sizeof(T);
   const uint32_t ld_xr = (uint32_t)(p.ld_xr * sizeof(T)), ld_gp = (uint32_t)(p.ld_gp * sizeof(T));

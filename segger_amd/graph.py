@@ -21,6 +21,10 @@ from . import _lib
 from .hetero import EdgeType
 
 
+ROW_ORDER_WINDOW = 64        # rows per balancing window (power of two <= 64)
+WAVE_PER_ROW_DEGREE = 32     # csrc/gatv2.hip kWavePerRowDegree: from this average degree a whole wave walks one row
+
+
 @dataclass
 class EdgeCSR:
     indptr: Tensor   # int64 [n_rows + 1]
@@ -28,6 +32,7 @@ class EdgeCSR:
     eid: Tensor      # int32 [n_edges]  original COO position of each slot
     n_rows: int
     n_cols: int
+    order: Optional[Tensor] = None   # int32 [n_rows]: degree-balanced visiting order (balanced_order), or None
 
     @property
     def n_edges(self) -> int:
@@ -37,7 +42,19 @@ class EdgeCSR:
         return _lib.Csr(self.indptr.data_ptr(),
                         self.col.data_ptr() if self.n_edges else None,
                         self.eid.data_ptr() if self.n_edges else None,
-                        self.n_rows, self.n_cols, self.n_edges)
+                        self.n_rows, self.n_cols, self.n_edges, _lib.ptr(self.order))
+
+    def balanced_order(self, window: int = ROW_ORDER_WINDOW) -> "EdgeCSR":
+        """Attach the visiting order of ``segger_csr_row_order`` (rows of near-equal degree share a wave; computed
+        once per view, results never depend on it).  Skipped for views the kernels walk one row per wave."""
+        if self.order is None and self.n_rows > 0 and self.n_edges < WAVE_PER_ROW_DEGREE * self.n_rows:
+            order = torch.empty(self.n_rows, dtype=torch.int32, device=self.indptr.device)
+            with torch.cuda.device(order.device):
+                rc = _lib.load().segger_csr_row_order(self.indptr.data_ptr(), self.n_rows, window, order.data_ptr(),
+                                                      _lib.stream_ptr(order.device))
+            _lib.check(rc, "segger_csr_row_order")
+            self.order = order
+        return self
 
 
 # ---- deferred validation -------------------------------------------------------------------------------
@@ -131,9 +148,10 @@ class EdgeGraph:
 def build_edge_graph(edge_index: Tensor, n_src: int, n_dst: int, *, need_by_dst: bool = True,
                      need_by_src: bool = True, validate=True) -> EdgeGraph:
     src, dst = edge_index[0], edge_index[1]
-    by_dst = csr_from_coo(dst, src, n_dst, n_src, validate) if need_by_dst else None
+    by_dst = csr_from_coo(dst, src, n_dst, n_src, validate).balanced_order() if need_by_dst else None
     # both views hold the same edges: one check is enough
-    by_src = csr_from_coo(src, dst, n_src, n_dst, False if need_by_dst else validate) if need_by_src else None
+    by_src = (csr_from_coo(src, dst, n_src, n_dst, False if need_by_dst else validate).balanced_order()
+              if need_by_src else None)
     return EdgeGraph(by_dst, by_src, n_src, n_dst, int(edge_index.shape[1]))
 
 

@@ -456,30 +456,43 @@ def segment_rowsum(x: Tensor, by_id: EdgeCSR) -> Tensor:
     return out
 
 
-_DW_SPLITS = 128
+def linear_wgrad_supported(m_out: int, k_in: int, dtype: torch.dtype) -> bool:
+    return dtype in (torch.bfloat16, torch.float16) and bool(
+        _lib.load().segger_linear_wgrad_supported(int(m_out), int(k_in), DTYPE_CODE[dtype]))
 
 
-def _weight_grad(gy: Tensor, x: Tensor) -> Tensor:
-    """dW[M, K] = gy^T x as a vendor GEMM.  A plain [M, n] x [n, K] product has only
-    (M/64)*(K/64) ~ 24 output tiles, i.e. 24 busy workgroups on a 256-CU chip (1.7 ms at n = 1M);
-    batching the reduction over 128 row slabs fills the chip (0.24 ms = the HBM time of reading
-    gy and x once); the slab partials are summed in fp32."""
+def linear_wgrad_launch(gy: Tensor, x: Tensor, want_bias: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    """(dW[M, K], db[M]) fp32 of ``y = x @ W.T + b`` from ``gy`` [n, M] and ``x`` [n, K] (row strides allowed):
+    one pass over both matrices on the MFMA weight-gradient kernel (``segger_linear_wgrad``)."""
+    _lib.require_cuda(gy, x)
+    lib = _lib.load()
     n, m = gy.shape
     k = x.shape[1]
-    s = _DW_SPLITS
-    if n < s * 256:
-        return (gy.t() @ x).float()
-    nn = n // s * s
-    gw = torch.bmm(gy[:nn].reshape(s, nn // s, m).transpose(1, 2), x[:nn].reshape(s, nn // s, k)).sum(0, dtype=torch.float32)
-    if nn < n:
-        gw += (gy[nn:].t() @ x[nn:]).float()
-    return gw
+    if x.shape[0] != n or gy.dtype != x.dtype:
+        raise ValueError("linear_wgrad: gy / x must share the row count and the dtype")
+    gp, ldg = _rows(gy, m, "gy")
+    xp, ldx = _rows(x, k, "x")
+    gw = torch.empty((m, k), dtype=torch.float32, device=x.device)
+    gb = torch.empty(m, dtype=torch.float32, device=x.device) if want_bias else None
+    ws_bytes = lib.segger_linear_wgrad_workspace_bytes(n, m, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = lib.segger_linear_wgrad(gp, ldg, xp, ldx, n, m, k, DTYPE_CODE[x.dtype], gw.data_ptr(), _lib.ptr(gb),
+                                     ws.data_ptr(), ws_bytes, _lib.stream_ptr(x.device))
+    _lib.check(rc, "segger_linear_wgrad")
+    return gw, gb
+
+
+def _weight_grad_gemm(gy: Tensor, x: Tensor) -> Tensor:
+    """dW[M, K] = gy^T x as a plain library GEMM: shapes the MFMA weight-gradient kernel does not cover
+    (``linear_wgrad_supported``).  fp32 result."""
+    return (gy.t() @ x).float()
 
 
 class _Linear(torch.autograd.Function):
     """x [n, K] (bf16/f16), weight [M, K] fp32 master, bias [M] fp32 -> [n, M].
-    Forward and the data gradient run on the hand-written MFMA kernel (x / dY read once);
-    the weight gradient (a [M, K] reduction over n rows) stays on the vendor GEMM."""
+    Forward, the data gradient and the weight / bias gradients run on the hand-written MFMA kernels
+    (csrc/linear.hip, csrc/linear_wgrad.hip)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -506,10 +519,16 @@ class _Linear(torch.autograd.Function):
                 gx = linear_fwd_launch(gy, wt, None)
             else:
                 gx = gy @ weight.detach().to(dt)
-        if ctx.needs_input_grad[1]:
-            gw = _weight_grad(gy, x).to(weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = colsum(gy).to(bias.dtype)
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if (want_w or want_b) and x.shape[0] > 0 and linear_wgrad_supported(m, k, dt):
+            gw, gb = linear_wgrad_launch(gy, x, want_bias=want_b)       # dY and X read once for both
+            gw = gw.to(weight.dtype) if want_w else None
+            gb = gb.to(bias.dtype) if want_b else None
+        else:
+            if want_w:
+                gw = _weight_grad_gemm(gy, x).to(weight.dtype)
+            if want_b:
+                gb = colsum(gy).to(bias.dtype)
         return gx, gw, gb
 
 

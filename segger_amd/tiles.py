@@ -210,7 +210,7 @@ class TilePartition:
             indptr = torch.empty(ptr.numel() + 1, dtype=torch.long, device=dev)
             indptr[:-1] = ptr
             indptr[-1:] = n_edges
-            out[side] = EdgeCSR(indptr, col, eid, n_nodes[row_t], n_nodes[col_t])
+            out[side] = EdgeCSR(indptr, col, eid, n_nodes[row_t], n_nodes[col_t]).balanced_order()
         return EdgeGraph(out["by_dst"], out["by_src"], n_nodes[s], n_nodes[d], n_edges)
 
     def add_node_attr(self, node_type: str, name: str, value: Tensor, permuted: bool = False) -> None:

@@ -86,7 +86,12 @@ def test_encoder_golden_loss_and_parameter_gradients(cuda, dtype):
     assert abs(loss.item() - ref_loss) < (2e-5 if dtype == torch.float32 else 2e-2)
     named = dict(m.named_parameters())
     checked = 0
+    # fp32: every tensor within 2e-3 of its own largest entry.  bf16 (activations and their gradients rounded to 8 bits
+    # through 4 layers): 12 % of the tensor's largest entry, plus a floor of 5e-3 of the largest gradient of the whole
+    # model for tensors whose gradient is a difference of nearly cancelling terms (e.g. lin_r of a late layer, 1e-5).
     rel = 2e-3 if dtype == torch.float32 else 0.12
+    gmax = max(np.abs(z[f"grad::{k}"]).max() for k in sd)
+    floor = 1e-7 if dtype == torch.float32 else 5e-3 * gmax
     for k in sd:
         ref = z[f"grad::{k}"].astype(np.float64)
         if k not in named or named[k].grad is None:
@@ -95,7 +100,7 @@ def test_encoder_golden_loss_and_parameter_gradients(cuda, dtype):
         got = named[k].grad.double().cpu().numpy()
         scale = max(np.abs(ref).max(), 1e-8)
         err = np.abs(got - ref).max()
-        assert err < rel * scale + 1e-7, f"{k}: grad err {err} (scale {scale})"
+        assert err < rel * scale + floor, f"{k}: grad err {err} (scale {scale})"
         checked += 1
     assert checked >= 40
     assert bg[TX_BD].edge_index.shape[1] == z["in::neg"].shape[0]

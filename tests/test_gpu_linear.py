@@ -61,6 +61,48 @@ def test_linear_autograd(cuda, k, m, n):
     assert torch.allclose(b.grad, br.grad, rtol=1e-3, atol=1e-2)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m,k", [(384, 256), (384, 128), (384, 64), (192, 64), (192, 256), (128, 256), (128, 128),
+                                 (128, 64), (64, 256), (64, 128), (64, 64)])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 70_001])
+def test_linear_wgrad_matches_fp64(cuda, dtype, m, k, n):
+    """segger_linear_wgrad: dW = dY^T X and db = sum dY in one pass (MFMA, fp32 accumulate) against float64 on the
+    same rounded inputs.  Error of an fp32 sum of n products of magnitude ~1: <= 1e-5 of sum |dY| |X| (+ the same for
+    the column sums); exact integers check the operand maps element by element."""
+    from segger_amd import ops
+    assert ops.linear_wgrad_supported(m, k, dtype)
+    g = torch.Generator(device=cuda).manual_seed(n + m + k)
+    gy = (torch.randn(n, m, device=cuda, generator=g) + 0.1).to(dtype)
+    x = torch.randn(n, k, device=cuda, generator=g).to(dtype)
+    gw, gb = ops.linear_wgrad_launch(gy, x)
+    assert gw.shape == (m, k) and gb.shape == (m,) and gw.dtype == gb.dtype == torch.float32
+    ref_w = gy.double().t() @ x.double()
+    ref_b = gy.double().sum(0)
+    bound_w = 1e-5 * (gy.double().abs().t() @ x.double().abs()) + 1e-6
+    assert bool(((gw.double() - ref_w).abs() <= bound_w).all())
+    assert bool(((gb.double() - ref_b).abs() <= 1e-5 * gy.double().abs().sum(0) + 1e-6).all())
+    gw2, gb2 = ops.linear_wgrad_launch(gy, x)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)                # deterministic
+    gw3, none = ops.linear_wgrad_launch(gy, x, want_bias=False)
+    assert none is None and torch.equal(gw3, gw)
+
+
+def test_linear_wgrad_operand_maps_exact_and_strided(cuda):
+    """Small exact integers (every product and sum representable): dW must equal the integer matmul bit for bit, for
+    an asymmetric pattern, with dY / X given as column windows of wider matrices (row stride != width)."""
+    from segger_amd import ops
+    n, m, k = 37, 384, 256
+    r = torch.arange(n, device=cuda)
+    big_y = ((r[:, None] * 3 + torch.arange(3 * m, device=cuda)[None] * 5) % 7 - 3).to(torch.bfloat16)
+    big_x = ((r[:, None] * 2 + torch.arange(2 * k, device=cuda)[None] * 11) % 5 - 2).to(torch.bfloat16)
+    gy, x = big_y[:, m:2 * m], big_x[:, k:]
+    gw, gb = ops.linear_wgrad_launch(gy, x)
+    assert torch.equal(gw, gy.float().t() @ x.float())
+    assert torch.equal(gb, gy.float().sum(0))
+    gw0, gb0 = ops.linear_wgrad_launch(gy[:0], x[:0])
+    assert not gw0.any() and not gb0.any()
+
+
 def test_unsupported_shapes_use_vendor_gemm(cuda):
     from segger_amd import ops
     assert not ops.linear_supported(100, 64, torch.bfloat16)

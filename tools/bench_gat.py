@@ -9,6 +9,8 @@ n = int(os.environ.get('N_TX', 1_000_000))
 b = make_graph(SyntheticSpec(n_tx=n, n_bd=n // 100, k_tx=15, seed=0))
 ei = b[TX_TX].edge_index.to(dev)
 g = build_edge_graph(ei, n, n)
+if os.environ.get('ORDER', '1') == '0':          # A/B of the degree-balanced visiting order
+    g.by_dst.order = g.by_src.order = None
 H, C = 2, 64; hc = H * C
 gen = torch.Generator(device=dev).manual_seed(0)
 xp = torch.randn(n, 3 * hc, device=dev, generator=gen).bfloat16()
@@ -25,4 +27,4 @@ def t(fn, it=20):
     torch.cuda.synchronize(); a = torch.cuda.Event(True); e = torch.cuda.Event(True); a.record()
     for _ in range(it): fn()
     e.record(); torch.cuda.synchronize(); return a.elapsed_time(e) / it
-print(os.environ.get('SEGGER_AMD_LIB', 'default'), 'drop', p, 'fwd %.3f ms  bwd(dst+src) %.3f ms' % (t(fwd), t(bwd)), flush=True)
+print(os.path.basename(os.environ.get('SEGGER_AMD_LIB', 'default')), 'order', os.environ.get('ORDER', '1'), 'drop', p, 'fwd %.3f ms  bwd(dst+src) %.3f ms' % (t(fwd), t(bwd)), flush=True)
