@@ -66,73 +66,87 @@ struct WgradParams {
   float* partial;            // [gridDim.x][M*K + M]
 };
 
+// One LDS-DMA wave-instruction: every lane fetches 16 bytes at rsrc + voffset + soffset (zeros when that is past
+// the resource's range) and the wave's 1 KiB lands at LDS byte address lds_dst + 16 * lane.  Written in asm so
+// that hipcc does not count it: it would otherwise drain vmcnt to 0 in front of every LDS read (it cannot tell
+// which LDS bytes an asynchronous load will write), which is the pipelining this kernel lives on.  M0 carries the
+// destination; it is saved and restored inside the statement (cdna_hip_programming.md 5.7).
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lds_dma16(i32x4 rsrc, uint32_t lds_dst, int voffset, int soffset) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 4\n\t"
+               "buffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_dst), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+}
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, int64_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  return i32x4{(int32_t)(uint32_t)a, (int32_t)((a >> 32) & 0xffffu), (int32_t)bytes, 0x00020000};
+}
+constexpr int kNBuf = 4;                   // LDS ring: stages s .. s+2 in flight while stage s is consumed
+constexpr int kAhead = kNBuf - 1;
+constexpr int kOutOfRange = 0x40000000;    // byte offset past every slab (host checks slabs < 1 GiB): reads as zeros
+
+template <int M, int K, int NW> struct WgGeo {
+  static constexpr int SY = M * 2 + 64, SX = K * 2 + 64;          // LDS row strides in bytes
+  static constexpr int IMG = kStageRows * (SY + SX);              // one stage: dY rows, then X rows
+  static constexpr int P = ((IMG + 1023) / 1024 + NW - 1) / NW;   // 1 KiB DMA chunks per wave per stage
+  static constexpr int BUF = P * NW * 1024;                       // ring slot (chunks past IMG receive zeros)
+  static constexpr int LDS = kNBuf * BUF;
+};
+
 template <typename T, int M, int K, int NW>
 __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
-  constexpr int NT = NW * 64;
+  using G = WgGeo<M, K, NW>;
   constexpr int WM = NW == 8 ? 4 : 2, WK = 2;          // wave grid over (M tiles, K tiles)
   static_assert(M * K / (64 * NW) <= 192, "accumulator does not fit the register file");
   constexpr int TM = M / 32, TK = K / 32;
   static_assert(TM % WM == 0 && TK % WK == 0, "tile grid does not split over the waves");
   constexpr int MT = TM / WM, KT = TK / WK;            // 32x32 tiles per wave
-  constexpr int SY = M * 2 + 64, SX = K * 2 + 64;      // LDS row strides in bytes
-  constexpr int BUF = kStageRows * (SY + SX);
-  constexpr int PY = kStageRows * (M / 8), PX = kStageRows * (K / 8);   // 16-byte pieces per stage
-  constexpr int NP = (PY + PX + NT - 1) / NT;          // pieces per thread
-  static_assert(PY % 64 == 0, "dY / X piece boundary must be wave aligned");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+  constexpr int SY = G::SY, SX = G::SX, P = G::P, BUF = G::BUF;
+  static_assert((kStageRows * SY) % 1024 == 0, "the dY / X boundary must fall on a DMA chunk boundary");
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave % WM, wk = wave / WM;
   const T* __restrict__ dy = static_cast<const T*>(p.dy);
   const T* __restrict__ x = static_cast<const T*>(p.x);
 
-  // ---- staging: thread -> (matrix, row, 16-byte chunk) for each of its pieces.  Loads go through buffer
-  //      resources based at this workgroup's first row: the address of a piece is an SGPR base + a per-thread
-  //      32-bit offset fixed for the whole kernel + a scalar stage offset, and rows past the end of the matrix
-  //      (the last, partial stage) come back as zeros from the range check -- no branches, no 64-bit VGPR math
+  // ---- staging by LDS-DMA through buffer resources based at this workgroup's first row: the source of a piece is
+  //      an SGPR base + a per-lane 32-bit offset fixed for the whole kernel + a scalar stage offset; rows past the
+  //      end of the matrix (the last, partial stage, and the stages the ring runs ahead of the slab) read as zeros
   const int64_t s_beg = (int64_t)blockIdx.x * p.stages_per_block;
   int64_t s_end = s_beg + p.stages_per_block;
   if (s_end > p.n_stages) s_end = p.n_stages;
+  const int n_local = (int)(s_end > s_beg ? s_end - s_beg : 0);
   const int64_t row_beg = s_beg * kStageRows;
-  const int64_t rows_here = p.n_rows > row_beg ? p.n_rows - row_beg : 0;       // valid rows from row_beg on
-  const int64_t span_rows = rows_here < p.stages_per_block * kStageRows ? rows_here : p.stages_per_block * kStageRows;
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(dy) + row_beg * p.ld_dy, 0, (int)(span_rows * p.ld_dy * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<T*>(x) + row_beg * p.ld_x, 0, (int)(span_rows * p.ld_x * 2), 0x00020000);
+  int64_t span_rows = p.n_rows > row_beg ? p.n_rows - row_beg : 0;             // valid rows from row_beg on ...
+  if (span_rows > (int64_t)n_local * kStageRows) span_rows = (int64_t)n_local * kStageRows;   // ... inside this slab
+  const i32x4 ry = make_rsrc(dy + row_beg * p.ld_dy, span_rows * p.ld_dy * 2);
+  const i32x4 rx = make_rsrc(x + row_beg * p.ld_x, span_rows * p.ld_x * 2);
   const int stage_bytes_y = kStageRows * (int)p.ld_dy * 2, stage_bytes_x = kStageRows * (int)p.ld_x * 2;
-  int voff[NP];
+  int voff[P];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int q = tid + i * NT;
-    if (q < PY) voff[i] = (q / (M / 8)) * (int)p.ld_dy * 2 + (q % (M / 8)) * 16;
-    else        voff[i] = ((q - PY) / (K / 8)) * (int)p.ld_x * 2 + ((q - PY) % (K / 8)) * 16;
-  }
-  u32x4 st[NP];
-  auto fetch = [&](int local_stage) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int q = tid + i * NT;                      // wave-uniform choice: PY is a multiple of 64
-      if (q < PY)
-        st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(ry, voff[i], local_stage * stage_bytes_y, 0));
-      else if (q < PY + PX)
-        st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, voff[i], local_stage * stage_bytes_x, 0));
+  for (int j = 0; j < P; ++j) {
+    const int o = (wave + j * NW) * 1024 + lane * 16;  // byte offset of this lane's piece in the stage image
+    if (o < kStageRows * SY) {
+      const int row = o / SY, w = o % SY;
+      voff[j] = row * (int)p.ld_dy * 2 + (w < M * 2 ? w : 0);      // a row's 64 pad bytes re-read its first bytes
+    } else if (o < G::IMG) {
+      const int oo = o - kStageRows * SY;
+      const int row = oo / SX, w = oo % SX;
+      voff[j] = row * (int)p.ld_x * 2 + (w < K * 2 ? w : 0);
+    } else {
+      voff[j] = kOutOfRange;
     }
-  };
-  auto commit = [&](int buf) {
-    unsigned char* by = lds + buf * BUF;
-    unsigned char* bx = by + kStageRows * SY;
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  auto issue = [&](int local_stage) {                  // always P loads per wave: the vmcnt arithmetic below relies on it
+    const uint32_t dst = lds_base + (uint32_t)((local_stage % kNBuf) * BUF + wave * 1024);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      const int q = tid + i * NT;
-      if (q < PY) {
-        const int row = q / (M / 8), ch = q % (M / 8);
-        *reinterpret_cast<u32x4*>(by + row * SY + ch * 16) = st[i];
-      } else if (q < PY + PX) {
-        const int qq = q - PY;
-        const int row = qq / (K / 8), ch = qq % (K / 8);
-        *reinterpret_cast<u32x4*>(bx + row * SX + ch * 16) = st[i];
-      }
+    for (int j = 0; j < P; ++j) {
+      const bool is_y = (wave + j * NW) * 1024 < kStageRows * SY;      // wave-uniform
+      lds_dma16(is_y ? ry : rx, dst + j * NW * 1024, voff[j], local_stage * (is_y ? stage_bytes_y : stage_bytes_x));
     }
   };
 
@@ -154,17 +168,15 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
 #pragma unroll
   for (int a = 0; a < MT; ++a) dbias[a] = 0.f;
 
-  const int n_local = (int)(s_end > s_beg ? s_end - s_beg : 0);
-  if (n_local > 0) {
-    fetch(0);
-    commit(0);
-  }
-  __syncthreads();
+  for (int d = 0; d < kAhead; ++d) issue(d);
   for (int s = 0; s < n_local; ++s) {
-    const int buf = s & 1;
-    const bool more = s + 1 < n_local;
-    if (more) fetch(s + 1);                            // global loads in flight under the MFMAs
-    const unsigned char* base = lds + buf * BUF;
+    // this wave's pieces of stage s have landed once at most (kAhead - 1) * P of its loads are outstanding;
+    // the barrier then makes every wave's pieces visible and retires all reads of stage s - 1, whose ring slot
+    // the next issue overwrites
+    __builtin_amdgcn_s_waitcnt(0x0F70 | (((kAhead - 1) * P) & 15) | ((((kAhead - 1) * P) >> 4) << 14));
+    __syncthreads();
+    issue(s + kAhead);
+    const unsigned char* base = lds + (s % kNBuf) * BUF;
     u32x4 fa[MT];
 #pragma unroll
     for (int a = 0; a < MT; ++a) {
@@ -189,9 +201,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
 #pragma unroll
       for (int a = 0; a < MT; ++a) acc[a][b] = WgMfma<T>::run(fa[a], fb, acc[a][b]);
     }
-    if (more) commit(buf ^ 1);
-    __syncthreads();
   }
+  // the ring ran kAhead stages past the slab (zero reads): let them land before the wave ends
+  __builtin_amdgcn_s_waitcnt(0x0F70);
 
   // ---- partial results: acc tile (a, b) element e of lane l is dW[m][k] with
   //      m = 32*(wm*MT + a) + (e & 3) + 8*(e >> 2) + 4*(l >> 5),  k = 32*(wk*KT + b) + (l & 31) -----------------------
@@ -218,19 +230,31 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
   }
 }
 
-// out[e] = sum_s partial[s][e]: grad_w = first M*K entries, grad_b the rest (fixed slab order: deterministic)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int64_t n_slabs, int64_t width,
-                                                          int64_t mk, float* __restrict__ grad_w, float* __restrict__ grad_b) {
+// out[e] = sum_s partial[s][e] in two deterministic stages (a single pass would leave each of the few thousand
+// threads a serial chain of up to 1024 dependent-latency loads): stage 1 sums every kRedGroups-th slab into
+// part2[g][e] (grid = columns x groups), stage 2 adds the groups in order; grad_w = first M*K entries, grad_b the rest
+constexpr int kRedGroups = 32;
+__global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restrict__ partial, int64_t n_slabs, int64_t width,
+                                                           float* __restrict__ part2) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= width) return;
+  const int g = blockIdx.y;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int64_t s = 0;
-  for (; s + 4 <= n_slabs; s += 4) {
-    s0 += partial[(s + 0) * width + e]; s1 += partial[(s + 1) * width + e];
-    s2 += partial[(s + 2) * width + e]; s3 += partial[(s + 3) * width + e];
+  int64_t s = g;
+  for (; s + 3 * kRedGroups < n_slabs; s += 4 * kRedGroups) {
+    s0 += partial[s * width + e];                    s1 += partial[(s + kRedGroups) * width + e];
+    s2 += partial[(s + 2 * kRedGroups) * width + e]; s3 += partial[(s + 3 * kRedGroups) * width + e];
   }
-  for (; s < n_slabs; ++s) s0 += partial[s * width + e];
-  const float t = (s0 + s1) + (s2 + s3);
+  for (; s < n_slabs; s += kRedGroups) s0 += partial[s * width + e];
+  part2[(int64_t)g * width + e] = (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restrict__ part2, int64_t width, int64_t mk,
+                                                           float* __restrict__ grad_w, float* __restrict__ grad_b) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= width) return;
+  float t = 0.f;
+#pragma unroll 8
+  for (int g = 0; g < kRedGroups; ++g) t += part2[(int64_t)g * width + e];
   if (e < mk) grad_w[e] = t;
   else if (grad_b) grad_b[e - mk] = t;
 }
@@ -241,12 +265,18 @@ bool shape_ok(int m, int k) {
   return (m == 384 || m == 192 || m == 128 || m == 64) && (k == 256 || k == 128 || k == 64);
 }
 int waves_for(int m) { return m % 128 == 0 ? 8 : 4; }
-// workgroups per CU the register / LDS footprint allows (accumulator registers per lane = M*K / (64*NW))
+// workgroups per CU the register and LDS footprints allow (accumulator registers per lane = M*K / (64*NW);
+// LDS = 4 ring slots of the stage image rounded up to whole 1 KiB chunks per wave)
 int blocks_per_cu(int m, int k) {
-  const int acc = m * k / (64 * waves_for(m));
-  if (acc > 96) return 1;
-  if (acc > 32) return 2;
-  return 4;
+  const int nw = waves_for(m);
+  const int acc = m * k / (64 * nw);
+  const int img = kStageRows * (m * 2 + 64 + k * 2 + 64);
+  const int lds = kNBuf * (((img + 1023) / 1024 + nw - 1) / nw) * nw * 1024;
+  int by_regs = acc > 64 ? 1 : (acc > 32 ? 2 : 4);
+  if (nw == 4 && by_regs < 4) by_regs *= 2;           // 4-wave workgroups: one wave per SIMD each
+  const int by_lds = (160 * 1024) / lds;
+  const int b = by_regs < by_lds ? by_regs : by_lds;
+  return b < 1 ? 1 : b;
 }
 int64_t grid_for(int64_t n_rows, int m, int k) {
   const int64_t stages = (n_rows + kStageRows - 1) / kStageRows;
@@ -283,7 +313,7 @@ extern "C" int segger_linear_wgrad_supported(int32_t m_out, int32_t k_in, int32_
 
 extern "C" size_t segger_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t m_out, int32_t k_in) {
   if (n_rows <= 0 || !shape_ok(m_out, k_in)) return 16;
-  return (size_t)grid_for(n_rows, m_out, k_in) * ((size_t)m_out * k_in + m_out) * sizeof(float);
+  return (size_t)(grid_for(n_rows, m_out, k_in) + kRedGroups) * ((size_t)m_out * k_in + m_out) * sizeof(float);
 }
 
 extern "C" int segger_linear_wgrad(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, int64_t n_rows,
@@ -316,7 +346,7 @@ extern "C" int segger_linear_wgrad(const void* dy, int64_t ld_dy, const void* x,
     // buffer resources address one workgroup's slab with 32-bit offsets
     const int64_t stages = (n_rows + kStageRows - 1) / kStageRows;
     const int64_t span = ((stages + grid - 1) / grid) * kStageRows * (ld_dy > ld_x ? ld_dy : ld_x) * 2;
-    SEGGER_REQUIRE(span < 0x7fffffffLL, "segger_linear_wgrad: a workgroup's row slab exceeds 2 GiB");
+    SEGGER_REQUIRE(span < (int64_t)kOutOfRange, "segger_linear_wgrad: a workgroup's row slab exceeds 1 GiB");
   }
   WgradParams p{dy, ld_dy, x, ld_x, n_rows, (n_rows + kStageRows - 1) / kStageRows, 0, static_cast<float*>(workspace)};
   p.stages_per_block = (p.n_stages + grid - 1) / grid;
@@ -325,8 +355,11 @@ extern "C" int segger_linear_wgrad(const void* dy, int64_t ld_dy, const void* x,
   if (rc != SEGGER_OK) return rc;
   SEGGER_LAUNCH_CHECK("wgrad_kernel");
   const int64_t width = (int64_t)m_out * k_in + m_out;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, stream,
-                     p.partial, grid, width, (int64_t)m_out * k_in, grad_w, grad_b);
+  float* part2 = p.partial + grid * width;             // behind the per-workgroup partials
+  hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((unsigned)((width + 255) / 256), kRedGroups), dim3(256), 0, stream,
+                     p.partial, grid, width, part2);
+  hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, stream,
+                     part2, width, (int64_t)m_out * k_in, grad_w, grad_b);
   SEGGER_LAUNCH_CHECK("wgrad_reduce_kernel");
   return SEGGER_OK;
 }
