@@ -193,10 +193,26 @@ typedef struct segger_gatv2_bwd_args {
   float* grad_bias;       /* [H*C] or NULL */
   void* workspace;        /* segger_gatv2_bwd_workspace_bytes() */
   size_t workspace_bytes;
+  int32_t src_unique;     /* non-zero: the caller asserts that no source node has more than one out-edge (segger's
+                             tx-belongs-bd: a transcript lies in at most one boundary; check with
+                             segger_coo_unique).  grad_xl[i] then has a single term, the destination-side pass
+                             stores it itself and by_src is ignored (may be all zero): no by-source sort, no
+                             source-side pass.  Needs a specialised geometry (segger_gatv2_has_specialised). */
 } segger_gatv2_bwd_args;
 
 size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads, int32_t channels);
 int segger_gatv2_bwd(const segger_gatv2_bwd_args* args, segger_stream_t stream);
+/* 1 when (heads, channels) runs on the specialised kernels (channels in {32,64}, heads in 1..4), 0 = generic kernels */
+int segger_gatv2_has_specialised(int32_t heads, int32_t channels);
+
+/*
+ * segger_coo_unique: *unique_out = 1 when no value occurs twice in ids[n] (values in [0, n_ids)), else 0.
+ * marks: caller-provided int32[n_ids] scratch (zeroed by the call).  Enqueue-only; read unique_out after the stream
+ * has passed.  Used once per batch on edge_index[0] of tx-belongs-bd (src/segger/data/utils/heterodata.py:147: each
+ * transcript is assigned to at most one boundary) to license src_unique above.
+ */
+int segger_coo_unique(const int64_t* ids, int64_t n, int64_t n_ids, int32_t* marks, int32_t* unique_out,
+                      segger_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Prediction head: cosine similarity on tx->bd candidate edges + per-transcript

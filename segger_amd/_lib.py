@@ -65,6 +65,7 @@ class GatBwdArgs(C.Structure):
         ("grad_xr", vp), ("ld_gxr", C.c_int64),
         ("grad_att", vp), ("grad_bias", vp),
         ("workspace", vp), ("workspace_bytes", C.c_size_t),
+        ("src_unique", C.c_int32),
     ]
 
 
@@ -104,6 +105,8 @@ EXPORTS = {
     "segger_gatv2_fwd": (C.c_int, [C.POINTER(GatFwdArgs), vp]),
     "segger_gatv2_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "segger_gatv2_bwd": (C.c_int, [C.POINTER(GatBwdArgs), vp]),
+    "segger_gatv2_has_specialised": (C.c_int, [C.c_int32, C.c_int32]),
+    "segger_coo_unique": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
     "segger_edge_cos_argmax": (C.c_int, [C.POINTER(EdgeArgmaxArgs), vp]),
     "segger_triplet_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "segger_triplet_fwd": (C.c_int, [C.POINTER(TripletArgs), vp]),

@@ -60,6 +60,15 @@ __global__ __launch_bounds__(256) void csr_row_order_kernel(const int64_t* __res
   if (row < n_rows) order[base + rank] = (int32_t)row;    // rows past the end rank last: ranks of real rows stay < count
 }
 
+__global__ __launch_bounds__(256) void coo_unique_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t n_ids,
+                                                        int32_t* __restrict__ marks, int32_t* __restrict__ unique) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int64_t i = ids[e];
+  if (i < 0 || i >= n_ids) return;                       // reported by the CSR build's own validation
+  if (atomicAdd(marks + i, 1) != 0) *unique = 0;
+}
+
 int key_bits(int64_t n_rows) {
   int b = 1;
   while (b < 32 && (1LL << b) < n_rows) ++b;
@@ -137,5 +146,21 @@ extern "C" int segger_csr_row_order(const int64_t* indptr, int64_t n_rows, int32
   hipLaunchKernelGGL(csr_row_order_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                      indptr, n_rows, (int)window, order_out);
   SEGGER_LAUNCH_CHECK("csr_row_order_kernel");
+  return SEGGER_OK;
+}
+
+extern "C" int segger_coo_unique(const int64_t* ids, int64_t n, int64_t n_ids, int32_t* marks, int32_t* unique_out,
+                                 segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGGER_REQUIRE(n >= 0 && n_ids >= 0, "segger_coo_unique: negative size");
+  SEGGER_REQUIRE(unique_out != nullptr, "segger_coo_unique: unique_out is NULL");
+  const int32_t one = 1;
+  SEGGER_HIP(hipMemsetD32Async((hipDeviceptr_t)unique_out, one, 1, stream));
+  if (n == 0) return SEGGER_OK;
+  SEGGER_REQUIRE(ids && marks, "segger_coo_unique: NULL pointer");
+  SEGGER_HIP(hipMemsetAsync(marks, 0, (size_t)n_ids * sizeof(int32_t), stream));
+  hipLaunchKernelGGL(coo_unique_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, ids, n, n_ids, marks,
+                     unique_out);
+  SEGGER_LAUNCH_CHECK("coo_unique_kernel");
   return SEGGER_OK;
 }

@@ -29,6 +29,21 @@
 namespace segger {
 namespace {
 
+#if SEGGER_INST_PASS == 1
+#define INST_LAUNCH(H, LPH, WPR)                                                                                   \
+  do {                                                                                                             \
+    if (p.direct_gxl)                                                                                              \
+      hipLaunchKernelGGL((gatv2_bwd_dst_kernel<INST_T, H, LPH, WPR, true>), dim3((unsigned)p.nblocks_padded),      \
+                         dim3(256), 0, stream, p);                                                                 \
+    else                                                                                                           \
+      hipLaunchKernelGGL((gatv2_bwd_dst_kernel<INST_T, H, LPH, WPR, false>), dim3((unsigned)p.nblocks_padded),     \
+                         dim3(256), 0, stream, p);                                                                 \
+  } while (0)
+#else
+#define INST_LAUNCH(H, LPH, WPR) \
+  hipLaunchKernelGGL((INST_KERNEL<INST_T, H, LPH, WPR>), dim3((unsigned)p.nblocks_padded), dim3(256), 0, stream, p)
+#endif
+
 template <int H, int LPH, bool WPR>
 int launch_one(GatParams& p, hipStream_t stream) {
   using G = Geo<H, LPH>;
@@ -42,7 +57,7 @@ int launch_one(GatParams& p, hipStream_t stream) {
     set_error("gatv2: %lld rows need more than 2^31 blocks", (long long)p.n_rows);
     return SEGGER_EUNSUPPORTED;
   }
-  hipLaunchKernelGGL((INST_KERNEL<INST_T, H, LPH, WPR>), dim3((unsigned)p.nblocks_padded), dim3(256), 0, stream, p);
+  INST_LAUNCH(H, LPH, WPR);
   SEGGER_LAUNCH_CHECK("gatv2 kernel launch");
   return SEGGER_OK;
 }

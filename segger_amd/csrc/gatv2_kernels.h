@@ -87,6 +87,7 @@ struct GatParams {
   const uint64_t* seed_dev;       // optional device word added to seed_raw before mixing (hipGraph replays)
   uint64_t seed_raw;
   int32_t apply_gelu;
+  int32_t direct_gxl;            // dst pass: store grad_xl rows itself (sources with at most one out-edge)
   int32_t rows_per_wave_iter;    // dst pass: row batches each wave walks
   int64_t nblocks, nblocks_padded;
 };
@@ -421,7 +422,10 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
 //   grad_xr[j] = att * (c1 * sum_i de_ij + c2 * sum_i de_ij * sgn(t_ij))
 //   grad_att   = c1 * sum_ij de_ij * t_ij + c2 * sum_ij de_ij * |t_ij| ;  grad_bias = sum_j g[j]
 // ============================================================================
-template <typename T, int H, int LPH, bool WPR>
+// DIRECT: every source node has at most one out-edge (segger's tx-belongs-bd: a transcript lies in at most one
+// boundary), so grad_xl[i] has a single term and this pass stores it itself -- no by-source view, no source pass.
+// The caller zero-fills grad_xl first (sources without an out-edge).
+template <typename T, int H, int LPH, bool WPR, bool DIRECT>
 __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kernel(GatParams p) {
   using G = Geo<H, LPH>;
   constexpr int GS = G::GS, NG = G::NG, U = SEGGER_DST_UNROLL < GS ? SEGGER_DST_UNROLL : GS, HC = G::HC;
@@ -440,6 +444,8 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
     seed_lo = (uint32_t)mixed; seed_hi = (uint32_t)(mixed >> 32);
   }
   constexpr int RPW = WPR ? 1 : NG;            // rows per wave per iteration
+  char* __restrict__ gxl_base = static_cast<char*>(p.gxl) + (size_t)ch0 * sizeof(T);
+  const uint32_t ld_gxl = (uint32_t)(p.ld_gxl * sizeof(T));
 
   f32x2 a1[4], na1[4], a2[4], Pt[4], Qt[4], dbias[4];
   load_att(p.att, ch0, p.slope, kLog2e, a1, a2);
@@ -502,17 +508,29 @@ __global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kerne
         const float pl = lane_block_sum<LPH>(logit_partial(nt, na1, a2));
         float da = lane_block_sum<LPH>(da2.x + da2.y);
         const float a = valid[u] ? fast_exp2(pl - lse) : 0.f;
-        if (dropout) da = dropout_keep((uint32_t)ed[u], H, h, seed_lo, seed_hi, p.drop_thr) ? da * p.drop_scale : 0.f;
+        float a_eff = a;
+        if (dropout) {
+          const bool keep = dropout_keep((uint32_t)ed[u], H, h, seed_lo, seed_hi, p.drop_thr);
+          da = keep ? da * p.drop_scale : 0.f;
+          a_eff = keep ? a * p.drop_scale : 0.f;
+        }
         const float de = a * (da - D);
         Sde += de;
         const float nde = -de;
         const f32x2 nde2 = splat(nde);
+        f32x2 gx[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const f32x2 sg = f32x2{sign_mul(nde, nt[i].x), sign_mul(nde, nt[i].y)};    // de * sgn(t)
           Pt[i] = pk_fma(nde2, nt[i], Pt[i]);                                        // de * t
           Qt[i] = pk_fma(-sg, nt[i], Qt[i]);                                         // de * |t|
           Sg[i] = Sg[i] + sg;
+          if constexpr (DIRECT)      // the source pass's formula with this edge as the only term
+            gx[i] = pk_fma(splat(a_eff), g[i], (a1[i] * de + a2[i] * sg) * kLn2);
+        }
+        if constexpr (DIRECT) {
+          if (valid[u] && L.lane_on)
+            store_pairs(reinterpret_cast<T*>(gxl_base + (uint64_t)(uint32_t)nbr[u] * ld_gxl), gx);
         }
       }
     };

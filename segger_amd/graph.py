@@ -11,6 +11,7 @@ and cached on the batch object, so the 4 layers x (forward + backward) reuse it.
 """
 from __future__ import annotations
 
+import weakref
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -21,7 +22,11 @@ from . import _lib
 from .hetero import EdgeType
 
 
-ROW_ORDER_WINDOW = 64        # rows per balancing window (power of two <= 64)
+# Degree-balanced row visiting order (segger_csr_row_order).  Measured on the C2 tile (rocprofv3 PMC, window 64): 8 %
+# fewer VALU instructions in the forward (lane efficiency 0.79 -> 0.89) but 34 % more L2 requests -- neighbouring rows
+# share neighbours, and rows that sit in one wave share cache lines within an instruction -- and the kernels got 3-10 %
+# SLOWER.  Kept as an option (``EdgeCSR.balanced_order(window)``) for graphs without that locality; off by default.
+ROW_ORDER_WINDOW = 0         # rows per balancing window (power of two <= 64); 0 = natural order
 WAVE_PER_ROW_DEGREE = 32     # csrc/gatv2.hip kWavePerRowDegree: from this average degree a whole wave walks one row
 
 
@@ -47,7 +52,8 @@ class EdgeCSR:
     def balanced_order(self, window: int = ROW_ORDER_WINDOW) -> "EdgeCSR":
         """Attach the visiting order of ``segger_csr_row_order`` (rows of near-equal degree share a wave; computed
         once per view, results never depend on it).  Skipped for views the kernels walk one row per wave."""
-        if self.order is None and self.n_rows > 0 and self.n_edges < WAVE_PER_ROW_DEGREE * self.n_rows:
+        if (window > 0 and self.order is None and self.n_rows > 0
+                and self.n_edges < WAVE_PER_ROW_DEGREE * self.n_rows):
             order = torch.empty(self.n_rows, dtype=torch.int32, device=self.indptr.device)
             with torch.cuda.device(order.device):
                 rc = _lib.load().segger_csr_row_order(self.indptr.data_ptr(), self.n_rows, window, order.data_ptr(),
@@ -135,20 +141,100 @@ def csr_from_coo(row: Tensor, col: Tensor, n_rows: int, n_cols: int, validate=Tr
     return EdgeCSR(indptr, ccol, eid, n_rows, n_cols)
 
 
+class DeferredFlag:
+    """A device int32 read on the host WITHOUT a device-wide sync: copied to pinned memory when created, examined
+    when first asked for -- by then (the backward of the step whose forward created it) the copy has long landed, and
+    if not, only the copy's own event is waited for."""
+
+    def __init__(self, dev_value: Tensor):
+        self._host = _pinned_slot(self)
+        self._host.copy_(dev_value, non_blocking=True)
+        self._event = torch.cuda.Event()
+        self._event.record(torch.cuda.current_stream(dev_value.device))
+        self._value: Optional[int] = None
+
+    def get(self) -> int:
+        if self._value is None:
+            self._event.synchronize()
+            self._value = int(self._host[0])
+        return self._value
+
+
+_flag_ring: Optional[Tensor] = None
+_flag_live: list = []
+_flag_next = 0
+
+
+def _pinned_slot(owner) -> Tensor:
+    """One int32 of a pinned ring (pinned allocations are too slow to make per batch)."""
+    global _flag_ring, _flag_next, _flag_live
+    if _flag_ring is None:
+        _flag_ring = torch.zeros(_PIN_SLOTS, dtype=torch.int32).pin_memory()
+        _flag_live = [None] * _PIN_SLOTS
+    slot = _flag_next
+    _flag_next = (_flag_next + 1) % _PIN_SLOTS
+    old = _flag_live[slot]() if _flag_live[slot] is not None else None
+    if old is not None:
+        old.get()                       # the ring came round: settle the flag that still owns this slot
+    _flag_live[slot] = weakref.ref(owner)
+    return _flag_ring[slot:slot + 1]
+
+
 @dataclass
 class EdgeGraph:
-    """Both sorted views of one edge type (src type -> dst type)."""
+    """Both sorted views of one edge type (src type -> dst type).  ``by_src`` may be deferred
+    (``need_by_src="lazy"``): the graph then carries the COO edge list and a flag telling whether every source has
+    at most one out-edge -- if so the backward needs no by-source view at all (``segger_gatv2_bwd_args.src_unique``),
+    otherwise :meth:`require_by_src` sorts it on first use."""
     by_dst: Optional[EdgeCSR]
     by_src: Optional[EdgeCSR]
     n_src: int
     n_dst: int
     n_edges: int
+    edge_index: Optional[Tensor] = None
+    unique_flag: Optional[object] = None        # DeferredFlag, or a plain bool when known
+
+    def src_unique(self) -> bool:
+        f = self.unique_flag
+        if f is None:
+            return False
+        if isinstance(f, DeferredFlag):
+            f = self.unique_flag = bool(f.get())
+        return bool(f)
+
+    def require_by_src(self) -> EdgeCSR:
+        if self.by_src is None:
+            if self.edge_index is None:
+                raise RuntimeError("this EdgeGraph was built without its by-source view")
+            src, dst = self.edge_index[0], self.edge_index[1]
+            self.by_src = csr_from_coo(src, dst, self.n_src, self.n_dst, False).balanced_order()
+        return self.by_src
+
+
+def sources_unique(src: Tensor, n_src: int) -> Tensor:
+    """Device int32[1]: 1 when no node id occurs twice in ``src`` (``segger_coo_unique``)."""
+    _lib.require_cuda(src)
+    lib = _lib.load()
+    dev = src.device
+    src = src.to(torch.int64).contiguous()
+    marks = torch.empty(max(n_src, 1), dtype=torch.int32, device=dev)
+    out = torch.empty(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = lib.segger_coo_unique(src.data_ptr(), int(src.numel()), int(n_src), marks.data_ptr(), out.data_ptr(),
+                                   _lib.stream_ptr(dev))
+    _lib.check(rc, "segger_coo_unique")
+    return out
 
 
 def build_edge_graph(edge_index: Tensor, n_src: int, n_dst: int, *, need_by_dst: bool = True,
-                     need_by_src: bool = True, validate=True) -> EdgeGraph:
+                     need_by_src=True, validate=True) -> EdgeGraph:
+    """``need_by_src``: True, False, or ``"lazy"`` (see :class:`EdgeGraph`)."""
     src, dst = edge_index[0], edge_index[1]
     by_dst = csr_from_coo(dst, src, n_dst, n_src, validate).balanced_order() if need_by_dst else None
+    if need_by_src == "lazy":
+        with torch.cuda.device(edge_index.device):
+            flag = DeferredFlag(sources_unique(src, n_src))
+        return EdgeGraph(by_dst, None, n_src, n_dst, int(edge_index.shape[1]), edge_index, flag)
     # both views hold the same edges: one check is enough
     by_src = (csr_from_coo(src, dst, n_src, n_dst, False if need_by_dst else validate).balanced_order()
               if need_by_src else None)

@@ -309,8 +309,11 @@ class ISTEncoder(Module):
 
         if graphs is None:       # sorted views of the edge stores: built once per batch, shared by all layers
             # the by-source view only serves the backward: inference sorts each edge store once, not twice
+            # tx-belongs-bd: a transcript lies in at most one boundary (heterodata.py:147), so its backward needs no
+            # by-source view; "lazy" verifies that on the device and sorts only if it does not hold (graph.EdgeGraph)
+            by_src = {TX_TX: True, TX_BD: "lazy"} if torch.is_grad_enabled() else {TX_TX: False, TX_BD: False}
             graphs = {et: edge_graph(cache, et, edge_index_dict[et], x[et[0]].shape[0], x[et[2]].shape[0],
-                                     need_by_src=torch.is_grad_enabled(),
+                                     need_by_src=by_src[et],
                                      validate="deferred")     # checked without a host sync (graph.py)
                       for et in (TX_TX, TX_BD) if et in edge_index_dict}
         step = self._step_dev

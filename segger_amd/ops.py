@@ -92,7 +92,11 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
     dev, dt = xl.device, xl.dtype
     n_dst = g.n_dst
     a = _lib.GatBwdArgs()
-    a.by_dst, a.by_src = g.by_dst.c_struct(), g.by_src.c_struct()
+    a.by_dst = g.by_dst.c_struct()
+    if g.by_src is None and g.src_unique() and lib.segger_gatv2_has_specialised(heads, channels):
+        a.src_unique = 1          # every source has at most one out-edge: the destination pass stores grad_xl itself
+    else:
+        a.by_src = g.require_by_src().c_struct()
     a.x_l, a.ld_xl = _rows(xl, hc, "x_l")
     a.x_r, a.ld_xr = _rows(xr, hc, "x_r")
     keep = (_f32_vec(att, hc, "att"), _f32_vec(bias, hc, "bias"))

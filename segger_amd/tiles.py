@@ -153,12 +153,16 @@ class TilePartition:
         contiguous, so the CSR views of any batch of tiles are concatenations of per-tile slices plus one offset
         per tile: :meth:`batch` then hands the encoder ready-made views and no batch is ever sorted again
         (5 radix sorts per batch otherwise).  Needs the partition on the GPU."""
-        from .graph import csr_from_coo
+        from .graph import csr_from_coo, sources_unique
         self.csr_max_tiles = 1
         self._csr: Dict[EdgeType, Dict[str, Dict[str, Tensor]]] = {}
+        self._src_unique: Dict[EdgeType, bool] = {}
         for et in (edge_types or list(self.data._edges.keys())):
             s, _, d = et
             ei = self.data[et].edge_index
+            # once per slide (one sync here, none per batch): does every source have at most one out-edge?  Then the
+            # backward of this edge type needs no by-source view (graph.EdgeGraph, segger_gatv2_bwd_args.src_unique)
+            self._src_unique[et] = bool(int(sources_unique(ei[0], self.data[s].num_nodes))) if ei.is_cuda else False
             n = {"by_dst": (self.data[d].num_nodes, self.data[s].num_nodes), "by_src": (self.data[s].num_nodes, self.data[d].num_nodes)}
             tile_of_edge = torch.repeat_interleave(torch.arange(self.num_tiles, device=ei.device), self.edge_sizes[et])
             views = {}
@@ -187,6 +191,9 @@ class TilePartition:
         n_edges = run
         single = len(tile_ids) == 1
         out = {"by_dst": None, "by_src": None}
+        unique = self._src_unique.get(et, False)
+        if need_by_src == "lazy":                            # skipped when the slide-level check allows it
+            need_by_src = not unique
         for side, row_t, col_t, need in (("by_dst", d, s, need_by_dst), ("by_src", s, d, need_by_src)):
             if not need:
                 continue
@@ -211,7 +218,7 @@ class TilePartition:
             indptr[:-1] = ptr
             indptr[-1:] = n_edges
             out[side] = EdgeCSR(indptr, col, eid, n_nodes[row_t], n_nodes[col_t]).balanced_order()
-        return EdgeGraph(out["by_dst"], out["by_src"], n_nodes[s], n_nodes[d], n_edges)
+        return EdgeGraph(out["by_dst"], out["by_src"], n_nodes[s], n_nodes[d], n_edges, None, unique)
 
     def add_node_attr(self, node_type: str, name: str, value: Tensor, permuted: bool = False) -> None:
         self.data[node_type][name] = value if permuted else value.index_select(0, self.node_perm[node_type])

@@ -176,6 +176,94 @@ def test_gatv2_edge_order_invariance_and_isolated(cuda):
     assert torch.equal(outs[0][0].cpu(), bias)          # dst 0 is isolated by construction
 
 
+@pytest.mark.parametrize("window", [4, 16, 64])
+def test_row_order_is_a_permutation_and_changes_nothing(cuda, window):
+    """segger_csr_row_order: a permutation of the rows, sorted by descending degree inside every window; forward and
+    backward results with the order attached are bit-identical to the natural order (rows are independent)."""
+    from segger_amd import ops
+    from segger_amd.graph import build_edge_graph
+    H, C, n_src, n_dst, E = 2, 64, 500, 333, 5000
+    g = torch.Generator().manual_seed(3)
+    ei = random_graph(n_src, n_dst, E, seed=5).to(cuda)
+    graph = build_edge_graph(ei, n_src, n_dst)
+    assert graph.by_dst.order is None                                      # off by default (graph.ROW_ORDER_WINDOW)
+    xl = torch.randn(n_src, H * C, generator=g).to(cuda).requires_grad_(True)
+    xr = torch.randn(n_dst, H * C, generator=g).to(cuda).requires_grad_(True)
+    att = (torch.randn(H * C, generator=g) * 0.3).to(cuda).requires_grad_(True)
+    w = torch.randn(n_dst, H * C, generator=g).to(cuda)
+
+    def run():
+        out = ops.gatv2_aggregate(xl, xr, att, None, graph, H, C, apply_gelu=True, dropout_p=0.2, seed=9)
+        grads = torch.autograd.grad((out * w).sum(), (xl, xr, att))
+        return (out.detach(),) + grads
+    base = run()
+    graph.by_dst.balanced_order(window)
+    graph.by_src.balanced_order(window)
+    order = graph.by_dst.order.long().cpu()
+    assert torch.equal(order.sort().values, torch.arange(n_dst))
+    deg = (graph.by_dst.indptr[1:] - graph.by_dst.indptr[:-1]).cpu()[order]
+    for b in range(0, n_dst, window):
+        d = deg[b:b + window]
+        assert bool((d[:-1] >= d[1:]).all()) and int(order[b:b + window].min()) >= b and int(order[b:b + window].max()) < b + window
+    again = run()
+    for a, b_ in zip(base[:3], again[:3]):                 # per-row results: bit-identical
+        assert torch.equal(a, b_)
+    # grad_att: block partials regroup an fp32 sum of ~5000 terms of either sign
+    assert (base[3] - again[3]).abs().max() <= 1e-5 * base[3].abs().max() + 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,C,n_src,n_dst,E", [(2, 64, 4000, 60, 2500), (2, 64, 900, 400, 700), (3, 32, 500, 7, 480),
+                                               (5, 16, 300, 20, 250)])
+def test_unique_sources_need_no_by_source_view(oracle, cuda, dtype, H, C, n_src, n_dst, E):
+    """tx-belongs-bd: every source has at most one out-edge, so the destination pass stores grad_x_l itself
+    (segger_gatv2_bwd_args.src_unique; by_src is never sorted).  Gradients equal the two-pass path's to the last bit or two and
+    the oracle's within the usual tolerance; a graph with a repeated source silently falls back to the sort."""
+    from segger_amd import ops
+    from segger_amd.graph import build_edge_graph
+    g = torch.Generator().manual_seed(E)
+    src = torch.randperm(n_src, generator=g)[:E]                          # distinct sources
+    dst = torch.randint(0, n_dst, (E,), generator=g)
+    ei = torch.stack([src, dst])
+    xl = torch.randn(n_src, H * C, generator=g).to(dtype)
+    xr = torch.randn(n_dst, H * C, generator=g).to(dtype)
+    att, bias = torch.randn(H * C, generator=g) * 0.3, torch.randn(H * C, generator=g) * 0.1
+    w = torch.randn(n_dst, H * C, generator=g)
+
+    def run(graph, p):
+        leaves = [t.to(cuda).requires_grad_(True) for t in (xl, xr, att, bias)]
+        out = ops.gatv2_aggregate(*leaves, graph, H, C, apply_gelu=True, dropout_p=p, seed=3)
+        (out.float() * w.to(cuda)).sum().backward()
+        return [out.detach()] + [t.grad for t in leaves]
+    lazy = build_edge_graph(ei.to(cuda), n_src, n_dst, need_by_src="lazy")
+    full = build_edge_graph(ei.to(cuda), n_src, n_dst)
+    assert lazy.by_src is None
+    def same(a, b):
+        # fp32: the one-pass form rounds a*g + rest once where the two-pass form rounds a*g first (last-bit differences).
+        # bf16: the two-pass form reads grad_pre back ROUNDED to bf16 (2^-9 relative) where the one-pass form still holds
+        # it in fp32, so the results differ by a few bf16 ulps -- in favour of the one-pass form
+        rt = 2e-6 if dtype == torch.float32 else 2.0 ** -5
+        for x, y in zip(a, b):
+            assert torch.allclose(x.float(), y.float(), rtol=rt, atol=rt * float(y.float().abs().max()) * 0.25 + 1e-9)
+    for p in (0.0, 0.3):
+        same(run(lazy, p), run(full, p))
+    assert lazy.src_unique() and (lazy.by_src is None) == (H != 5)          # (5, 16) has no specialised kernel: sorted lazily
+    # against the oracle (no dropout)
+    got = run(lazy, 0.0)
+    o = [t.double().requires_grad_(True) for t in (xl, xr, att, bias)]
+    ref, _, _ = oracle_conv(oracle, o[0], o[1], ei, o[2], o[3], H, True)
+    (ref * w.double()).sum().backward()
+    close(got[0], ref, dtype, what="out")
+    close(got[1], o[0].grad, dtype, scale=4.0, what="grad_xl")
+    close(got[2], o[1].grad, dtype, scale=4.0 * max(1.0, E / n_dst) ** 0.5, what="grad_xr")
+    # a repeated source: the flag says so and the by-source view is built on first use
+    ei2 = ei.clone(); ei2[0, 1] = ei2[0, 0]
+    dup = build_edge_graph(ei2.to(cuda), n_src, n_dst, need_by_src="lazy")
+    full2 = build_edge_graph(ei2.to(cuda), n_src, n_dst)
+    same(run(dup, 0.0), run(full2, 0.0))                                   # same kernels, same views
+    assert not dup.src_unique() and dup.by_src is not None
+
+
 def test_rejects_bad_arguments(cuda):
     from segger_amd import ops, _lib
     from segger_amd.graph import build_edge_graph
