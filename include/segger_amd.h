@@ -280,6 +280,13 @@ typedef struct segger_triplet_args {
                              caller sums the rows grouped by boundary with segger_segment_rowsum; grad_b is ignored */
   void* workspace;
   size_t workspace_bytes;
+  const int64_t* pos_indptr; /* bwd, optional: [n_b + 1] and ... */
+  const int32_t* pos_eid;    /* ... [n_edges]: the triplets grouped by their positive row (for tx-belongs-bd edges this is
+                                the by-destination CSR the encoder already built).  When given (separate z_b, fp32
+                                grad_b), the positive side of grad_b is a segmented sum over these groups -- written,
+                                not accumulated, so grad_b needs no zero-fill -- and only the negatives, which are
+                                sampled uniformly and therefore uncontended, use fp32 atomics.  (Positives are the hot
+                                rows: a boundary's ~40 edges sit next to each other and hammer one row.) */
 } segger_triplet_args;
 
 size_t segger_triplet_workspace_bytes(int64_t n_edges);

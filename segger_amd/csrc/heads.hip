@@ -145,6 +145,8 @@ struct TripletParams {
   void* ga; void* gb;    // bwd: [n_a, C], [n_b, C]; fp32, or the embedding dtype when *_packed
   int ga_packed, gb_packed;
   void* contrib;          // bwd, optional: [n_edges][2][C] fp32 -- (-d/d pos, +d/d neg) per triplet INSTEAD of gb atomics
+  const int64_t* pos_indptr; const int32_t* pos_eid;   // bwd, optional: triplets grouped by positive row
+  int skip_pos;           // bwd: the positive side of gb is written by triplet_pos_kernel
 };
 
 // gradient accumulation into one row: fp32 atomics, or -- for 16-bit embeddings -- packed 2-channel atomics in the
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void triplet_kernel(TripletParams p) {
           const float dn0 = (a0 - load1(zb + in * p.ld_zb + c) + p.eps) * in_;
           const float dn1 = (a1 - load1(zb + in * p.ld_zb + c + 1) + p.eps) * in_;
           grad_add2<T>(p.ga, p.ga_packed, ia * C + c, dp0 - dn0, dp1 - dn1);
-          grad_add2<T>(p.gb, p.gb_packed, ip * C + c, -dp0, -dp1);
+          if (!p.skip_pos) grad_add2<T>(p.gb, p.gb_packed, ip * C + c, -dp0, -dp1);
           grad_add2<T>(p.gb, p.gb_packed, in * C + c, dn0, dn1);
         }
       } else {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(256) void triplet_kernel(TripletParams p) {
           const float dp = (a - load1(zb + ip * p.ld_zb + c) + p.eps) * ip_;
           const float dn = (a - load1(zb + in * p.ld_zb + c) + p.eps) * in_;
           atomicAdd(ga + ia * C + c, dp - dn);
-          atomicAdd(gb + ip * C + c, -dp);
+          if (!p.skip_pos) atomicAdd(gb + ip * C + c, -dp);
           atomicAdd(gb + in * C + c, dn);
         }
       }
@@ -272,6 +274,61 @@ __global__ __launch_bounds__(256) void triplet_kernel(TripletParams p) {
     if (lane == 0) wsum[wave] = acc;
     __syncthreads();
     if (threadIdx.x == 0) p.partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+}
+
+// Positive side of the boundary gradient without atomics: one wave per positive row j walks the triplets whose
+// positive is j (pos_indptr / pos_eid), four at a time (16 lanes each), recomputes their distances and keeps
+// -sum_e scale_e * (a_e - z_b[j] + eps) / ||.|| in registers; gb[j, :] is WRITTEN (rows without triplets: zeros).
+template <typename T>
+__global__ __launch_bounds__(256) void triplet_pos_kernel(TripletParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane >> 4, gl = lane & 15;
+  const int C = p.channels;
+  const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+  if (j >= p.n_b) return;                               // wave-uniform
+  const T* za = static_cast<const T*>(p.za);
+  const T* zb = static_cast<const T*>(p.zb);
+  float* gb = static_cast<float*>(p.gb);
+  const int64_t beg = p.pos_indptr[j], end = p.pos_indptr[j + 1];
+  const float sc = p.scale_dev ? p.scale * p.scale_dev[0] : p.scale;
+  // channels c = gl + 16*k: up to 8 per lane in registers (C <= 128), more in further sweeps
+  for (int c0 = 0; c0 < C; c0 += 128) {
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int64_t s0 = beg; s0 < end; s0 += 4) {
+      const int64_t s = s0 + grp;
+      bool ok = s < end;
+      const int64_t e = ok ? (int64_t)p.pos_eid[s] : 0;
+      int64_t ia = ok ? p.src[e] : 0, in = ok ? p.neg[e] : 0;
+      if ((uint64_t)ia >= (uint64_t)p.n_a || (uint64_t)in >= (uint64_t)p.n_b) { ok = false; ia = in = 0; }
+      float sp = 0.f, sn = 0.f;
+      for (int c = gl; c < C; c += 16) {
+        const float a = load1(za + ia * p.ld_za + c);
+        const float dp = a - load1(zb + j * p.ld_zb + c) + p.eps;
+        const float dn = a - load1(zb + in * p.ld_zb + c) + p.eps;
+        sp = fmaf(dp, dp, sp); sn = fmaf(dn, dn, sn);
+      }
+      sp = lane_block_sum<16>(sp);
+      sn = lane_block_sum<16>(sn);
+      const float dap = sqrtf(sp), dan = sqrtf(sn);
+      const bool active = ok && (dap - dan + p.margin > 0.f) && dap > 0.f;
+      const float w = active ? sc / dap : 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = c0 + gl + 16 * k;
+        if (c < C) acc[k] -= (load1(za + ia * p.ld_za + c) - load1(zb + j * p.ld_zb + c) + p.eps) * w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float v = acc[k];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      const int c = c0 + gl + 16 * k;
+      if (grp == 0 && c < C) gb[j * C + c] = v;
+    }
   }
 }
 
@@ -412,7 +469,8 @@ static int triplet_common(const segger_triplet_args* a, bool bwd, hipStream_t st
   const int64_t nb = triplet_blocks(a->n_edges);
   TripletParams p{a->src, a->pos, a->neg, a->n_edges, a->z_a, a->ld_za, a->z_b, a->ld_zb, a->n_a, a->n_b, a->channels, a->margin, a->eps,
                   static_cast<float*>(a->workspace), 0.f, nullptr, a->grad_a, a->grad_b,
-                  a->grad_a_packed, a->grad_b_packed, bwd ? a->contrib : nullptr};
+                  a->grad_a_packed, a->grad_b_packed, bwd ? a->contrib : nullptr,
+                  bwd ? a->pos_indptr : nullptr, bwd ? a->pos_eid : nullptr, 0};
   if (!bwd) {
     const size_t need = segger_triplet_workspace_bytes(a->n_edges);
     if (!a->workspace || a->workspace_bytes < need) {
@@ -429,6 +487,11 @@ static int triplet_common(const segger_triplet_args* a, bool bwd, hipStream_t st
                    "segger_triplet_bwd: one shared gradient buffer cannot be both packed and fp32");
     p.scale = a->grad_scale / (float)a->n_edges;
     p.scale_dev = a->grad_scale_dev;
+    if (p.pos_indptr) {
+      SEGGER_REQUIRE(p.pos_eid && a->grad_b && a->grad_b != a->grad_a && !a->grad_b_packed && !a->contrib,
+                     "segger_triplet_bwd: pos_indptr needs pos_eid and a separate fp32 grad_b (no contrib)");
+      p.skip_pos = 1;
+    }
   }
   dim3 grid((unsigned)nb), block(256);
   // C == 64 with rows that admit 4-channel vector loads -> the vectorised kernel
@@ -437,6 +500,8 @@ static int triplet_common(const segger_triplet_args* a, bool bwd, hipStream_t st
                    ((uintptr_t)a->z_a % (4 * es)) == 0 && ((uintptr_t)a->z_b % (4 * es)) == 0;
 #define LAUNCH(T)                                                                                \
   do {                                                                                           \
+    if (bwd && p.skip_pos)   /* first: it WRITES grad_b; the per-triplet kernel then adds the negatives */            \
+      hipLaunchKernelGGL((triplet_pos_kernel<T>), dim3((unsigned)((a->n_b + 3) / 4)), block, 0, stream, p);   \
     if (c64 && !bwd) {   /* backward: the lane-strided pair layout of triplet_kernel keeps each atomic   */ \
       /* instruction on consecutive dwords; the 4-channel layout measured 60 % slower (0.71 vs 0.44 ms) */   \
       hipLaunchKernelGGL((triplet_c64_kernel<T, false>), grid, block, 0, stream, p);             \

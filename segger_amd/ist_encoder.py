@@ -182,10 +182,9 @@ class SkipGAT(Module):
                       for et in (TX_TX, TX_BD)}
         tt, tb = self.conv[TX_TX], self.conv[TX_BD]
         dt = x_tx.dtype
-        # one fused projection for the three linear maps that read x_tx
-        w_tx = torch.cat([tt.lin_l.weight, tt.lin_r.weight, tb.lin_l.weight], 0)
-        b_tx = torch.cat([tt.lin_l.bias, tt.lin_r.bias, tb.lin_l.bias], 0)
-        xp_tx = ops.linear(x_tx, w_tx, b_tx)
+        # one fused projection for the three linear maps that read x_tx (stacked and cast once per optimizer step)
+        xp_tx = ops.linear(x_tx, (tt.lin_l.weight, tt.lin_r.weight, tb.lin_l.weight),
+                           (tt.lin_l.bias, tt.lin_r.bias, tb.lin_l.bias))
         xp_bd = ops.linear(x_bd, tb.lin_r.weight, tb.lin_r.bias)
         p = tt.dropout if self.training else 0.0
         y_tx, y_bd, alpha = ops.hetero_gat_layer(

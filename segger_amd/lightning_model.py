@@ -164,7 +164,12 @@ class LitISTEncoder(_Base):
         if dst_neg is None:                                                  # :178-180
             dst_neg = (dst_pos + torch.randint(1, num_bd, (n,), device=dst_pos.device)) % num_bd
         if self._sg_loss_type == 'triplet':
-            return ops.triplet_edge_loss(z_tx, z_bd, src_pos, dst_pos, dst_neg, self._sg_margin, eps=1e-6)
+            # the positives are the edges' own destinations: their grouping is the by-destination view of this edge
+            # store, which the encoder's forward has already built and cached on the batch
+            g = edge_graph(batch_cache(batch), TX_BD, batch[TX_BD].edge_index, z_tx.size(0), num_bd,
+                           need_by_src="lazy" if torch.is_grad_enabled() else False, validate="deferred")
+            return ops.triplet_edge_loss(z_tx, z_bd, src_pos, dst_pos, dst_neg, self._sg_margin, eps=1e-6,
+                                         pos_groups=g.by_dst)
         # BCE on dot-product logits (:190-207); unique/inverse in the reference only dedups gathers
         src = torch.cat([src_pos, src_pos]).long()
         dst = torch.cat([dst_pos, dst_neg]).long()

@@ -303,7 +303,7 @@ class _TripletEdgeLoss(torch.autograd.Function):
     (loss_tx); one gradient buffer receives all three contributions."""
 
     @staticmethod
-    def forward(ctx, za, zb, src, pos, neg, margin, eps):
+    def forward(ctx, za, zb, src, pos, neg, margin, eps, pos_groups):
         same = zb is None
         zb_ = za if same else zb
         _lib.require_cuda(za, zb_, src)
@@ -322,6 +322,7 @@ class _TripletEdgeLoss(torch.autograd.Function):
         _lib.check(rc, "segger_triplet_fwd")
         ctx.save_for_backward(za, zb_, src, pos, neg)
         ctx.cfg = (margin, eps, same)
+        ctx.pos_groups = pos_groups
         return loss[0]
 
     @staticmethod
@@ -333,22 +334,23 @@ class _TripletEdgeLoss(torch.autograd.Function):
         a = _triplet_args(src, pos, neg, za, zb, margin, eps)
         # anchor-matrix rows collect a handful of terms: packed 16-bit atomics straight into a gradient of the
         # embeddings' dtype; a separate (boundary) matrix sums dozens of terms per row and stays fp32
-        # (small batches measured no gain from either variant: they keep fp32 atomics on both sides)
+        # (small batches measured no gain from the packed variant: they keep fp32 atomics)
         packed = (za.dtype in (torch.bfloat16, torch.float16) and za.shape[1] % 2 == 0
                   and src.numel() >= _CONTRIB_MIN_EDGES)
         ga = torch.zeros(za.shape, dtype=za.dtype if packed else torch.float32, device=dev)
         a.grad_a, a.grad_a_packed, a.grad_b_packed = ga.data_ptr(), int(packed), int(packed and same)
-        contrib = None
+        pg = ctx.pos_groups
         if same:
             gb = ga
             a.grad_b = ga.data_ptr()
-        elif za.shape[1] % 8 == 0 and src.numel() >= _CONTRIB_MIN_EDGES:
-            # boundary side without atomics: a 10^4-row matrix under 8 * 10^5 x C fp32 atomic adds made this the
-            # slowest kernel of the loss backward (0.58 ms; 0.14 ms + a sort and a segmented sum this way).  Small
-            # batches keep the atomics: the sort's ~25 launches cost more than they save there.
-            contrib = torch.empty((2 * int(src.numel()), za.shape[1]), dtype=torch.float32, device=dev)
-            a.contrib, a.grad_b = contrib.data_ptr(), None
-            gb = None
+        elif pg is not None:
+            # boundary side: the positives -- a boundary's ~40 edges sit next to each other and would hammer one row
+            # (0.58 ms of contended fp32 atomics at C2) -- are a segmented sum over the triplets grouped by positive
+            # row (for tx-belongs-bd edges: the by-destination view the encoder already built), which also WRITES
+            # every row of grad_b; the uniformly sampled negatives add themselves with (uncontended) fp32 atomics
+            gb = torch.empty(zb.shape, dtype=torch.float32, device=dev)
+            a.grad_b = gb.data_ptr()
+            a.pos_indptr, a.pos_eid = pg.indptr.data_ptr(), (pg.eid.data_ptr() if pg.n_edges else None)
         else:
             gb = torch.zeros(zb.shape, dtype=torch.float32, device=dev)
             a.grad_b = gb.data_ptr()
@@ -357,19 +359,20 @@ class _TripletEdgeLoss(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = lib.segger_triplet_bwd(C.byref(a), _lib.stream_ptr(dev))
         _lib.check(rc, "segger_triplet_bwd")
-        if contrib is not None:
-            ids = torch.stack([pos, neg], 1).reshape(-1)                 # row 2e -> pos[e], row 2e + 1 -> neg[e]
-            gb = segment_rowsum(contrib, rows_by_id(ids, int(zb.shape[0])))
-        return ga.to(za.dtype), (None if same else gb.to(zb.dtype)), None, None, None, None, None
+        return ga.to(za.dtype), (None if same else gb.to(zb.dtype)), None, None, None, None, None, None
 
 
 def triplet_edge_loss(za: Tensor, zb: Optional[Tensor], src: Tensor, pos: Tensor, neg: Tensor,
-                      margin: float, eps: float = 1e-6) -> Tensor:
+                      margin: float, eps: float = 1e-6, pos_groups: Optional[EdgeCSR] = None) -> Tensor:
     """mean_e max(||za[src]-zb[pos]+eps|| - ||za[src]-zb[neg]+eps|| + margin, 0).
-    Pass ``zb=None`` (or ``zb is za``) when positives / negatives index the anchor matrix itself."""
+    Pass ``zb=None`` (or ``zb is za``) when positives / negatives index the anchor matrix itself.
+    ``pos_groups``: the triplets grouped by positive row (``indptr`` over rows of ``zb``, ``eid`` = triplet ids), e.g.
+    the by-destination view of the edge store the triplets come from: the backward then needs no atomics for them."""
     if zb is za:
         zb = None
-    return _TripletEdgeLoss.apply(za, zb, src, pos, neg, float(margin), float(eps))
+    if pos_groups is not None and (zb is None or pos_groups.n_rows != zb.shape[0] or pos_groups.n_edges != src.numel()):
+        raise ValueError("triplet_edge_loss: pos_groups does not describe these triplets")
+    return _TripletEdgeLoss.apply(za, zb, src, pos, neg, float(margin), float(eps), pos_groups)
 
 
 # --------------------------------------------------------------------------
@@ -493,62 +496,135 @@ def _weight_grad_gemm(gy: Tensor, x: Tensor) -> Tensor:
     return (gy.t() @ x).float()
 
 
-class _Linear(torch.autograd.Function):
-    """x [n, K] (bf16/f16), weight [M, K] fp32 master, bias [M] fp32 -> [n, M].
-    Forward, the data gradient and the weight / bias gradients run on the hand-written MFMA kernels
-    (csrc/linear.hip, csrc/linear_wgrad.hip)."""
+class _Pack:
+    """Compute-dtype copy of one or several row-stacked fp32 master weights (+ the fp32 stacked bias, + the transposed
+    copy the data gradient streams), rebuilt only when a parameter changed (optimizer step, load_state_dict, .to()):
+    the three projections that read x_tx (lin_l / lin_r of tx-neighbors-tx, lin_l of tx-belongs-bd) are ONE GEMM
+    without a per-layer, per-step cat + cast + transpose (and without autograd's slice-copies on the way back)."""
+    __slots__ = ("key", "w", "b", "_wt", "__weakref__")
+
+    def __init__(self):
+        self.key, self.w, self.b, self._wt = None, None, None, None
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        w = weight.detach().to(x.dtype).contiguous()
-        y = linear_fwd_launch(x, w, bias)
-        ctx.save_for_backward(x, weight, bias if bias is not None else weight.new_empty(0))
-        ctx.has_bias = bias is not None
-        ctx.w_cast = w                       # the backward transposes this copy instead of casting again
+    def _key(dtype, weights, biases):
+        ps = tuple(weights) + tuple(b for b in biases if b is not None)
+        return (dtype,) + tuple((p.data_ptr(), p._version) for p in ps)
+
+    def get(self, dtype, weights, biases):
+        key = self._key(dtype, weights, biases)
+        if key != self.key:
+            with torch.no_grad():
+                w = weights[0].detach() if len(weights) == 1 else torch.cat([p.detach() for p in weights], 0)
+                self.w = w.to(dtype).contiguous()
+                if all(b is None for b in biases):
+                    self.b = None
+                else:
+                    parts = [b.detach().float() if b is not None else w.new_zeros(p.shape[0], dtype=torch.float32)
+                             for p, b in zip(weights, biases)]
+                    self.b = (parts[0] if len(parts) == 1 else torch.cat(parts, 0)).contiguous()
+            self._wt, self.key = None, key
+        return self
+
+    @property
+    def wt(self) -> Tensor:                              # [K, M]: dX = dY @ W
+        if self._wt is None:
+            self._wt = self.w.t().contiguous()
+        return self._wt
+
+
+_PACKS: dict = {}
+
+
+def _pack_for(weights) -> _Pack:
+    """The cache entry of a parameter group, keyed by the tensors' identities (dropped when the first one dies)."""
+    import weakref
+    ids = tuple(id(w) for w in weights)
+    pk = _PACKS.get(ids)
+    if pk is None:
+        pk = _PACKS[ids] = _Pack()
+        weakref.finalize(weights[0], _PACKS.pop, ids, None)
+    return pk
+
+
+class _Linear(torch.autograd.Function):
+    """x [n, K] (bf16/f16); ``n_w`` fp32 master weights [M_i, K] stacked by rows, ``n_w`` fp32 biases (or None)
+    -> [n, sum M_i].  Forward, the data gradient and the weight / bias gradients run on the hand-written MFMA kernels
+    (csrc/linear.hip, csrc/linear_wgrad.hip); each parameter's gradient is a row window of the one fused result."""
+
+    @staticmethod
+    def forward(ctx, x, n_w, *params):
+        weights, biases = params[:n_w], params[n_w:]
+        pk = _pack_for(weights).get(x.dtype, weights, biases)
+        y = linear_fwd_launch(x, pk.w, pk.b)
+        ctx.save_for_backward(x)
+        ctx.pack, ctx.n_w = pk, n_w
+        ctx.rows = [int(w.shape[0]) for w in weights]
+        ctx.has_bias = [b is not None for b in biases]
+        # the pack may be rebuilt (optimizer step) before a late backward runs: keep THIS forward's weights alive
+        ctx.w, ctx.wt_of = pk.w, pk
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, bias = ctx.saved_tensors
+        (x,) = ctx.saved_tensors
         dt = x.dtype
+        n_w = ctx.n_w
         if gy.dtype != dt:
             gy = gy.to(dt)
         if gy.dim() != 2 or (gy.shape[0] > 1 and gy.stride(1) != 1):
             gy = gy.contiguous()
-        m, k = weight.shape
-        gx = gw = gb = None
+        w = ctx.w
+        m, k = w.shape
+        gx = None
         if ctx.needs_input_grad[0]:
+            wt = ctx.wt_of.wt if ctx.wt_of.w is w else w.t().contiguous()      # [K, M]: dX = dY @ W
             if linear_supported(m, k, dt):
-                wt = ctx.w_cast.t().contiguous()                      # [K, M]: dX = dY @ W
                 gx = linear_fwd_launch(gy, wt, None)
             else:
-                gx = gy @ weight.detach().to(dt)
-        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+                gx = gy @ w
+        want_w = any(ctx.needs_input_grad[2:2 + n_w])
+        want_b = any(h and g for h, g in zip(ctx.has_bias, ctx.needs_input_grad[2 + n_w:]))
+        gw = gb = None
         if (want_w or want_b) and x.shape[0] > 0 and linear_wgrad_supported(m, k, dt):
             gw, gb = linear_wgrad_launch(gy, x, want_bias=want_b)       # dY and X read once for both
-            gw = gw.to(weight.dtype) if want_w else None
-            gb = gb.to(bias.dtype) if want_b else None
         else:
             if want_w:
-                gw = _weight_grad_gemm(gy, x).to(weight.dtype)
+                gw = _weight_grad_gemm(gy, x)
             if want_b:
-                gb = colsum(gy).to(bias.dtype)
-        return gx, gw, gb
+                gb = colsum(gy)
+        grads_w, grads_b, r0 = [], [], 0
+        for i, r in enumerate(ctx.rows):
+            grads_w.append(gw[r0:r0 + r] if (gw is not None and ctx.needs_input_grad[2 + i]) else None)
+            grads_b.append(gb[r0:r0 + r] if (gb is not None and ctx.has_bias[i] and ctx.needs_input_grad[2 + n_w + i])
+                           else None)
+            r0 += r
+        return (gx, None) + tuple(grads_w) + tuple(grads_b)
 
 
-def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor]) -> Tensor:
-    """``F.linear`` for node-feature matrices.  bf16/f16 activations with a covered (K, M) use the
-    MFMA kernel; fp32 activations (parity mode) and uncovered shapes use the vendor GEMM."""
+def linear(x: Tensor, weight, bias) -> Tensor:
+    """``F.linear`` for node-feature matrices.  ``weight`` / ``bias`` may be sequences of tensors: the maps are
+    stacked by rows into one GEMM (``[lin_l | lin_r | ...](x)``).  bf16/f16 activations with a covered (K, M) use
+    the MFMA kernels; fp32 activations (parity mode) and uncovered shapes use the vendor GEMM."""
+    weights = tuple(weight) if isinstance(weight, (list, tuple)) else (weight,)
+    biases = tuple(bias) if isinstance(bias, (list, tuple)) else (bias,)
+    if len(biases) != len(weights):
+        raise ValueError("linear: one bias (or None) per weight")
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
-    if x2.is_cuda and linear_supported(x2.shape[1], weight.shape[0], x2.dtype) and x2.shape[0] > 0:
+    m_out = sum(int(w.shape[0]) for w in weights)
+    if x2.is_cuda and linear_supported(x2.shape[1], m_out, x2.dtype) and x2.shape[0] > 0:
         if x2.shape[0] > 1 and x2.stride(1) != 1:
             x2 = x2.contiguous()
-        y = _Linear.apply(x2, weight, bias)
+        y = _Linear.apply(x2, len(weights), *weights, *biases)
     else:
         _lib.require_cuda(x2)
-        y = torch.nn.functional.linear(x2, weight.to(x2.dtype), None if bias is None else bias.to(x2.dtype))
-    return y.reshape(*lead, weight.shape[0])
+        w = weights[0] if len(weights) == 1 else torch.cat(weights, 0)
+        b = None
+        if any(bb is not None for bb in biases):
+            b = torch.cat([bb if bb is not None else ww.new_zeros(ww.shape[0]) for ww, bb in zip(weights, biases)], 0)
+        y = torch.nn.functional.linear(x2, w.to(x2.dtype), None if b is None else b.to(x2.dtype))
+    return y.reshape(*lead, m_out)
 
 
 # --------------------------------------------------------------------------

@@ -54,23 +54,29 @@ def test_edge_cos_argmax(oracle, cuda, dtype, C):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("C", [64, 32, 21])           # 64: vectorised kernel; 32: pair atomics; 21: scalar fp32 atomics
-@pytest.mark.parametrize("boundary_side", ["atomics", "segment_sum"])
+@pytest.mark.parametrize("boundary_side", ["atomics", "packed_anchor", "segment_sum"])
 def test_triplet_edge_loss(oracle, cuda, dtype, C, boundary_side, monkeypatch):
     from segger_amd import ops
-    # large edge lists sum the boundary-side gradient without atomics (per-triplet rows + segmented sum)
-    monkeypatch.setattr(ops, "_CONTRIB_MIN_EDGES", 0 if boundary_side == "segment_sum" else 1 << 60)
+    from segger_amd.graph import csr_from_coo
+    # "packed_anchor": the anchor side accumulates with packed 16-bit atomics (large edge lists); "segment_sum": the
+    # positives of the boundary side are a segmented sum over the triplets grouped by positive row, no atomics
+    monkeypatch.setattr(ops, "_CONTRIB_MIN_EDGES", 1 << 60 if boundary_side == "atomics" else 0)
     g = torch.Generator().manual_seed(5)
     n_tx, n_bd, E = 700, 30, 2000
     z_tx = torch.nn.functional.normalize(torch.randn(n_tx, C, generator=g), dim=-1).to(dtype)
     z_bd = torch.nn.functional.normalize(torch.randn(n_bd, C, generator=g), dim=-1).to(dtype)
     src = torch.randint(0, n_tx, (E,), generator=g)
     dst = torch.randint(0, n_bd, (E,), generator=g)
+    dst[dst == 7] = 8                                    # a boundary that is nobody's positive
     neg = (dst + torch.randint(1, n_bd, (E,), generator=g)) % n_bd
     a, b = z_tx.double().requires_grad_(True), z_bd.double().requires_grad_(True)
     ref = oracle.segmentation_loss(a, b, torch.stack([src, dst]), neg, "triplet", 0.4)
     (ref * 0.37).backward()
     da, db = z_tx.to(cuda).requires_grad_(True), z_bd.to(cuda).requires_grad_(True)
-    loss = ops.triplet_edge_loss(da, db, src.to(cuda), dst.to(cuda), neg.to(cuda), 0.4)
+    groups = None
+    if boundary_side == "segment_sum":          # triplets grouped by positive row (boundary 7 gets none: dst != 7 below)
+        groups = csr_from_coo(dst.to(cuda), src.to(cuda), n_bd, n_tx, validate=False)
+    loss = ops.triplet_edge_loss(da, db, src.to(cuda), dst.to(cuda), neg.to(cuda), 0.4, pos_groups=groups)
     (loss * 0.37).backward()
     assert abs(loss.item() - ref.item()) < 1e-5
     # fp32: atomics reorder fp32 sums; 16-bit: the anchor-side gradient is accumulated in the embedding dtype
