@@ -425,8 +425,9 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
 // DIRECT: every source node has at most one out-edge (segger's tx-belongs-bd: a transcript lies in at most one
 // boundary), so grad_xl[i] has a single term and this pass stores it itself -- no by-source view, no source pass.
 // The caller zero-fills grad_xl first (sources without an out-edge).
+// (the direct form keeps 8 more values per lane live: it is built for 2 waves per SIMD instead of spilling)
 template <typename T, int H, int LPH, bool WPR, bool DIRECT>
-__global__ __launch_bounds__(256, SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kernel(GatParams p) {
+__global__ __launch_bounds__(256, DIRECT ? 2 : SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kernel(GatParams p) {
   using G = Geo<H, LPH>;
   constexpr int GS = G::GS, NG = G::NG, U = SEGGER_DST_UNROLL < GS ? SEGGER_DST_UNROLL : GS, HC = G::HC;
   __shared__ float red[4][2][HC];

@@ -8,6 +8,13 @@ dev = torch.device('cuda')
 n = int(os.environ.get('N_TX', 1_000_000))
 b = make_graph(SyntheticSpec(n_tx=n, n_bd=n // 100, k_tx=15, seed=0))
 ei = b[TX_TX].edge_index.to(dev)
+mode = os.environ.get('GRAPH', 'knn')            # locality experiments: same degrees, other neighbours
+if mode == 'band':                               # neighbours = the adjacent rows: every gather hits L1 / L2
+    dst = ei[1]
+    off = torch.arange(ei.shape[1], device=dev) % 15 - 7
+    ei = torch.stack([(dst + off).clamp_(0, n - 1), dst])
+elif mode == 'random':                           # uniformly random neighbours: every gather misses
+    ei = torch.stack([torch.randint(0, n, (ei.shape[1],), device=dev), ei[1]])
 g = build_edge_graph(ei, n, n)
 if os.environ.get('ORDER', '1') == '0':          # A/B of the degree-balanced visiting order
     g.by_dst.order = g.by_src.order = None
@@ -27,4 +34,4 @@ def t(fn, it=20):
     torch.cuda.synchronize(); a = torch.cuda.Event(True); e = torch.cuda.Event(True); a.record()
     for _ in range(it): fn()
     e.record(); torch.cuda.synchronize(); return a.elapsed_time(e) / it
-print(os.path.basename(os.environ.get('SEGGER_AMD_LIB', 'default')), 'order', os.environ.get('ORDER', '1'), 'drop', p, 'fwd %.3f ms  bwd(dst+src) %.3f ms' % (t(fwd), t(bwd)), flush=True)
+print(mode, os.path.basename(os.environ.get('SEGGER_AMD_LIB', 'default')), 'order', os.environ.get('ORDER', '1'), 'drop', p, 'fwd %.3f ms  bwd(dst+src) %.3f ms' % (t(fwd), t(bwd)), flush=True)
