@@ -10,7 +10,23 @@ One step = one pass of the hot path over one synthetic tile per rank (weak
 scaling: every rank owns a tile of the same size, different seed): encoder
 forward, the three losses, backward, one flat-bucket gradient all-reduce (N>1),
 Adam.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE
-JSON line (schema: task contract + `roofline` + `cpu_baseline`).
+JSON line:
+
+  metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling ("weak") /
+  vs_baseline / dtype / data / config {workload, tiles_per_step, parallelism}      -- the task contract
+  mp_edges_per_s, loss                                                              -- message-passing edges / s
+  roofline {bound, kernel, achieved, peak, unit, frac, traffic, algorithmic_bytes_per_launch, ms_per_launch}
+  roofline_other {gatv2_bwd_tx_tx, gatv2_fwd_tx_tx_eval}                            -- the other aggregation kernels
+  predict {ms_per_batch, edges_scored_per_s}                                        -- inference on the same tile
+  f32 {ms_per_step, value}          (N = 1)  the same step at the reference's own arithmetic width (fp32 storage)
+  cpu_baseline {value, unit, cores, kind, sample, ...}   (N = 1)  the oracle on the host cores, C2/10 tile
+  strong {scaling: "strong", workload, n_gpus, world_size, n_ranks_seen, census, batches, steps_per_rank,
+          epoch_s, value, unit, mp_edges_per_s}
+      BASELINE config 4 as SURVEY.md 8(d) defines it: ONE fixed synthetic FOV (seed 0; every rank builds the same
+      one, no data-path collective) streamed as packed tile batches that `dp.rank_schedule` deals to the ranks by
+      balanced edge counts; one flat RCCL all-reduce per step; `epoch_s` = max over ranks between two barriers;
+      `value` = 2 * Etb of the whole FOV / epoch_s.  Total work is independent of N: value(N) / value(1) is the
+      strong-scaling speed-up.  `census` is an all-reduced one-hot of the ranks (all ones <=> RCCL saw N ranks).
 """
 from __future__ import annotations
 
@@ -66,9 +82,9 @@ def host_threads():
     return max(1, min(n, 16))           # the GPU box gives 16 cores per GPU
 
 
-def cpu_baseline(sample_tx=50_000, sample_bd=500, k=15, budget_s=25.0):
+def cpu_baseline(sample_tx=100_000, sample_bd=1_000, k=15, budget_s=30.0):
     """The oracle (pure-torch CPU restatement of the PyG path, fp32) timed on the
-    host cores over a bounded sample of the same workload: fwd + seg loss + bwd."""
+    host cores over a bounded sample of the same workload (C2/10): fwd + seg loss + bwd."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import segger_oracle as O
     from segger_amd.synthetic import SyntheticSpec, make_graph
@@ -91,12 +107,13 @@ def cpu_baseline(sample_tx=50_000, sample_bd=500, k=15, budget_s=25.0):
         for v in sd.values():
             v.grad = None
     t_all = time.perf_counter()
-    for w in range(2):                       # 2 warm-ups, then the median of 5
+    n_warm = 1
+    for w in range(n_warm):                  # one warm-up, then the median of up to 3 steps inside the time budget
         step()
-        log(f"[bench] cpu_baseline warm-up {w + 1}/2 done at {time.perf_counter() - t_all:.1f}s")
+        log(f"[bench] cpu_baseline warm-up {w + 1}/{n_warm} done at {time.perf_counter() - t_all:.1f}s")
     t_all = time.perf_counter()
     ts = []
-    while len(ts) < 5 and (not ts or time.perf_counter() - t_all + ts[-1] < budget_s):
+    while len(ts) < 3 and (not ts or time.perf_counter() - t_all + ts[-1] < budget_s):
         t = time.perf_counter(); step(); ts.append(time.perf_counter() - t)
         log(f"[bench] cpu_baseline step {ts[-1]:.2f}s")
     reps = len(ts)
@@ -112,8 +129,10 @@ def cpu_baseline(sample_tx=50_000, sample_bd=500, k=15, budget_s=25.0):
     return {
         "value": 2 * etb / dt, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
         "host": {"cpu": cpu_model, "os_cpu_count": os.cpu_count(), "threads_used": torch.get_num_threads()},
-        "sample": f"oracle fp32 fwd+seg-loss+bwd on a {sample_tx}-tx/{sample_bd}-bd k={k} tile "
-                  f"(Etb={etb}), median of {reps} after 2 warm-ups, {dt:.2f} s/step",
+        "sample": f"oracle fp32 fwd+seg-loss+bwd on a {sample_tx}-tx/{sample_bd}-bd k={k} tile = C2/10 "
+                  f"(Etb={etb}; the GPU step also runs loss_tx, loss_bd and Adam), median of {reps} after "
+                  f"{n_warm} warm-up, {dt:.2f} s/step",
+        "size_ratio_to_gpu_workload": sample_tx / 1_000_000,
         "mp_edges_per_s": mp_edges / dt,
     }
 
@@ -128,6 +147,12 @@ def main():
     ap.add_argument("--k", type=int, default=15)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-f32", action="store_true", help="skip the fp32 secondary line")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling (fixed FOV) record")
+    ap.add_argument("--strong-n-tx", type=int, default=50_000_000, help="transcripts of the fixed FOV (BASELINE C3/C4)")
+    ap.add_argument("--strong-n-bd", type=int, default=500_000)
+    ap.add_argument("--strong-edges-per-batch", type=int, default=1_000_000,
+                    help="segger's edges_per_batch default (data_module.py:158)")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     args = ap.parse_args()
@@ -272,6 +297,70 @@ def main():
                    "note": "predict_step incl. mask + D2H of the 4-tuple, eager (no hipGraph), same dtype"}
         log(f"[bench] predict_step {ms_pred:.2f} ms -> {ep / (ms_pred * 1e-3):.3e} tx->cell edges/s")
 
+    # ---- secondary figure: the same training step with fp32 storage (the reference's arithmetic width) ---------
+    f32 = None
+    if rank == 0 and world == 1 and not args.no_f32 and dtype != torch.float32:
+        model.model.compute_dtype = torch.float32
+        model.train(not args.no_dropout)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n32 = max(3, args.steps // 2)
+        for _ in range(n32):
+            step()
+        torch.cuda.synchronize()
+        d32 = (time.perf_counter() - t0) / n32
+        f32 = {"ms_per_step": d32 * 1e3, "value": 2.0 * etb / d32, "unit": "edges/s", "steps": n32,
+               "note": "same tile and step, activations stored in fp32 (projections on the vendor GEMM)"}
+        model.model.compute_dtype = dtype
+        log(f"[bench] f32 step {d32 * 1e3:.2f} ms")
+
+    # ---- strong scaling: ONE fixed FOV streamed as packed tile batches over all ranks (BASELINE config 4) ----
+    strong = None
+    if not args.no_strong:
+        from segger_amd.dp import seed_rank, strong_scaling_epoch
+        from segger_amd.fov import batch_weights, build_fov_batches
+        del batch, batch_cpu
+        if rank == 0:
+            del xp, out, pre, lse, gy, gxp, g_tt, fwd, bwd
+        opt.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()
+        t = time.perf_counter()
+        sspec = SyntheticSpec(n_tx=args.strong_n_tx, n_bd=args.strong_n_bd, k_tx=args.k, seed=0)
+        part, batches, saux, tiling = build_fov_batches(sspec, dev, edges_per_batch=args.strong_edges_per_batch)
+        torch.cuda.synchronize()
+        log(f"[bench r{rank}] fixed FOV: {args.strong_n_tx} tx -> {len(tiling)} tiles, {len(batches)} batches "
+            f"in {time.perf_counter() - t:.1f}s")
+        model.set_similarities(saux["tx_similarity"].to(dev), saux["bd_similarity"].to(dev))
+        model.train(not args.no_dropout)
+        seed_rank(0, rank, model.model)
+        e_tb, e_tt = part.edge_sizes[TX_BD].tolist(), part.edge_sizes[TX_TX].tolist()
+
+        def strong_step(k, i):
+            opt.zero_grad(set_to_none=True)
+            if k is not None:
+                model.training_step(part.batch(batches[k]), i).backward()
+            bucket.all_reduce_mean()
+            opt.step()
+
+        rec = strong_scaling_epoch(batch_weights(part, batches), strong_step,
+                                   lambda k: (sum(e_tb[t] for t in batches[k]), sum(e_tt[t] for t in batches[k])),
+                                   sync=torch.cuda.synchronize, device=dev, warmup=3)
+        etb_f, ett_f = rec.pop("units_total")
+        strong = dict(rec)
+        strong.update({
+            "workload": f"C4: fixed synthetic FOV (seed 0), {args.strong_n_tx} tx / {args.strong_n_bd} nuclei, k={args.k}, "
+                        f"{len(tiling)} tiles packed into {len(batches)} batches of <= {args.strong_edges_per_batch} edges, "
+                        f"one training epoch, {args.dtype}",
+            "n_gpus": world, "value": 2.0 * etb_f / rec["epoch_s"], "unit": "edges/s",
+            "mp_edges_per_s": 4.0 * (ett_f + etb_f) / rec["epoch_s"],
+            "ms_per_step": rec["epoch_s"] / max(rec["steps_per_rank"], 1) * 1e3,
+            "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30})
+        if rank == 0:
+            log(f"[bench] strong: {strong}")
+        del part, batches
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -296,6 +385,7 @@ def main():
             "mp_edges_per_s": n_layers * (ett_all + etb_all) * args.steps / dt,
             "loss": loss_val,
             "roofline": roof, "roofline_other": extra, "cpu_baseline": cpu, "predict": predict,
+            "f32": f32, "strong": strong,
         }
         print(json.dumps(res), flush=True)
     if world > 1:

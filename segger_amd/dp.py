@@ -102,3 +102,61 @@ def seed_rank(base_seed: int, rank: int, encoder=None) -> None:
     if encoder is not None and hasattr(encoder, "_step_dev"):
         with torch.no_grad():
             encoder._step_dev.fill_(int(rank) << 40)
+
+
+def rank_census(device=None, group=None) -> dict:
+    """Evidence that the collective really spans ``world_size`` distinct ranks: every rank adds a one-hot of its own
+    rank; the all-reduced vector must be all ones.  -> ``{"world_size", "n_ranks_seen", "census"}``."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return {"world_size": 1, "n_ranks_seen": 1, "census": [1]}
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    v = torch.zeros(world, dtype=torch.int32, device=device)
+    v[rank] = 1
+    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+    census = [int(x) for x in v.tolist()]
+    return {"world_size": world, "n_ranks_seen": sum(1 for c in census if c == 1), "census": census}
+
+
+def strong_scaling_epoch(batch_weights: Sequence[float], step, units=None, *, sync=None, device=None,
+                         warmup: int = 0, group=None) -> dict:
+    """One data-parallel epoch over a FIXED list of packed batches (BASELINE config 4: total work does not grow
+    with the number of ranks).  ``step(k, i)`` runs optimizer step ``i`` on batch ``k`` (``None``: this rank ran out
+    of batches -- it must still take part in the gradient all-reduce, see :func:`rank_schedule`); ``units(k)`` returns
+    the work units of batch ``k`` (a sequence of numbers, summed over all ranks); ``sync()`` drains the device.
+    The epoch is bracketed by barrier + sync on both sides and the reported time is the MAX over ranks."""
+    import time
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    sched = rank_schedule(batch_weights, world)[rank]
+    sync = sync or (lambda: None)
+    for k in sched[:warmup]:
+        step(k, 0)
+    sync()
+    if on:
+        dist.barrier(group)
+    sync()
+    t0 = time.perf_counter()
+    done = None
+    for i, k in enumerate(sched):
+        step(k, i)
+        if k is not None and units is not None:
+            u = [float(x) for x in units(k)]
+            done = u if done is None else [a + b for a, b in zip(done, u)]
+    sync()
+    if on:
+        dist.barrier(group)
+    sync()
+    dt = time.perf_counter() - t0
+    n_units = len(done) if done is not None else (len(units(0)) if (units is not None and len(batch_weights)) else 0)
+    stats = torch.tensor([dt] + (done if done is not None else [0.0] * n_units), dtype=torch.float64, device=device)
+    if on:
+        tmax = stats[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX, group=group)
+        sums = stats[1:].clone(); dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+        dt, total = float(tmax[0]), [float(x) for x in sums.tolist()]
+    else:
+        total = [float(x) for x in stats[1:].tolist()]
+    out = {"scaling": "strong", "batches": len(batch_weights), "steps_per_rank": len(sched),
+           "own_batches": sum(1 for k in sched if k is not None), "epoch_s": dt, "units_total": total}
+    out.update(rank_census(device, group))
+    return out

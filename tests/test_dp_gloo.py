@@ -128,3 +128,59 @@ def test_uneven_batch_counts_take_empty_steps_world2():
                 (lin(data[b]).sum() / 2).backward()          # mean over the world size, empty rank = zeros
         opt.step()
     assert torch.allclose(torch.tensor(w), torch.cat([p.detach().reshape(-1) for p in lin.parameters()]), atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py's strong-scaling record (BASELINE config 4) as a 2-rank gloo dry run: the schedule, the empty steps, the
+# rank census and the unit / time reductions of dp.strong_scaling_epoch, with a CPU stand-in for the training step
+def _strong_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from segger_amd.dp import FlatGradBucket, strong_scaling_epoch
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(4, 3)
+    bucket = FlatGradBucket(lin.parameters())
+    weights = [5.0, 3.0, 9.0, 1.0, 2.0]                     # 5 batches over 2 ranks: LPT -> {2, 4 | ...}: uneven counts
+    ran = []
+
+    def step(k, i):
+        lin.zero_grad(set_to_none=True)
+        if k is not None:
+            ran.append(k)
+            x = torch.full((2, 4), float(k + 1))
+            lin(x).sum().backward()
+        bucket.all_reduce_mean()                            # every rank, every step (empty steps send zeros)
+
+    rec = strong_scaling_epoch(weights, step, lambda k: (weights[k], 1.0), warmup=1)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, ran)
+    if rank == 0:
+        out.put((rec, gathered))
+    dist.destroy_process_group()
+
+
+def test_strong_scaling_epoch_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_strong_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rec, ran = q.get(timeout=180)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert rec["scaling"] == "strong" and rec["world_size"] == 2 and rec["n_ranks_seen"] == 2 and rec["census"] == [1, 1]
+    assert rec["batches"] == 5 and rec["steps_per_rank"] == 3
+    assert rec["units_total"] == [20.0, 5.0]                # every batch counted exactly once over the two ranks
+    timed = [r[1:] for r in ran]                            # the first entry of each rank is its warm-up step
+    assert sorted(k for r in timed for k in r) == [0, 1, 2, 3, 4]
+    assert abs(sum([5, 3, 9, 1, 2][k] for k in timed[0]) - sum([5, 3, 9, 1, 2][k] for k in timed[1])) <= 2   # balanced
+    assert rec["epoch_s"] > 0
+
+
+def test_strong_scaling_epoch_single_process():
+    from segger_amd.dp import strong_scaling_epoch
+    seen = []
+    rec = strong_scaling_epoch([2.0, 1.0, 4.0], lambda k, i: seen.append(k), lambda k: (1.0,))
+    assert seen == [2, 0, 1] and rec["units_total"] == [3.0] and rec["n_ranks_seen"] == 1 and rec["steps_per_rank"] == 3
