@@ -289,6 +289,24 @@ typedef struct segger_triplet_args {
                                 rows: a boundary's ~40 edges sit next to each other and hammer one row.) */
 } segger_triplet_args;
 
+/*
+ * segger_triplet_sample: FastTripletSelector.sample_triplets (src/segger/models/triplet_loss.py:83-125) for all
+ * nodes in one launch: per node i with cluster r = lab[i], draw the positive cluster from row r of cdf_pos and the
+ * negative cluster from row r of cdf_neg (first column whose cumulative probability >= u, as torch.searchsorted),
+ * then the member  members[offsets[c] + floor(u' * counts[c])]  of the drawn cluster c.
+ *   lab      [n] int64 cluster id per node; ids >= n_clusters (the "masked out" cluster) get pos = neg = -1
+ *   cdf_pos / cdf_neg [n_clusters, n_clusters] fp32 row-wise cumulative distributions
+ *   counts / offsets  [n_clusters (+1)] int64, members [n] int64 (nodes grouped by cluster)
+ *   uniforms [4, n] fp32 (cluster+, member+, cluster-, member-) or NULL: then U[0,1) comes from a counter-based
+ *            generator keyed by (seed + *seed_dev, node, draw) -- same construction as the dropout stream
+ *   dists    [n_clusters, n_clusters] fp32 or NULL; when given d_pos / d_neg [n] receive dists[r, cluster of pick]
+ */
+int segger_triplet_sample(const int64_t* lab, int64_t n, int32_t n_clusters, const float* cdf_pos, const float* cdf_neg,
+                          const int64_t* counts, const int64_t* offsets, const int64_t* members,
+                          const float* uniforms, uint64_t seed, const uint64_t* seed_dev,
+                          const float* dists, int64_t* pos, int64_t* neg, float* d_pos, float* d_neg,
+                          segger_stream_t stream);
+
 size_t segger_triplet_workspace_bytes(int64_t n_edges);
 int segger_triplet_fwd(const segger_triplet_args* args, segger_stream_t stream);
 int segger_triplet_bwd(const segger_triplet_args* args, segger_stream_t stream);

@@ -109,6 +109,7 @@ EXPORTS = {
     "segger_gatv2_has_specialised": (C.c_int, [C.c_int32, C.c_int32]),
     "segger_coo_unique": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
     "segger_edge_cos_argmax": (C.c_int, [C.POINTER(EdgeArgmaxArgs), vp]),
+    "segger_triplet_sample": (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]),
     "segger_triplet_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "segger_triplet_fwd": (C.c_int, [C.POINTER(TripletArgs), vp]),
     "segger_triplet_bwd": (C.c_int, [C.POINTER(TripletArgs), vp]),
@@ -170,6 +171,26 @@ def check(rc: int, what: str) -> None:
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device):
+    """``torch.cuda.device(device)`` only when it is not the current device already (the context manager costs
+    ~10 us per launch; one process drives one GPU, so this is the common case)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
 
 
 def stream_ptr(device) -> int:

@@ -420,6 +420,59 @@ __global__ __launch_bounds__(256) void triplet_finish_kernel(const float* __rest
   if (threadIdx.x == 0) loss[0] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_n;
 }
 
+// ---- cluster-aware triplet sampling (loss_tx / loss_bd), one thread per node -----------------------------------
+struct SampleParams {
+  const int64_t* lab; int64_t n; int n_clusters;
+  const float* cdf_pos; const float* cdf_neg;
+  const int64_t* counts; const int64_t* offsets; const int64_t* members;
+  const float* uniforms; uint32_t seed_lo, seed_hi; uint64_t seed_raw; const uint64_t* seed_dev;
+  const float* dists; int64_t* pos; int64_t* neg; float* d_pos; float* d_neg;
+};
+
+__device__ __forceinline__ float uniform01(uint32_t node, uint32_t draw, uint32_t lo, uint32_t hi) {
+  uint32_t x = (node * 4u + draw) ^ lo;
+  x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16; x ^= hi;
+  x *= 0x9e3779b1u; x ^= x >> 15;
+  return (float)(x >> 8) * (1.0f / 16777216.0f);          // 24 bits: [0, 1)
+}
+
+__global__ __launch_bounds__(256) void triplet_sample_kernel(SampleParams p) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  const int K = p.n_clusters;
+  const int64_t r = p.lab[i];
+  if (r < 0 || r >= K) {                                   // masked-out node: no triplet
+    p.pos[i] = -1; p.neg[i] = -1;
+    if (p.d_pos) { p.d_pos[i] = 0.f; p.d_neg[i] = 0.f; }
+    return;
+  }
+  uint32_t lo = p.seed_lo, hi = p.seed_hi;
+  if (!p.uniforms && p.seed_dev) {
+    const uint64_t mixed = splitmix64(p.seed_raw + *p.seed_dev);
+    lo = (uint32_t)mixed; hi = (uint32_t)(mixed >> 32);
+  }
+  float u[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) u[d] = p.uniforms ? p.uniforms[(int64_t)d * p.n + i] : uniform01((uint32_t)i, d, lo, hi);
+  int64_t pick[2];
+  int cl[2];
+#pragma unroll
+  for (int side = 0; side < 2; ++side) {
+    const float* row = (side == 0 ? p.cdf_pos : p.cdf_neg) + r * K;
+    int c = 0;
+    while (c < K - 1 && row[c] < u[2 * side]) ++c;         // first column with cdf >= u (searchsorted, left)
+    const int64_t cnt = p.counts[c];
+    int64_t w = (int64_t)floorf(u[2 * side + 1] * (float)cnt);
+    int64_t slot = p.offsets[c] + w;
+    if (slot >= p.n) slot = p.n - 1;
+    if (slot < 0) slot = 0;
+    pick[side] = p.members[slot];
+    cl[side] = c;
+  }
+  p.pos[i] = pick[0]; p.neg[i] = pick[1];
+  if (p.d_pos) { p.d_pos[i] = p.dists[r * K + cl[0]]; p.d_neg[i] = p.dists[r * K + cl[1]]; }
+}
+
 int64_t triplet_blocks(int64_t n_edges) { return (n_edges + kTripletEdgesPerBlock - 1) / kTripletEdgesPerBlock; }
 
 }  // namespace
@@ -530,4 +583,22 @@ extern "C" int segger_triplet_fwd(const segger_triplet_args* a, segger_stream_t 
 }
 extern "C" int segger_triplet_bwd(const segger_triplet_args* a, segger_stream_t stream) {
   return triplet_common(a, true, (hipStream_t)stream);
+}
+
+extern "C" int segger_triplet_sample(const int64_t* lab, int64_t n, int32_t n_clusters, const float* cdf_pos,
+                                     const float* cdf_neg, const int64_t* counts, const int64_t* offsets,
+                                     const int64_t* members, const float* uniforms, uint64_t seed, const uint64_t* seed_dev,
+                                     const float* dists, int64_t* pos, int64_t* neg, float* d_pos, float* d_neg,
+                                     segger_stream_t stream) {
+  SEGGER_REQUIRE(n >= 0 && n_clusters > 0, "segger_triplet_sample: bad sizes");
+  if (n == 0) return SEGGER_OK;
+  SEGGER_REQUIRE(lab && cdf_pos && cdf_neg && counts && offsets && members && pos && neg,
+                 "segger_triplet_sample: NULL pointer");
+  SEGGER_REQUIRE(!dists == !d_pos && !d_pos == !d_neg, "segger_triplet_sample: dists, d_pos and d_neg go together");
+  const uint64_t mixed = splitmix64(seed);
+  SampleParams p{lab, n, n_clusters, cdf_pos, cdf_neg, counts, offsets, members, uniforms,
+                 (uint32_t)mixed, (uint32_t)(mixed >> 32), seed, seed_dev, dists, pos, neg, d_pos, d_neg};
+  hipLaunchKernelGGL(triplet_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  SEGGER_LAUNCH_CHECK("triplet_sample_kernel");
+  return SEGGER_OK;
 }

@@ -55,7 +55,7 @@ class EdgeCSR:
         if (window > 0 and self.order is None and self.n_rows > 0
                 and self.n_edges < WAVE_PER_ROW_DEGREE * self.n_rows):
             order = torch.empty(self.n_rows, dtype=torch.int32, device=self.indptr.device)
-            with torch.cuda.device(order.device):
+            with _lib.on_device(order.device):
                 rc = _lib.load().segger_csr_row_order(self.indptr.data_ptr(), self.n_rows, window, order.data_ptr(),
                                                       _lib.stream_ptr(order.device))
             _lib.check(rc, "segger_csr_row_order")
@@ -125,14 +125,14 @@ def csr_from_coo(row: Tensor, col: Tensor, n_rows: int, n_cols: int, validate=Tr
     bad = torch.zeros(1, dtype=torch.int32, device=dev) if validate else None
     ws_bytes = lib.segger_csr_from_coo_workspace_bytes(E, n_rows)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.segger_csr_from_coo(row.data_ptr(), col.data_ptr(), E, n_rows, n_cols,
                                      indptr.data_ptr(), ccol.data_ptr(), eid.data_ptr(), _lib.ptr(bad),
                                      ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
     _lib.check(rc, "segger_csr_from_coo")
     msg = f"edge_index holds {{n}} edge(s) with node ids outside [0,{n_rows}) x [0,{n_cols})"
     if validate == "deferred":
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _defer_validation(bad, msg)
     elif validate:
         n_bad = int(bad.item())          # one host sync per edge type per batch
@@ -219,7 +219,7 @@ def sources_unique(src: Tensor, n_src: int) -> Tensor:
     src = src.to(torch.int64).contiguous()
     marks = torch.empty(max(n_src, 1), dtype=torch.int32, device=dev)
     out = torch.empty(1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.segger_coo_unique(src.data_ptr(), int(src.numel()), int(n_src), marks.data_ptr(), out.data_ptr(),
                                    _lib.stream_ptr(dev))
     _lib.check(rc, "segger_coo_unique")
@@ -232,7 +232,7 @@ def build_edge_graph(edge_index: Tensor, n_src: int, n_dst: int, *, need_by_dst:
     src, dst = edge_index[0], edge_index[1]
     by_dst = csr_from_coo(dst, src, n_dst, n_src, validate).balanced_order() if need_by_dst else None
     if need_by_src == "lazy":
-        with torch.cuda.device(edge_index.device):
+        with _lib.on_device(edge_index.device):
             flag = DeferredFlag(sources_unique(src, n_src))
         return EdgeGraph(by_dst, None, n_src, n_dst, int(edge_index.shape[1]), edge_index, flag)
     # both views hold the same edges: one check is enough

@@ -187,7 +187,7 @@ class LitISTEncoder(_Base):
         tx_mask = batch['tx']['mask']
         bd_mask = batch['bd']['mask'] & (batch['bd']['cluster'] >= 0)
         loss_tx = self.loss_tx.forward_masked(embeddings['tx'], batch['tx']['cluster'], tx_mask, batch_cache(batch))
-        loss_bd = self.loss_bd.forward(embeddings['bd'][bd_mask], batch['bd']['cluster'][bd_mask])
+        loss_bd = self.loss_bd.forward_masked(embeddings['bd'], batch['bd']['cluster'], bd_mask, cache=batch_cache(batch))
         loss_sg = self._segmentation_loss(embeddings, batch, dst_neg)
         w_tx, w_bd, w_sg = (float(v) for v in self._scheduled_weights(self._w_start, self._w_end))
         loss = w_tx * loss_tx + w_bd * loss_bd + w_sg * loss_sg

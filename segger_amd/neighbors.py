@@ -48,7 +48,7 @@ def knn_grid(points: Tensor, k: int, max_dist: float = math.inf, query: Optional
     nx, ny = int(w / cell) + 1, int(h / cell) + 1
     ws_bytes = lib.segger_knn_workspace_bytes(n, nx, ny)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.segger_knn_grid(pts.data_ptr(), n, None if query is None else q.data_ptr(), m, k, float(max_dist),
                                  x0, y0, cell, nx, ny, nbr.data_ptr(), _lib.ptr(dist), ws.data_ptr(), ws_bytes,
                                  _lib.stream_ptr(dev))

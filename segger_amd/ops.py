@@ -76,7 +76,7 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
     if pre is not None:
         a.pre, a.ld_pre = _rows(pre, hc, "pre")
     a.lse, a.alpha = _lib.ptr(lse), _lib.ptr(alpha)
-    with torch.cuda.device(xl.device):
+    with _lib.on_device(xl.device):
         rc = lib.segger_gatv2_fwd(C.byref(a), _lib.stream_ptr(xl.device))
     _lib.check(rc, "segger_gatv2_fwd")
 
@@ -122,7 +122,7 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
     ws_bytes = lib.segger_gatv2_bwd_workspace_bytes(n_dst, heads, channels)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.segger_gatv2_bwd(C.byref(a), _lib.stream_ptr(dev))
     _lib.check(rc, "segger_gatv2_bwd")
     return gparams[0], gparams[1]
@@ -275,7 +275,7 @@ def edge_cos_argmax(by_src: EdgeCSR, z_src: Tensor, z_dst: Tensor, *, dst_index:
     seg = torch.empty(n, dtype=torch.int64, device=dev)
     sim = torch.empty(by_src.n_edges, dtype=torch.float32, device=dev) if return_sim else None
     a.max_sim, a.max_eid, a.seg_idx, a.sim = max_sim.data_ptr(), max_eid.data_ptr(), seg.data_ptr(), _lib.ptr(sim)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.segger_edge_cos_argmax(C.byref(a), _lib.stream_ptr(dev))
     _lib.check(rc, "segger_edge_cos_argmax")
     return max_sim, max_eid, seg, sim
@@ -317,7 +317,7 @@ class _TripletEdgeLoss(torch.autograd.Function):
         ws_bytes = lib.segger_triplet_workspace_bytes(a.n_edges)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         a.loss, a.workspace, a.workspace_bytes = loss.data_ptr(), ws.data_ptr(), ws_bytes
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = lib.segger_triplet_fwd(C.byref(a), _lib.stream_ptr(dev))
         _lib.check(rc, "segger_triplet_fwd")
         ctx.save_for_backward(za, zb_, src, pos, neg)
@@ -356,7 +356,7 @@ class _TripletEdgeLoss(torch.autograd.Function):
             a.grad_b = gb.data_ptr()
         gs = g.detach().to(torch.float32).reshape(1).contiguous()   # upstream scalar stays on the device
         a.grad_scale, a.grad_scale_dev = 1.0, gs.data_ptr()
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = lib.segger_triplet_bwd(C.byref(a), _lib.stream_ptr(dev))
         _lib.check(rc, "segger_triplet_bwd")
         return ga.to(za.dtype), (None if same else gb.to(zb.dtype)), None, None, None, None, None, None
@@ -373,6 +373,35 @@ def triplet_edge_loss(za: Tensor, zb: Optional[Tensor], src: Tensor, pos: Tensor
     if pos_groups is not None and (zb is None or pos_groups.n_rows != zb.shape[0] or pos_groups.n_edges != src.numel()):
         raise ValueError("triplet_edge_loss: pos_groups does not describe these triplets")
     return _TripletEdgeLoss.apply(za, zb, src, pos, neg, float(margin), float(eps), pos_groups)
+
+
+@torch.no_grad()
+def triplet_sample(index: dict, uniforms=None):
+    """``FastTripletSelector.sample_triplets`` in one launch (``segger_triplet_sample``) from the selector's index
+    (``triplet_loss.FastTripletSelector.build_index``).  ``uniforms``: four [n] tensors, or None for the kernel's own
+    counter-based U[0,1) stream, seeded from torch's CPU generator (so ``torch.manual_seed`` still fixes a run)."""
+    lab = index["lab"]
+    _lib.require_cuda(lab)
+    lib = _lib.load()
+    dev = lab.device
+    n = int(lab.numel())
+    u = None
+    seed = 0
+    if uniforms is not None:
+        u = torch.stack([t.to(device=dev, dtype=torch.float32) for t in uniforms]).contiguous()
+    else:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # CPU generator: no kernel, no sync
+    pos = torch.empty(n, dtype=torch.int64, device=dev)
+    neg = torch.empty(n, dtype=torch.int64, device=dev)
+    dd = torch.empty((2, n), dtype=torch.float32, device=dev)
+    with _lib.on_device(dev):
+        rc = lib.segger_triplet_sample(lab.data_ptr(), n, int(index["n_clusters"]), index["cdf_pos_t"].data_ptr(),
+                                       index["cdf_neg_t"].data_ptr(), index["counts"].data_ptr(),
+                                       index["offsets"].data_ptr(), index["members"].data_ptr(), _lib.ptr(u), seed, None,
+                                       index["dists"].data_ptr(), pos.data_ptr(), neg.data_ptr(), dd[0].data_ptr(),
+                                       dd[1].data_ptr(), _lib.stream_ptr(dev))
+    _lib.check(rc, "segger_triplet_sample")
+    return pos, neg, dd[0], dd[1]
 
 
 # --------------------------------------------------------------------------
@@ -393,7 +422,7 @@ def segment_minmax(pos: Tensor, batch: Optional[Tensor], num_graphs: int) -> Tup
             raise ValueError("segment_minmax: batch / pos length mismatch")
     mins = torch.empty((num_graphs, 2), dtype=torch.float32, device=dev)
     maxs = torch.empty((num_graphs, 2), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.segger_segment_minmax(pos.data_ptr(), _lib.ptr(batch), int(pos.shape[0]), int(num_graphs),
                                        mins.data_ptr(), maxs.data_ptr(), _lib.stream_ptr(dev))
     _lib.check(rc, "segger_segment_minmax")
@@ -420,7 +449,7 @@ def linear_fwd_launch(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Optiona
     y = out if out is not None else torch.empty((n, m), dtype=x.dtype, device=x.device)
     yp, ldy = _rows(y, m, "y")
     b = _f32_vec(bias, m, "bias")
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = lib.segger_linear_fwd(xp, ldx, w.data_ptr(), _lib.ptr(b), yp, ldy, n, k, m, DTYPE_CODE[x.dtype],
                                    _lib.stream_ptr(x.device))
     _lib.check(rc, "segger_linear_fwd")
@@ -438,7 +467,7 @@ def colsum(x: Tensor) -> Tensor:
     out = torch.empty(cols, dtype=torch.float32, device=x.device)
     ws_bytes = lib.segger_colsum_workspace_bytes(n, cols)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = lib.segger_colsum(xp, ld, n, cols, DTYPE_CODE[x.dtype], out.data_ptr(), ws.data_ptr(), ws_bytes,
                                _lib.stream_ptr(x.device))
     _lib.check(rc, "segger_colsum")
@@ -455,7 +484,7 @@ def segment_rowsum(x: Tensor, by_id: EdgeCSR) -> Tensor:
     out = torch.empty((n_seg, d), dtype=torch.float32, device=x.device)
     ws_bytes = lib.segger_segment_rowsum_workspace_bytes(n, n_seg, d)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = lib.segger_segment_rowsum(xp, ld, n, d, DTYPE_CODE[x.dtype], by_id.indptr.data_ptr(),
                                        by_id.col.data_ptr() if n else None, n_seg, out.data_ptr(), ws.data_ptr(),
                                        ws_bytes, _lib.stream_ptr(x.device))
@@ -483,7 +512,7 @@ def linear_wgrad_launch(gy: Tensor, x: Tensor, want_bias: bool = True) -> Tuple[
     gb = torch.empty(m, dtype=torch.float32, device=x.device) if want_bias else None
     ws_bytes = lib.segger_linear_wgrad_workspace_bytes(n, m, k)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = lib.segger_linear_wgrad(gp, ldg, xp, ldx, n, m, k, DTYPE_CODE[x.dtype], gw.data_ptr(), _lib.ptr(gb),
                                      ws.data_ptr(), ws_bytes, _lib.stream_ptr(x.device))
     _lib.check(rc, "segger_linear_wgrad")
@@ -642,7 +671,7 @@ def posfreq(pos: Tensor, batch: Optional[Tensor], mins: Tensor, maxs: Tensor, fr
     if batch is not None:
         batch = batch.to(device=dev, dtype=torch.int64).contiguous()
     out = torch.empty((n, 2, freq_dim), dtype=dtype, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = lib.segger_posfreq(pos.data_ptr(), _lib.ptr(batch), mins.data_ptr(), maxs.data_ptr(), n, freq_dim,
                                 eps, max_period, out.data_ptr(), DTYPE_CODE[dtype], _lib.stream_ptr(dev))
     _lib.check(rc, "segger_posfreq")
@@ -660,7 +689,7 @@ class _EmbedGelu(torch.autograd.Function):
         g = table.shape[0]
         out = torch.empty((n, 2 * d), dtype=pe.dtype, device=pe.device)
         pp, ldp = _rows(pe, d, "pe")
-        with torch.cuda.device(pe.device):
+        with _lib.on_device(pe.device):
             rc = lib.segger_embed_gelu_fwd(table.data_ptr(), ids.data_ptr(), pp, ldp, n, g, d, out.data_ptr(), 2 * d,
                                            DTYPE_CODE[pe.dtype], _lib.stream_ptr(pe.device))
         _lib.check(rc, "segger_embed_gelu_fwd")
@@ -689,7 +718,7 @@ class _EmbedGelu(torch.autograd.Function):
         by_gene = ctx.by_gene
         if want_table and by_gene is None:
             by_gene = rows_by_id(ids, g)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = lib.segger_embed_gelu_bwd(gp, ldg, table.data_ptr(), pp, ldp, n, g, d, gpe.data_ptr(), d, _lib.ptr(gtable),
                                            by_gene.indptr.data_ptr() if want_table else None,
                                            (by_gene.col.data_ptr() if n else None) if want_table else None,
@@ -723,7 +752,7 @@ class _L2Norm(torch.autograd.Function):
         n, c = y.shape
         z = torch.empty((n, c), dtype=y.dtype, device=y.device)
         yp, ldy = _rows(y, c, "y")
-        with torch.cuda.device(y.device):
+        with _lib.on_device(y.device):
             rc = lib.segger_l2norm_fwd(yp, ldy, n, c, eps, z.data_ptr(), c, DTYPE_CODE[y.dtype], _lib.stream_ptr(y.device))
         _lib.check(rc, "segger_l2norm_fwd")
         ctx.save_for_backward(y)
@@ -742,7 +771,7 @@ class _L2Norm(torch.autograd.Function):
         gy = torch.empty((n, c), dtype=y.dtype, device=y.device)
         yp, ldy = _rows(y, c, "y")
         gp, ldg = _rows(gz, c, "gz")
-        with torch.cuda.device(y.device):
+        with _lib.on_device(y.device):
             rc = lib.segger_l2norm_bwd(yp, ldy, gp, ldg, n, c, ctx.eps, gy.data_ptr(), c, DTYPE_CODE[y.dtype],
                                        _lib.stream_ptr(y.device))
         _lib.check(rc, "segger_l2norm_bwd")

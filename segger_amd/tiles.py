@@ -146,6 +146,30 @@ class TilePartition:
     def __len__(self) -> int:
         return self.num_tiles
 
+    # ---- helpers that keep batch assembly free of host <-> device synchronisation ------------------------
+    def _zeros(self, nt: str, n: int) -> Tensor:
+        """``batch`` vector of a single-tile batch: a view of one persistent zero vector."""
+        z = self.__dict__.setdefault("_zero_vec", {}).get(nt)
+        if z is None or z.numel() < n:
+            z = torch.zeros(max(n, int(max(self._nptr[nt][i + 1] - self._nptr[nt][i] for i in range(self.num_tiles)))),
+                            dtype=torch.long, device=self.node_perm[nt].device)
+            self._zero_vec[nt] = z
+        return z[:n]
+
+    def _tile_shift(self, et: EdgeType) -> Tensor:
+        c = self.__dict__.setdefault("_shift_cache", {})
+        if et not in c:
+            s, _, d = et
+            c[et] = torch.stack([self.node_indptr[s][:-1], self.node_indptr[d][:-1]]).to(self.data[et].edge_index.dtype)
+        return c[et]
+
+    @staticmethod
+    def _h2d(values: List[int], device) -> Tensor:
+        """A small int64 list on the device through pinned memory (a pageable copy stalls the host on the stream)."""
+        if torch.device(device).type != "cuda":
+            return torch.tensor(values, dtype=torch.long, device=device)
+        return torch.tensor(values, dtype=torch.long).pin_memory().to(device, non_blocking=True)
+
     # ---- sorted edge views, once per slide ----------------------------------------------------------
     def build_csr(self, edge_types: Optional[Sequence[EdgeType]] = None) -> None:
         """Sort every edge store ONCE for the whole slide (``segger_csr_from_coo``: by destination and by source)
@@ -206,7 +230,7 @@ class TilePartition:
             else:                                            # one H2D copy of all per-tile offsets
                 r_sizes = [nptr[t + 1] - nptr[t] for t in tile_ids]
                 k = len(tile_ids)
-                meta = torch.tensor(e_sizes + e_base + r_sizes + list(base[col_t]), device=dev, dtype=torch.long)
+                meta = self._h2d(e_sizes + e_base + r_sizes + list(base[col_t]), dev)
                 es, eb, rs, cb = meta[:k], meta[k:2 * k], meta[2 * k:3 * k], meta[3 * k:]
                 e_off = torch.repeat_interleave(eb, es, output_size=n_edges)
                 ptr = (torch.cat([v["ptr"][nptr[t]:nptr[t + 1]] for t in tile_ids])
@@ -240,6 +264,7 @@ class TilePartition:
                 raise IndexError(f"Index {t} is out of range for dataset with {self.num_tiles} partitions.")
         out = HeteroBatch(num_graphs=len(tile_ids))
         base: Dict[str, List[int]] = {}
+        single = len(tile_ids) == 1
         for nt, store in self.data._nodes.items():
             ptr = self._nptr[nt]
             dev = self.node_perm[nt].device
@@ -251,25 +276,41 @@ class TilePartition:
             base[nt] = offs
             for a, v in store.items():
                 if isinstance(v, Tensor):
-                    out[nt][a] = torch.cat([v[ptr[t]:ptr[t + 1]] for t in tile_ids], 0) if tile_ids else v[:0]
+                    if single:                               # a tile is a contiguous slice: a view, no copy
+                        out[nt][a] = v[ptr[tile_ids[0]]:ptr[tile_ids[0] + 1]]
+                    else:
+                        out[nt][a] = torch.cat([v[ptr[t]:ptr[t + 1]] for t in tile_ids], 0) if tile_ids else v[:0]
                 else:
                     out[nt][a] = v
-            out[nt]["batch"] = torch.repeat_interleave(
-                torch.arange(len(tile_ids), device=dev), torch.tensor(sizes, device=dev, dtype=torch.long))
+            if single:
+                out[nt]["batch"] = self._zeros(nt, run)
+            else:                                            # output_size: no device -> host sync for the length
+                out[nt]["batch"] = torch.repeat_interleave(
+                    torch.arange(len(tile_ids), device=dev), self._h2d(sizes, dev), output_size=run)
         for et, store in self.data._edges.items():
             s, _, d = et
             ptr = self._eptr[et]
             ei = store["edge_index"]
-            parts = []
-            for k, t in enumerate(tile_ids):
-                e = ei[:, ptr[t]:ptr[t + 1]]
-                shift = torch.tensor([[base[s][k] - self._nptr[s][t]], [base[d][k] - self._nptr[d][t]]],
-                                     device=ei.device, dtype=ei.dtype)
-                parts.append(e + shift)
-            out[et]["edge_index"] = torch.cat(parts, 1) if parts else ei[:, :0]
+            shifts = self._tile_shift(et)                    # [2, num_tiles]: first node of every tile, per end
+            if single:
+                t = tile_ids[0]
+                out[et]["edge_index"] = ei[:, ptr[t]:ptr[t + 1]] - shifts[:, t:t + 1]
+            elif tile_ids:
+                e_sizes = [ptr[t + 1] - ptr[t] for t in tile_ids]
+                n_e = sum(e_sizes)
+                meta = self._h2d(list(tile_ids) + e_sizes + base[s] + base[d], ei.device)
+                k = len(tile_ids)
+                tid, es = meta[:k], meta[k:2 * k]
+                shift = torch.stack([meta[2 * k:3 * k], meta[3 * k:]]) - shifts[:, tid]      # [2, k]
+                per_edge = torch.repeat_interleave(shift, es, dim=1, output_size=n_e)
+                out[et]["edge_index"] = torch.cat([ei[:, ptr[t]:ptr[t + 1]] for t in tile_ids], 1) + per_edge
+            else:
+                out[et]["edge_index"] = ei[:, :0]
+        from .graph import batch_cache
+        # what never changes for this set of tiles (labels, masks -> the loss samplers' indices) survives the batch object
+        batch_cache(out)["persistent"] = self.__dict__.setdefault("_persist", {}).setdefault(tuple(tile_ids), {})
         if getattr(self, "_csr", None) and tile_ids:
             # graph.edge_graph() asks this factory before it sorts a batch's edge store itself
-            from .graph import batch_cache
             n_nodes = {nt: out[nt].num_nodes for nt in self.data._nodes}
             ids = list(tile_ids)
             mine = {et: (out[et]["edge_index"].data_ptr(), int(out[et]["edge_index"].shape[1])) for et in self._csr}

@@ -142,7 +142,7 @@ def test_reference_triplet_vectors_on_device(cuda):
     # ... and through the module, with torch's device RNG replaced by the reference's draws
     tl = TripletLoss(sim.to(cuda), margin=float(z["margin"]))
     ml = MetricLoss(sim.to(cuda))
-    tl.selector.build_index = ml.selector.build_index = lambda labels_: index
+    tl.selector.build_index = ml.selector.build_index = lambda labels_, mask_=None: index
     assert abs(float(tl.forward(e, labels.to(cuda), uniforms=ud)) - float(z["triplet_loss"])) < 1e-6
     mask = torch.ones(n, dtype=torch.bool, device=cuda)
     assert abs(float(tl.forward_masked(e, labels.to(cuda), mask, {}, uniforms=ud)) - float(z["triplet_loss"])) < 1e-6

@@ -86,28 +86,50 @@ def test_triplet_edge_loss(oracle, cuda, dtype, C, boundary_side, monkeypatch):
     assert torch.allclose(db.grad.cpu().double(), b.grad, rtol=rtol, atol=atol)
 
 
-def test_masked_tx_triplet_loss_equals_gathered_form(cuda):
-    """loss_tx through the fused kernel (anchors / positives / negatives index one matrix) equals
-    TripletLoss.forward on the gathered embeddings, values and gradients."""
-    from segger_amd.triplet_loss import TripletLoss
+def test_masked_losses_equal_the_gathered_form(cuda):
+    """loss_tx / loss_bd under a mask (no compaction, no host sync: the selector works under the mask, the fused
+    triplet kernel skips the unmasked anchors) equal TripletLoss / MetricLoss on ``embeddings[mask], labels[mask]`` --
+    the reference's call (lightning_model.py:158-165) -- for the same per-node uniform draws: same triplets, same
+    values, same gradients."""
+    from segger_amd.triplet_loss import MetricLoss, TripletLoss
     g = torch.Generator().manual_seed(9)
     n, c, k = 5000, 64, 6
     a = torch.randn(k, 4, generator=g); a = a / a.norm(dim=1, keepdim=True)
     sim = a @ a.t()
     z = torch.nn.functional.normalize(torch.randn(n, c, generator=g), dim=-1)
     labels = torch.randint(0, k, (n,), generator=g)
-    mask = torch.rand(n, generator=g) < 0.8
+    labels[labels == 2] = 3                                   # an absent cluster
+    mask = (torch.rand(n, generator=g) < 0.8).to(cuda)
+    u = tuple(torch.rand(n, generator=g).to(cuda) for _ in range(4))
+    um = tuple(t[mask] for t in u)
+    lab = labels.to(cuda)
+    idx = mask.nonzero().squeeze(1)
     loss_fn = TripletLoss(sim, margin=0.3)
+    # the triplets themselves: masked selection == selection on the compacted arrays, mapped back
+    pos_m, neg_m, dp_m, dn_m = loss_fn.selector.sample_triplets(lab, u, mask=mask)
+    pos_c, neg_c, dp_c, dn_c = loss_fn.selector.sample_triplets(lab[mask], um)
+    assert torch.equal(pos_m[mask], idx[pos_c]) and torch.equal(neg_m[mask], idx[neg_c])
+    assert bool((pos_m[~mask] == -1).all()) and torch.equal(dp_m[mask], dp_c) and torch.equal(dn_m[mask], dn_c)
     zd = z.to(cuda).requires_grad_(True)
-    torch.manual_seed(77)
-    l1 = loss_fn.forward_masked(zd, labels.to(cuda), mask.to(cuda))
+    l1 = loss_fn.forward_masked(zd, lab, mask, uniforms=u)
     (l1 * 0.5).backward()
     zr = z.to(cuda).requires_grad_(True)
-    torch.manual_seed(77)
-    l2 = loss_fn.forward(zr[mask.to(cuda)], labels.to(cuda)[mask.to(cuda)])
+    l2 = loss_fn.forward(zr[mask], lab[mask], uniforms=um)
     (l2 * 0.5).backward()
     assert abs(l1.item() - l2.item()) < 1e-6
     assert torch.allclose(zd.grad, zr.grad, atol=1e-7, rtol=1e-4)
+    ml = MetricLoss(sim)
+    z1, z2 = z.to(cuda).requires_grad_(True), z.to(cuda).requires_grad_(True)
+    m1 = ml.forward_masked(z1, lab, mask, uniforms=u)
+    m2 = ml.forward(z2[mask], lab[mask], uniforms=um)
+    m1.backward(); m2.backward()
+    assert abs(m1.item() - m2.item()) < 1e-6 and torch.allclose(z1.grad, z2.grad, atol=1e-7, rtol=1e-4)
+    # an empty mask: zero loss, zero gradient, no NaN
+    none = torch.zeros_like(mask)
+    z3 = z.to(cuda).requires_grad_(True)
+    l3 = loss_fn.forward_masked(z3, lab, none) + ml.forward_masked(z3, lab, none)
+    l3.backward()
+    assert l3.item() == 0.0 and not z3.grad.any()
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
