@@ -177,17 +177,23 @@ class LitISTEncoder(_Base):
         labels = torch.cat([torch.ones(n, device=logits.device), torch.zeros(n, device=logits.device)])
         return BCEWithLogitsLoss()(logits, labels)
 
-    def get_losses(self, batch, dst_neg: Optional[Tensor] = None, embeddings: Optional[dict] = None):
+    def get_losses(self, batch, dst_neg: Optional[Tensor] = None, embeddings: Optional[dict] = None,
+                   uniforms: Optional[tuple] = None):
         """(loss_tx, loss_bd, loss_sg, loss), lightning_model.py:151-213.  ``embeddings`` lets a caller supply
-        the encoder output it already has (e.g. from a hipGraph replay, ``train_graph.GraphedEncoder``)."""
+        the encoder output it already has (e.g. from a hipGraph replay, ``train_graph.GraphedEncoder``);
+        ``dst_neg`` / ``uniforms`` = (per-transcript, per-boundary) selector draws replace the random numbers
+        (replaying recorded vectors)."""
         if self.loss_tx is None or self.loss_bd is None:
             raise RuntimeError("call setup() (or set_similarities) before computing losses")
         if embeddings is None:
             embeddings = self.forward(batch)
         tx_mask = batch['tx']['mask']
         bd_mask = batch['bd']['mask'] & (batch['bd']['cluster'] >= 0)
-        loss_tx = self.loss_tx.forward_masked(embeddings['tx'], batch['tx']['cluster'], tx_mask, batch_cache(batch))
-        loss_bd = self.loss_bd.forward_masked(embeddings['bd'], batch['bd']['cluster'], bd_mask, cache=batch_cache(batch))
+        u_tx, u_bd = uniforms if uniforms is not None else (None, None)
+        loss_tx = self.loss_tx.forward_masked(embeddings['tx'], batch['tx']['cluster'], tx_mask, batch_cache(batch),
+                                              uniforms=u_tx)
+        loss_bd = self.loss_bd.forward_masked(embeddings['bd'], batch['bd']['cluster'], bd_mask, uniforms=u_bd,
+                                              cache=batch_cache(batch))
         loss_sg = self._segmentation_loss(embeddings, batch, dst_neg)
         w_tx, w_bd, w_sg = (float(v) for v in self._scheduled_weights(self._w_start, self._w_end))
         loss = w_tx * loss_tx + w_bd * loss_bd + w_sg * loss_sg

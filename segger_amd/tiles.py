@@ -394,8 +394,8 @@ def harmonic_k(items: Sequence[float], bin_capacity: float, k: int = 6, skip_too
 
 def first_fit_decreasing_bucketed(items: Sequence[float], bin_capacity: float, skip_too_big: bool = False,
                                   n_buckets: Optional[int] = 1, rng: Optional[random.Random] = None) -> List[List[int]]:
-    """First-fit over a descending order that is shuffled inside ``n_buckets`` value buckets
-    (None / >= n: plain FFD; 1: fully random first-fit), sampler.py:181-289."""
+    """First-fit over the descending order (``n_buckets`` None / >= n / >= 2: plain FFD -- see the note on the
+    bucket shuffle below; 1: fully random first-fit, what ``PartitionSampler`` uses), sampler.py:186-289."""
     rng = rng or random
     todo = sorted(_indexed(items, bin_capacity, skip_too_big), key=lambda x: x[0], reverse=True)
     n = len(todo)
@@ -409,9 +409,10 @@ def first_fit_decreasing_bucketed(items: Sequence[float], bin_capacity: float, s
             cuts = sorted({pos for _, pos in gaps[:n_buckets - 1]} | {n})
             start = 0
             for c in cuts:
-                seg = todo[start:c]
-                rng.shuffle(seg)            # NB: the reference shuffles a slice COPY (a no-op); we shuffle in place
-                todo[start:c] = seg
+                # the reference shuffles a temporary slice here (sampler.py:268: ``rng.shuffle(indexed_items[start:i])``):
+                # the packing order stays the plain descending one and only the RNG advances.  Reproduced as is, so
+                # that the same seed yields the same bins (and the same later draws) as the reference
+                rng.shuffle(todo[start:c])
                 start = c
     bins: List[List[int]] = []
     room: List[float] = []

@@ -194,3 +194,79 @@ def test_postprocess_consumes_predict_step_output(cuda):
     assert np.array_equal(got["row_index"].cpu().numpy(), ref["row_index"])
     assert np.array_equal(got["cell_encoding"].cpu().numpy(), ref["cell_encoding"])
     assert np.allclose(got["similarity_threshold"].cpu().numpy(), ref["similarity_threshold"], atol=1e-9, equal_nan=True)
+
+
+# ---------------------------------------------------------------- reference_heads.npz: genuine reference outputs
+def _heads():
+    return np.load(os.path.join(GOLD, "reference_heads.npz"))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_positional_embedder_matches_reference_outputs(cuda, dtype):
+    """Row a3 on the MI355X (segment min/max + sinusoid kernels + MFMA projections) against outputs of the
+    reference's own ``Positional2dEmbedder`` (ist_encoder.py:33-79).  fp32: the fp32 rounding of positions ~5e3
+    before normalisation bounds the agreement (2e-5, as for the oracle); bf16 activations: 3e-2."""
+    from segger_amd.ist_encoder import Positional2dEmbedder
+    z = _heads()
+    emb = Positional2dEmbedder(32)
+    emb.load_state_dict({k[len("pe::w::"):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("pe::w::")})
+    emb = emb.to(cuda)
+    pos, batch = torch.from_numpy(z["pe::pos"]).to(cuda), torch.from_numpy(z["pe::batch"]).to(cuda)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    with torch.no_grad():
+        for key, b in (("pe::out_batched", batch), ("pe::out_one_graph", torch.zeros_like(batch)), ("pe::out_unbatched", None)):
+            got = emb(pos, b, dtype=dtype).float().cpu().numpy()
+            assert got.shape == z[key].shape and np.abs(got - z[key]).max() < tol, key
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_get_losses_matches_reference_outputs(cuda, dtype):
+    """Rows a9 / a10 / N1 on the MI355X: ``LitISTEncoder.get_losses`` (fused triplet kernels, device selector, masked
+    losses, schedule) on GIVEN embeddings against the values the reference's own ``get_losses``
+    (lightning_model.py:151-213, with its TripletLoss / MetricLoss) returned for the same embeddings, masks, clusters,
+    edges and random draws.  fp32 embeddings: 1e-5; bf16 embeddings (rounded inputs): 2e-2."""
+    from test_oracle import replay_reference_draws
+    from segger_amd import LitISTEncoder, TX_BD
+    from segger_amd.hetero import HeteroBatch
+    z = _heads()
+    n_tx, n_bd = z["loss::z_tx"].shape[0], z["loss::z_bd"].shape[0]
+    b = HeteroBatch(num_graphs=1)
+    b["tx"]["mask"], b["tx"]["cluster"] = torch.from_numpy(z["loss::tx_mask"]), torch.from_numpy(z["loss::tx_cluster"])
+    b["bd"]["mask"], b["bd"]["cluster"] = torch.from_numpy(z["loss::bd_mask"]), torch.from_numpy(z["loss::bd_cluster"])
+    b["tx"]["x"], b["bd"]["x"] = torch.zeros(n_tx, dtype=torch.int32), torch.zeros(n_bd, 4)
+    b[TX_BD]["edge_index"] = torch.from_numpy(z["loss::edge_index"])
+    bg = b.to(cuda)
+    emb = {"tx": torch.from_numpy(z["loss::z_tx"]).to(cuda).to(dtype), "bd": torch.from_numpy(z["loss::z_bd"]).to(cuda).to(dtype)}
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    for row in z["loss::results"]:
+        m = LitISTEncoder(n_genes=4, in_channels=16, sg_loss_type="triplet" if row[0] == 0 else "bce",
+                          tx_margin=0.3, sg_margin=0.4).to(cuda)
+        m.set_similarities(torch.from_numpy(z["loss::tx_sim"]).to(cuda), torch.from_numpy(z["loss::bd_sim"]).to(cuda))
+        m._max_epochs_override, m.current_epoch = 20, int(row[2])
+        tx_mask, bd_mask, u_tx, u_bd, dst_neg = replay_reference_draws(z, row)
+
+        def per_node(us, mask, n):          # the reference draws one number per MASKED node; the product per node
+            out = []
+            for u in us:
+                full = torch.zeros(n)
+                full[mask] = u
+                out.append(full.to(cuda))
+            return tuple(out)
+        # WHICH member of a drawn cluster comes back depends on the order ``torch.argsort`` leaves equal labels in
+        # (triplet_loss.py:41) -- implementation-defined, and different between torch's CPU sort (which made the
+        # vectors) and its GPU sort: hand the device selectors the CPU member order, as test_reference_triplet_vectors does
+        from segger_amd.graph import batch_cache
+
+        def pin_members(loss, labels, mask):
+            ix = loss.selector.build_index(labels.to(cuda), mask.to(cuda))
+            idx = mask.nonzero().squeeze(1)
+            ix["members"][: idx.numel()] = idx[torch.argsort(labels[mask])].to(cuda)
+            return ix
+        cache = batch_cache(bg)
+        cache.clear()
+        cache["persistent"] = {"tx_triplet_index": pin_members(m.loss_tx, b["tx"]["cluster"], tx_mask),
+                               "bd_metric_index": pin_members(m.loss_bd, b["bd"]["cluster"], bd_mask)}
+        losses = m.get_losses(bg, dst_neg=dst_neg.to(cuda), embeddings=emb,
+                              uniforms=(per_node(u_tx, tx_mask, n_tx), per_node(u_bd, bd_mask, n_bd)))
+        got = [float(v) for v in losses]
+        assert np.allclose(got, row[3:7], atol=tol), (row.tolist(), got)

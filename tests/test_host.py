@@ -161,6 +161,19 @@ def test_scheduled_weights_match_oracle(oracle):
         assert torch.allclose(w, oracle.scheduled_weights(m._w_start, m._w_end, epoch, 20), atol=1e-7)
 
 
+def test_scheduled_weights_match_reference_outputs():
+    """The product's ``_scheduled_weights`` against the table the reference's own method produced
+    (tests/golden/reference_heads.npz, lightning_model.py:136-149)."""
+    from segger_amd import LitISTEncoder
+    z = np.load(os.path.join(GOLD, "reference_heads.npz"))
+    m = LitISTEncoder(n_genes=3, in_channels=8)
+    ws, we = torch.from_numpy(z["sched::w_start"]), torch.from_numpy(z["sched::w_end"])
+    for row in z["sched::table"]:
+        m._max_epochs_override, m.current_epoch = int(row[0]), int(row[1])
+        assert np.allclose(m._scheduled_weights(ws, we).numpy(), row[2:5], atol=1e-6)
+        assert np.allclose(m._scheduled_weights(ws, we, normalize=False).numpy(), row[5:8], atol=1e-6)
+
+
 def test_hetero_batch_contract_and_collate():
     from segger_amd.hetero import TX_BD, TX_NB_BD, TX_TX, collate
     from segger_amd.synthetic import SyntheticSpec, make_graph

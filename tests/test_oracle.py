@@ -195,3 +195,68 @@ def test_sinusoidal_embedding_known_answer(oracle):
     assert abs(e[1, 0].item() - math.cos(1.0)) < 1e-12 and abs(e[1, 128].item() - math.sin(1.0)) < 1e-12
     odd = oracle.sinusoidal_embedding(torch.tensor([0.5], dtype=torch.float64), 7, max_period=1000)
     assert odd.shape == (1, 7) and odd[0, 6] == 0
+
+
+# ---------------------------------------------------------------- vectors produced by RUNNING reference code
+def _heads_golden():
+    return np.load(os.path.join(GOLD, "reference_heads.npz"))
+
+
+def replay_reference_draws(z, row):
+    """The random numbers ``get_losses`` consumed for one row of ``loss::results``, regenerated from its seed in the
+    reference's order (lightning_model.py:157-180): 4 x rand(masked tx), 4 x rand(masked bd), randint(1, num_bd, (N,))."""
+    tx_mask = torch.from_numpy(z["loss::tx_mask"])
+    bd_mask = torch.from_numpy(z["loss::bd_mask"]) & (torch.from_numpy(z["loss::bd_cluster"]) >= 0)
+    ei = torch.from_numpy(z["loss::edge_index"])
+    n_bd = z["loss::z_bd"].shape[0]
+    torch.manual_seed(int(row[1]))
+    u_tx = [torch.rand(int(tx_mask.sum())) for _ in range(4)]
+    u_bd = [torch.rand(int(bd_mask.sum())) for _ in range(4)]
+    dst_neg = (ei[1] + torch.randint(1, n_bd, (ei.shape[1],))) % n_bd
+    return tx_mask, bd_mask, u_tx, u_bd, dst_neg
+
+
+def test_oracle_positional_embedding_matches_reference_outputs(oracle):
+    """reference_heads.npz: outputs of the reference's own ``sinusoidal_embedding`` / ``Positional2dEmbedder``
+    (ist_encoder.py:22-79, run by tests/golden/make_reference_heads_golden.py).  The reference computes in fp32, the
+    oracle in fp64: agreement to fp32 rounding of sin/cos arguments up to ~1 (positions normalised to [0, 1])."""
+    z = _heads_golden()
+    x = torch.from_numpy(z["sin::x"]).double()
+    assert np.abs(oracle.sinusoidal_embedding(x, 256, 10000).numpy() - z["sin::dim256_p10000"]).max() < 2e-6
+    assert np.abs(oracle.sinusoidal_embedding(x, 7, 1000).numpy() - z["sin::dim7_p1000"]).max() < 2e-6
+    w = {k[len("pe::w::"):]: torch.from_numpy(z[k]).double() for k in z.files if k.startswith("pe::w::")}
+    pos, batch = torch.from_numpy(z["pe::pos"]).double(), torch.from_numpy(z["pe::batch"])
+    args = (w["mlp.0.weight"], w["mlp.0.bias"], w["mlp.2.weight"], w["mlp.2.bias"])
+    # the reference normalises fp32 positions of magnitude ~5e3 (ulp 5e-4) to [0, 1]: a relative 1e-6 on the
+    # normalised coordinate times the highest frequency (1) through an MLP with |w| ~ 0.06 * 256 inputs
+    for key, b in (("pe::out_batched", batch), ("pe::out_unbatched", None), ("pe::out_one_graph", torch.zeros_like(batch))):
+        got = oracle.positional_2d_embed(pos, b, *args)
+        assert got.shape == z[key].shape
+        assert np.abs(got.numpy() - z[key]).max() < 2e-5, key
+
+
+def test_oracle_schedule_and_losses_match_reference_outputs(oracle):
+    """``_scheduled_weights`` and ``get_losses`` of the reference's LitISTEncoder (lightning_model.py:136-213), run on
+    given embeddings by make_reference_heads_golden.py, against the oracle fed the same random draws."""
+    z = _heads_golden()
+    ws, we = torch.from_numpy(z["sched::w_start"]), torch.from_numpy(z["sched::w_end"])
+    for row in z["sched::table"]:
+        w = oracle.scheduled_weights(ws, we, int(row[1]), int(row[0]))
+        wn = oracle.scheduled_weights(ws, we, int(row[1]), int(row[0]), normalize=False)
+        assert np.allclose(w.numpy(), row[2:5], atol=1e-6) and np.allclose(wn.numpy(), row[5:8], atol=1e-6)
+    z_tx, z_bd = torch.from_numpy(z["loss::z_tx"]).double(), torch.from_numpy(z["loss::z_bd"]).double()
+    tx_cl, bd_cl = torch.from_numpy(z["loss::tx_cluster"]), torch.from_numpy(z["loss::bd_cluster"])
+    ei = torch.from_numpy(z["loss::edge_index"])
+    sel_tx = oracle.FastTripletSelectorOracle(torch.from_numpy(z["loss::tx_sim"]))
+    sel_bd = oracle.FastTripletSelectorOracle(torch.from_numpy(z["loss::bd_sim"]))
+    for row in z["loss::results"]:
+        tx_mask, bd_mask, u_tx, u_bd, dst_neg = replay_reference_draws(z, row)
+        pos, neg, _, _ = sel_tx.sample(tx_cl[tx_mask], *u_tx)
+        l_tx = oracle.tx_triplet_loss(z_tx[tx_mask], pos, neg, 0.3)
+        pos, neg, dp, dn = sel_bd.sample(bd_cl[bd_mask], *u_bd)
+        l_bd = oracle.bd_metric_loss(z_bd[bd_mask], pos, neg, dp, dn)
+        l_sg = oracle.segmentation_loss(z_tx, z_bd, ei, dst_neg, "triplet" if row[0] == 0 else "bce", 0.4)
+        w = oracle.scheduled_weights(ws, we, int(row[2]), 20)
+        total = w[0] * l_tx + w[1] * l_bd + w[2] * l_sg
+        got = [float(l_tx), float(l_bd), float(l_sg), float(total)]
+        assert np.allclose(got, row[3:7], atol=2e-6), (row, got)

@@ -170,3 +170,36 @@ def test_predict_tile_index_equals_predict_tiles(graph, side, margin):
     assert all(bool((v == -1).all()) for v in fast._new_id.values())       # scratch map restored
     with pytest.raises(ValueError):
         T.PredictTileIndex(graph, tiling, margin=side * 1.5)
+
+
+def test_bin_packers_reproduce_reference_vectors():
+    """N2 pin: ``tests/golden/bin_packing.npz`` holds outputs of the reference's own ``partition/sampler.py``
+    (``best_fit_decreasing`` :11-82, ``harmonic_k`` :85-183, ``first_fit_decreasing_bucketed`` :186-289; generated by
+    tests/golden/make_bin_packing_golden.py).  The product's packers must return the very same bins -- same item
+    indices, same order inside a bin, same bin order -- including the randomised variants given the same
+    ``random.Random`` and the error raised for oversize items."""
+    import json
+    import os
+    import random
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "bin_packing.npz"))
+    blob = json.loads(bytes(z["json"]).decode())
+    assert len(blob["cases"]) >= 12
+    for rec in blob["cases"]:
+        items, cap, skip = rec["items"], rec["capacity"], rec["skip_too_big"]
+        assert T.best_fit_decreasing(items, cap, skip_too_big=skip) == rec["best_fit_decreasing"]
+        assert T.first_fit_decreasing_bucketed(items, cap, skip_too_big=skip, n_buckets=None) == rec["first_fit_decreasing"]
+        for k in (2, 3, 6, 10):
+            assert T.harmonic_k(items, cap, k=k, skip_too_big=skip) == rec[f"harmonic_{k}"], k
+        for nb in (1, 3):
+            got = T.first_fit_decreasing_bucketed(items, cap, skip_too_big=skip, n_buckets=nb, rng=random.Random(7))
+            assert got == rec[f"ffd_buckets_{nb}_seed7"], nb
+    err = blob["errors"]
+    for name, fn in (("best_fit_decreasing", T.best_fit_decreasing), ("harmonic_k", T.harmonic_k),
+                     ("first_fit_decreasing_bucketed", T.first_fit_decreasing_bucketed)):
+        with pytest.raises(ValueError) as e:
+            fn([3.0, 11.0], 10.0)
+        assert [type(e.value).__name__, str(e.value)] == err[name]
+    with pytest.raises(ValueError) as e:
+        T.harmonic_k([1.0], 10.0, k=1)
+    assert str(e.value) == err["harmonic_k_k1"][1]
