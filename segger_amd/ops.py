@@ -525,11 +525,28 @@ def _weight_grad_gemm(gy: Tensor, x: Tensor) -> Tensor:
     return (gy.t() @ x).float()
 
 
+# Parameters change between forwards in ways their version counters do not always show: torch's FUSED optimizers
+# update them in place without bumping ``_version`` (measured: fused Adam 0 -> 0, foreach Adam 0 -> 1).  Every
+# optimizer step therefore advances a global generation through torch's optimizer post-step hook; anything else that
+# writes parameters behind autograd's back (``p.data`` arithmetic) must call :func:`invalidate_weight_cache`.
+_WEIGHT_GENERATION = [0]
+
+
+def invalidate_weight_cache(*_args, **_kwargs) -> None:
+    """Forget every cached compute-dtype copy of the projection weights (they are rebuilt on next use)."""
+    _WEIGHT_GENERATION[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
+
+_register_step_hook(invalidate_weight_cache)
+
+
 class _Pack:
     """Compute-dtype copy of one or several row-stacked fp32 master weights (+ the fp32 stacked bias, + the transposed
     copy the data gradient streams), rebuilt only when a parameter changed (optimizer step, load_state_dict, .to()):
     the three projections that read x_tx (lin_l / lin_r of tx-neighbors-tx, lin_l of tx-belongs-bd) are ONE GEMM
-    without a per-layer, per-step cat + cast + transpose (and without autograd's slice-copies on the way back)."""
+    without a per-forward cat + cast + transpose (and without autograd's slice-copies on the way back)."""
     __slots__ = ("key", "w", "b", "_wt", "__weakref__")
 
     def __init__(self):
@@ -538,7 +555,7 @@ class _Pack:
     @staticmethod
     def _key(dtype, weights, biases):
         ps = tuple(weights) + tuple(b for b in biases if b is not None)
-        return (dtype,) + tuple((p.data_ptr(), p._version) for p in ps)
+        return (dtype, _WEIGHT_GENERATION[0]) + tuple((p.data_ptr(), p._version) for p in ps)
 
     def get(self, dtype, weights, biases):
         key = self._key(dtype, weights, biases)

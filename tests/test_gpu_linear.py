@@ -103,6 +103,34 @@ def test_linear_wgrad_operand_maps_exact_and_strided(cuda):
     assert not gw0.any() and not gb0.any()
 
 
+@pytest.mark.parametrize("fused", [True, False])
+def test_cached_weight_copies_follow_the_optimizer(cuda, fused):
+    """The compute-dtype weight copies are cached between forwards; a FUSED optimizer updates parameters in place
+    without bumping their version counters, so the cache is keyed on the optimizer-step generation as well: after
+    every step the projection must use the new weights (a stale copy trains nothing -- caught by the FOV AUROC run)."""
+    from segger_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(0)
+    w1 = torch.nn.Parameter(torch.randn(64, 128, device=cuda, generator=g) / 11)
+    w2 = torch.nn.Parameter(torch.randn(64, 128, device=cuda, generator=g) / 11)
+    b1 = torch.nn.Parameter(torch.zeros(64, device=cuda))
+    x = torch.randn(500, 128, device=cuda, generator=g).to(torch.bfloat16)
+    opt = torch.optim.Adam([w1, w2, b1], lr=0.05, fused=fused, foreach=not fused)
+    for _ in range(3):
+        y = ops.linear(x, (w1, w2), (b1, None))
+        ref = x.float() @ torch.cat([w1, w2]).detach().to(torch.bfloat16).float().t() + torch.cat([b1.detach(), b1.new_zeros(64)])
+        assert torch.allclose(y.float(), ref, rtol=2 ** -7, atol=2e-2)
+        opt.zero_grad()
+        y.float().pow(2).mean().backward()
+        before = w1.detach().clone()
+        opt.step()
+        assert not torch.equal(before, w1.detach())
+    with torch.no_grad():                                # parameters written behind autograd's back need the explicit call
+        w1.data.mul_(2.0)
+    ops.invalidate_weight_cache()
+    y = ops.linear(x, (w1, w2), (b1, None))
+    assert torch.allclose(y[:, :64].float(), x.float() @ w1.detach().to(torch.bfloat16).float().t() + b1.detach(), rtol=2 ** -7, atol=2e-2)
+
+
 def test_unsupported_shapes_use_vendor_gemm(cuda):
     from segger_amd import ops
     assert not ops.linear_supported(100, 64, torch.bfloat16)
