@@ -544,51 +544,112 @@ _register_step_hook(invalidate_weight_cache)
 
 class _Pack:
     """Compute-dtype copy of one or several row-stacked fp32 master weights (+ the fp32 stacked bias, + the transposed
-    copy the data gradient streams), rebuilt only when a parameter changed (optimizer step, load_state_dict, .to()):
+    copy the data gradient streams), refreshed only when a parameter changed (optimizer step, load_state_dict, .to()):
     the three projections that read x_tx (lin_l / lin_r of tx-neighbors-tx, lin_l of tx-belongs-bd) are ONE GEMM
-    without a per-forward cat + cast + transpose (and without autograd's slice-copies on the way back)."""
-    __slots__ = ("key", "w", "b", "_wt", "__weakref__")
+    without a per-forward cat + cast + transpose (and without autograd's slice-copies on the way back).  The copies
+    live in persistent buffers; after an optimizer step ALL packs of the process are refreshed by one multi-tensor
+    copy (``torch._foreach_copy_`` casts fp32 -> bf16 into row windows of the stacked buffers in a single launch)."""
 
-    def __init__(self):
-        self.key, self.w, self.b, self._wt = None, None, None, None
+    def __init__(self, weights, biases):
+        import weakref
+        self.params = [weakref.ref(p) for p in tuple(weights) + tuple(b for b in biases if b is not None)]
+        self.rows = [int(w.shape[0]) for w in weights]
+        self.has_bias = [b is not None for b in biases]
+        self.k = int(weights[0].shape[1])
+        self.dtype = None
+        self.w = self.b = self._wt = None
+        self._wt_fresh = False
+        self.key = None
+        self.views: list = []
 
-    @staticmethod
-    def _key(dtype, weights, biases):
-        ps = tuple(weights) + tuple(b for b in biases if b is not None)
-        return (dtype, _WEIGHT_GENERATION[0]) + tuple((p.data_ptr(), p._version) for p in ps)
+    def _alloc(self, dtype, device):
+        m = sum(self.rows)
+        self.w = torch.empty((m, self.k), dtype=dtype, device=device)
+        self.b = torch.zeros(m, dtype=torch.float32, device=device) if any(self.has_bias) else None
+        self._wt, self._wt_fresh, self.dtype = None, False, dtype
+        self.views, r0 = [], 0
+        for r in self.rows:
+            self.views.append(self.w[r0:r0 + r]); r0 += r
+        r0 = 0
+        for r, hb in zip(self.rows, self.has_bias):
+            if hb:
+                self.views.append(self.b[r0:r0 + r])
+            r0 += r
 
-    def get(self, dtype, weights, biases):
-        key = self._key(dtype, weights, biases)
-        if key != self.key:
-            with torch.no_grad():
-                w = weights[0].detach() if len(weights) == 1 else torch.cat([p.detach() for p in weights], 0)
-                self.w = w.to(dtype).contiguous()
-                if all(b is None for b in biases):
-                    self.b = None
-                else:
-                    parts = [b.detach().float() if b is not None else w.new_zeros(p.shape[0], dtype=torch.float32)
-                             for p, b in zip(weights, biases)]
-                    self.b = (parts[0] if len(parts) == 1 else torch.cat(parts, 0)).contiguous()
-            self._wt, self.key = None, key
+    def _current_key(self):
+        ps = [r() for r in self.params]
+        if any(p is None for p in ps):
+            return None, ps
+        return tuple((p.data_ptr(), p._version) for p in ps), ps
+
+    def get(self, dtype, device):
+        key, ps = self._current_key()
+        gen = _WEIGHT_GENERATION[0]
+        if self.w is None or self.dtype != dtype or self.w.device != device:
+            self._alloc(dtype, device)
+            self.key = None
+        if self.key != (gen, key):
+            if _REFRESHED_GENERATION[0] != gen and self.key is not None:
+                _refresh_all_packs()                         # one launch for every pack of the process
+            if self.key != (gen, key):                       # (first use, or a change outside an optimizer step)
+                with torch.no_grad():
+                    _copy_groups(self.views, [p.detach() for p in ps])
+                self.key, self._wt_fresh = (gen, key), False
         return self
 
     @property
     def wt(self) -> Tensor:                              # [K, M]: dX = dY @ W
         if self._wt is None:
-            self._wt = self.w.t().contiguous()
+            self._wt = torch.empty((self.k, sum(self.rows)), dtype=self.dtype, device=self.w.device)
+        if not self._wt_fresh:
+            self._wt.copy_(self.w.t())
+            self._wt_fresh = True
         return self._wt
 
 
 _PACKS: dict = {}
+_REFRESHED_GENERATION = [-1]
 
 
-def _pack_for(weights) -> _Pack:
+def _copy_groups(dsts, srcs) -> None:
+    """``torch._foreach_copy_`` per destination dtype: one multi-tensor launch casts all fp32 weights into their bf16 /
+    f16 row windows, one copies the fp32 biases.  (A single call over destinations of mixed dtypes mis-copied the fp32
+    -> fp32 part on torch 2.10 / ROCm: biases came out wrong while the weights were right.)"""
+    by_dtype: dict = {}
+    for d, s_ in zip(dsts, srcs):
+        g = by_dtype.setdefault(d.dtype, ([], []))
+        g[0].append(d); g[1].append(s_)
+    for d_list, s_list in by_dtype.values():
+        torch._foreach_copy_(d_list, s_list)
+
+
+@torch.no_grad()
+def _refresh_all_packs() -> None:
+    gen = _WEIGHT_GENERATION[0]
+    dsts, srcs, live = [], [], []
+    for pk in _PACKS.values():
+        if pk.w is None:
+            continue
+        key, ps = pk._current_key()
+        if key is None:
+            continue
+        dsts += pk.views
+        srcs += [p.detach() for p in ps]
+        live.append((pk, key))
+    if dsts:
+        _copy_groups(dsts, srcs)
+    for pk, key in live:
+        pk.key, pk._wt_fresh = (gen, key), False
+    _REFRESHED_GENERATION[0] = gen
+
+
+def _pack_for(weights, biases) -> _Pack:
     """The cache entry of a parameter group, keyed by the tensors' identities (dropped when the first one dies)."""
     import weakref
-    ids = tuple(id(w) for w in weights)
+    ids = tuple(id(w) for w in weights) + tuple(id(b) for b in biases)
     pk = _PACKS.get(ids)
     if pk is None:
-        pk = _PACKS[ids] = _Pack()
+        pk = _PACKS[ids] = _Pack(weights, biases)
         weakref.finalize(weights[0], _PACKS.pop, ids, None)
     return pk
 
@@ -601,14 +662,15 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n_w, *params):
         weights, biases = params[:n_w], params[n_w:]
-        pk = _pack_for(weights).get(x.dtype, weights, biases)
+        pk = _pack_for(weights, biases).get(x.dtype, x.device)
         y = linear_fwd_launch(x, pk.w, pk.b)
         ctx.save_for_backward(x)
         ctx.pack, ctx.n_w = pk, n_w
         ctx.rows = [int(w.shape[0]) for w in weights]
         ctx.has_bias = [b is not None for b in biases]
-        # the pack may be rebuilt (optimizer step) before a late backward runs: keep THIS forward's weights alive
-        ctx.w, ctx.wt_of = pk.w, pk
+        # the pack is refreshed IN PLACE after an optimizer step; a backward that runs later than that (not the case in
+        # forward -> backward -> step training) would see the new weights: remember which generation this forward used
+        ctx.w, ctx.wt_of, ctx.w_key = pk.w, pk, pk.key
         return y
 
     @staticmethod
@@ -624,7 +686,10 @@ class _Linear(torch.autograd.Function):
         m, k = w.shape
         gx = None
         if ctx.needs_input_grad[0]:
-            wt = ctx.wt_of.wt if ctx.wt_of.w is w else w.t().contiguous()      # [K, M]: dX = dY @ W
+            if ctx.wt_of.key != ctx.w_key:
+                raise RuntimeError("the projection weights changed between this forward and its backward "
+                                   "(optimizer step in between?): run backward before stepping")
+            wt = ctx.wt_of.wt                                                   # [K, M]: dX = dY @ W
             if linear_supported(m, k, dt):
                 gx = linear_fwd_launch(gy, wt, None)
             else:

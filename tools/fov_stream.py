@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--edges-per-batch", type=int, default=1_000_000)
     ap.add_argument("--margin", type=float, default=10.0, help="tile margin excluded from the losses (um)")
     ap.add_argument("--train-batches", type=int, default=0, help="0 = one full epoch")
+    ap.add_argument("--train-epochs", type=int, default=1,
+                    help="epochs over the batch stream; the LAST one is reported as `train`, all of them in "
+                         "`train.epochs_s` (the first epoch builds the per-tile sampler indices)")
     ap.add_argument("--train-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--score-dtypes", default="f32,bf16,f16")
     ap.add_argument("--graphed", action="store_true", help="also run the hipGraph-captured predictor (fp16)")
@@ -163,17 +166,21 @@ def main():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    with Phase("train_s", times):
-        for i, k in enumerate(sched):
-            l = train_step(k, i)
-            if k is not None:
-                loss = l
-                etb_seen += sum(eptr_tb[t] for t in todo[k])
-                ett_seen += sum(eptr_tt[t] for t in todo[k])
-            if i % 200 == 0 and loss is not None:
-                log(f"[fov r{rank}] train step {i}/{len(sched)} loss {float(loss.detach()):.4f}")
-        if world > 1:
-            dist.barrier()
+    epochs_s = []
+    for ep in range(max(1, args.train_epochs)):
+        etb_seen = ett_seen = 0
+        with Phase("train_s", times):
+            for i, k in enumerate(sched):
+                l = train_step(k, i)
+                if k is not None:
+                    loss = l
+                    etb_seen += sum(eptr_tb[t] for t in todo[k])
+                    ett_seen += sum(eptr_tt[t] for t in todo[k])
+                if i % 200 == 0 and loss is not None:
+                    log(f"[fov r{rank}] epoch {ep} train step {i}/{len(sched)} loss {float(loss.detach()):.4f}")
+            if world > 1:
+                dist.barrier()
+        epochs_s.append(times["train_s"])
     stats = torch.tensor([times["train_s"], float(etb_seen), float(ett_seen)], dtype=torch.float64, device=dev)
     if world > 1:
         tmax = stats[:1].clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -185,6 +192,7 @@ def main():
         "edges_scored_per_s": 2.0 * etb_seen / times["train_s"],
         "mp_edges_per_s": 4.0 * (ett_seen + etb_seen) / times["train_s"],
         "final_loss": float(loss.detach()) if loss is not None else None,
+        "epochs_s": epochs_s, "ms_per_step_by_epoch": [e / max(len(sched), 1) * 1e3 for e in epochs_s],
     }
     if rank != 0:                                            # scoring / prediction: rank 0 only
         dist.destroy_process_group()
