@@ -122,7 +122,9 @@ def strong_scaling_epoch(batch_weights: Sequence[float], step, units=None, *, sy
     """One data-parallel epoch over a FIXED list of packed batches (BASELINE config 4: total work does not grow
     with the number of ranks).  ``step(k, i)`` runs optimizer step ``i`` on batch ``k`` (``None``: this rank ran out
     of batches -- it must still take part in the gradient all-reduce, see :func:`rank_schedule`); ``units(k)`` returns
-    the work units of batch ``k`` (a sequence of numbers, summed over all ranks); ``sync()`` drains the device.
+    the work units of batch ``k`` (a sequence of numbers, summed over all ranks); ``sync()`` drains the device;
+    ``warmup`` untimed steps come first (negative: this rank's whole schedule once, i.e. the timed epoch is a second
+    epoch and finds every per-tile cache warm).
     The epoch is bracketed by barrier + sync on both sides and the reported time is the MAX over ranks."""
     import time
     on = dist.is_available() and dist.is_initialized()
@@ -130,7 +132,7 @@ def strong_scaling_epoch(batch_weights: Sequence[float], step, units=None, *, sy
     rank = dist.get_rank(group) if on else 0
     sched = rank_schedule(batch_weights, world)[rank]
     sync = sync or (lambda: None)
-    for k in sched[:warmup]:
+    for k in (sched if warmup < 0 else sched[:warmup]):     # warmup < 0: one whole untimed epoch first
         step(k, 0)
     sync()
     if on:
