@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEGGER_ABI_VERSION 2
+#define SEGGER_ABI_VERSION 3
 
 enum segger_status {
   SEGGER_OK = 0,
