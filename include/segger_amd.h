@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEGGER_ABI_VERSION 3
+#define SEGGER_ABI_VERSION 4
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -149,6 +149,10 @@ typedef struct segger_gatv2_fwd_args {
                              NULL = skip */
   float* alpha;           /* [n_edges, H] attention (after dropout) by ORIGINAL edge id; NULL = skip
                              (SkipGAT.attention_weights, ist_encoder.py:146-158,192-211) */
+  const uint8_t* keep_bits; /* optional, [n_edges] in by_dst SLOT order: bit h = keep(e, h) of the mask defined
+                               above, precomputed by segger_dropout_bits for this layer's seed.  The kernels then test
+                               a bit instead of hashing per (edge, head); results are identical.  Ignored when alpha
+                               is requested or the geometry runs on the generic kernels. */
 } segger_gatv2_fwd_args;
 
 int segger_gatv2_fwd(const segger_gatv2_fwd_args* args, segger_stream_t stream);
@@ -193,6 +197,8 @@ typedef struct segger_gatv2_bwd_args {
   float* grad_bias;       /* [H*C] or NULL */
   void* workspace;        /* segger_gatv2_bwd_workspace_bytes() */
   size_t workspace_bytes;
+  const uint8_t* keep_bits_dst; /* optional dropout bit planes (see forward) in by_dst / by_src slot order */
+  const uint8_t* keep_bits_src;
   int32_t src_unique;     /* non-zero: the caller asserts that no source node has more than one out-edge (segger's
                              tx-belongs-bd: a transcript lies in at most one boundary; check with
                              segger_coo_unique).  grad_xl[i] then has a single term, the destination-side pass
@@ -202,6 +208,15 @@ typedef struct segger_gatv2_bwd_args {
 
 size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads, int32_t channels);
 int segger_gatv2_bwd(const segger_gatv2_bwd_args* args, segger_stream_t stream);
+/*
+ * segger_dropout_bits: the attention-dropout mask of n_seeds layers as bit planes over the slots of one CSR view:
+ *   bits[l * n_edges + slot] = sum_h keep(eid[slot], h; seeds[l] + *seed_dev) << h        (heads <= 8)
+ * with keep() exactly the counter-based mask of segger_gatv2_fwd.  One launch per view per training step replaces
+ * 3 passes x n_seeds layers of per-(edge, head) hashing inside the aggregation kernels.  seeds is a HOST array.
+ */
+int segger_dropout_bits(const int32_t* eid, int64_t n_edges, int32_t heads, float dropout_p, const uint64_t* seeds,
+                        int32_t n_seeds, const uint64_t* seed_dev, uint8_t* bits, segger_stream_t stream);
+
 /* 1 when (heads, channels) runs on the specialised kernels (channels in {32,64}, heads in 1..4), 0 = generic kernels */
 int segger_gatv2_has_specialised(int32_t heads, int32_t channels);
 

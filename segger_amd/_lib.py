@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
@@ -45,6 +45,7 @@ class GatFwdArgs(C.Structure):
         ("out", vp), ("ld_out", C.c_int64),
         ("pre", vp), ("ld_pre", C.c_int64),
         ("lse", vp), ("alpha", vp),
+        ("keep_bits", vp),
     ]
 
 
@@ -65,6 +66,7 @@ class GatBwdArgs(C.Structure):
         ("grad_xr", vp), ("ld_gxr", C.c_int64),
         ("grad_att", vp), ("grad_bias", vp),
         ("workspace", vp), ("workspace_bytes", C.c_size_t),
+        ("keep_bits_dst", vp), ("keep_bits_src", vp),
         ("src_unique", C.c_int32),
     ]
 
@@ -106,6 +108,7 @@ EXPORTS = {
     "segger_gatv2_fwd": (C.c_int, [C.POINTER(GatFwdArgs), vp]),
     "segger_gatv2_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "segger_gatv2_bwd": (C.c_int, [C.POINTER(GatBwdArgs), vp]),
+    "segger_dropout_bits": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_float, vp, C.c_int32, vp, vp, vp]),
     "segger_gatv2_has_specialised": (C.c_int, [C.c_int32, C.c_int32]),
     "segger_coo_unique": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
     "segger_edge_cos_argmax": (C.c_int, [C.POINTER(EdgeArgmaxArgs), vp]),

@@ -40,6 +40,23 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(char* __restrict__ base,
   *reinterpret_cast<u32x4*>(base + (i / pieces) * pitch + (i % pieces) * 16) = u32x4{0u, 0u, 0u, 0u};
 }
 
+// bits[l][slot] = OR_h keep(eid[slot], h; seed_l) << h   (one thread per slot, all layers)
+struct BitsParams { const int32_t* eid; int64_t n_edges; int heads; uint32_t thr; int n_seeds; uint64_t seeds[16];
+                    const uint64_t* seed_dev; uint8_t* bits; };
+__global__ __launch_bounds__(256) void dropout_bits_kernel(BitsParams p) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= p.n_edges) return;
+  const uint32_t e = (uint32_t)p.eid[s];
+  const uint64_t dev = p.seed_dev ? *p.seed_dev : 0ull;
+  for (int l = 0; l < p.n_seeds; ++l) {
+    const uint64_t mixed = splitmix64(p.seeds[l] + dev);
+    const uint32_t lo = (uint32_t)mixed, hi = (uint32_t)(mixed >> 32);
+    uint32_t b = 0;
+    for (int h = 0; h < p.heads; ++h) b |= (uint32_t)dropout_keep(e, p.heads, h, lo, hi, p.thr) << h;
+    p.bits[(int64_t)l * p.n_edges + s] = (uint8_t)b;
+  }
+}
+
 namespace {
 
 // average-degree threshold above which the NG groups of a wave split ONE row
@@ -127,8 +144,8 @@ extern "C" int segger_gatv2_fwd(const segger_gatv2_fwd_args* a, segger_stream_t 
     CHECK_RC(check_rows("pre", a->pre, a->ld_pre, a->dtype, hc));
     SEGGER_REQUIRE(!(a->pre == a->out && a->apply_gelu), "segger_gatv2_fwd: pre may alias out only without GELU");
   }
-  SEGGER_REQUIRE(!(a->dropout_p > 0.f || a->alpha) || a->by_dst.n_edges == 0 || a->by_dst.eid != nullptr,
-                 "segger_gatv2_fwd: by_dst.eid is required for dropout / alpha output");
+  SEGGER_REQUIRE(!((a->dropout_p > 0.f && !a->keep_bits) || a->alpha) || a->by_dst.n_edges == 0 || a->by_dst.eid != nullptr,
+                 "segger_gatv2_fwd: by_dst.eid is required for dropout (without keep_bits) / alpha output");
   GatParams p{};
   p.indptr = a->by_dst.indptr; p.col = a->by_dst.col; p.eid = a->by_dst.eid; p.order = a->by_dst.row_order;
   p.n_rows = a->by_dst.n_rows; p.n_edges = a->by_dst.n_edges;
@@ -136,6 +153,7 @@ extern "C" int segger_gatv2_fwd(const segger_gatv2_fwd_args* a, segger_stream_t 
   p.att = a->att; p.bias = a->bias;
   p.out = a->out; p.ld_out = a->ld_out; p.pre = a->pre; p.ld_pre = a->ld_pre;
   p.lse = a->lse; p.alpha = a->alpha;
+  p.bits = a->alpha ? nullptr : a->keep_bits;
   p.slope = a->negative_slope; p.apply_gelu = a->apply_gelu; p.rows_per_wave_iter = 1;
   set_dropout(p, a->dropout_p, a->seed, a->seed_dev);
   return launch(Pass::Fwd, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), (hipStream_t)stream);
@@ -180,8 +198,9 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
     CHECK_RC(check_rows("x_l", a->x_l, a->ld_xl, a->dtype, hc));
     CHECK_RC(check_rows("grad_xl", a->grad_xl, a->ld_gxl, a->dtype, hc));
   }
-  SEGGER_REQUIRE(!(a->dropout_p > 0.f) || n_edges == 0 || (a->by_dst.eid && (direct || a->by_src.eid)),
-                 "segger_gatv2_bwd: eid arrays are required for dropout");
+  SEGGER_REQUIRE(!(a->dropout_p > 0.f) || n_edges == 0 ||
+                     ((a->by_dst.eid || a->keep_bits_dst) && (direct || a->by_src.eid || a->keep_bits_src)),
+                 "segger_gatv2_bwd: eid arrays (or keep_bits) are required for dropout");
   const size_t need = segger_gatv2_bwd_workspace_bytes(n_dst, a->heads, a->channels);
   if (a->workspace == nullptr || a->workspace_bytes < need) {
     set_error("segger_gatv2_bwd: workspace %zu < %zu bytes", a->workspace_bytes, need);
@@ -201,6 +220,7 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
   // ---- destination side ------------------------------------------------------
   p.indptr = a->by_dst.indptr; p.col = a->by_dst.col; p.eid = a->by_dst.eid; p.order = a->by_dst.row_order;
   p.n_rows = n_dst; p.n_edges = n_edges; p.rows_per_wave_iter = bwd_row_iters(n_dst);
+  p.bits = a->keep_bits_dst;
   p.direct_gxl = direct ? 1 : 0;
   if (direct && n_src > 0) {
     // sources without an out-edge keep a zero gradient; the others are stored by the destination pass
@@ -232,6 +252,7 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
   if (direct) return SEGGER_OK;
   p.direct_gxl = 0;
   p.indptr = a->by_src.indptr; p.col = a->by_src.col; p.eid = a->by_src.eid; p.order = a->by_src.row_order;
+  p.bits = a->keep_bits_src;
   p.n_rows = n_src; p.rows_per_wave_iter = 1;
   if (n_src > 0) CHECK_RC(launch(Pass::BwdSrc, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_src), stream));
   return SEGGER_OK;
@@ -239,4 +260,21 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
 
 extern "C" int segger_gatv2_has_specialised(int32_t heads, int32_t channels) {
   return gatv2_has_specialised(heads, channels) ? 1 : 0;
+}
+
+extern "C" int segger_dropout_bits(const int32_t* eid, int64_t n_edges, int32_t heads, float dropout_p,
+                                   const uint64_t* seeds, int32_t n_seeds, const uint64_t* seed_dev, uint8_t* bits,
+                                   segger_stream_t stream) {
+  SEGGER_REQUIRE(n_edges >= 0 && heads > 0 && heads <= 8, "segger_dropout_bits: heads must be in 1..8");
+  SEGGER_REQUIRE(n_seeds > 0 && n_seeds <= 16 && seeds, "segger_dropout_bits: 1..16 seeds");
+  SEGGER_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "segger_dropout_bits: dropout_p must be in [0,1)");
+  if (n_edges == 0) return SEGGER_OK;
+  SEGGER_REQUIRE(eid && bits, "segger_dropout_bits: NULL pointer");
+  BitsParams p{};
+  p.eid = eid; p.n_edges = n_edges; p.heads = heads; p.n_seeds = n_seeds; p.seed_dev = seed_dev; p.bits = bits;
+  p.thr = (uint32_t)((double)dropout_p * 16777216.0);
+  for (int l = 0; l < n_seeds; ++l) p.seeds[l] = seeds[l];
+  hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  SEGGER_LAUNCH_CHECK("dropout_bits_kernel");
+  return SEGGER_OK;
 }

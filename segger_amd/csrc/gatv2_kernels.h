@@ -59,6 +59,7 @@ struct GatParams {
   const int64_t* indptr;
   const int32_t* col;
   const int32_t* eid;
+  const uint8_t* bits;           // nullable: per slot, bit h = dropout keep of head h (segger_dropout_bits): replaces the hash
   const int32_t* order;          // nullable: position -> row (degree-balanced visiting order, group-per-row mode)
   int64_t n_rows;
   int64_t n_edges;
@@ -113,9 +114,14 @@ constexpr int kDppRowRor0 = 0x120;   // row_ror:n
 // for successive batches of U edges of this group's share of row [beg,end).
 // All lanes of a group see identical arguments.  In wave-per-row mode the loop
 // is wave-uniform and a group may be handed a batch with valid[0] == false.
-template <int GS, bool WPR, bool NEED_EID, int U, typename Body>
-__device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const int32_t* __restrict__ eid,
+// per-edge side information handed to the body next to the neighbour id
+constexpr int kMetaNone = 0, kMetaEid = 1, kMetaBits = 2;
+template <int GS, bool WPR, int META, int U, typename Body>
+__device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const void* __restrict__ meta,
                                          int64_t beg, int64_t end, int lane, int grp, int gl, Body&& body) {
+  constexpr bool NEED_EID = META != kMetaNone;
+  const int32_t* __restrict__ eid = static_cast<const int32_t*>(meta);
+  const uint8_t* __restrict__ bits = static_cast<const uint8_t*>(meta);
   constexpr int NG = 64 / GS;
   constexpr int CHUNK = WPR ? 64 : GS;      // ids fetched per coalesced load (per wave / per group)
   constexpr bool kDpp = !WPR && GS == 16;
@@ -125,7 +131,8 @@ __device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const 
     int myc = 0, myeid = 0;
     if (e0 + me < end) {
       myc = col[e0 + me];
-      if constexpr (NEED_EID) myeid = eid[e0 + me];
+      if constexpr (META == kMetaEid) myeid = eid[e0 + me];
+      if constexpr (META == kMetaBits) myeid = bits[e0 + me];
     }
 #pragma unroll 1
     for (int t = 0; t < GS; t += U) {
@@ -148,7 +155,7 @@ __device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const 
           ed[u] = NEED_EID ? __builtin_amdgcn_ds_bpermute(slot << 2, myeid) : 0;
         }
       });
-      body(valid, nbr, ed);
+      body(std::integral_constant<int, META>{}, valid, nbr, ed);
       if constexpr (kDpp) {
         myc = dpp_i<kDppRowRor0 + 16 - U>(myc);   // lane i <- lane i+U
         if constexpr (NEED_EID) myeid = dpp_i<kDppRowRor0 + 16 - U>(myeid);
@@ -320,7 +327,9 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
 
   float m = -INFINITY, s = 0.f;                       // online softmax state
 
-  auto body = [&](const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
+  const int hbit = 1 << h;
+  auto body = [&](auto meta_c, const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
+    constexpr int META = decltype(meta_c)::value;
     if (!valid[0]) return;                            // wave-per-row tail (group-uniform)
     Raw8<T> raw[U];
 #pragma unroll
@@ -348,8 +357,12 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
       const float pe = fast_exp2(e[u] - mx);          // invalid -> 0
       s += pe;
       float w = pe;
-      if (dropout) w = dropout_keep((uint32_t)ed[u], H, h, seed_lo, seed_hi, p.drop_thr) ? pe * p.drop_scale : 0.f;
-      if (want_alpha && valid[u] && head_leader) p.alpha[(int64_t)ed[u] * H + h] = e[u];
+      if constexpr (META == kMetaBits) {
+        w = (ed[u] & hbit) ? pe * p.drop_scale : 0.f;
+      } else if constexpr (META == kMetaEid) {
+        if (dropout) w = dropout_keep((uint32_t)ed[u], H, h, seed_lo, seed_hi, p.drop_thr) ? pe * p.drop_scale : 0.f;
+        if (want_alpha && valid[u] && head_leader) p.alpha[(int64_t)ed[u] * H + h] = e[u];
+      }
       f32x2 v[4];
       raw[u].get(v);
       const f32x2 w2 = splat(w);
@@ -357,10 +370,12 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
       for (int i = 0; i < 4; ++i) acc[i] = pk_fma(w2, v[i], acc[i]);
     }
   };
-  if (dropout || want_alpha)
-    walk_row<GS, WPR, true, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+  if (want_alpha || (dropout && !p.bits))
+    walk_row<GS, WPR, kMetaEid, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+  else if (dropout)
+    walk_row<GS, WPR, kMetaBits, U>(p.col, p.bits, beg, end, L.lane, L.grp, L.gl, body);
   else
-    walk_row<GS, WPR, false, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+    walk_row<GS, WPR, kMetaNone, U>(p.col, nullptr, beg, end, L.lane, L.grp, L.gl, body);
 
   if constexpr (WPR) {
     // merge the NG groups' online-softmax states
@@ -494,7 +509,9 @@ __global__ __launch_bounds__(256, DIRECT ? 2 : SEGGER_BWD_DST_WAVES) void gatv2_
       for (int i = 0; i < 4; ++i) dbias[i] = dbias[i] + g[i];
     }
 
-    auto body = [&](const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
+    const int hbit = 1 << h;
+    auto body = [&](auto meta_c, const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
+      constexpr int META = decltype(meta_c)::value;
       if (!valid[0]) return;
       Raw8<T> raw[U];
 #pragma unroll
@@ -510,8 +527,9 @@ __global__ __launch_bounds__(256, DIRECT ? 2 : SEGGER_BWD_DST_WAVES) void gatv2_
         float da = lane_block_sum<LPH>(da2.x + da2.y);
         const float a = valid[u] ? fast_exp2(pl - lse) : 0.f;
         float a_eff = a;
-        if (dropout) {
-          const bool keep = dropout_keep((uint32_t)ed[u], H, h, seed_lo, seed_hi, p.drop_thr);
+        if constexpr (META != kMetaNone) {
+          const bool keep = META == kMetaBits ? (ed[u] & hbit) != 0
+                                              : dropout_keep((uint32_t)ed[u], H, h, seed_lo, seed_hi, p.drop_thr);
           da = keep ? da * p.drop_scale : 0.f;
           a_eff = keep ? a * p.drop_scale : 0.f;
         }
@@ -535,10 +553,12 @@ __global__ __launch_bounds__(256, DIRECT ? 2 : SEGGER_BWD_DST_WAVES) void gatv2_
         }
       }
     };
-    if (dropout)
-      walk_row<GS, WPR, true, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+    if (dropout && p.bits)
+      walk_row<GS, WPR, kMetaBits, U>(p.col, p.bits, beg, end, L.lane, L.grp, L.gl, body);
+    else if (dropout)
+      walk_row<GS, WPR, kMetaEid, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
     else
-      walk_row<GS, WPR, false, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+      walk_row<GS, WPR, kMetaNone, U>(p.col, nullptr, beg, end, L.lane, L.grp, L.gl, body);
 
     if constexpr (WPR) {
 #pragma unroll
@@ -634,7 +654,9 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
     for (int i = 0; i < 4; ++i) nv[i] = neg_canon_zero(v[i]);
   }
 
-  auto body = [&](const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
+  const int hbit = 1 << h;
+  auto body = [&](auto meta_c, const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
+    constexpr int META = decltype(meta_c)::value;
     if (!valid[0]) return;
     Raw8<T> rxr[U], rg[U];
     float lse[U], D[U];
@@ -657,8 +679,9 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
       float da = -lane_block_sum<LPH>(nda2.x + nda2.y);
       const float a = valid[u] ? fast_exp2(pl - lse[u]) : 0.f;
       float a_eff = a;
-      if (dropout) {
-        const bool keep = dropout_keep((uint32_t)ed[u], H, h, seed_lo, seed_hi, p.drop_thr);
+      if constexpr (META != kMetaNone) {
+        const bool keep = META == kMetaBits ? (ed[u] & hbit) != 0
+                                            : dropout_keep((uint32_t)ed[u], H, h, seed_lo, seed_hi, p.drop_thr);
         da = keep ? da * p.drop_scale : 0.f;
         a_eff = keep ? a * p.drop_scale : 0.f;
       }
@@ -673,10 +696,12 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
       }
     }
   };
-  if (dropout)
-    walk_row<GS, WPR, true, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+  if (dropout && p.bits)
+    walk_row<GS, WPR, kMetaBits, U>(p.col, p.bits, beg, end, L.lane, L.grp, L.gl, body);
+  else if (dropout)
+    walk_row<GS, WPR, kMetaEid, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
   else
-    walk_row<GS, WPR, false, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+    walk_row<GS, WPR, kMetaNone, U>(p.col, nullptr, beg, end, L.lane, L.grp, L.gl, body);
 
 #pragma unroll
   for (int i = 0; i < 4; ++i) acc[i] = acc[i] + (a1[i] * Sde + a2[i] * Sg[i]) * kLn2;

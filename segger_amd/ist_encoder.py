@@ -170,7 +170,7 @@ class SkipGAT(Module):
 
     def forward(self, x_dict: Dict[str, Tensor], edge_index_dict: Dict[EdgeType, Tensor], *,
                 graphs: Optional[Dict[EdgeType, EdgeGraph]] = None, apply_gelu: bool = False,
-                seed=0) -> Dict[str, Tensor]:
+                seed=0, keep_bits: Optional[Dict[EdgeType, tuple]] = None) -> Dict[str, Tensor]:
         for et in (TX_TX, TX_BD):
             if et not in edge_index_dict:
                 raise KeyError(f"edge type {et} missing from edge_index_dict: segger's HeteroConv would "
@@ -190,7 +190,9 @@ class SkipGAT(Module):
         y_tx, y_bd, alpha = ops.hetero_gat_layer(
             xp_tx, xp_bd, tt.att, tt.bias, tb.att, tb.bias, graphs[TX_TX], graphs[TX_BD],
             self.n_heads, self.out_channels, apply_gelu=apply_gelu, negative_slope=tt.negative_slope,
-            dropout_p=p, seed_tt=_layer_seed(seed, 0), seed_tb=_layer_seed(seed, 1), return_alpha=self.store_attention)
+            dropout_p=p, seed_tt=_layer_seed(seed, 0), seed_tb=_layer_seed(seed, 1), return_alpha=self.store_attention,
+            bits_tt=None if keep_bits is None else keep_bits.get(TX_TX),
+            bits_tb=None if keep_bits is None else keep_bits.get(TX_BD))
         if self.store_attention:
             self._attn_weights[TX_TX] = alpha
         return {"tx": y_tx, "bd": y_bd}
@@ -270,6 +272,25 @@ class ISTEncoder(Module):
         for k in [k for k in state_dict if k.startswith(prefix) and "<bd___contains___tx>" in k]:
             del state_dict[k]
 
+    def _dropout_planes(self, graphs, step):
+        """The attention-dropout masks of all layers as bit planes per CSR view (``ops.dropout_bits``): one launch per
+        view per step; the 12 aggregation launches of the step then test a bit per (edge, head) instead of hashing."""
+        n_layers = len(self.conv_layers)
+        first = self.conv_layers[0]
+        if n_layers > 16 or self.n_heads > 8 or not (first.conv[TX_TX].dropout > 0):
+            return None
+        p = first.conv[TX_TX].dropout
+        out = {}
+        for which, et in ((0, TX_TX), (1, TX_BD)):
+            g = graphs.get(et)
+            if g is None or g.by_dst is None:
+                continue
+            seeds = [2 * li + which for li in range(n_layers)]
+            d = ops.dropout_bits(g.by_dst, self.n_heads, p, seeds, step)
+            s_ = ops.dropout_bits(g.by_src, self.n_heads, p, seeds, step) if g.by_src is not None else None
+            out[et] = (d, s_)
+        return out
+
     def _materialize_bd(self, d_in: int, device) -> None:
         if "bd" not in self.lin_first:
             self.lin_first["bd"] = Linear(d_in, self.in_channels).to(device)
@@ -322,8 +343,10 @@ class ISTEncoder(Module):
             # the masks the first backward regenerates.  Capture-safe: the clone lives in the graph's pool.
             self._step_dev.add_(256)
             step = self._step_dev.clone()
+        planes = self._dropout_planes(graphs, step) if self.training else None
         for li, layer in enumerate(self.conv_layers):
-            x = layer(x, edge_index_dict, graphs=graphs, apply_gelu=True, seed=(li, step))   # conv + GELU (:324-325)
+            kb = None if planes is None else {et: (d[li], None if s_ is None else s_[li]) for et, (d, s_) in planes.items()}
+            x = layer(x, edge_index_dict, graphs=graphs, apply_gelu=True, seed=(li, step), keep_bits=kb)   # conv + GELU (:324-325)
 
         x = self.lin_last(x)
         if self.normalize_embeddings:

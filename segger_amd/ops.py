@@ -39,6 +39,29 @@ def _seed_parts(seed):
     return int(seed) & 0xFFFFFFFFFFFFFFFF, None
 
 
+def _bits_ptr(bits: Tensor, n_edges: int) -> int:
+    if bits.dtype != torch.uint8 or bits.numel() != n_edges or not bits.is_contiguous():
+        raise ValueError("keep_bits must be a contiguous uint8 tensor with one entry per edge slot")
+    return bits.data_ptr()
+
+
+@torch.no_grad()
+def dropout_bits(csr: EdgeCSR, heads: int, dropout_p: float, seeds, seed_dev: Optional[Tensor] = None) -> Tensor:
+    """uint8 [len(seeds), n_edges]: the attention-dropout keep bits (bit h = head h) of ``len(seeds)`` layers over the
+    slots of one CSR view (``segger_dropout_bits``) -- generated once per training step per view, then every forward /
+    backward pass of every layer tests a bit instead of hashing per (edge, head)."""
+    _lib.require_cuda(csr.col)
+    lib = _lib.load()
+    seeds = [int(v) & 0xFFFFFFFFFFFFFFFF for v in seeds]
+    out = torch.empty((len(seeds), csr.n_edges), dtype=torch.uint8, device=csr.col.device)
+    arr = (C.c_uint64 * len(seeds))(*seeds)
+    with _lib.on_device(out.device):
+        rc = lib.segger_dropout_bits(csr.eid.data_ptr() if csr.n_edges else None, csr.n_edges, heads, dropout_p, arr,
+                                     len(seeds), _lib.ptr(seed_dev), out.data_ptr(), _lib.stream_ptr(out.device))
+    _lib.check(rc, "segger_dropout_bits")
+    return out
+
+
 def _f32_vec(t: Optional[Tensor], n: int, name: str) -> Optional[Tensor]:
     if t is None:
         return None
@@ -55,7 +78,7 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
                      heads: int, channels: int, out: Tensor, *, pre: Optional[Tensor] = None,
                      lse: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
                      apply_gelu: bool = False, negative_slope: float = 0.2,
-                     dropout_p: float = 0.0, seed: int = 0) -> None:
+                     dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tensor] = None) -> None:
     _lib.require_cuda(xl, xr, att, out)
     lib = _lib.load()
     hc = heads * channels
@@ -76,6 +99,8 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
     if pre is not None:
         a.pre, a.ld_pre = _rows(pre, hc, "pre")
     a.lse, a.alpha = _lib.ptr(lse), _lib.ptr(alpha)
+    if keep_bits is not None and dropout_p > 0.0:
+        a.keep_bits = _bits_ptr(keep_bits, by_dst.n_edges)
     with _lib.on_device(xl.device):
         rc = lib.segger_gatv2_fwd(C.byref(a), _lib.stream_ptr(xl.device))
     _lib.check(rc, "segger_gatv2_fwd")
@@ -84,7 +109,7 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
 def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optional[Tensor],
                      heads: int, channels: int, grad_out: Tensor, pre: Tensor, lse: Tensor,
                      grad_xl: Tensor, grad_xr: Tensor, *, apply_gelu: bool, negative_slope: float = 0.2,
-                     dropout_p: float = 0.0, seed: int = 0) -> Tuple[Tensor, Tensor]:
+                     dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tuple] = None) -> Tuple[Tensor, Tensor]:
     """Writes grad_xl / grad_xr (views allowed); returns (grad_att[HC], grad_bias[HC]) fp32."""
     _lib.require_cuda(xl, xr, grad_out)
     lib = _lib.load()
@@ -104,6 +129,11 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
     a.heads, a.channels, a.dtype, a.apply_gelu = heads, channels, DTYPE_CODE[dt], int(apply_gelu)
     a.negative_slope, a.dropout_p = negative_slope, dropout_p
     a.seed, a.seed_dev = _seed_parts(seed)
+    if keep_bits is not None and dropout_p > 0.0:
+        if keep_bits[0] is not None:
+            a.keep_bits_dst = _bits_ptr(keep_bits[0], g.n_edges)
+        if keep_bits[1] is not None:
+            a.keep_bits_src = _bits_ptr(keep_bits[1], g.n_edges)
     if grad_out.dtype != dt:
         grad_out = grad_out.to(dt)
     if grad_out.dim() == 2 and grad_out.shape[0] > 1 and grad_out.stride(1) != 1:
@@ -133,7 +163,7 @@ class _GatV2Aggregate(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xl, xr, att, bias, graph: EdgeGraph, heads, channels, apply_gelu,
-                negative_slope, dropout_p, seed, want_alpha):
+                negative_slope, dropout_p, seed, want_alpha, keep_bits=None):
         hc = heads * channels
         dev, dt = xl.device, xl.dtype
         n_dst = graph.n_dst
@@ -143,10 +173,12 @@ class _GatV2Aggregate(torch.autograd.Function):
         lse = torch.empty((n_dst, heads), dtype=torch.float32, device=dev) if need_grad else None
         alpha = torch.empty((graph.n_edges, heads), dtype=torch.float32, device=dev) if want_alpha else None
         gatv2_fwd_launch(graph.by_dst, xl, xr, att, bias, heads, channels, out, pre=pre, lse=lse, alpha=alpha,
-                         apply_gelu=apply_gelu, negative_slope=negative_slope, dropout_p=dropout_p, seed=seed)
+                         apply_gelu=apply_gelu, negative_slope=negative_slope, dropout_p=dropout_p, seed=seed,
+                         keep_bits=None if keep_bits is None else keep_bits[0])
         if need_grad:
             ctx.save_for_backward(xl, xr, att, bias, pre if apply_gelu else out, lse)
             ctx.graph, ctx.cfg = graph, (heads, channels, apply_gelu, negative_slope, dropout_p, seed)
+            ctx.keep_bits = keep_bits
         if want_alpha:
             ctx.mark_non_differentiable(alpha)
             return out, alpha
@@ -161,17 +193,19 @@ class _GatV2Aggregate(torch.autograd.Function):
         gxl = torch.empty((g.n_src, hc), dtype=xl.dtype, device=xl.device)
         gxr = torch.empty((g.n_dst, hc), dtype=xl.dtype, device=xl.device)
         gatt, gbias = gatv2_bwd_launch(g, xl, xr, att, bias, heads, channels, grad_out, pre, lse, gxl, gxr,
-                                       apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed)
+                                       apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed,
+                                       keep_bits=ctx.keep_bits)
         gatt = gatt.reshape(att.shape).to(att.dtype)
         gbias = gbias.reshape(bias.shape).to(bias.dtype) if bias is not None else None
-        return gxl, gxr, gatt, gbias, None, None, None, None, None, None, None, None
+        return gxl, gxr, gatt, gbias, None, None, None, None, None, None, None, None, None
 
 
 def gatv2_aggregate(xl: Tensor, xr: Tensor, att: Tensor, bias: Optional[Tensor], graph: EdgeGraph,
                     heads: int, channels: int, *, apply_gelu: bool = False, negative_slope: float = 0.2,
-                    dropout_p: float = 0.0, seed: int = 0, return_alpha: bool = False):
+                    dropout_p: float = 0.0, seed: int = 0, return_alpha: bool = False, keep_bits=None):
+    """``keep_bits`` = (by_dst bits, by_src bits or None): one layer's planes of :func:`dropout_bits` for ``seed``."""
     out, alpha = _GatV2Aggregate.apply(xl, xr, att, bias, graph, heads, channels, apply_gelu,
-                                       negative_slope, dropout_p, seed, return_alpha)
+                                       negative_slope, dropout_p, seed, return_alpha, keep_bits)
     return (out, alpha) if return_alpha else out
 
 
@@ -186,7 +220,7 @@ class _HeteroGatLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb, g_tt: EdgeGraph, g_tb: EdgeGraph,
-                heads, channels, apply_gelu, slope, dropout_p, seed_tt, seed_tb, want_alpha):
+                heads, channels, apply_gelu, slope, dropout_p, seed_tt, seed_tb, want_alpha, bits_tt=None, bits_tb=None):
         hc = heads * channels
         dev, dt = xp_tx.device, xp_tx.dtype
         need_grad = any(ctx.needs_input_grad[:6])
@@ -200,14 +234,17 @@ class _HeteroGatLayer(torch.autograd.Function):
         lse_bd = torch.empty((nb, heads), dtype=torch.float32, device=dev) if need_grad else None
         alpha = torch.empty((g_tt.n_edges, heads), dtype=torch.float32, device=dev) if want_alpha else None
         gatv2_fwd_launch(g_tt.by_dst, xl_tt, xr_tt, att_tt, bias_tt, heads, channels, y_tx, pre=pre_tx, lse=lse_tx,
-                         alpha=alpha, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tt)
+                         alpha=alpha, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tt,
+                         keep_bits=None if bits_tt is None else bits_tt[0])
         gatv2_fwd_launch(g_tb.by_dst, xl_tb, xp_bd, att_tb, bias_tb, heads, channels, y_bd, pre=pre_bd, lse=lse_bd,
-                         apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tb)
+                         apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tb,
+                         keep_bits=None if bits_tb is None else bits_tb[0])
         if need_grad:
             ctx.save_for_backward(xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb,
                                   pre_tx if apply_gelu else y_tx, pre_bd if apply_gelu else y_bd, lse_tx, lse_bd)
             ctx.graphs = (g_tt, g_tb)
             ctx.cfg = (heads, channels, apply_gelu, slope, dropout_p, seed_tt, seed_tb)
+            ctx.bits = (bits_tt, bits_tb)
         if want_alpha:
             ctx.mark_non_differentiable(alpha)
         return y_tx, y_bd, alpha
@@ -226,19 +263,23 @@ class _HeteroGatLayer(torch.autograd.Function):
             gy_bd = torch.zeros_like(pre_bd)
         gatt_tt, gbias_tt = gatv2_bwd_launch(
             g_tt, xp_tx[:, :hc], xp_tx[:, hc:2 * hc], att_tt, bias_tt, heads, channels, gy_tx, pre_tx, lse_tx,
-            gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc], apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tt)
+            gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc], apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tt,
+            keep_bits=ctx.bits[0])
         gatt_tb, gbias_tb = gatv2_bwd_launch(
             g_tb, xp_tx[:, 2 * hc:], xp_bd, att_tb, bias_tb, heads, channels, gy_bd, pre_bd, lse_bd,
-            gxp_tx[:, 2 * hc:], gxp_bd, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb)
+            gxp_tx[:, 2 * hc:], gxp_bd, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb,
+            keep_bits=ctx.bits[1])
         r = lambda gt, ref: gt.reshape(ref.shape).to(ref.dtype) if ref is not None else None
         return (gxp_tx, gxp_bd, r(gatt_tt, att_tt), r(gbias_tt, bias_tt), r(gatt_tb, att_tb), r(gbias_tb, bias_tb),
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def hetero_gat_layer(xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb, g_tt, g_tb, heads, channels, *,
-                     apply_gelu=True, negative_slope=0.2, dropout_p=0.0, seed_tt=0, seed_tb=0, return_alpha=False):
+                     apply_gelu=True, negative_slope=0.2, dropout_p=0.0, seed_tt=0, seed_tb=0, return_alpha=False,
+                     bits_tt=None, bits_tb=None):
+    """``bits_tt`` / ``bits_tb`` = (by_dst plane, by_src plane or None) of :func:`dropout_bits` for this layer."""
     return _HeteroGatLayer.apply(xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb, g_tt, g_tb, heads, channels,
-                                 apply_gelu, negative_slope, dropout_p, seed_tt, seed_tb, return_alpha)
+                                 apply_gelu, negative_slope, dropout_p, seed_tt, seed_tb, return_alpha, bits_tt, bits_tb)
 
 
 # --------------------------------------------------------------------------

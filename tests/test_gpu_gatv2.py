@@ -264,6 +264,47 @@ def test_unique_sources_need_no_by_source_view(oracle, cuda, dtype, H, C, n_src,
     assert not dup.src_unique() and dup.by_src is not None
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("H,C,n_src,n_dst,E", [(2, 64, 300, 257, 3000), (2, 64, 50, 7, 1500), (4, 32, 64, 40, 900), (3, 64, 90, 50, 400)])
+def test_dropout_bit_planes_equal_the_hash(cuda, dtype, H, C, n_src, n_dst, E):
+    """segger_dropout_bits precomputes keep(e, h) of several layers as bit planes per CSR view; forward, both backward
+    passes (and the one-pass backward) fed the planes give bit-identical results to hashing inside the kernels."""
+    from segger_amd import ops
+    from segger_amd.graph import build_edge_graph
+    g = torch.Generator().manual_seed(E + H)
+    ei = random_graph(n_src, n_dst, E, seed=E).to(cuda)
+    graph = build_edge_graph(ei, n_src, n_dst)
+    xl = torch.randn(n_src, H * C, generator=g).to(dtype).to(cuda)
+    xr = torch.randn(n_dst, H * C, generator=g).to(dtype).to(cuda)
+    att, bias = (torch.randn(H * C, generator=g) * 0.3).to(cuda), (torch.randn(H * C, generator=g) * 0.1).to(cuda)
+    w = torch.randn(n_dst, H * C, generator=g).to(cuda)
+    step = torch.tensor([512], dtype=torch.int64, device=cuda)
+    seeds = [0, 2, 4, 6]
+    planes_d = ops.dropout_bits(graph.by_dst, H, 0.25, seeds, step)
+    planes_s = ops.dropout_bits(graph.by_src, H, 0.25, seeds, step)
+    assert planes_d.shape == (4, E) and planes_d.dtype == torch.uint8
+    # the planes are the oracle-tested mask itself: plane l, slot s, bit h == keep(eid[s], h; seed_l + step)
+    keep = ops.dropout_bits(graph.by_dst, H, 0.25, [seeds[2]], step)[0]
+    assert torch.equal(keep, planes_d[2]) and 0.6 < float(((planes_d[1] >> 1) & 1).float().mean()) < 0.9
+    # same edge, both views: planes agree through the edge ids
+    full_d = torch.empty(E, dtype=torch.uint8, device=cuda); full_d[graph.by_dst.eid.long()] = planes_d[3]
+    full_s = torch.empty(E, dtype=torch.uint8, device=cuda); full_s[graph.by_src.eid.long()] = planes_s[3]
+    assert torch.equal(full_d, full_s)
+
+    def run(bits, li):
+        leaves = [t.clone().requires_grad_(True) for t in (xl, xr, att, bias)]
+        out = ops.gatv2_aggregate(*leaves, graph, H, C, apply_gelu=True, dropout_p=0.25, seed=(seeds[li], step), keep_bits=bits)
+        (out.float() * w).sum().backward()
+        return [out.detach()] + [t.grad for t in leaves]
+    for li in (0, 3):
+        a, b = run(None, li), run((planes_d[li], planes_s[li]), li)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+        c = run((planes_d[li], None), li)                   # planes for one view only: the other pass hashes
+        for x, y in zip(a, c):
+            assert torch.equal(x, y)
+
+
 def test_rejects_bad_arguments(cuda):
     from segger_amd import ops, _lib
     from segger_amd.graph import build_edge_graph

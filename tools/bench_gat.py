@@ -27,11 +27,14 @@ out = torch.empty(n, hc, dtype=torch.bfloat16, device=dev); pre = torch.empty_li
 lse = torch.empty(n, H, device=dev)
 gy = torch.randn(n, hc, device=dev, generator=gen).bfloat16(); gxp = torch.empty_like(xp)
 p = float(os.environ.get('DROP', 0.0))
-fwd = lambda: ops.gatv2_fwd_launch(g.by_dst, xp[:, :hc], xp[:, hc:2*hc], att, bias, H, C, out, pre=pre, lse=lse, apply_gelu=True, dropout_p=p, seed=5)
-bwd = lambda: ops.gatv2_bwd_launch(g, xp[:, :hc], xp[:, hc:2*hc], att, bias, H, C, gy, pre, lse, gxp[:, :hc], gxp[:, hc:2*hc], apply_gelu=True, dropout_p=p, seed=5)
+bits = None
+if os.environ.get('BITS', '0') == '1' and p > 0:    # dropout mask as precomputed bit planes (ops.dropout_bits)
+    bits = (ops.dropout_bits(g.by_dst, H, p, [5])[0], ops.dropout_bits(g.by_src, H, p, [5])[0])
+fwd = lambda: ops.gatv2_fwd_launch(g.by_dst, xp[:, :hc], xp[:, hc:2*hc], att, bias, H, C, out, pre=pre, lse=lse, apply_gelu=True, dropout_p=p, seed=5, keep_bits=None if bits is None else bits[0])
+bwd = lambda: ops.gatv2_bwd_launch(g, xp[:, :hc], xp[:, hc:2*hc], att, bias, H, C, gy, pre, lse, gxp[:, :hc], gxp[:, hc:2*hc], apply_gelu=True, dropout_p=p, seed=5, keep_bits=bits)
 def t(fn, it=20):
     for _ in range(3): fn()
     torch.cuda.synchronize(); a = torch.cuda.Event(True); e = torch.cuda.Event(True); a.record()
     for _ in range(it): fn()
     e.record(); torch.cuda.synchronize(); return a.elapsed_time(e) / it
-print(mode, os.path.basename(os.environ.get('SEGGER_AMD_LIB', 'default')), 'order', os.environ.get('ORDER', '1'), 'drop', p, 'fwd %.3f ms  bwd(dst+src) %.3f ms' % (t(fwd), t(bwd)), flush=True)
+print(mode, os.path.basename(os.environ.get('SEGGER_AMD_LIB', 'default')), 'bits', os.environ.get('BITS', '0'), 'drop', p, 'fwd %.3f ms  bwd(dst+src) %.3f ms' % (t(fwd), t(bwd)), flush=True)
