@@ -322,6 +322,23 @@ int segger_triplet_sample(const int64_t* lab, int64_t n, int32_t n_clusters, con
                           const float* dists, int64_t* pos, int64_t* neg, float* d_pos, float* d_neg,
                           segger_stream_t stream);
 
+/*
+ * segger_metric_fwd / _bwd: MetricLoss.forward (src/segger/models/triplet_loss.py:163-204) on sampled triplets,
+ *   loss = sum_i w_i * [ (cos(z_i, z_pos_i) - (1 - d_pos_i))^2 + (cos(z_i, z_neg_i) - (1 - d_neg_i))^2 ]
+ * with cos(x, y) = sum (x / max(|x|, eps)) * (y / max(|y|, eps)) (torch.cosine_similarity, eps = 1e-8) and w_i the
+ * weight of node i (1/n for the reference's plain mean; mask_i / #masked for the masked form).  pos_i / neg_i < 0
+ * (or w_i == 0) skip the node.  ~40 torch launches forward and as many backward become one kernel each.
+ *   fwd: partial sums in workspace (segger_triplet_workspace_bytes(n)), mean in loss[0].
+ *   bwd: grad_z [n, C] fp32, ZERO-FILLED by the caller, receives d loss / d z scaled by grad_scale_dev[0]
+ *        (own row: plain add by the owning lanes; positive / negative rows: fp32 atomics).
+ */
+int segger_metric_fwd(const void* z, int64_t ld_z, int64_t n, int32_t channels, int32_t dtype, const int64_t* pos,
+                      const int64_t* neg, const float* d_pos, const float* d_neg, const float* w, float eps,
+                      float* loss, void* workspace, size_t workspace_bytes, segger_stream_t stream);
+int segger_metric_bwd(const void* z, int64_t ld_z, int64_t n, int32_t channels, int32_t dtype, const int64_t* pos,
+                      const int64_t* neg, const float* d_pos, const float* d_neg, const float* w, float eps,
+                      const float* grad_scale_dev, float* grad_z, segger_stream_t stream);
+
 size_t segger_triplet_workspace_bytes(int64_t n_edges);
 int segger_triplet_fwd(const segger_triplet_args* args, segger_stream_t stream);
 int segger_triplet_bwd(const segger_triplet_args* args, segger_stream_t stream);

@@ -113,6 +113,9 @@ EXPORTS = {
     "segger_coo_unique": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
     "segger_edge_cos_argmax": (C.c_int, [C.POINTER(EdgeArgmaxArgs), vp]),
     "segger_triplet_sample": (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]),
+    "segger_metric_fwd": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.c_float, vp, vp,
+                                    C.c_size_t, vp]),
+    "segger_metric_bwd": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp]),
     "segger_triplet_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "segger_triplet_fwd": (C.c_int, [C.POINTER(TripletArgs), vp]),
     "segger_triplet_bwd": (C.c_int, [C.POINTER(TripletArgs), vp]),

@@ -473,6 +473,67 @@ __global__ __launch_bounds__(256) void triplet_sample_kernel(SampleParams p) {
   if (p.d_pos) { p.d_pos[i] = p.dists[r * K + cl[0]]; p.d_neg[i] = p.dists[r * K + cl[1]]; }
 }
 
+// ---- MetricLoss on sampled triplets: 16 lanes per node, 4 nodes per wave-iteration ----------------------------------
+struct MetricParams {
+  const void* z; int64_t ld; int64_t n; int channels;
+  const int64_t* pos; const int64_t* neg; const float* dpos; const float* dneg; const float* w; float eps;
+  float* partial; const float* scale_dev; float* gz;
+};
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void metric_kernel(MetricParams p) {
+  __shared__ float wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane >> 4, gl = lane & 15;
+  const int C = p.channels;
+  const T* z = static_cast<const T*>(p.z);
+  float acc = 0.f;
+  const int64_t base = (int64_t)blockIdx.x * kTripletEdgesPerBlock;
+#pragma unroll 1
+  for (int k = wave * 4 + grp; k < kTripletEdgesPerBlock; k += 16) {
+    const int64_t i = base + k;
+    bool ok = i < p.n;
+    int64_t ip = ok ? p.pos[i] : 0, in = ok ? p.neg[i] : 0;
+    const float w = ok ? p.w[i] : 0.f;
+    if ((uint64_t)ip >= (uint64_t)p.n || (uint64_t)in >= (uint64_t)p.n || w == 0.f) { ok = false; ip = in = 0; }
+    const int64_t ii = ok ? i : 0;
+    float sxx = 0.f, spp = 0.f, snn = 0.f, sxp = 0.f, sxn = 0.f;
+    for (int c = gl; c < C; c += 16) {
+      const float x = load1(z + ii * p.ld + c), yp = load1(z + ip * p.ld + c), yn = load1(z + in * p.ld + c);
+      sxx = fmaf(x, x, sxx); spp = fmaf(yp, yp, spp); snn = fmaf(yn, yn, snn);
+      sxp = fmaf(x, yp, sxp); sxn = fmaf(x, yn, sxn);
+    }
+    sxx = lane_block_sum<16>(sxx); spp = lane_block_sum<16>(spp); snn = lane_block_sum<16>(snn);
+    sxp = lane_block_sum<16>(sxp); sxn = lane_block_sum<16>(sxn);
+    const float nx = sqrtf(sxx), np_ = sqrtf(spp), nn_ = sqrtf(snn);
+    const float cx = fmaxf(nx, p.eps), cp = fmaxf(np_, p.eps), cn = fmaxf(nn_, p.eps);
+    const float cos_p = sxp / (cx * cp), cos_n = sxn / (cx * cn);
+    const float rp = cos_p - (1.f - (ok ? p.dpos[i] : 0.f)), rn = cos_n - (1.f - (ok ? p.dneg[i] : 0.f));
+    if (!BWD) {
+      if (ok && gl == 0) acc += w * (rp * rp + rn * rn);
+    } else if (ok) {
+      const float sc = p.scale_dev ? p.scale_dev[0] : 1.f;
+      const float gp = 2.f * w * rp * sc, gn = 2.f * w * rn * sc;         // d loss / d cos
+      // d cos(x, y) / d x = y / (cx cy) - [|x| > eps] cos x / |x|^2     (a clamped norm is a constant)
+      const float ax = (nx > p.eps ? (gp * cos_p + gn * cos_n) / sxx : 0.f);
+      const float bp = (np_ > p.eps ? gp * cos_p / spp : 0.f), bn = (nn_ > p.eps ? gn * cos_n / snn : 0.f);
+      const float ip_ = gp / (cx * cp), in_ = gn / (cx * cn);
+      for (int c = gl; c < C; c += 16) {
+        const float x = load1(z + i * p.ld + c), yp = load1(z + ip * p.ld + c), yn = load1(z + in * p.ld + c);
+        atomicAdd(p.gz + i * C + c, ip_ * yp + in_ * yn - ax * x);
+        atomicAdd(p.gz + ip * C + c, ip_ * x - bp * yp);
+        atomicAdd(p.gz + in * C + c, in_ * x - bn * yn);
+      }
+    }
+  }
+  if (!BWD) {
+    acc = wave_sum(acc);
+    if (lane == 0) wsum[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) p.partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+}
+
 int64_t triplet_blocks(int64_t n_edges) { return (n_edges + kTripletEdgesPerBlock - 1) / kTripletEdgesPerBlock; }
 
 }  // namespace
@@ -601,4 +662,60 @@ extern "C" int segger_triplet_sample(const int64_t* lab, int64_t n, int32_t n_cl
   hipLaunchKernelGGL(triplet_sample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
   SEGGER_LAUNCH_CHECK("triplet_sample_kernel");
   return SEGGER_OK;
+}
+
+static int metric_common(const void* z, int64_t ld_z, int64_t n, int32_t channels, int32_t dtype, const int64_t* pos,
+                         const int64_t* neg, const float* d_pos, const float* d_neg, const float* w, float eps,
+                         float* loss, void* workspace, size_t workspace_bytes, const float* scale_dev, float* grad_z,
+                         bool bwd, hipStream_t stream) {
+  SEGGER_REQUIRE(n >= 0 && channels > 0 && ld_z >= channels, "segger_metric: bad sizes");
+  if (n == 0) {
+    if (!bwd && loss) SEGGER_HIP(hipMemsetAsync(loss, 0, sizeof(float), stream));
+    return SEGGER_OK;
+  }
+  SEGGER_REQUIRE(z && pos && neg && d_pos && d_neg && w, "segger_metric: NULL input");
+  const int64_t nb = triplet_blocks(n);
+  MetricParams p{z, ld_z, n, channels, pos, neg, d_pos, d_neg, w, eps, static_cast<float*>(workspace), scale_dev, grad_z};
+  if (!bwd) {
+    SEGGER_REQUIRE(loss != nullptr, "segger_metric_fwd: loss is NULL");
+    const size_t need = segger_triplet_workspace_bytes(n);
+    if (!workspace || workspace_bytes < need) {
+      set_error("segger_metric_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+      return SEGGER_EWORKSPACE;
+    }
+  } else {
+    SEGGER_REQUIRE(grad_z != nullptr, "segger_metric_bwd: grad_z is NULL");
+  }
+  dim3 grid((unsigned)nb), block(256);
+#define LAUNCH_M(T)                                                                                \
+  do {                                                                                             \
+    if (bwd) hipLaunchKernelGGL((metric_kernel<T, true>), grid, block, 0, stream, p);              \
+    else     hipLaunchKernelGGL((metric_kernel<T, false>), grid, block, 0, stream, p);             \
+  } while (0)
+  switch (dtype) {
+    case SEGGER_F32:  LAUNCH_M(float); break;
+    case SEGGER_BF16: LAUNCH_M(bf16_t); break;
+    case SEGGER_F16:  LAUNCH_M(f16_t); break;
+    default: set_error("segger_metric: unknown dtype %d", dtype); return SEGGER_EINVAL;
+  }
+#undef LAUNCH_M
+  SEGGER_LAUNCH_CHECK("metric_kernel");
+  if (!bwd) {
+    hipLaunchKernelGGL(triplet_finish_kernel, dim3(1), dim3(256), 0, stream, p.partial, nb, 1.0f, loss);
+    SEGGER_LAUNCH_CHECK("triplet_finish_kernel");
+  }
+  return SEGGER_OK;
+}
+
+extern "C" int segger_metric_fwd(const void* z, int64_t ld_z, int64_t n, int32_t channels, int32_t dtype, const int64_t* pos,
+                                 const int64_t* neg, const float* d_pos, const float* d_neg, const float* w, float eps,
+                                 float* loss, void* workspace, size_t workspace_bytes, segger_stream_t stream) {
+  return metric_common(z, ld_z, n, channels, dtype, pos, neg, d_pos, d_neg, w, eps, loss, workspace, workspace_bytes,
+                       nullptr, nullptr, false, (hipStream_t)stream);
+}
+extern "C" int segger_metric_bwd(const void* z, int64_t ld_z, int64_t n, int32_t channels, int32_t dtype, const int64_t* pos,
+                                 const int64_t* neg, const float* d_pos, const float* d_neg, const float* w, float eps,
+                                 const float* grad_scale_dev, float* grad_z, segger_stream_t stream) {
+  return metric_common(z, ld_z, n, channels, dtype, pos, neg, d_pos, d_neg, w, eps, nullptr, nullptr, 0, grad_scale_dev,
+                       grad_z, true, (hipStream_t)stream);
 }

@@ -416,6 +416,53 @@ def triplet_edge_loss(za: Tensor, zb: Optional[Tensor], src: Tensor, pos: Tensor
     return _TripletEdgeLoss.apply(za, zb, src, pos, neg, float(margin), float(eps), pos_groups)
 
 
+class _MetricLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, pos, neg, d_pos, d_neg, w, eps):
+        _lib.require_cuda(z, pos)
+        lib = _lib.load()
+        dev = z.device
+        if z.dtype not in DTYPE_CODE:
+            raise TypeError("metric_loss: unsupported embedding dtype")
+        n, c = z.shape
+        zp, ld = _rows(z, c, "z")
+        pos, neg = pos.to(torch.int64).contiguous(), neg.to(torch.int64).contiguous()
+        d_pos, d_neg, w = (t.to(torch.float32).contiguous() for t in (d_pos, d_neg, w))
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        ws_bytes = lib.segger_triplet_workspace_bytes(n)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _lib.on_device(dev):
+            rc = lib.segger_metric_fwd(zp, ld, n, c, DTYPE_CODE[z.dtype], pos.data_ptr(), neg.data_ptr(), d_pos.data_ptr(),
+                                       d_neg.data_ptr(), w.data_ptr(), eps, loss.data_ptr(), ws.data_ptr(), ws_bytes,
+                                       _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_metric_fwd")
+        ctx.save_for_backward(z, pos, neg, d_pos, d_neg, w)
+        ctx.eps = eps
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        z, pos, neg, d_pos, d_neg, w = ctx.saved_tensors
+        lib = _lib.load()
+        dev = z.device
+        n, c = z.shape
+        zp, ld = _rows(z, c, "z")
+        gz = torch.zeros((n, c), dtype=torch.float32, device=dev)
+        gs = g.detach().to(torch.float32).reshape(1).contiguous()
+        with _lib.on_device(dev):
+            rc = lib.segger_metric_bwd(zp, ld, n, c, DTYPE_CODE[z.dtype], pos.data_ptr(), neg.data_ptr(), d_pos.data_ptr(),
+                                       d_neg.data_ptr(), w.data_ptr(), ctx.eps, gs.data_ptr(), gz.data_ptr(),
+                                       _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_metric_bwd")
+        return gz.to(z.dtype), None, None, None, None, None, None
+
+
+def metric_loss(z: Tensor, pos: Tensor, neg: Tensor, d_pos: Tensor, d_neg: Tensor, w: Tensor, eps: float = 1e-8) -> Tensor:
+    """sum_i w_i [(cos(z_i, z_pos_i) - (1 - d_pos_i))^2 + (cos(z_i, z_neg_i) - (1 - d_neg_i))^2]: MetricLoss
+    (triplet_loss.py:176-204) on sampled triplets, one kernel forward and one backward; ``pos_i < 0`` skips node i."""
+    return _MetricLoss.apply(z, pos, neg, d_pos, d_neg, w, float(eps))
+
+
 @torch.no_grad()
 def triplet_sample(index: dict, uniforms=None):
     """``FastTripletSelector.sample_triplets`` in one launch (``segger_triplet_sample``) from the selector's index

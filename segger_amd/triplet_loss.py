@@ -197,6 +197,9 @@ class MetricLoss:
         if "weight" not in index:
             index["weight"] = mask.float() / _masked_count(mask)
         pos, neg, d_pos, d_neg = self.selector.sample_triplets(labels, uniforms, index=index)
+        if embeddings.is_cuda:
+            from . import ops
+            return ops.metric_loss(embeddings, pos, neg, d_pos, d_neg, index["weight"])
         e = embeddings.float()
         w = index["weight"]
         cos_pos = torch.cosine_similarity(e, e[pos.clamp(min=0)])
