@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEGGER_ABI_VERSION 4
+#define SEGGER_ABI_VERSION 5
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -188,7 +188,7 @@ typedef struct segger_gatv2_bwd_args {
   const float* lse;       /* [n_dst, H] from forward */
   void* grad_pre;         /* [n_dst, H*C] scratch+output: dL/d pre (dtype) */
   int64_t ld_gp;
-  float* dsum;            /* [n_dst, H] scratch: sum_c grad_pre * (pre - bias) */
+  float* dsum;            /* [n_dst, H, 2] scratch: (lse, D) pairs, D = sum_c grad_pre * (pre - bias) */
   void* grad_xl;          /* [n_src, H*C] */
   int64_t ld_gxl;
   void* grad_xr;          /* [n_dst, H*C] */

@@ -76,7 +76,7 @@ struct GatParams {
   // backward
   const void* gout; int64_t ld_go;
   void* gpre; int64_t ld_gp;     // dst pass: output; src pass: input
-  float* dsum;                   // dst pass: output; src pass: input
+  float* dsum;                   // [n_dst, H, 2] = (lse, D) pairs -- dst pass: output; src pass: input
   void* gxl; int64_t ld_gxl;
   void* gxr; int64_t ld_gxr;
   float* slab;                   // [nblocks][2][HC] partial grad_att | grad_bias
@@ -506,7 +506,8 @@ __global__ __launch_bounds__(256, DIRECT ? 2 : SEGGER_BWD_DST_WAVES) void gatv2_
     const bool writer = row_ok && L.lane_on && (!WPR || L.grp == 0);
     if (writer) {
       store_pairs(static_cast<T*>(p.gpre) + row * p.ld_gp + ch0, g);
-      if (head_leader) p.dsum[row * H + h] = D;
+      if (head_leader)      // (lse, D) side by side: the source pass fetches both with one 8-byte load per (edge, head)
+        *reinterpret_cast<float2*>(p.dsum + (row * H + h) * 2) = float2{lse, D};
 #pragma unroll
       for (int i = 0; i < 4; ++i) dbias[i] = dbias[i] + g[i];
     }
@@ -666,8 +667,8 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
     for (int u = 0; u < U; ++u) {
       rxr[u].load(row_ptr(xr_base, nbr[u], ld_xr));
       rg[u].load(row_ptr(g_base, nbr[u], ld_gp));
-      lse[u] = p.lse[(int64_t)nbr[u] * H + h];
-      D[u] = p.dsum[(int64_t)nbr[u] * H + h];
+      const float2 ld = *reinterpret_cast<const float2*>(p.dsum + ((int64_t)nbr[u] * H + h) * 2);
+      lse[u] = ld.x; D[u] = ld.y;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {

@@ -142,7 +142,7 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
     a.pre, a.ld_pre = _rows(pre, hc, "pre")
     a.lse = lse.data_ptr()
     grad_pre = torch.empty((n_dst, hc), dtype=dt, device=dev)
-    dsum = torch.empty((n_dst, heads), dtype=torch.float32, device=dev)
+    dsum = torch.empty((n_dst, heads, 2), dtype=torch.float32, device=dev)     # (lse, D) pairs for the source pass
     a.grad_pre, a.ld_gp = _rows(grad_pre, hc, "grad_pre")
     a.dsum = dsum.data_ptr()
     a.grad_xl, a.ld_gxl = _rows(grad_xl, hc, "grad_xl")
