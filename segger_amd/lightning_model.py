@@ -230,7 +230,9 @@ class LitISTEncoder(_Base):
         flush_validation()                 # the copies above synchronised: surface a bad edge_index of this batch now
         return out
 
-    def configure_optimizers(self) -> torch.optim.Optimizer:
+    def configure_optimizers(self, capturable: bool = False) -> torch.optim.Optimizer:
+        """Adam as in the reference (lightning_model.py:300-303).  ``capturable`` (not in the reference): keep the
+        step counters on the device so that ``train_step_graph.GraphedTrainStep`` can capture ``optimizer.step()``."""
         params = list(self.parameters())
         fused = bool(params) and all(p.is_cuda for p in params)     # one multi-tensor kernel on the GPU
-        return torch.optim.Adam(params, lr=self.learning_rate, fused=fused)
+        return torch.optim.Adam(params, lr=self.learning_rate, fused=fused, capturable=bool(capturable and fused))

@@ -464,10 +464,11 @@ def metric_loss(z: Tensor, pos: Tensor, neg: Tensor, d_pos: Tensor, d_neg: Tenso
 
 
 @torch.no_grad()
-def triplet_sample(index: dict, uniforms=None):
+def triplet_sample(index: dict, uniforms=None, seed_dev: Optional[Tensor] = None, seed: Optional[int] = None):
     """``FastTripletSelector.sample_triplets`` in one launch (``segger_triplet_sample``) from the selector's index
     (``triplet_loss.FastTripletSelector.build_index``).  ``uniforms``: four [n] tensors, or None for the kernel's own
-    counter-based U[0,1) stream, seeded from torch's CPU generator (so ``torch.manual_seed`` still fixes a run)."""
+    counter-based U[0,1) stream, seeded from torch's CPU generator (so ``torch.manual_seed`` still fixes a run) or from
+    ``seed`` + the device word ``seed_dev`` (read at run time: a captured hipGraph draws afresh on every replay)."""
     lab = index["lab"]
     _lib.require_cuda(lab)
     lib = _lib.load()
@@ -477,7 +478,7 @@ def triplet_sample(index: dict, uniforms=None):
     seed = 0
     if uniforms is not None:
         u = torch.stack([t.to(device=dev, dtype=torch.float32) for t in uniforms]).contiguous()
-    else:
+    elif seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # CPU generator: no kernel, no sync
     pos = torch.empty(n, dtype=torch.int64, device=dev)
     neg = torch.empty(n, dtype=torch.int64, device=dev)
@@ -485,7 +486,8 @@ def triplet_sample(index: dict, uniforms=None):
     with _lib.on_device(dev):
         rc = lib.segger_triplet_sample(lab.data_ptr(), n, int(index["n_clusters"]), index["cdf_pos_t"].data_ptr(),
                                        index["cdf_neg_t"].data_ptr(), index["counts"].data_ptr(),
-                                       index["offsets"].data_ptr(), index["members"].data_ptr(), _lib.ptr(u), seed, None,
+                                       index["offsets"].data_ptr(), index["members"].data_ptr(), _lib.ptr(u),
+                                       int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(seed_dev),
                                        index["dists"].data_ptr(), pos.data_ptr(), neg.data_ptr(), dd[0].data_ptr(),
                                        dd[1].data_ptr(), _lib.stream_ptr(dev))
     _lib.check(rc, "segger_triplet_sample")

@@ -75,7 +75,7 @@ class FastTripletSelector:
 
     @torch.no_grad()
     def sample_triplets(self, labels: Tensor, uniforms: Optional[Tuple[Tensor, Tensor, Tensor, Tensor]] = None,
-                        index: Optional[dict] = None, mask: Optional[Tensor] = None):
+                        index: Optional[dict] = None, mask: Optional[Tensor] = None, device_seed=None):
         """-> positives, negatives, dists_pos, dists_neg (all [N]).  ``uniforms`` overrides the
         four U[0,1) draws (positive cluster, positive member, negative cluster, negative member).
         With a ``mask`` (given here or baked into ``index``), rows outside it hold ``-1``."""
@@ -85,6 +85,8 @@ class FastTripletSelector:
         n = ix["labels"].numel()
         if dev.type == "cuda":                               # one fused kernel (segger_triplet_sample)
             from . import ops
+            if device_seed is not None:                      # (constant, device word): fresh draws on every graph replay
+                return ops.triplet_sample(ix, uniforms, seed=device_seed[0], seed_dev=device_seed[1])
             return ops.triplet_sample(ix, uniforms)
         if uniforms is None:
             u = [torch.rand(n, device=dev) for _ in range(4)]

@@ -1,0 +1,123 @@
+"""Whole-step hipGraph (segger_amd.train_step_graph): the padded, captured step must compute the gradients of the eager
+step on the real batch, must not count its warm-up as a training step, and must draw afresh on every replay."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(spec, dev, dtype):
+    from tests.test_gpu_model import build
+    m, _, b, _ = build(spec, dev, dtype=dtype)
+    m.train()
+    m._max_epochs_override, m.current_epoch = 20, 12
+    return m, b.to(dev)
+
+
+def _fixed_draws(m, bg):
+    tx, bd = bg["tx"], bg["bd"]
+    from segger_amd.hetero import TX_BD
+    pos, neg, _, _ = m.loss_tx.selector.sample_triplets(tx["cluster"], mask=tx["mask"])
+    bmask = bd["mask"] & (bd["cluster"] >= 0)
+    bpos, bneg, dp, dn = m.loss_bd.selector.sample_triplets(bd["cluster"], mask=bmask)
+    dst = bg[TX_BD].edge_index[1]
+    n_bd = bd.num_nodes
+    dst_neg = (dst + torch.randint(1, n_bd, dst.shape, device=dst.device)) % n_bd
+    return dict(tx=(pos, neg), bd=(bpos, bneg, dp, dn), dst_neg=dst_neg, bmask=bmask)
+
+
+def _eager_grads(m, bg, d):
+    """The eager step's loss (lightning_model.get_losses) with the draws given instead of sampled."""
+    from segger_amd import ops
+    from segger_amd.hetero import TX_BD
+    m.zero_grad(set_to_none=True)
+    z = m(bg)
+    n = bg["tx"].num_nodes
+    l_tx = ops.triplet_edge_loss(z["tx"], None, torch.arange(n, device=z["tx"].device), *d["tx"], m.loss_tx.margin,
+                                 eps=m.loss_tx.eps) * (n / bg["tx"]["mask"].sum().float())
+    l_bd = ops.metric_loss(z["bd"], *d["bd"], d["bmask"].float() / d["bmask"].sum().float())
+    l_sg = m._segmentation_loss(z, bg, d["dst_neg"])
+    w = m._scheduled_weights(m._w_start, m._w_end)
+    loss = float(w[0]) * l_tx + float(w[1]) * l_bd + float(w[2]) * l_sg
+    loss.backward()
+    return torch.stack([l_tx, l_bd, l_sg, loss]).detach().float(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+
+def _pad_draws(step, d):
+    s = step.sizes
+    def pad(t, n, fill):
+        return torch.cat([t, torch.full((n - t.numel(),), fill, dtype=t.dtype, device=t.device)])
+    return dict(tx=tuple(pad(t, s["tx"], -1) for t in d["tx"]),
+                bd=tuple(pad(t, s["bd"], -1 if i < 2 else 0) for i, t in enumerate(d["bd"])),
+                dst_neg=pad(d["dst_neg"], s["e_tb"], 0))
+
+
+@pytest.mark.parametrize("capture", [False, True])
+def test_graphed_step_gradients_equal_eager_step(cuda, capture):
+    from segger_amd.synthetic import SyntheticSpec
+    from segger_amd.train_step_graph import GraphedTrainStep, step_bucket
+    spec = SyntheticSpec(n_tx=5000, n_bd=170, k_tx=7, seed=31)
+    m, bg = _model(spec, cuda, torch.float32)
+    torch.manual_seed(5)
+    d = _fixed_draws(m, bg)
+    m2 = copy.deepcopy(m)
+    m2.set_similarities(m.loss_tx.selector.similarity, m.loss_bd.selector.similarity)
+    ref_losses, ref = _eager_grads(m, bg, d)              # dropout stream: counter 0 -> 256 in both models
+    before = {k: p.detach().clone() for k, p in m2.named_parameters()}
+    opt = m2.configure_optimizers(capturable=True)
+    step = GraphedTrainStep(m2, opt, step_bucket(bg, granularity=1.3), bg)
+    step.draws = _pad_draws(step, d)
+    out = step.step(bg, capture=capture).clone()
+    assert int(m2.model._step_dev) == 256                  # the warm-up run was rolled back: ONE step happened
+    assert torch.allclose(out, ref_losses, rtol=1e-4, atol=1e-6)
+    moved = 0
+    for k, p in m2.named_parameters():
+        g, r = p.grad, ref[k]
+        assert (g - r).abs().max().item() <= 2e-4 * r.abs().max().item() + 1e-7, k
+        # one Adam step from zero state moves every weight with a gradient by ~lr, the others not at all
+        delta = (p.detach() - before[k]).abs()
+        assert delta.max().item() <= 1.01 * m2.learning_rate
+        moved += int((delta > 0).sum())
+    assert moved > 0
+    st = opt.state[next(iter(m2.parameters()))]
+    assert float(st["step"]) == 1.0
+
+
+def test_graphed_trainer_replays_learn_and_draw_afresh(cuda):
+    from segger_amd import tiles as T
+    from segger_amd.synthetic import SyntheticSpec
+    from segger_amd.train_step_graph import GraphedTrainer
+    spec = SyntheticSpec(n_tx=30000, n_bd=900, k_tx=6, seed=37)
+    m, bg = _model(spec, cuda, torch.bfloat16)
+    for nt in ("tx", "bd"):
+        del bg[nt]["mask"]                                  # the tiling assigns its own margin mask
+    tiling = T.SquareTiling(torch.cat([bg["tx"].pos, bg["bd"].pos]).cpu(), 60.0)
+    part = T.partition_by_tiling(bg, tiling, margin=3.0)
+    part.build_csr()
+    sampler = T.TileBatchSampler(part, max_num=max(part.weights("edge")) * 4, mode="edge", skip_too_big=True)
+    batches = [ids for ids in sampler if all(part.node_sizes["bd"][t] > 1 for t in ids)]
+    assert len(batches) >= 3
+    opt = m.configure_optimizers(capturable=True)
+    trainer = GraphedTrainer(m, opt, granularity=1.5)
+    first, last = [], []
+    for ep in range(8):
+        for ids in batches:
+            out = trainer.step(part.batch(ids)).clone()
+            assert torch.isfinite(out).all()
+            if ep in (0, 7):
+                (first if ep == 0 else last).append(float(out[3]))
+    assert trainer.n_captures < len(batches) * 8            # replays, not a capture per step
+    assert sum(last) < sum(first)          # it learns
+    # same batch, same weights cannot be arranged (the step trains); but the sampler stream must move: two replays of
+    # one batch give different loss_tx AND the dropout counter advanced once per step
+    a = trainer.step(part.batch(batches[0])).clone()
+    b = trainer.step(part.batch(batches[0])).clone()
+    assert not torch.equal(a, b)
+    assert int(m.model._step_dev) == 256 * (8 * len(batches) + 2)
+    # eager evaluation after graphed training sees the trained weights (cache invalidated after every replay)
+    m.eval()
+    with torch.no_grad():
+        z = m(part.batch(batches[0]))
+    assert torch.isfinite(z["tx"].float()).all()

@@ -68,6 +68,9 @@ def main():
                     help="epochs over the batch stream; the LAST one is reported as `train`, all of them in "
                          "`train.epochs_s` (the first epoch builds the per-tile sampler indices)")
     ap.add_argument("--train-dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--graphed-train", action="store_true",
+                    help="single rank: the whole step (fwd + losses + bwd + Adam) as one hipGraph replay per batch "
+                         "(segger_amd.train_step_graph)")
     ap.add_argument("--score-dtypes", default="f32,bf16,f16")
     ap.add_argument("--graphed", action="store_true", help="also run the hipGraph-captured predictor (fp16)")
     ap.add_argument("--overlap-predict", action="store_true",
@@ -136,7 +139,8 @@ def main():
     model.set_similarities(aux["tx_similarity"].to(dev), aux["bd_similarity"].to(dev))
     model._max_epochs_override = 20
     model.current_epoch = 10
-    opt = model.configure_optimizers()
+    graphed_train = bool(args.graphed_train and world == 1)
+    opt = model.configure_optimizers(capturable=graphed_train)
     broadcast_parameters(model)
     seed_rank(args.seed, rank, model.model)
     bucket = FlatGradBucket(model.parameters())
@@ -148,7 +152,14 @@ def main():
     w_all = part.weights("edge")
     sched = rank_schedule([sum(w_all[t] for t in ids) for ids in todo], world)[rank]
 
+    trainer = None
+    if graphed_train:
+        from segger_amd.train_step_graph import GraphedTrainer
+        trainer = GraphedTrainer(model, opt)
+
     def train_step(k, i):
+        if trainer is not None:
+            return trainer.step(part.batch(todo[k]))[3]
         opt.zero_grad(set_to_none=True)
         loss = None
         if k is not None:                                    # None: this rank ran out of batches (empty step)
@@ -193,6 +204,7 @@ def main():
         "mp_edges_per_s": 4.0 * (ett_seen + etb_seen) / times["train_s"],
         "final_loss": float(loss.detach()) if loss is not None else None,
         "epochs_s": epochs_s, "ms_per_step_by_epoch": [e / max(len(sched), 1) * 1e3 for e in epochs_s],
+        "graphed": graphed_train, "graph_buckets": None if trainer is None else [b.sizes for b in trainer.buckets],
     }
     if rank != 0:                                            # scoring / prediction: rank 0 only
         dist.destroy_process_group()
