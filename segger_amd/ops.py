@@ -475,9 +475,9 @@ def triplet_sample(index: dict, uniforms=None, seed_dev: Optional[Tensor] = None
     dev = lab.device
     n = int(lab.numel())
     u = None
-    seed = 0
     if uniforms is not None:
         u = torch.stack([t.to(device=dev, dtype=torch.float32) for t in uniforms]).contiguous()
+        seed = 0
     elif seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # CPU generator: no kernel, no sync
     pos = torch.empty(n, dtype=torch.int64, device=dev)

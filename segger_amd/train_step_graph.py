@@ -8,8 +8,10 @@ batch padded into the bucket's static buffers:
 
 * nodes are padded with copies of node 0 (positions included: per-graph min / max unchanged), ``mask`` False;
 * padding edges touch dummy nodes only and are laid out so that the CSR views need no sort: tx-neighbors-tx pads with
-  self-loops on the dummies (identical by-destination and by-source views), tx-belongs-bd gives every padding edge a
-  dummy source of its own (the one-pass backward's "at most one out-edge per source" keeps holding);
+  self-loops on the dummies (identical by-destination and by-source views); tx-belongs-bd pads run from the dummy
+  transcripts (round robin) to the dummy boundaries.  No loss term reads a dummy row, so every gradient that reaches a
+  dummy is exactly zero: the one-pass tx-belongs-bd backward, which WRITES one source row per edge, may see a dummy
+  source twice -- both writes store zero -- and the weight gradients, which sum over all rows, are untouched;
 * the real part of every view is copied from the batch's own CSR (sliced from the slide-level sort by
   ``tiles.TilePartition``), the padding part is index arithmetic; real edges keep their COO positions, so the
   attention-dropout masks of real edges are the ones the eager step would draw;
@@ -35,19 +37,20 @@ from .hetero import TX_BD, TX_TX
 _NODE_ATTRS = ("x", "pos", "batch", "mask", "cluster")
 
 
-def step_bucket(batch, granularity: float = 1.15, floor: int = 1024) -> Dict[str, int]:
+def step_bucket(batch, granularity: float = 1.06, floor: int = 256) -> Dict[str, int]:
     """Bucket sizes for one batch: counts rounded up to the next power of ``granularity`` (> the count: every node type
-    keeps at least one dummy); the transcript bucket leaves one dummy per tx-belongs-bd padding edge."""
-    def up(n: int) -> int:
+    keeps at least one dummy).  The boundary-side counts are a small part of the work and get one granule of headroom
+    more, so that batches which agree on the transcript side share a bucket."""
+    def up(n: int, extra: int = 0) -> int:
         b = floor
         while b <= n:
             b = int(b * granularity) + 1
+        for _ in range(extra):
+            b = int(b * granularity) + 1
         return b
     e_tt, e_tb = int(batch[TX_TX].edge_index.shape[1]), int(batch[TX_BD].edge_index.shape[1])
-    sizes = {"bd": up(batch["bd"].num_nodes), "e_tt": up(e_tt), "e_tb": up(e_tb),
-             "graphs": up(int(getattr(batch, "num_graphs", 1)))}
-    sizes["tx"] = up(batch["tx"].num_nodes + sizes["e_tb"] - e_tb)
-    return sizes
+    return {"tx": up(batch["tx"].num_nodes), "bd": up(batch["bd"].num_nodes, 1), "e_tt": up(e_tt), "e_tb": up(e_tb, 1),
+            "graphs": up(int(getattr(batch, "num_graphs", 1)), 1)}
 
 
 class GraphedTrainStep:
@@ -72,7 +75,7 @@ class GraphedTrainStep:
             return EdgeCSR(z(n_rows + 1, dtype=torch.long), z(n_edges, dtype=torch.int32),
                            z(n_edges, dtype=torch.int32), n_rows, n_cols)
         self.g_tt = EdgeGraph(csr(nt, nt, ett), csr(nt, nt, ett), nt, nt, ett)
-        self.g_tb = EdgeGraph(csr(nb, nt, etb), None, nt, nb, etb, None, True)        # unique sources by construction
+        self.g_tb = EdgeGraph(csr(nb, nt, etb), None, nt, nb, etb, None, True)        # one-pass backward (see above)
         self.ei_tb = z(2, etb, dtype=torch.long)
         self.counts = z(3, dtype=torch.long)                  # real n_tx, n_bd, e_tb of the staged batch
         self.weights = z(3)                                   # scheduled loss weights (tx, bd, sg)
@@ -87,14 +90,19 @@ class GraphedTrainStep:
         s = self.sizes
         e_tb = int(batch[TX_BD].edge_index.shape[1])
         return (batch["bd"].num_nodes < s["bd"] and int(batch[TX_TX].edge_index.shape[1]) <= s["e_tt"]
-                and e_tb <= s["e_tb"] and batch["tx"].num_nodes + max(s["e_tb"] - e_tb, 1) <= s["tx"]
+                and e_tb <= s["e_tb"] and batch["tx"].num_nodes < s["tx"]
                 and int(getattr(batch, "num_graphs", 1)) <= s["graphs"])
+
+    def waste(self, batch) -> float:
+        """Padded / real size of the transcript side (what a step costs)."""
+        s = self.sizes
+        return max(s["e_tt"] / max(int(batch[TX_TX].edge_index.shape[1]), 1), s["tx"] / max(batch["tx"].num_nodes, 1))
 
     # ------------------------------------------------------------------------------------------- staging
     @torch.no_grad()
-    def _stage_view(self, dst: EdgeCSR, src: EdgeCSR, n_real: int, pad_col_base: Optional[int]) -> None:
+    def _stage_view(self, dst: EdgeCSR, src: EdgeCSR, n_real: int, pad_cols: Optional[Tensor]) -> None:
         """Real rows / slots from ``src``; padding edges spread evenly over the dummy rows n_real .. n_rows-1 with
-        col = the row itself (``pad_col_base`` None) or a dummy column of their own (pad_col_base + k)."""
+        col = the row itself (``pad_cols`` None) or the given dummy columns."""
         e, e_pad = src.n_edges, dst.n_edges
         dst.indptr[: n_real + 1].copy_(src.indptr)
         dst.col[:e].copy_(src.col)
@@ -103,7 +111,7 @@ class GraphedTrainStep:
         q = max(-(-pad // n_dummy), 1)                        # padding edges per dummy row
         dst.indptr[n_real + 1:] = e + torch.clamp((self._iota[:n_dummy] + 1) * q, max=pad)
         k = self._iota[:pad]
-        dst.col[e:] = ((n_real + k // q) if pad_col_base is None else (pad_col_base + k)).to(torch.int32)
+        dst.col[e:] = ((n_real + k // q) if pad_cols is None else pad_cols).to(torch.int32)
         dst.eid[e:] = (e + k).to(torch.int32)
 
     @torch.no_grad()
@@ -128,15 +136,16 @@ class GraphedTrainStep:
         if not g_tb.src_unique():
             raise NotImplementedError("a transcript with two tx-belongs-bd edges (heterodata.py:147 assigns one)")
         e_tb = g_tb.n_edges
+        pad = self.sizes["e_tb"] - e_tb
+        k = self._iota[:pad]
+        pad_src = n_tx + k % (self.sizes["tx"] - n_tx)        # dummy transcripts, round robin
         self._stage_view(self.g_tt.by_dst, g_tt.by_dst, n_tx, None)
         self._stage_view(self.g_tt.by_src, g_tt.require_by_src(), n_tx, None)
-        self._stage_view(self.g_tb.by_dst, g_tb.by_dst, n_bd, n_tx)
+        self._stage_view(self.g_tb.by_dst, g_tb.by_dst, n_bd, pad_src)
         # the COO list of tx-belongs-bd for the segmentation loss, padding edges in the order of their CSR slots
-        pad = self.sizes["e_tb"] - e_tb
         q = max(-(-pad // (nb - n_bd)), 1)
-        k = self._iota[:pad]
         self.ei_tb[:, :e_tb].copy_(batch[TX_BD].edge_index)
-        self.ei_tb[0, e_tb:] = n_tx + k
+        self.ei_tb[0, e_tb:] = pad_src
         self.ei_tb[1, e_tb:] = n_bd + k // q
         w = self.lit._scheduled_weights(self.lit._w_start, self.lit._w_end)
         self._host[:3] = torch.tensor([n_tx, n_bd, e_tb], dtype=torch.float64)
@@ -244,21 +253,24 @@ class GraphedTrainStep:
 
 
 class GraphedTrainer:
-    """``trainer.step(batch)``: stage the batch into the first bucket it fits (a new one is captured when none does)
-    and replay.  Batches of one tile set fall into a handful of buckets (the edge budget fixes ``e_tt``)."""
+    """``trainer.step(batch)``: stage the batch into the tightest bucket it fits and replay.  A new bucket is captured
+    when none fits or the tightest one would pad the transcript side by more than two granules; with ``max_buckets``
+    captured, the tightest fit is used whatever it wastes, and a batch no bucket holds is an error."""
 
-    def __init__(self, lit_model, optimizer, granularity: float = 1.15, max_buckets: int = 16):
+    def __init__(self, lit_model, optimizer, granularity: float = 1.06, max_buckets: int = 24):
         self.lit, self.opt, self.granularity, self.max_buckets = lit_model, optimizer, granularity, max_buckets
         self.buckets: List[GraphedTrainStep] = []
         self.n_captures = 0
 
     def step(self, batch) -> Tensor:
-        for b in self.buckets:
-            if b.fits(batch):
-                return b.step(batch)
-        if len(self.buckets) >= self.max_buckets:
-            raise RuntimeError(f"more than {self.max_buckets} shape buckets: raise `granularity`")
-        b = GraphedTrainStep(self.lit, self.opt, step_bucket(batch, self.granularity), batch)
-        self.buckets.append(b)
-        self.n_captures += 1
-        return b.step(batch)
+        fit = [b for b in self.buckets if b.fits(batch)]
+        best = min(fit, key=lambda b: b.waste(batch)) if fit else None
+        full = len(self.buckets) >= self.max_buckets
+        if best is None or (best.waste(batch) > self.granularity ** 2 and not full):
+            if full:
+                raise RuntimeError(f"no captured bucket holds this batch and {self.max_buckets} buckets exist: "
+                                   f"raise `granularity` or `max_buckets`")
+            best = GraphedTrainStep(self.lit, self.opt, step_bucket(batch, self.granularity), batch)
+            self.buckets.append(best)
+            self.n_captures += 1
+        return best.step(batch)

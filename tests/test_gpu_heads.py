@@ -227,3 +227,35 @@ def test_gelu_kernel_accuracy(cuda):
     ref = xs * 0.5 * torch.erfc(-xs / 2 ** 0.5)
     err = (out.double().cpu() - ref).abs()
     assert float(err.max()) <= 5e-7
+
+
+def test_sampler_stream_is_fresh_per_call_and_follows_manual_seed(cuda):
+    """Without given uniforms the fused sampler draws from its own counter-based stream: seeded from torch's CPU
+    generator (eager) or from a device word (graph replays) -- never the same draws twice in a row; the drawn
+    positives share the anchor's cluster at the rate the similarity matrix dictates."""
+    from segger_amd.triplet_loss import FastTripletSelector
+    k, n = 6, 20000
+    g = torch.Generator().manual_seed(3)
+    sim = torch.rand(k, k, generator=g) * 2 - 1
+    sim = (sim + sim.t()) / 2
+    lab = torch.randint(0, k, (n,), generator=g).to(cuda)
+    sel = FastTripletSelector(sim)
+    ix = sel.build_index(lab)
+    torch.manual_seed(11)
+    a = sel.sample_triplets(lab, index=ix)
+    b = sel.sample_triplets(lab, index=ix)
+    torch.manual_seed(11)
+    c = sel.sample_triplets(lab, index=ix)
+    assert not torch.equal(a[0], b[0]) and not torch.equal(a[1], b[1])
+    assert all(torch.equal(x, y) for x, y in zip(a, c))
+    word = torch.zeros(1, dtype=torch.int64, device=cuda)
+    d0 = sel.sample_triplets(lab, index=ix, device_seed=(5, word))
+    d0b = sel.sample_triplets(lab, index=ix, device_seed=(5, word))
+    word += 256
+    d1 = sel.sample_triplets(lab, index=ix, device_seed=(5, word))
+    assert torch.equal(d0[0], d0b[0]) and not torch.equal(d0[0], d1[0])
+    # P(positive in own cluster) = sim'[r, r] / sum_c sim'[r, c] over present clusters, sim' = clamp(sim with diag 1)
+    s = sel.similarity
+    want = float((s.diag() / s.sum(1))[lab.cpu()].mean())
+    got = float((lab[a[0]] == lab).float().mean())
+    assert abs(got - want) < 0.02
