@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEGGER_ABI_VERSION 5
+#define SEGGER_ABI_VERSION 6
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -229,6 +229,31 @@ int segger_gatv2_has_specialised(int32_t heads, int32_t channels);
 int segger_coo_unique(const int64_t* ids, int64_t n, int64_t n_ids, int32_t* marks, int32_t* unique_out,
                       segger_stream_t stream);
 
+/*
+ * segger_stage: n_segs independent "copy a prefix, fill the rest" jobs in one launch -- how a batch is written into the
+ * static, padded buffers a captured training step (hipGraph) replays on (no counterpart in the reference, which
+ * re-launches every op of every step; lightning_model.py:151-231 is what the captured step computes).
+ * Element i of segment s:   i < n_copy: src[i] (read as src_bytes-wide integer, stored dst_bytes-wide; equal sizes
+ * copy bit patterns, so floats pass unchanged);  otherwise with k = i - n_copy:
+ *   SEGGER_FILL_CONST  a                       (bit pattern of the value, e.g. 0 for 0.0f)
+ *   SEGGER_FILL_TILE   src[k % a]              (replicate the first a elements: "copies of row 0")
+ *   SEGGER_FILL_DIV    a + k / b               (b = 1: an iota)
+ *   SEGGER_FILL_MOD    a + k % b
+ *   SEGGER_FILL_RAMP   a + min((k + 1) * b, c) (row pointers of rows holding b padding edges each, c in total)
+ * segs is a HOST array (copied into the kernel arguments).
+ */
+enum { SEGGER_FILL_CONST = 0, SEGGER_FILL_TILE = 1, SEGGER_FILL_DIV = 2, SEGGER_FILL_MOD = 3, SEGGER_FILL_RAMP = 4 };
+typedef struct {
+  void* dst;
+  const void* src;
+  int64_t n_copy, n_total;   /* elements */
+  int64_t a, b, c;           /* fill parameters */
+  int32_t dst_bytes, src_bytes;
+  int32_t fill;
+  int32_t reserved_;
+} segger_stage_seg;
+int segger_stage(const segger_stage_seg* segs, int32_t n_segs, segger_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Prediction head: cosine similarity on tx->bd candidate edges + per-transcript
  * arg-max + assignment.  Replaces torch.cosine_similarity on two gathered
@@ -321,6 +346,15 @@ int segger_triplet_sample(const int64_t* lab, int64_t n, int32_t n_clusters, con
                           const float* uniforms, uint64_t seed, const uint64_t* seed_dev,
                           const float* dists, int64_t* pos, int64_t* neg, float* d_pos, float* d_neg,
                           segger_stream_t stream);
+
+/*
+ * segger_sample_negatives: the negative destinations of the segmentation loss (lightning_model.py:178-180:
+ *   dst_neg = (dst_pos + randint(1, n_b)) % n_b ) in one launch:  neg[e] = (pos[e] + 1 + floor(u * (n_b - 1))) % n_b
+ * with u from the counter-based generator keyed by (seed + *seed_dev, e); pos[e] < 0 (a padded triplet) gives -1.
+ * n_b_dev (optional) overrides n_b with a device value (a captured step padded to a static size); n_b <= 1 gives 0.
+ */
+int segger_sample_negatives(const int64_t* pos, int64_t n, int64_t n_b, const int64_t* n_b_dev, uint64_t seed,
+                            const uint64_t* seed_dev, int64_t* neg, segger_stream_t stream);
 
 /*
  * segger_metric_fwd / _bwd: MetricLoss.forward (src/segger/models/triplet_loss.py:163-204) on sampled triplets,

@@ -664,6 +664,35 @@ extern "C" int segger_triplet_sample(const int64_t* lab, int64_t n, int32_t n_cl
   return SEGGER_OK;
 }
 
+namespace segger {
+__global__ __launch_bounds__(256) void sample_negatives_kernel(const int64_t* pos, int64_t n, int64_t n_b,
+                                                               const int64_t* n_b_dev, uint64_t seed_raw,
+                                                               const uint64_t* seed_dev, int64_t* neg) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const int64_t ip = pos[e];
+  if (ip < 0) { neg[e] = -1; return; }
+  if (n_b_dev) n_b = *n_b_dev;
+  if (n_b <= 1) { neg[e] = 0; return; }
+  const uint64_t mixed = splitmix64(seed_raw + (seed_dev ? *seed_dev : 0ull));
+  const float u = uniform01((uint32_t)e, (uint32_t)(e >> 30), (uint32_t)mixed, (uint32_t)(mixed >> 32));
+  int64_t shift = 1 + (int64_t)floorf(u * (float)(n_b - 1));
+  if (shift > n_b - 1) shift = n_b - 1;                    // u * (n_b - 1) may round up to n_b - 1
+  neg[e] = (ip + shift) % n_b;
+}
+}  // namespace segger
+
+extern "C" int segger_sample_negatives(const int64_t* pos, int64_t n, int64_t n_b, const int64_t* n_b_dev, uint64_t seed,
+                                       const uint64_t* seed_dev, int64_t* neg, segger_stream_t stream) {
+  SEGGER_REQUIRE(n >= 0 && n_b >= 0, "segger_sample_negatives: negative size");
+  if (n == 0) return SEGGER_OK;
+  SEGGER_REQUIRE(pos && neg, "segger_sample_negatives: NULL pointer");
+  hipLaunchKernelGGL(sample_negatives_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos,
+                     n, n_b, n_b_dev, seed, seed_dev, neg);
+  SEGGER_LAUNCH_CHECK("sample_negatives_kernel");
+  return SEGGER_OK;
+}
+
 static int metric_common(const void* z, int64_t ld_z, int64_t n, int32_t channels, int32_t dtype, const int64_t* pos,
                          const int64_t* neg, const float* d_pos, const float* d_neg, const float* w, float eps,
                          float* loss, void* workspace, size_t workspace_bytes, const float* scale_dev, float* grad_z,

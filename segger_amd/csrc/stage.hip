@@ -1,0 +1,94 @@
+// segger_stage: many small "copy a prefix, fill the rest by a formula" jobs in ONE launch.
+//
+// A captured training step (hipGraph) reads static, padded buffers; every batch has to be written into them first.
+// Done with framework copies / fills that is ~95 launches of 3-5 us per 1 M-edge batch -- more than the GATv2 forward
+// of the batch.  Here the host describes all of them as segments and one grid (blockIdx.y = segment) executes them.
+#include "common.h"
+
+namespace segger {
+
+constexpr int kStageMaxSegs = 48;        // 48 x 64 B by value in the kernel arguments
+
+struct StageBatch {
+  segger_stage_seg s[kStageMaxSegs];
+};
+
+template <typename T>
+__device__ __forceinline__ int64_t load_int(const void* p, int64_t i) { return (int64_t)static_cast<const T*>(p)[i]; }
+
+__device__ __forceinline__ int64_t load_elem(const void* p, int64_t i, int bytes) {
+  switch (bytes) {
+    case 1:  return load_int<uint8_t>(p, i);
+    case 2:  return load_int<uint16_t>(p, i);
+    case 4:  return load_int<int32_t>(p, i);
+    default: return load_int<int64_t>(p, i);
+  }
+}
+
+__device__ __forceinline__ void store_elem(void* p, int64_t i, int bytes, int64_t v) {
+  switch (bytes) {
+    case 1:  static_cast<uint8_t*>(p)[i] = (uint8_t)v; break;
+    case 2:  static_cast<uint16_t*>(p)[i] = (uint16_t)v; break;
+    case 4:  static_cast<int32_t*>(p)[i] = (int32_t)v; break;
+    default: static_cast<int64_t*>(p)[i] = v; break;
+  }
+}
+
+__global__ __launch_bounds__(256) void stage_kernel(StageBatch b) {
+  const segger_stage_seg& g = b.s[blockIdx.y];
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < g.n_total; i += stride) {
+    int64_t v;
+    if (i < g.n_copy) {
+      v = load_elem(g.src, i, g.src_bytes);
+    } else {
+      const int64_t k = i - g.n_copy;
+      switch (g.fill) {
+        case SEGGER_FILL_TILE: v = load_elem(g.src, k % g.a, g.src_bytes); break;
+        case SEGGER_FILL_DIV:  v = g.a + k / g.b; break;
+        case SEGGER_FILL_MOD:  v = g.a + k % g.b; break;
+        case SEGGER_FILL_RAMP: { const int64_t t = (k + 1) * g.b; v = g.a + (t < g.c ? t : g.c); break; }
+        default:               v = g.a; break;
+      }
+    }
+    store_elem(g.dst, i, g.dst_bytes, v);
+  }
+}
+
+}  // namespace segger
+
+using namespace segger;
+
+extern "C" int segger_stage(const segger_stage_seg* segs, int32_t n_segs, segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGGER_REQUIRE(n_segs >= 0, "segger_stage: negative segment count");
+  SEGGER_REQUIRE(n_segs == 0 || segs != nullptr, "segger_stage: segs is NULL");
+  for (int32_t s0 = 0; s0 < n_segs; s0 += kStageMaxSegs) {
+    StageBatch b;
+    const int n = (n_segs - s0 < kStageMaxSegs) ? (n_segs - s0) : kStageMaxSegs;
+    int64_t longest = 0;
+    for (int i = 0; i < n; ++i) {
+      const segger_stage_seg& g = segs[s0 + i];
+      auto size_ok = [](int32_t v) { return v == 1 || v == 2 || v == 4 || v == 8; };
+      SEGGER_REQUIRE(g.n_copy >= 0 && g.n_total >= g.n_copy, "segger_stage: segment %d: need 0 <= n_copy <= n_total", s0 + i);
+      SEGGER_REQUIRE(size_ok(g.dst_bytes) && size_ok(g.src_bytes), "segger_stage: segment %d: element size must be 1, 2, 4 or 8", s0 + i);
+      SEGGER_REQUIRE(g.n_total == 0 || g.dst != nullptr, "segger_stage: segment %d: dst is NULL", s0 + i);
+      SEGGER_REQUIRE(g.n_copy == 0 || g.src != nullptr, "segger_stage: segment %d: src is NULL", s0 + i);
+      SEGGER_REQUIRE(g.fill >= SEGGER_FILL_CONST && g.fill <= SEGGER_FILL_RAMP, "segger_stage: segment %d: unknown fill", s0 + i);
+      if (g.n_total > g.n_copy) {
+        if (g.fill == SEGGER_FILL_TILE)
+          SEGGER_REQUIRE(g.src != nullptr && g.a >= 1, "segger_stage: segment %d: TILE needs src and a period >= 1", s0 + i);
+        if (g.fill == SEGGER_FILL_DIV || g.fill == SEGGER_FILL_MOD)
+          SEGGER_REQUIRE(g.b >= 1, "segger_stage: segment %d: DIV / MOD need b >= 1", s0 + i);
+      }
+      b.s[i] = g;
+      if (g.n_total > longest) longest = g.n_total;
+    }
+    if (longest == 0) continue;
+    int64_t gx = (longest + 1023) / 1024;                 // ~4 elements per thread on the longest segment
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(stage_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, stream, b);
+    SEGGER_LAUNCH_CHECK("stage_kernel");
+  }
+  return SEGGER_OK;
+}

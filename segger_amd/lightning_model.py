@@ -162,7 +162,10 @@ class LitISTEncoder(_Base):
         if num_bd <= 1:                                                      # :173-175
             return torch.tensor(0.0, device=z_bd.device, requires_grad=True)
         if dst_neg is None:                                                  # :178-180
-            dst_neg = (dst_pos + torch.randint(1, num_bd, (n,), device=dst_pos.device)) % num_bd
+            if dst_pos.is_cuda:
+                dst_neg = ops.sample_negatives(dst_pos, num_bd)              # the same draw, one launch
+            else:
+                dst_neg = (dst_pos + torch.randint(1, num_bd, (n,), device=dst_pos.device)) % num_bd
         if self._sg_loss_type == 'triplet':
             # the positives are the edges' own destinations: their grouping is the by-destination view of this edge
             # store, which the encoder's forward has already built and cached on the batch

@@ -494,6 +494,66 @@ def triplet_sample(index: dict, uniforms=None, seed_dev: Optional[Tensor] = None
     return pos, neg, dd[0], dd[1]
 
 
+@torch.no_grad()
+def sample_negatives(pos: Tensor, n_b: int, n_b_dev: Optional[Tensor] = None, seed: Optional[int] = None,
+                     seed_dev: Optional[Tensor] = None) -> Tensor:
+    """``(pos + randint(1, n_b)) % n_b`` (the segmentation loss's negatives, lightning_model.py:178-180) in one launch
+    (``segger_sample_negatives``); entries with ``pos < 0`` stay ``-1``.  The stream is seeded like
+    :func:`triplet_sample`; ``n_b_dev`` (int64[1] on the device) overrides ``n_b`` at run time."""
+    _lib.require_cuda(pos)
+    lib = _lib.load()
+    dev = pos.device
+    pos = pos.to(torch.int64).contiguous()
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    neg = torch.empty_like(pos)
+    with _lib.on_device(dev):
+        rc = lib.segger_sample_negatives(pos.data_ptr(), int(pos.numel()), int(n_b), _lib.ptr(n_b_dev),
+                                         int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.ptr(seed_dev), neg.data_ptr(),
+                                         _lib.stream_ptr(dev))
+    _lib.check(rc, "segger_sample_negatives")
+    return neg
+
+
+_FILLS = {"const": _lib.FILL_CONST, "tile": _lib.FILL_TILE, "div": _lib.FILL_DIV, "mod": _lib.FILL_MOD,
+          "ramp": _lib.FILL_RAMP}
+
+
+def float_bits(x: float) -> int:
+    """The int whose low 32 bits are the fp32 pattern of ``x`` (a ``const`` fill of a float buffer)."""
+    import struct
+    return struct.unpack("<i", struct.pack("<f", float(x)))[0]
+
+
+@torch.no_grad()
+def stage(segments, device) -> None:
+    """``segger_stage``: all of ``segments`` in one launch.  A segment is ``(dst, src, fill, a, b, c)``: ``dst`` a
+    contiguous tensor written in full; ``src`` a contiguous tensor (or None) copied to its front; the rest filled by
+    ``fill`` in ("const", "tile", "div", "mod", "ramp") with integer parameters a, b, c (see include/segger_amd.h)."""
+    lib = _lib.load()
+    n = len(segments)
+    arr = (_lib.StageSeg * n)()
+    for i, (dst, src, fill, a, b, c) in enumerate(segments):
+        if not dst.is_contiguous() or (src is not None and not src.is_contiguous()):
+            raise ValueError("stage: tensors must be contiguous")
+        n_copy = 0 if src is None else int(src.numel())
+        g = arr[i]
+        g.dst, g.src = dst.data_ptr(), (src.data_ptr() if src is not None and src.numel() else None)
+        g.n_copy, g.n_total = n_copy, int(dst.numel())
+        g.a, g.b, g.c = int(a), int(b), int(c)
+        g.dst_bytes, g.src_bytes = dst.element_size(), (src.element_size() if src is not None else dst.element_size())
+        g.fill = _FILLS[fill]
+        if n_copy > g.n_total:
+            raise ValueError(f"stage: segment {i}: source longer than destination")
+        if src is not None and src.is_floating_point() != dst.is_floating_point():
+            raise TypeError(f"stage: segment {i}: no conversion between float and integer")
+        if dst.is_floating_point() and src is not None and src.dtype != dst.dtype:
+            raise TypeError(f"stage: segment {i}: float segments copy bit patterns, dtypes must agree")
+    with _lib.on_device(device):
+        rc = lib.segger_stage(arr, n, _lib.stream_ptr(device))
+    _lib.check(rc, "segger_stage")
+
+
 # --------------------------------------------------------------------------
 # Positional embedder: per-graph min / max
 # --------------------------------------------------------------------------

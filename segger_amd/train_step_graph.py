@@ -54,36 +54,52 @@ def step_bucket(batch, granularity: float = 1.06, floor: int = 256) -> Dict[str,
 
 
 class GraphedTrainStep:
-    """The captured step of ONE shape bucket (see :class:`GraphedTrainer` for the per-batch dispatch)."""
+    """The captured step of ONE shape bucket (see :class:`GraphedTrainer` for the per-batch dispatch).  A batch is
+    written into the bucket's static buffers by ONE launch (``ops.stage`` -> ``segger_stage``): node features, the three
+    CSR views, the rows-by-gene grouping of the embedding gradient, the segmentation triplets and the loss samplers'
+    indices are all "copy the batch's own (cached) arrays, fill the padding by a formula" segments."""
 
     def __init__(self, lit_model, optimizer, sizes: Dict[str, int], template):
         if lit_model._sg_loss_type != "triplet":
             raise NotImplementedError("the graphed step covers the (default) triplet segmentation loss")
-        self.lit, self.opt, self.sizes = lit_model, optimizer, dict(sizes)
         if lit_model.loss_tx is None or lit_model.loss_bd is None:
             raise RuntimeError("call setup() (or set_similarities) before training")
+        self.lit, self.opt, self.sizes = lit_model, optimizer, dict(sizes)
         dev = next(lit_model.parameters()).device
         self.dev = dev
         for sel in (lit_model.loss_tx.selector, lit_model.loss_bd.selector):      # no host -> device copy in a capture
             sel.similarity, sel.dissimilarity = sel.similarity.to(dev), sel.dissimilarity.to(dev)
         nt, nb, ett, etb = sizes["tx"], sizes["bd"], sizes["e_tt"], sizes["e_tb"]
         z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)
-        self.nodes = {k: {a: z(n, *template[k][a].shape[1:], dtype=template[k][a].dtype) for a in _NODE_ATTRS}
-                      for k, n in (("tx", nt), ("bd", nb))}
+        i32, i64 = torch.int32, torch.int64
+        self.n_genes = int(lit_model.model.lin_first["tx"].weight.shape[0])
+        self.nodes = {"tx": {"x": z(nt, dtype=i32), "pos": z(nt, 2), "batch": z(nt, dtype=i64)},
+                      "bd": {"x": z(nb, *template["bd"]["x"].shape[1:], dtype=template["bd"]["x"].dtype),
+                             "pos": z(nb, 2), "batch": z(nb, dtype=i64)}}
 
         def csr(n_rows, n_cols, n_edges):
-            return EdgeCSR(z(n_rows + 1, dtype=torch.long), z(n_edges, dtype=torch.int32),
-                           z(n_edges, dtype=torch.int32), n_rows, n_cols)
+            return EdgeCSR(z(n_rows + 1, dtype=i64), z(n_edges, dtype=i32), z(n_edges, dtype=i32), n_rows, n_cols)
         self.g_tt = EdgeGraph(csr(nt, nt, ett), csr(nt, nt, ett), nt, nt, ett)
         self.g_tb = EdgeGraph(csr(nb, nt, etb), None, nt, nb, etb, None, True)        # one-pass backward (see above)
-        self.ei_tb = z(2, etb, dtype=torch.long)
-        self.counts = z(3, dtype=torch.long)                  # real n_tx, n_bd, e_tb of the staged batch
-        self.weights = z(3)                                   # scheduled loss weights (tx, bd, sg)
-        self._host = torch.zeros(6, dtype=torch.float64).pin_memory()
+        by_gene_col = z(nt, dtype=i32)
+        self.by_gene = EdgeCSR(z(self.n_genes + 1, dtype=i64), by_gene_col, by_gene_col, self.n_genes, nt)
+        self.sg_src, self.sg_pos = z(etb, dtype=i64), z(etb, dtype=i64)
+
+        def sampler_index(selector, n):
+            k = int(selector.similarity.shape[0])
+            return dict(lab=z(n, dtype=i64), members=z(n, dtype=i64), counts=z(k + 1, dtype=i64),
+                        offsets=z(k + 1, dtype=i64), cdf_pos_t=z(k, k), cdf_neg_t=z(k, k),
+                        dists=(1.0 - selector.similarity).contiguous(), n_clusters=k)
+        self.ix_tx = sampler_index(lit_model.loss_tx.selector, nt)
+        self.ix_bd = sampler_index(lit_model.loss_bd.selector, nb)
+        self.bd_weight = z(nb)
+        self.n_bd = z(1, dtype=i64)                           # real boundary count of the staged batch
+        self.scal = z(6)                      # 1 / masked tx count, 1, e_tb_pad / e_tb_real (0: <= 1 boundary), loss weights
+        self._unit = torch.tensor([float(nt), 1.0, 1.0], device=dev)
         self.out: Optional[Tensor] = None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._training: Optional[bool] = None
-        self._iota = torch.arange(max(nt, nb, ett, etb), device=dev)
+        self._iota = torch.arange(nt, device=dev)
         self.draws = None                                     # tests: fixed (tx pos/neg, bd pos/neg/dp/dn, dst_neg)
 
     def fits(self, batch) -> bool:
@@ -99,110 +115,118 @@ class GraphedTrainStep:
         return max(s["e_tt"] / max(int(batch[TX_TX].edge_index.shape[1]), 1), s["tx"] / max(batch["tx"].num_nodes, 1))
 
     # ------------------------------------------------------------------------------------------- staging
-    @torch.no_grad()
-    def _stage_view(self, dst: EdgeCSR, src: EdgeCSR, n_real: int, pad_cols: Optional[Tensor]) -> None:
-        """Real rows / slots from ``src``; padding edges spread evenly over the dummy rows n_real .. n_rows-1 with
-        col = the row itself (``pad_cols`` None) or the given dummy columns."""
-        e, e_pad = src.n_edges, dst.n_edges
-        dst.indptr[: n_real + 1].copy_(src.indptr)
-        dst.col[:e].copy_(src.col)
-        dst.eid[:e].copy_(src.eid)
-        pad, n_dummy = e_pad - e, dst.n_rows - n_real
-        q = max(-(-pad // n_dummy), 1)                        # padding edges per dummy row
-        dst.indptr[n_real + 1:] = e + torch.clamp((self._iota[:n_dummy] + 1) * q, max=pad)
-        k = self._iota[:pad]
-        dst.col[e:] = ((n_real + k // q) if pad_cols is None else pad_cols).to(torch.int32)
-        dst.eid[e:] = (e + k).to(torch.int32)
+    @staticmethod
+    def _view_segments(dst: EdgeCSR, src: EdgeCSR, n_real: int, pad_cols) -> list:
+        """Real rows / slots from ``src``; padding edges spread evenly over the dummy rows n_real .. n_rows-1 (q each),
+        their columns = the row itself (``pad_cols`` None) or ``pad_cols`` = (fill, a, b)."""
+        e = src.n_edges
+        pad, n_dummy = dst.n_edges - e, dst.n_rows - n_real
+        q = max(-(-pad // n_dummy), 1)
+        col_fill = ("div", n_real, q) if pad_cols is None else pad_cols
+        return [(dst.indptr, src.indptr, "ramp", e, q, pad),
+                (dst.col, src.col, *col_fill, 0),
+                (dst.eid, src.eid, "div", e, 1, 0)]
+
+    def _sampler_segments(self, dst: dict, ix: dict, n_total: int) -> list:
+        n = int(ix["lab"].numel())
+        return [(dst["lab"], ix["lab"], "const", dst["n_clusters"], 0, 0),          # padding: the masked-out cluster
+                (dst["members"], ix["members"], "div", n, 1, 0),
+                (dst["counts"], ix["counts"], "const", 0, 0, 0), (dst["offsets"], ix["offsets"], "const", 0, 0, 0),
+                (dst["cdf_pos_t"], ix["cdf_pos_t"], "const", 0, 0, 0), (dst["cdf_neg_t"], ix["cdf_neg_t"], "const", 0, 0, 0)]
 
     @torch.no_grad()
     def stage(self, batch) -> None:
+        from .triplet_loss import _cached_index, _masked_count
         if not self.fits(batch):
             raise ValueError("batch does not fit this bucket")
-        n_tx, n_bd = batch["tx"].num_nodes, batch["bd"].num_nodes
-        nb = self.sizes["bd"]
-        for k, n in (("tx", n_tx), ("bd", n_bd)):
-            for a, buf in self.nodes[k].items():
-                v = batch[k][a]
-                buf[:n].copy_(v)
-                if a == "mask":
-                    buf[n:] = False
-                elif a == "cluster":
-                    buf[n:] = 0
-                else:
-                    buf[n:] = v[0]
+        lit, s = self.lit, self.sizes
+        tx, bd = batch["tx"], batch["bd"]
+        n_tx, n_bd, nt = tx.num_nodes, bd.num_nodes, s["tx"]
         cache = batch_cache(batch)
+        store = cache.get("persistent")
         g_tt = edge_graph(cache, TX_TX, batch[TX_TX].edge_index, n_tx, n_tx, need_by_src=True, validate="deferred")
         g_tb = edge_graph(cache, TX_BD, batch[TX_BD].edge_index, n_tx, n_bd, need_by_src="lazy", validate="deferred")
         if not g_tb.src_unique():
             raise NotImplementedError("a transcript with two tx-belongs-bd edges (heterodata.py:147 assigns one)")
         e_tb = g_tb.n_edges
-        pad = self.sizes["e_tb"] - e_tb
-        k = self._iota[:pad]
-        pad_src = n_tx + k % (self.sizes["tx"] - n_tx)        # dummy transcripts, round robin
-        self._stage_view(self.g_tt.by_dst, g_tt.by_dst, n_tx, None)
-        self._stage_view(self.g_tt.by_src, g_tt.require_by_src(), n_tx, None)
-        self._stage_view(self.g_tb.by_dst, g_tb.by_dst, n_bd, pad_src)
-        # the COO list of tx-belongs-bd for the segmentation loss, padding edges in the order of their CSR slots
-        q = max(-(-pad // (nb - n_bd)), 1)
-        self.ei_tb[:, :e_tb].copy_(batch[TX_BD].edge_index)
-        self.ei_tb[0, e_tb:] = pad_src
-        self.ei_tb[1, e_tb:] = n_bd + k // q
-        w = self.lit._scheduled_weights(self.lit._w_start, self.lit._w_end)
-        self._host[:3] = torch.tensor([n_tx, n_bd, e_tb], dtype=torch.float64)
-        self._host[3:] = w.double()
-        self.counts.copy_(self._host[:3], non_blocking=True)
-        self.weights.copy_(self._host[3:], non_blocking=True)
+        # what depends on the tile set only (kept across epochs by tiles.TilePartition; per batch object otherwise)
+        keep = store if store is not None else cache
+        ix_tx = keep.get("tx_triplet_index") if store is not None else None
+        if ix_tx is None:
+            ix_tx = _cached_index(lit.loss_tx.selector, "tx_triplet_index", tx["cluster"], tx["mask"], cache)
+        if "inv_count" not in ix_tx:
+            ix_tx["inv_count"] = (1.0 / _masked_count(ix_tx["mask"])).reshape(1)
+        ix_bd = keep.get("bd_metric_index") if store is not None else None
+        if ix_bd is None:
+            ix_bd = _cached_index(lit.loss_bd.selector, "bd_metric_index", bd["cluster"],
+                                  bd["mask"] & (bd["cluster"] >= 0), cache)
+        if "weight" not in ix_bd:
+            ix_bd["weight"] = ix_bd["mask"].float() / _masked_count(ix_bd["mask"])
+        by_gene = keep.get("tx_by_gene")
+        if by_gene is None:
+            by_gene = keep["tx_by_gene"] = ops.rows_by_id(tx["x"], self.n_genes)
+        ei = batch[TX_BD].edge_index
+        w = lit._scheduled_weights(lit._w_start, lit._w_end)
+        fb = ops.float_bits
+        dummies = ("mod", n_tx, nt - n_tx)                    # dummy transcripts, round robin
+        N = self.nodes
+        segs = [
+            # nodes: dummies are copies of node 0 (gene id: the last gene, whose rows-by-gene group they extend)
+            (N["tx"]["x"], tx["x"], "const", self.n_genes - 1, 0, 0),
+            (N["tx"]["pos"], tx["pos"], "tile", 2, 0, 0), (N["tx"]["batch"], tx["batch"], "tile", 1, 0, 0),
+            (N["bd"]["x"], bd["x"], "tile", max(int(bd["x"][0].numel()), 1), 0, 0),
+            (N["bd"]["pos"], bd["pos"], "tile", 2, 0, 0), (N["bd"]["batch"], bd["batch"], "tile", 1, 0, 0),
+            (self.by_gene.indptr, by_gene.indptr[: self.n_genes], "const", nt, 0, 0),
+            (self.by_gene.col, by_gene.col, "div", n_tx, 1, 0),
+            # segmentation triplets: padded ones carry -1 and are skipped by the kernels
+            (self.sg_src, ei[0], *dummies, 0), (self.sg_pos, ei[1], "const", -1, 0, 0),
+            (self.bd_weight, ix_bd["weight"], "const", 0, 0, 0),
+            (self.n_bd, None, "const", n_bd, 0, 0),
+            (self.scal[0:1], ix_tx["inv_count"], "const", 0, 0, 0), (self.scal[1:2], None, "const", fb(1.0), 0, 0),
+            (self.scal[2:3], None, "const", fb(s["e_tb"] / max(e_tb, 1) if n_bd > 1 else 0.0), 0, 0),   # :173-175
+            (self.scal[3:4], None, "const", fb(w[0]), 0, 0), (self.scal[4:5], None, "const", fb(w[1]), 0, 0),
+            (self.scal[5:6], None, "const", fb(w[2]), 0, 0),
+        ]
+        segs += self._view_segments(self.g_tt.by_dst, g_tt.by_dst, n_tx, None)
+        segs += self._view_segments(self.g_tt.by_src, g_tt.require_by_src(), n_tx, None)
+        segs += self._view_segments(self.g_tb.by_dst, g_tb.by_dst, n_bd, dummies)
+        segs += self._sampler_segments(self.ix_tx, ix_tx, nt)
+        segs += self._sampler_segments(self.ix_bd, ix_bd, s["bd"])
+        ops.stage(segs, self.dev)
 
     # ------------------------------------------------------------------------------------------- the step
     def _run(self) -> None:
         lit, enc, s = self.lit, self.lit.model, self.sizes
-        nt, etb = s["tx"], s["e_tb"]
+        nt = s["tx"]
         tx, bd = self.nodes["tx"], self.nodes["bd"]
         self.opt.zero_grad(set_to_none=True)
         z = enc({"tx": tx["x"], "bd": bd["x"]}, {TX_TX: None, TX_BD: None}, {"tx": tx["pos"], "bd": bd["pos"]},
                 {"tx": tx["batch"], "bd": bd["batch"]}, num_graphs=s["graphs"],
-                graphs={TX_TX: self.g_tt, TX_BD: self.g_tb})
+                graphs={TX_TX: self.g_tt, TX_BD: self.g_tb, "tx_by_gene": self.by_gene})
         step = enc._step_dev                                  # advanced by the forward: a fresh stream per replay
-        n_bd, e_real = self.counts[1], self.counts[2]
         fixed = self.draws
-        # loss_tx / loss_bd: the masked forms of triplet_loss.py, the selector's index rebuilt from the staged labels
+        # loss_tx / loss_bd: the masked forms of triplet_loss.py on the staged sampler indices; means are taken over
+        # the padded rows by the kernels and rescaled to the masked real ones here
         if fixed is None:
-            sel = lit.loss_tx.selector
-            pos, neg, _, _ = sel.sample_triplets(tx["cluster"], index=sel.build_index(tx["cluster"], tx["mask"]),
-                                                 device_seed=(0x7478, step))
+            pos, neg, _, _ = ops.triplet_sample(self.ix_tx, seed=0x7478, seed_dev=step)
         else:
             pos, neg = fixed["tx"]
-        l_tx = ops.triplet_edge_loss(z["tx"], None, self._iota[:nt], pos, neg, lit.loss_tx.margin, eps=lit.loss_tx.eps)
-        l_tx = l_tx * (float(nt) / tx["mask"].sum().clamp(min=1).float())
-        bmask = bd["mask"] & (bd["cluster"] >= 0)
+        l_tx = ops.triplet_edge_loss(z["tx"], None, self._iota, pos, neg, lit.loss_tx.margin, eps=lit.loss_tx.eps)
         if fixed is None:
-            sel = lit.loss_bd.selector
-            pos, neg, dp, dn = sel.sample_triplets(bd["cluster"], index=sel.build_index(bd["cluster"], bmask),
-                                                   device_seed=(0x6264, step))
+            pos, neg, dp, dn = ops.triplet_sample(self.ix_bd, seed=0x6264, seed_dev=step)
         else:
             pos, neg, dp, dn = fixed["bd"]
-        l_bd = ops.metric_loss(z["bd"], pos, neg, dp, dn, bmask.float() / bmask.sum().clamp(min=1).float())
-        # segmentation loss over the real tx-belongs-bd edges (lightning_model.py:167-189): negatives in
-        # [0, n_bd_real), padded triplets = -1 (skipped), mean over the real edges
-        src, dst = self.ei_tb[0], self.ei_tb[1]
-        valid = self._iota[:etb] < e_real
-        minus = torch.full_like(dst, -1)
-        if fixed is None:
-            span = (n_bd - 1).clamp(min=1)
-            shift = 1 + (torch.rand(etb, device=self.dev) * span.float()).long().clamp(max=span - 1)
-            dst_neg = (dst + shift) % n_bd.clamp(min=1)
-        else:
-            dst_neg = fixed["dst_neg"]
-        l_sg = ops.triplet_edge_loss(z["tx"], z["bd"], src, torch.where(valid, dst, minus),
-                                     torch.where(valid, dst_neg, minus), lit._sg_margin, eps=1e-6,
+        l_bd = ops.metric_loss(z["bd"], pos, neg, dp, dn, self.bd_weight)
+        # segmentation loss over the real tx-belongs-bd edges (lightning_model.py:167-189): negatives in [0, n_bd_real)
+        dst_neg = (ops.sample_negatives(self.sg_pos, 0, self.n_bd, seed=0x7367, seed_dev=step) if fixed is None
+                   else fixed["dst_neg"])
+        l_sg = ops.triplet_edge_loss(z["tx"], z["bd"], self.sg_src, self.sg_pos, dst_neg, lit._sg_margin, eps=1e-6,
                                      pos_groups=self.g_tb.by_dst)
-        l_sg = l_sg * (float(etb) / e_real.clamp(min=1).float())
-        l_sg = torch.where(n_bd > 1, l_sg, torch.zeros_like(l_sg))              # :173-175
-        loss = self.weights[0] * l_tx + self.weights[1] * l_bd + self.weights[2] * l_sg
+        terms = torch.stack([l_tx.float(), l_bd.float(), l_sg.float()]) * self._unit * self.scal[0:3]
+        loss = (terms * self.scal[3:6]).sum()
         loss.backward()
         self.opt.step()
-        self.out = torch.stack([l_tx.detach().float(), l_bd.detach().float(), l_sg.detach().float(),
-                                loss.detach().float()])
+        self.out = torch.cat([terms.detach(), loss.detach().reshape(1)])
 
     @torch.no_grad()
     def _snapshot(self):

@@ -259,3 +259,61 @@ def test_sampler_stream_is_fresh_per_call_and_follows_manual_seed(cuda):
     want = float((s.diag() / s.sum(1))[lab.cpu()].mean())
     got = float((lab[a[0]] == lab).float().mean())
     assert abs(got - want) < 0.02
+
+
+def test_sample_negatives_is_a_uniform_nonzero_shift(cuda):
+    """segger_sample_negatives == (pos + randint(1, n_b)) % n_b (lightning_model.py:178-180): never the positive
+    itself, every other row equally likely; -1 positives stay -1; n_b may come from the device."""
+    from segger_amd import ops
+    n_b, n = 7, 70000
+    pos = torch.randint(0, n_b, (n,), device=cuda)
+    pos[::10] = -1
+    torch.manual_seed(2)
+    neg = ops.sample_negatives(pos, n_b)
+    live = pos >= 0
+    assert bool((neg[~live] == -1).all())
+    assert bool(((neg[live] >= 0) & (neg[live] < n_b) & (neg[live] != pos[live])).all())
+    shift = (neg[live] - pos[live]) % n_b
+    freq = torch.bincount(shift, minlength=n_b).float() / live.sum()
+    assert freq[0] == 0 and bool(((freq[1:] - 1 / (n_b - 1)).abs() < 0.01).all())
+    assert not torch.equal(neg, ops.sample_negatives(pos, n_b))           # a fresh draw per call
+    torch.manual_seed(2)
+    assert torch.equal(neg, ops.sample_negatives(pos, n_b))
+    dev_n = torch.tensor([n_b], device=cuda)
+    torch.manual_seed(2)
+    assert torch.equal(neg, ops.sample_negatives(pos, 0, dev_n))
+    assert bool((ops.sample_negatives(pos.clamp(min=0) * 0, 1) == 0).all())   # a single boundary: the reference skips
+
+
+def test_stage_segments_copy_and_fill(cuda):
+    """segger_stage: every fill rule against its torch formula, mixed element sizes, one launch."""
+    from segger_amd import ops
+    src64 = torch.arange(100, 137, device=cuda)
+    srcf = torch.randn(11, 2, device=cuda)
+    srcb = torch.tensor([True, False, True], device=cuda)
+    d_narrow = torch.full((50,), -7, dtype=torch.int32, device=cuda)
+    d_tile = torch.zeros(20, 2, device=cuda)
+    d_bool = torch.ones(9, dtype=torch.bool, device=cuda)
+    d_div = torch.zeros(30, dtype=torch.int32, device=cuda)
+    d_mod = torch.zeros(30, dtype=torch.int64, device=cuda)
+    d_ramp = torch.zeros(12, dtype=torch.int64, device=cuda)
+    d_const = torch.zeros(3, device=cuda)
+    d_full = torch.zeros(37, dtype=torch.int64, device=cuda)
+    ops.stage([(d_narrow, src64, "const", 5, 0, 0), (d_tile, srcf, "tile", 2, 0, 0), (d_bool, srcb, "const", 0, 0, 0),
+               (d_div, src64[:4].to(torch.int32), "div", 1000, 3, 0), (d_mod, src64[:4], "mod", 50, 7, 0),
+               (d_ramp, src64[:5], "ramp", 200, 4, 10), (d_const, None, "const", ops.float_bits(2.5), 0, 0),
+               (d_full, src64, "const", 0, 0, 0)], cuda)
+    k = torch.arange(64, device=cuda)
+    assert torch.equal(d_narrow, torch.cat([src64.int(), torch.full((13,), 5, dtype=torch.int32, device=cuda)]))
+    assert torch.equal(d_tile, torch.cat([srcf, srcf[:1].expand(9, 2)]))
+    assert torch.equal(d_bool, torch.tensor([1, 0, 1, 0, 0, 0, 0, 0, 0], dtype=torch.bool, device=cuda))
+    assert torch.equal(d_div, torch.cat([src64[:4].int(), (1000 + k[:26] // 3).int()]))
+    assert torch.equal(d_mod, torch.cat([src64[:4], 50 + k[:26] % 7]))
+    assert torch.equal(d_ramp, torch.cat([src64[:5], 200 + torch.clamp((k[:7] + 1) * 4, max=10)]))
+    assert torch.equal(d_const, torch.full((3,), 2.5, device=cuda))
+    assert torch.equal(d_full, src64)
+    with pytest.raises(TypeError):
+        ops.stage([(d_const, src64[:2], "const", 0, 0, 0)], cuda)
+    many = [(torch.zeros(5, dtype=torch.int64, device=cuda), None, "div", i, 1, 0) for i in range(101)]   # > one launch
+    ops.stage(many, cuda)
+    assert all(torch.equal(t[0], i + k[:5]) for i, t in enumerate(many))

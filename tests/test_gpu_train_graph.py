@@ -51,7 +51,7 @@ def _pad_draws(step, d):
         return torch.cat([t, torch.full((n - t.numel(),), fill, dtype=t.dtype, device=t.device)])
     return dict(tx=tuple(pad(t, s["tx"], -1) for t in d["tx"]),
                 bd=tuple(pad(t, s["bd"], -1 if i < 2 else 0) for i, t in enumerate(d["bd"])),
-                dst_neg=pad(d["dst_neg"], s["e_tb"], 0))
+                dst_neg=pad(d["dst_neg"], s["e_tb"], -1))
 
 
 @pytest.mark.parametrize("capture", [False, True])
