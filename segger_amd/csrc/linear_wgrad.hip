@@ -259,7 +259,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
   else if (grad_b) grad_b[e - mk] = t;
 }
 
+// few slabs (small batches): one pass, each thread sums its column over all slabs in slab order
+constexpr int kSinglePassSlabs = 128;
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int64_t n_slabs, int64_t width,
+                                                          int64_t mk, float* __restrict__ grad_w, float* __restrict__ grad_b) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= width) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t s = 0;
+  for (; s + 3 < n_slabs; s += 4) {
+    s0 += partial[s * width + e];       s1 += partial[(s + 1) * width + e];
+    s2 += partial[(s + 2) * width + e]; s3 += partial[(s + 3) * width + e];
+  }
+  for (; s < n_slabs; ++s) s0 += partial[s * width + e];
+  const float t = (s0 + s1) + (s2 + s3);
+  if (e < mk) grad_w[e] = t;
+  else if (grad_b) grad_b[e - mk] = t;
+}
+
 constexpr int kNumCu = 256;
+constexpr int kMinStagesPerBlock = 32;     // 512 rows: below that a workgroup's partial [M*K] costs more than its GEMM
 
 bool shape_ok(int m, int k) {
   return (m == 384 || m == 192 || m == 128 || m == 64) && (k == 256 || k == 128 || k == 64);
@@ -281,7 +300,8 @@ int blocks_per_cu(int m, int k) {
 int64_t grid_for(int64_t n_rows, int m, int k) {
   const int64_t stages = (n_rows + kStageRows - 1) / kStageRows;
   const int64_t cap = (int64_t)kNumCu * blocks_per_cu(m, k);
-  return stages < cap ? (stages < 1 ? 1 : stages) : cap;
+  const int64_t want = (stages + kMinStagesPerBlock - 1) / kMinStagesPerBlock;
+  return want < cap ? (want < 1 ? 1 : want) : cap;
 }
 
 template <typename T, int M, int K>
@@ -355,6 +375,12 @@ extern "C" int segger_linear_wgrad(const void* dy, int64_t ld_dy, const void* x,
   if (rc != SEGGER_OK) return rc;
   SEGGER_LAUNCH_CHECK("wgrad_kernel");
   const int64_t width = (int64_t)m_out * k_in + m_out;
+  if (grid <= kSinglePassSlabs) {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, stream, p.partial, grid,
+                       width, (int64_t)m_out * k_in, grad_w, grad_b);
+    SEGGER_LAUNCH_CHECK("wgrad_reduce_kernel");
+    return SEGGER_OK;
+  }
   float* part2 = p.partial + grid * width;             // behind the per-workgroup partials
   hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((unsigned)((width + 255) / 256), kRedGroups), dim3(256), 0, stream,
                      p.partial, grid, width, part2);

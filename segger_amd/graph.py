@@ -227,10 +227,13 @@ def sources_unique(src: Tensor, n_src: int) -> Tensor:
 
 
 def build_edge_graph(edge_index: Tensor, n_src: int, n_dst: int, *, need_by_dst: bool = True,
-                     need_by_src=True, validate=True) -> EdgeGraph:
-    """``need_by_src``: True, False, or ``"lazy"`` (see :class:`EdgeGraph`)."""
+                     need_by_src=True, validate=True, known_unique: bool = False) -> EdgeGraph:
+    """``need_by_src``: True, False, or ``"lazy"`` (see :class:`EdgeGraph`).  ``known_unique``: the caller vouches that
+    no source has two out-edges (e.g. checked once for the whole slide): "lazy" then needs no check of its own."""
     src, dst = edge_index[0], edge_index[1]
     by_dst = csr_from_coo(dst, src, n_dst, n_src, validate).balanced_order() if need_by_dst else None
+    if need_by_src == "lazy" and known_unique:
+        return EdgeGraph(by_dst, None, n_src, n_dst, int(edge_index.shape[1]), edge_index, True)
     if need_by_src == "lazy":
         with _lib.on_device(edge_index.device):
             flag = DeferredFlag(sources_unique(src, n_src))
@@ -264,6 +267,7 @@ def edge_graph(cache: Optional[dict], key, edge_index: Tensor, n_src: int, n_dst
         if factory is not None:
             g = factory(key, edge_index, n_src, n_dst, kw.get("need_by_dst", True), kw.get("need_by_src", True))
         if g is None:
-            g = build_edge_graph(edge_index, n_src, n_dst, **kw)
+            unique = bool(cache.get("src_unique", {}).get(key, False))     # tiles.TilePartition: slide-level check
+            g = build_edge_graph(edge_index, n_src, n_dst, known_unique=unique, **kw)
         cache[k] = g
     return g

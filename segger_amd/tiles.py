@@ -322,6 +322,7 @@ class TilePartition:
                     return self._batch_graph(key, ids, base, n_nodes, need_by_dst, need_by_src)
                 return None
             batch_cache(out)["graph_factory"] = factory
+            batch_cache(out)["src_unique"] = self._src_unique      # slide-level: holds for every subset of its edges
         return out
 
 

@@ -22,3 +22,13 @@ span = (int(rows[-1]['End_Timestamp']) - int(rows[0]['Start_Timestamp'])) / 1e6
 print('last %d steps: busy %.3f ms/step, span %.3f ms/step, %.1f launches/step' % (steps, tot / steps, span / steps, len(rows) / steps))
 for n, (c, t) in sorted(d.items(), key=lambda kv: -kv[1][1])[:top]:
     print(f"{t/steps:7.3f} ms/step calls/step={c/steps:6.1f} avg={t/c*1e3:8.1f}us {n[:110]}")
+if len(sys.argv) > 4:                                   # the launch sequence of the last step
+    seq = rows[-(len(rows) // steps):]
+    t0 = int(seq[0]['Start_Timestamp'])
+    with open(sys.argv[4], 'w') as fh:
+        prev_end = t0
+        for r in seq:
+            n = re.sub(r'at::native::|\(anonymous namespace\)::', '', r['Kernel_Name'])
+            s_, e_ = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+            fh.write(f"{(s_ - t0) / 1e3:9.1f}us gap={(s_ - prev_end) / 1e3:6.1f} dur={(e_ - s_) / 1e3:7.1f} grid={r.get('Grid_Size_X', r.get('Grid_Size', '?'))} {n[:120]}\n")
+            prev_end = e_
