@@ -100,6 +100,17 @@ class GraphedTrainStep:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self._training: Optional[bool] = None
         self._iota = torch.arange(nt, device=dev)
+        # The captured forward runs on ALIASES of the parameters (same storage, distinct autograd leaves).  A leaf's
+        # gradient sink (its AccumulateGrad node) belongs to the stream it was created on and lives as long as any
+        # autograd graph mentions it: after an eager step whose loss the caller still holds, the parameters' own
+        # sinks sit on the default stream and would pull that stream into the capture (hipStreamEndCapture then
+        # crashes).  The aliases' sinks are born inside the capture; the gradients are handed to the optimizer's
+        # parameters by assignment.
+        lit_model.model._materialize_bd(int(template["bd"]["x"].shape[1]), dev)
+        self._alias = {n: p.detach().requires_grad_(p.requires_grad) for n, p in lit_model.model.named_parameters()}
+        by_id = {id(p): self._alias[n] for n, p in lit_model.model.named_parameters()}
+        self._params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad and id(p) in by_id]
+        self._leaves = [by_id[id(p)] for p in self._params]
         self.draws = None                                     # tests: fixed (tx pos/neg, bd pos/neg/dp/dn, dst_neg)
 
     def fits(self, batch) -> bool:
@@ -199,10 +210,11 @@ class GraphedTrainStep:
         lit, enc, s = self.lit, self.lit.model, self.sizes
         nt = s["tx"]
         tx, bd = self.nodes["tx"], self.nodes["bd"]
-        self.opt.zero_grad(set_to_none=True)
-        z = enc({"tx": tx["x"], "bd": bd["x"]}, {TX_TX: None, TX_BD: None}, {"tx": tx["pos"], "bd": bd["pos"]},
-                {"tx": tx["batch"], "bd": bd["batch"]}, num_graphs=s["graphs"],
-                graphs={TX_TX: self.g_tt, TX_BD: self.g_tb, "tx_by_gene": self.by_gene})
+        z = torch.func.functional_call(
+            enc, self._alias,
+            ({"tx": tx["x"], "bd": bd["x"]}, {TX_TX: None, TX_BD: None}, {"tx": tx["pos"], "bd": bd["pos"]},
+             {"tx": tx["batch"], "bd": bd["batch"]}),
+            dict(num_graphs=s["graphs"], graphs={TX_TX: self.g_tt, TX_BD: self.g_tb, "tx_by_gene": self.by_gene}))
         step = enc._step_dev                                  # advanced by the forward: a fresh stream per replay
         fixed = self.draws
         # loss_tx / loss_bd: the masked forms of triplet_loss.py on the staged sampler indices; means are taken over
@@ -224,7 +236,9 @@ class GraphedTrainStep:
                                      pos_groups=self.g_tb.by_dst)
         terms = torch.stack([l_tx.float(), l_bd.float(), l_sg.float()]) * self._unit * self.scal[0:3]
         loss = (terms * self.scal[3:6]).sum()
-        loss.backward()
+        grads = torch.autograd.grad(loss, self._leaves, allow_unused=True)
+        for p, g in zip(self._params, grads):
+            p.grad = g
         self.opt.step()
         self.out = torch.cat([terms.detach(), loss.detach().reshape(1)])
 

@@ -100,6 +100,11 @@ def test_graphed_trainer_replays_learn_and_draw_afresh(cuda):
     batches = [ids for ids in sampler if all(part.node_sizes["bd"][t] > 1 for t in ids)]
     assert len(batches) >= 3
     opt = m.configure_optimizers(capturable=True)
+    # an eager step first, its loss (and with it the autograd graph and the parameters' AccumulateGrad nodes, bound to
+    # the default stream) kept alive: the capture must not depend on those nodes
+    stale = m.training_step(part.batch(batches[0]), 0)
+    stale.backward()
+    opt.step()
     trainer = GraphedTrainer(m, opt, granularity=1.5)
     first, last = [], []
     for ep in range(8):
@@ -115,7 +120,7 @@ def test_graphed_trainer_replays_learn_and_draw_afresh(cuda):
     a = trainer.step(part.batch(batches[0])).clone()
     b = trainer.step(part.batch(batches[0])).clone()
     assert not torch.equal(a, b)
-    assert int(m.model._step_dev) == 256 * (8 * len(batches) + 2)
+    assert int(m.model._step_dev) == 256 * (8 * len(batches) + 3)
     # eager evaluation after graphed training sees the trained weights (cache invalidated after every replay)
     m.eval()
     with torch.no_grad():
