@@ -1,12 +1,15 @@
 """One whole training step -- encoder forward, the three losses, backward, Adam -- as a single hipGraph replay.
 
 At segger's default batch budget (``edges_per_batch = 1 000 000``, reference ``data/data_module.py:158``) a step is
-~2.8 ms of device work behind ~280 launches; eager, the host needs ~4 ms to queue them.  Everything in the step is free
+under 2 ms of device work; eager, the host needs ~4 ms to queue its ~280 launches (50M-transcript FOV, one MI355X:
+4.2 ms per step eager, 1.8 ms replayed).  Everything in the step is free
 of host synchronisation and of data-dependent shapes (masks are weights, not compactions; samplers are kernels; the
 dropout / sampling streams read DEVICE counters), so the step is captured ONCE per shape bucket and replayed for every
 batch padded into the bucket's static buffers:
 
-* nodes are padded with copies of node 0 (positions included: per-graph min / max unchanged), ``mask`` False;
+* nodes are padded with copies of node 0 (positions included: per-graph min / max unchanged; dummy transcripts carry
+  the last gene id, so the rows-by-gene grouping of the embedding gradient only grows at its end), masked out of the
+  losses (the samplers put them in the cluster nobody draws from);
 * padding edges touch dummy nodes only and are laid out so that the CSR views need no sort: tx-neighbors-tx pads with
   self-loops on the dummies (identical by-destination and by-source views); tx-belongs-bd pads run from the dummy
   transcripts (round robin) to the dummy boundaries.  No loss term reads a dummy row, so every gradient that reaches a
@@ -33,8 +36,6 @@ from torch import Tensor
 from . import ops
 from .graph import EdgeCSR, EdgeGraph, batch_cache, edge_graph
 from .hetero import TX_BD, TX_TX
-
-_NODE_ATTRS = ("x", "pos", "batch", "mask", "cluster")
 
 
 def step_bucket(batch, granularity: float = 1.06, floor: int = 256) -> Dict[str, int]:
@@ -64,8 +65,13 @@ class GraphedTrainStep:
             raise NotImplementedError("the graphed step covers the (default) triplet segmentation loss")
         if lit_model.loss_tx is None or lit_model.loss_bd is None:
             raise RuntimeError("call setup() (or set_similarities) before training")
+        if not all(g.get("capturable", False) for g in optimizer.param_groups):
+            raise ValueError("the optimizer must keep its step counters on the device: "
+                             "LitISTEncoder.configure_optimizers(capturable=True)")
         self.lit, self.opt, self.sizes = lit_model, optimizer, dict(sizes)
         dev = next(lit_model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("GraphedTrainStep needs the model on a GPU (hipGraph capture)")
         self.dev = dev
         for sel in (lit_model.loss_tx.selector, lit_model.loss_bd.selector):      # no host -> device copy in a capture
             sel.similarity, sel.dissimilarity = sel.similarity.to(dev), sel.dissimilarity.to(dev)
