@@ -368,23 +368,26 @@ def main():
             "ms_per_step": rec["epoch_s"] / max(rec["steps_per_rank"], 1) * 1e3,
             "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30})
         if world == 1:
-            # the same epoch with every step replayed as ONE hipGraph (segger_amd.train_step_graph): single rank only,
-            # the data-parallel step keeps its all-reduce between backward and Adam outside a capture
-            from segger_amd.train_step_graph import GraphedTrainer
-            trainer = GraphedTrainer(model, model.configure_optimizers(capturable=True))
-            rec_g = strong_scaling_epoch(batch_weights(part, batches),
-                                         lambda k, i: trainer.step(part.batch(batches[k])),
-                                         lambda k: (sum(e_tb[t] for t in batches[k]), sum(e_tt[t] for t in batches[k])),
-                                         sync=torch.cuda.synchronize, device=dev, warmup=-1)
-            etb_g, ett_g = rec_g["units_total"]
-            strong["graphed"] = {
-                "what": "the same second epoch, each training step (stage + forward + losses + backward + Adam) as one "
-                        "hipGraph replay on static buffers padded to a shape bucket",
-                "value": 2.0 * etb_g / rec_g["epoch_s"], "unit": "edges/s", "epoch_s": rec_g["epoch_s"],
-                "mp_edges_per_s": 4.0 * (ett_g + etb_g) / rec_g["epoch_s"],
-                "ms_per_step": rec_g["epoch_s"] / max(rec_g["steps_per_rank"], 1) * 1e3,
-                "shape_buckets": len(trainer.buckets)}
-            del trainer
+            try:
+                # the same epoch with every step replayed as ONE hipGraph (segger_amd.train_step_graph): single rank only,
+                # the data-parallel step keeps its all-reduce between backward and Adam outside a capture
+                from segger_amd.train_step_graph import GraphedTrainer
+                trainer = GraphedTrainer(model, model.configure_optimizers(capturable=True))
+                rec_g = strong_scaling_epoch(batch_weights(part, batches),
+                                             lambda k, i: trainer.step(part.batch(batches[k])),
+                                             lambda k: (sum(e_tb[t] for t in batches[k]), sum(e_tt[t] for t in batches[k])),
+                                             sync=torch.cuda.synchronize, device=dev, warmup=-1)
+                etb_g, ett_g = rec_g["units_total"]
+                strong["graphed"] = {
+                    "what": "the same second epoch, each training step (stage + forward + losses + backward + Adam) as one "
+                            "hipGraph replay on static buffers padded to a shape bucket",
+                    "value": 2.0 * etb_g / rec_g["epoch_s"], "unit": "edges/s", "epoch_s": rec_g["epoch_s"],
+                    "mp_edges_per_s": 4.0 * (ett_g + etb_g) / rec_g["epoch_s"],
+                    "ms_per_step": rec_g["epoch_s"] / max(rec_g["steps_per_rank"], 1) * 1e3,
+                    "shape_buckets": len(trainer.buckets)}
+                del trainer
+            except Exception as e:  # noqa: BLE001  (the eager record above stands on its own)
+                strong["graphed"] = {"value": None, "error": repr(e)}
         if rank == 0:
             log(f"[bench] strong: {strong}")
         del part, batches

@@ -126,3 +126,29 @@ def test_graphed_trainer_replays_learn_and_draw_afresh(cuda):
     with torch.no_grad():
         z = m(part.batch(batches[0]))
     assert torch.isfinite(z["tx"].float()).all()
+
+
+def test_graphed_step_degenerate_batches(cuda):
+    """No tx-belongs-bd edge at all, and nothing inside the margin mask: the step must replay, report zero for the
+    terms that have no triplets, and leave finite parameters."""
+    from segger_amd.hetero import TX_BD
+    from segger_amd.synthetic import SyntheticSpec
+    from segger_amd.train_step_graph import GraphedTrainer
+    spec = SyntheticSpec(n_tx=3000, n_bd=90, k_tx=5, seed=41)
+    m, bg = _model(spec, cuda, torch.bfloat16)
+    opt = m.configure_optimizers(capturable=True)
+    trainer = GraphedTrainer(m, opt, granularity=1.3)
+    a = trainer.step(bg).clone()
+    assert torch.isfinite(a).all() and float(a[2]) > 0
+    bg[TX_BD]["edge_index"] = bg[TX_BD].edge_index[:, :0].contiguous()
+    if hasattr(bg, "_segger_amd_cache"):                    # derived structures of the old edge list
+        bg._segger_amd_cache.clear()
+    b = trainer.step(bg).clone()
+    assert torch.isfinite(b).all() and float(b[2]) == 0.0 and float(b[0]) > 0
+    bg["tx"]["mask"] = torch.zeros_like(bg["tx"]["mask"])
+    bg["bd"]["mask"] = torch.zeros_like(bg["bd"]["mask"])
+    if hasattr(bg, "_segger_amd_cache"):
+        bg._segger_amd_cache.clear()
+    c = trainer.step(bg).clone()
+    assert torch.equal(c, torch.zeros_like(c))
+    assert all(torch.isfinite(p).all() for p in m.parameters())
