@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the fp32 secondary line")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling (fixed FOV) record")
+    ap.add_argument("--strong-graphed-dp", action="store_true",
+                    help="N > 1: also run the strong epoch with captured steps (two hipGraphs around the all-reduce); "
+                         "default off until it has run over RCCL on a multi-GPU box (N = 1 always reports it)")
     ap.add_argument("--strong-n-tx", type=int, default=50_000_000, help="transcripts of the fixed FOV (BASELINE C3/C4)")
     ap.add_argument("--strong-n-bd", type=int, default=500_000)
     ap.add_argument("--strong-edges-per-batch", type=int, default=1_000_000,
@@ -367,14 +370,15 @@ def main():
             "mp_edges_per_s": 4.0 * (ett_f + etb_f) / rec["epoch_s"],
             "ms_per_step": rec["epoch_s"] / max(rec["steps_per_rank"], 1) * 1e3,
             "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30})
-        if world == 1:
+        if world == 1 or args.strong_graphed_dp:
             try:
-                # the same epoch with every step replayed as ONE hipGraph (segger_amd.train_step_graph): single rank only,
-                # the data-parallel step keeps its all-reduce between backward and Adam outside a capture
+                # the same epoch with every step replayed as ONE hipGraph (segger_amd.train_step_graph); with several
+                # ranks (opt-in) as two graphs around the eager all-reduce of the flat gradient bucket
                 from segger_amd.train_step_graph import GraphedTrainer
-                trainer = GraphedTrainer(model, model.configure_optimizers(capturable=True))
+                trainer = GraphedTrainer(model, model.configure_optimizers(capturable=True),
+                                         grad_sync=bucket.all_reduce_mean if world > 1 else None)
                 rec_g = strong_scaling_epoch(batch_weights(part, batches),
-                                             lambda k, i: trainer.step(part.batch(batches[k])),
+                                             lambda k, i: trainer.step(part.batch(batches[k]) if k is not None else None),
                                              lambda k: (sum(e_tb[t] for t in batches[k]), sum(e_tt[t] for t in batches[k])),
                                              sync=torch.cuda.synchronize, device=dev, warmup=-1)
                 etb_g, ett_g = rec_g["units_total"]

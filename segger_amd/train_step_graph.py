@@ -25,6 +25,11 @@ What it computes is ``LitISTEncoder.training_step`` + ``optimizer.step()`` (refe
 Lightning's automatic optimisation), for the default ``sg_loss_type='triplet'``.  The optimizer must be capturable
 (``LitISTEncoder.configure_optimizers(capturable=True)``); ``ops.invalidate_weight_cache()`` is called after every
 replay because the parameters change without Python noticing.
+
+Data parallelism (``GraphedTrainer(..., grad_sync=bucket.all_reduce_mean)``): the step is captured as TWO graphs --
+forward + backward, and Adam -- with the gradient exchange between them run eagerly (one collective per step on every
+rank, whatever a rank is capturing; a rank that ran out of batches zeroes its gradients instead of replaying the first
+graph).  Covered by a two-rank gloo test on one GPU; not yet run over RCCL on a multi-GPU box.
 """
 from __future__ import annotations
 
@@ -60,7 +65,8 @@ class GraphedTrainStep:
     CSR views, the rows-by-gene grouping of the embedding gradient, the segmentation triplets and the loss samplers'
     indices are all "copy the batch's own (cached) arrays, fill the padding by a formula" segments."""
 
-    def __init__(self, lit_model, optimizer, sizes: Dict[str, int], template):
+    def __init__(self, lit_model, optimizer, sizes: Dict[str, int], template, grad_sync=None):
+        self.grad_sync = grad_sync
         if lit_model._sg_loss_type != "triplet":
             raise NotImplementedError("the graphed step covers the (default) triplet segmentation loss")
         if lit_model.loss_tx is None or lit_model.loss_bd is None:
@@ -104,6 +110,8 @@ class GraphedTrainStep:
         self._unit = torch.tensor([float(nt), 1.0, 1.0], device=dev)
         self.out: Optional[Tensor] = None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.graph_opt: Optional[torch.cuda.CUDAGraph] = None      # split mode (grad_sync): Adam as a graph of its own
+        self._grads: list = []
         self._training: Optional[bool] = None
         self._iota = torch.arange(nt, device=dev)
         # The captured forward runs on ALIASES of the parameters (same storage, distinct autograd leaves).  A leaf's
@@ -213,6 +221,10 @@ class GraphedTrainStep:
 
     # ------------------------------------------------------------------------------------------- the step
     def _run(self) -> None:
+        self._run_grads()
+        self.opt.step()
+
+    def _run_grads(self) -> None:
         lit, enc, s = self.lit, self.lit.model, self.sizes
         nt = s["tx"]
         tx, bd = self.nodes["tx"], self.nodes["bd"]
@@ -245,7 +257,6 @@ class GraphedTrainStep:
         grads = torch.autograd.grad(loss, self._leaves, allow_unused=True)
         for p, g in zip(self._params, grads):
             p.grad = g
-        self.opt.step()
         self.out = torch.cat([terms.detach(), loss.detach().reshape(1)])
 
     @torch.no_grad()
@@ -286,14 +297,43 @@ class GraphedTrainStep:
             self._restore(keep)                               # ... which must not count as a training step
             ops.invalidate_weight_cache()                     # the captured step starts with the weight refresh
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
-                self._run()
+            if self.grad_sync is None:
+                with torch.cuda.graph(self.graph):
+                    self._run()
+            else:                                             # forward + backward | <gradient exchange> | Adam
+                with torch.cuda.graph(self.graph):
+                    self._run_grads()
+                self.graph_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                    self.opt.step()
+            self._grads = [p.grad for p in self._params]
             self._training = lit.model.training
-            self.graph.replay()                               # (capturing runs nothing)
+            self._replay()                                    # (capturing runs nothing)
         else:
-            self.graph.replay()
+            self._replay()
         ops.invalidate_weight_cache()                         # parameters changed behind Python's back
         return self.out
+
+    def _replay(self, empty: bool = False) -> None:
+        """Fused mode: one replay.  Split mode: replay forward + backward (``empty``: zero the gradients instead -- this
+        rank ran out of batches), hand this bucket's gradient tensors to the parameters, let ``grad_sync`` exchange
+        them (exactly ONE collective per step on every rank: the warm-up of a capture never synchronises), replay
+        Adam."""
+        if self.grad_sync is None:
+            self.graph.replay()
+            return
+        if empty:
+            torch._foreach_zero_([g for g in self._grads if g is not None])
+        else:
+            self.graph.replay()
+        for p, g in zip(self._params, self._grads):
+            p.grad = g
+        self.grad_sync()
+        self.graph_opt.replay()
+
+    def empty_step(self) -> None:
+        self._replay(empty=True)
+        ops.invalidate_weight_cache()
 
 
 class GraphedTrainer:
@@ -301,12 +341,34 @@ class GraphedTrainer:
     when none fits or the tightest one would pad the transcript side by more than two granules; with ``max_buckets``
     captured, the tightest fit is used whatever it wastes, and a batch no bucket holds is an error."""
 
-    def __init__(self, lit_model, optimizer, granularity: float = 1.06, max_buckets: int = 24):
+    def __init__(self, lit_model, optimizer, granularity: float = 1.06, max_buckets: int = 24, grad_sync=None):
+        """``grad_sync`` (data parallelism): a callable that averages the parameters' ``.grad`` over the ranks, e.g.
+        ``dp.FlatGradBucket(model.parameters()).all_reduce_mean``.  The step is then two graphs with the exchange
+        between them, run eagerly (one collective per ``step`` call on every rank; ``step(None)`` is the empty step
+        of a rank that ran out of batches: zeros into the exchange, then Adam)."""
         self.lit, self.opt, self.granularity, self.max_buckets = lit_model, optimizer, granularity, max_buckets
+        self.grad_sync = grad_sync
         self.buckets: List[GraphedTrainStep] = []
         self.n_captures = 0
+        self._last: Optional[GraphedTrainStep] = None
 
-    def step(self, batch) -> Tensor:
+    def _empty_step(self) -> None:
+        if self.grad_sync is None:
+            return
+        if self._last is not None and self._last.graph_opt is not None:
+            self._last.empty_step()
+            return
+        for g in self.opt.param_groups:                       # no bucket captured yet on this rank: eager
+            for p in g["params"]:
+                if p.requires_grad:
+                    p.grad = torch.zeros_like(p)
+        self.grad_sync()
+        self.opt.step()
+        ops.invalidate_weight_cache()
+
+    def step(self, batch) -> Optional[Tensor]:
+        if batch is None:
+            return self._empty_step()
         fit = [b for b in self.buckets if b.fits(batch)]
         best = min(fit, key=lambda b: b.waste(batch)) if fit else None
         full = len(self.buckets) >= self.max_buckets
@@ -314,7 +376,8 @@ class GraphedTrainer:
             if full:
                 raise RuntimeError(f"no captured bucket holds this batch and {self.max_buckets} buckets exist: "
                                    f"raise `granularity` or `max_buckets`")
-            best = GraphedTrainStep(self.lit, self.opt, step_bucket(batch, self.granularity), batch)
+            best = GraphedTrainStep(self.lit, self.opt, step_bucket(batch, self.granularity), batch, self.grad_sync)
             self.buckets.append(best)
             self.n_captures += 1
+        self._last = best
         return best.step(batch)

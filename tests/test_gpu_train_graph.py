@@ -152,3 +152,31 @@ def test_graphed_step_degenerate_batches(cuda):
     c = trainer.step(bg).clone()
     assert torch.equal(c, torch.zeros_like(c))
     assert all(torch.isfinite(p).all() for p in m.parameters())
+
+
+def test_graphed_trainer_data_parallel(cuda, tmp_path):
+    """Two ranks (gloo, both on this GPU), uneven batch counts: forward + backward graph | one gradient exchange |
+    Adam graph.  Replicas must stay bit-identical (same averaged gradients, same Adam state), every rank takes the same
+    number of optimizer steps, and the loss goes down."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "tests", "dp_graphed_worker.py")],
+                       capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert sorted(x["rank"] for x in recs) == [0, 1]
+    assert {x["own"] for x in recs} == {recs[0]["steps_per_epoch"], recs[0]["steps_per_epoch"] - 1}   # one empty step
+    for x in recs:
+        assert x["finite"] and x["max_param_diff"] == 0.0
+        assert x["adam_steps"] == x["epochs"] * x["steps_per_epoch"]
+        assert x["last"] < x["first"]

@@ -69,8 +69,8 @@ def main():
                          "`train.epochs_s` (the first epoch builds the per-tile sampler indices)")
     ap.add_argument("--train-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--graphed-train", action="store_true",
-                    help="single rank: the whole step (fwd + losses + bwd + Adam) as one hipGraph replay per batch "
-                         "(segger_amd.train_step_graph)")
+                    help="the whole step (fwd + losses + bwd + Adam) as one hipGraph replay per batch "
+                         "(segger_amd.train_step_graph); with several ranks: two graphs around the gradient all-reduce")
     ap.add_argument("--score-dtypes", default="f32,bf16,f16")
     ap.add_argument("--graphed", action="store_true", help="also run the hipGraph-captured predictor (fp16)")
     ap.add_argument("--overlap-predict", action="store_true",
@@ -139,7 +139,7 @@ def main():
     model.set_similarities(aux["tx_similarity"].to(dev), aux["bd_similarity"].to(dev))
     model._max_epochs_override = 20
     model.current_epoch = 10
-    graphed_train = bool(args.graphed_train and world == 1)
+    graphed_train = bool(args.graphed_train)
     opt = model.configure_optimizers(capturable=graphed_train)
     broadcast_parameters(model)
     seed_rank(args.seed, rank, model.model)
@@ -155,11 +155,12 @@ def main():
     trainer = None
     if graphed_train:
         from segger_amd.train_step_graph import GraphedTrainer
-        trainer = GraphedTrainer(model, opt)
+        trainer = GraphedTrainer(model, opt, grad_sync=bucket.all_reduce_mean if world > 1 else None)
 
     def train_step(k, i):
-        if trainer is not None:
-            return trainer.step(part.batch(todo[k]))[3]
+        if trainer is not None:                              # (k None: the empty step of a rank out of batches)
+            out = trainer.step(part.batch(todo[k]) if k is not None else None)
+            return None if out is None else out[3]
         opt.zero_grad(set_to_none=True)
         loss = None
         if k is not None:                                    # None: this rank ran out of batches (empty step)
