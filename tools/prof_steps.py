@@ -16,6 +16,6 @@ for r in rows:
     n=r['Kernel_Name']; n=re.sub(r'at::native::','',n); n=re.sub(r'\(anonymous namespace\)::','',n)
     d[n][0]+=1; d[n][1]+=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6
 tot=sum(v[1] for v in d.values())
-print('kernels in steps (incl. the synthetic tile builder between steps): busy %.2f ms/step, %d launches/step'%(tot/steps, len(rows)/steps))
+print('kernels in steps (warm-up steps included: the first one also sorts the edge stores): busy %.2f ms/step, %d launches/step'%(tot/steps, len(rows)/steps))
 for n,(c,t) in sorted(d.items(), key=lambda kv:-kv[1][1])[:top]:
     print(f"{t/steps:7.3f} ms/step calls/step={c/steps:6.1f} avg={t/c*1e3:8.1f}us {n[:105]}")
