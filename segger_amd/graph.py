@@ -244,6 +244,22 @@ def build_edge_graph(edge_index: Tensor, n_src: int, n_dst: int, *, need_by_dst:
     return EdgeGraph(by_dst, by_src, n_src, n_dst, int(edge_index.shape[1]))
 
 
+def padded_view_segments(dst: EdgeCSR, src: EdgeCSR, n_real: int, pad_cols=None) -> list:
+    """``ops.stage`` segments that write the CSR view ``src`` (``n_real`` rows) into the larger static view ``dst`` of a
+    captured graph: real rows / slots are copied, the padding edges are spread evenly over the dummy rows
+    n_real .. dst.n_rows-1 (q each) with columns = the row itself (``pad_cols`` None: self-loops) or given as a fill
+    ``(kind, a, b)``, and edge ids continuing after the real ones.  No sort: the padded view is a valid CSR as is."""
+    e = src.n_edges
+    pad, n_dummy = dst.n_edges - e, dst.n_rows - n_real
+    if pad < 0 or n_dummy < 1:
+        raise ValueError("padded_view_segments: the static view must hold every edge and at least one dummy row")
+    q = max(-(-pad // n_dummy), 1)
+    col_fill = ("div", n_real, q) if pad_cols is None else tuple(pad_cols)
+    return [(dst.indptr, src.indptr, "ramp", e, q, pad),
+            (dst.col, src.col, *col_fill, 0),
+            (dst.eid, src.eid, "div", e, 1, 0)]
+
+
 def batch_cache(batch) -> dict:
     """Per-batch scratch dict; works for HeteroBatch and for a PyG Batch."""
     c = getattr(batch, "_segger_amd_cache", None)

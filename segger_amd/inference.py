@@ -5,10 +5,13 @@ kernels per tile batch; at prediction-tile sizes (<= 50 k nodes, ``data_module.p
 launch-bound.  :class:`GraphedPredictor` captures encoder forward + the fused cosine / arg-max / assignment
 kernel into one HIP graph per *shape bucket* and replays it for every batch padded to that bucket:
 
-* :func:`pad_batch` pads a batch to bucket sizes with isolated dummy nodes and dummy->dummy edges, so real
-  nodes see exactly their own neighbourhoods (outputs of the real rows are unchanged);
-* the CSR views are rebuilt eagerly per batch (a radix sort, outside the graph) into the captured buffers;
-* masks (``predict_mask``) and the device->host copy stay outside the graph, as in the reference.
+* a batch is padded to bucket sizes with isolated dummy nodes and dummy->dummy edges, so real nodes see exactly
+  their own neighbourhoods (outputs of the real rows are unchanged);
+* one ``segger_stage`` launch per batch writes node attributes and the three CSR views (copied from the batch's own
+  views, padding by index arithmetic) into the captured buffers -- no per-batch sort or concatenation;
+* masks (``predict_mask``) and the device->host copy stay outside the graph, as in the reference; ``predict_device``
+  defers both to the caller so that a loop over batches never waits for the GPU.
+(:func:`pad_batch` builds an explicitly padded batch; ``train_graph.GraphedEncoder`` still uses it.)
 
 hipGraph capture works because every C-ABI entry point only enqueues on the caller's stream and never
 allocates or synchronises (include/segger_amd.h conventions).
@@ -21,7 +24,7 @@ import torch
 from torch import Tensor
 
 from . import ops
-from .graph import EdgeGraph, build_edge_graph
+from .graph import EdgeCSR, EdgeGraph, batch_cache, build_edge_graph, edge_graph, padded_view_segments
 from .hetero import HeteroBatch, TX_BD, TX_NB_BD, TX_TX
 
 _EDGE_TYPES = (TX_TX, TX_BD, TX_NB_BD)
@@ -76,46 +79,75 @@ def pad_batch(batch, sizes: Dict[str, int]) -> HeteroBatch:
 
 
 class GraphedPredictor:
-    """Replays ``model.predict_step`` for batches of ONE bucket shape through a captured HIP graph."""
+    """Replays ``model.predict_step`` for batches of ONE bucket shape through a captured HIP graph.
+
+    A batch is written into the static buffers by ONE launch (``ops.stage`` -> ``segger_stage``): node attributes are
+    copied and padded with copies of node 0; the three CSR views (tx-neighbors-tx and tx-belongs-bd by destination,
+    tx-neighbors-bd by source) are copied from the batch's own views -- slices of the slide-level sort when the batch
+    comes from ``tiles.TilePartition`` -- and their padding edges are index arithmetic on the dummy rows
+    (``graph.padded_view_segments``): no per-batch sort, no concatenation."""
 
     def __init__(self, model, sizes: Dict[str, int], bd_dim: int, min_similarity: Optional[float] = None,
                  max_graphs: int = 64):
         self.model, self.sizes, self.min_similarity = model, dict(sizes), min_similarity
         dev = next(model.parameters()).device
+        self.dev = dev
         nt, nb = sizes["tx"], sizes["bd"]
+        z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)
         self.inp = {
-            "tx_x": torch.zeros(nt, dtype=torch.int32, device=dev),
-            "tx_pos": torch.zeros(nt, 2, device=dev), "tx_batch": torch.zeros(nt, dtype=torch.long, device=dev),
-            "bd_x": torch.zeros(nb, bd_dim, device=dev), "bd_pos": torch.zeros(nb, 2, device=dev),
-            "bd_batch": torch.zeros(nb, dtype=torch.long, device=dev),
-            "bd_index": torch.zeros(nb, dtype=torch.long, device=dev),
+            "tx_x": z(nt, dtype=torch.int32), "tx_pos": z(nt, 2), "tx_batch": z(nt, dtype=torch.long),
+            "bd_x": z(nb, bd_dim), "bd_pos": z(nb, 2), "bd_batch": z(nb, dtype=torch.long),
+            "bd_index": z(nb, dtype=torch.long),
         }
-        self.graphs: Dict[Tuple[str, str, str], EdgeGraph] = {}
-        self._csr_buffers: Dict = {}
+
+        def csr(n_rows, n_cols, n_edges):
+            return EdgeCSR(z(n_rows + 1, dtype=torch.long), z(n_edges, dtype=torch.int32),
+                           z(n_edges, dtype=torch.int32), n_rows, n_cols)
+        e = {et: sizes["__".join(et)] for et in _EDGE_TYPES}
+        self.graphs: Dict[Tuple[str, str, str], EdgeGraph] = {
+            TX_TX: EdgeGraph(csr(nt, nt, e[TX_TX]), None, nt, nt, e[TX_TX]),
+            TX_BD: EdgeGraph(csr(nb, nt, e[TX_BD]), None, nt, nb, e[TX_BD]),
+            TX_NB_BD: EdgeGraph(None, csr(nt, nb, e[TX_NB_BD]), nt, nb, e[TX_NB_BD]),
+        }
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out: Dict[str, Tensor] = {}
         # the per-graph min / max tables are sized for max_graphs, so one captured graph serves batches of any
         # number of tiles up to that (graphs without nodes are never read)
         self.num_graphs = int(max_graphs)
 
+    def fits(self, batch) -> bool:
+        s = self.sizes
+        return (batch["tx"].num_nodes < s["tx"] and batch["bd"].num_nodes < s["bd"]
+                and all(int(batch[et].edge_index.shape[1]) <= s["__".join(et)] for et in _EDGE_TYPES)
+                and int(getattr(batch, "num_graphs", 1)) <= self.num_graphs)
+
+    def waste(self, batch) -> float:
+        s = self.sizes
+        return max(s["__".join(TX_TX)] / max(int(batch[TX_TX].edge_index.shape[1]), 1),
+                   s["tx"] / max(batch["tx"].num_nodes, 1))
+
     # -- staging ------------------------------------------------------------------------------
-    def _stage(self, pb) -> None:
-        self.inp["tx_x"].copy_(pb["tx"]["x"]); self.inp["tx_pos"].copy_(pb["tx"]["pos"])
-        self.inp["tx_batch"].copy_(pb["tx"]["batch"])
-        self.inp["bd_x"].copy_(pb["bd"]["x"]); self.inp["bd_pos"].copy_(pb["bd"]["pos"])
-        self.inp["bd_batch"].copy_(pb["bd"]["batch"]); self.inp["bd_index"].copy_(pb["bd"]["index"])
-        n = {"tx": self.sizes["tx"], "bd": self.sizes["bd"]}
-        for et in _EDGE_TYPES:
-            s, _, d = et
-            g = build_edge_graph(pb[et].edge_index, n[s], n[d], need_by_dst=et != TX_NB_BD,
-                                 need_by_src=et == TX_NB_BD, validate=False)
-            if et not in self.graphs:
-                self.graphs[et] = g                      # first batch: these tensors become the captured buffers
-            else:
-                for side in ("by_dst", "by_src"):
-                    cur, new = getattr(self.graphs[et], side), getattr(g, side)
-                    if cur is not None:
-                        cur.indptr.copy_(new.indptr); cur.col.copy_(new.col); cur.eid.copy_(new.eid)
+    @torch.no_grad()
+    def _stage(self, batch) -> None:
+        if not self.fits(batch):
+            raise ValueError("batch does not fit this predictor's bucket")
+        tx, bd = batch["tx"], batch["bd"]
+        n_tx, n_bd, nt, nb = tx.num_nodes, bd.num_nodes, self.sizes["tx"], self.sizes["bd"]
+        cache = batch_cache(batch)
+        # the same cache keys the eager predict_step uses: a batch scored both ways is sorted (or sliced) once
+        g_tt = edge_graph(cache, TX_TX, batch[TX_TX].edge_index, n_tx, n_tx, need_by_src=False, validate=False)
+        g_tb = edge_graph(cache, TX_BD, batch[TX_BD].edge_index, n_tx, n_bd, need_by_src=False, validate=False)
+        g_nb = edge_graph(cache, TX_NB_BD, batch[TX_NB_BD].edge_index, n_tx, n_bd, need_by_dst=False, validate=False)
+        I = self.inp
+        segs = [(I["tx_x"], tx["x"], "const", 0, 0, 0), (I["tx_pos"], tx["pos"], "tile", 2, 0, 0),
+                (I["tx_batch"], tx["batch"], "tile", 1, 0, 0),
+                (I["bd_x"], bd["x"], "tile", max(int(bd["x"][0].numel()), 1), 0, 0),
+                (I["bd_pos"], bd["pos"], "tile", 2, 0, 0), (I["bd_batch"], bd["batch"], "tile", 1, 0, 0),
+                (I["bd_index"], bd["index"], "tile", 1, 0, 0)]
+        segs += padded_view_segments(self.graphs[TX_TX].by_dst, g_tt.by_dst, n_tx, None)
+        segs += padded_view_segments(self.graphs[TX_BD].by_dst, g_tb.by_dst, n_bd, ("mod", n_tx, nt - n_tx))
+        segs += padded_view_segments(self.graphs[TX_NB_BD].by_src, g_nb.by_src, n_tx, ("mod", n_bd, nb - n_bd))
+        ops.stage(segs, self.dev)
 
     def _run(self) -> None:
         m = self.model.model
@@ -132,14 +164,13 @@ class GraphedPredictor:
 
     # -- public -------------------------------------------------------------------------------
     @torch.no_grad()
-    def predict(self, batch):
-        """-> (tx_index, seg_idx, max_sim, gene_id) on the CPU, exactly like ``predict_step``."""
+    def predict_device(self, batch):
+        """-> (tx_index, seg_idx, max_sim, gene_id, predict_mask) on the DEVICE, all [n_tx] and NOT yet filtered by the
+        mask: nothing here waits for the GPU, so a loop over batches queues ahead of it; apply the mask (one
+        compaction, one sync) after the loop."""
         if self.model.training:
             raise RuntimeError("GraphedPredictor needs model.eval()")
-        if getattr(batch, "num_graphs", 1) > self.num_graphs:
-            raise ValueError(f"batch holds {batch.num_graphs} graphs, predictor was built for <= {self.num_graphs}")
-        pb = pad_batch(batch, self.sizes)
-        self._stage(pb)
+        self._stage(batch)
         if self.graph is None:
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
@@ -151,7 +182,44 @@ class GraphedPredictor:
                 self._run()
         self.graph.replay()
         n = batch["tx"].num_nodes
-        mask = batch["tx"]["predict_mask"]
-        out = (batch["tx"]["index"][mask], self.out["seg_idx"][:n][mask], self.out["max_sim"][:n][mask],
-               batch["tx"]["x"][mask])
-        return tuple(t.cpu() for t in out)
+        return (batch["tx"]["index"], self.out["seg_idx"][:n].clone(), self.out["max_sim"][:n].clone(),
+                batch["tx"]["x"], batch["tx"]["predict_mask"])
+
+    @torch.no_grad()
+    def predict(self, batch):
+        """-> (tx_index, seg_idx, max_sim, gene_id) on the CPU, exactly like ``predict_step``."""
+        index, seg, sim, gene, mask = self.predict_device(batch)
+        return tuple(t[mask].cpu() for t in (index, seg, sim, gene))
+
+
+class GraphedPredictorPool:
+    """``pool.predict(batch)`` / ``pool.predict_device(batch)``: the tightest captured bucket the batch fits; a new
+    one is captured when none fits or the tightest would pad the transcript side by more than two granules."""
+
+    def __init__(self, model, bd_dim: int, min_similarity: Optional[float] = None, granularity: float = 1.08,
+                 max_buckets: int = 32, max_graphs: int = 64):
+        self.model, self.bd_dim, self.min_similarity = model, bd_dim, min_similarity
+        self.granularity, self.max_buckets, self.max_graphs = granularity, max_buckets, max_graphs
+        self.buckets: list = []
+
+    def _pick(self, batch) -> GraphedPredictor:
+        fit = [b for b in self.buckets if b.fits(batch)]
+        best = min(fit, key=lambda b: b.waste(batch)) if fit else None
+        full = len(self.buckets) >= self.max_buckets
+        if best is None or (best.waste(batch) > self.granularity ** 2 and not full):
+            if full:
+                raise RuntimeError(f"no captured bucket holds this batch and {self.max_buckets} buckets exist")
+            sizes = bucket_sizes(batch, self.granularity, floor=256)
+            for k in sizes:                               # the boundary side is cheap: one granule of headroom more
+                if k != "tx" and k != "__".join(TX_TX):
+                    sizes[k] = int(sizes[k] * self.granularity) + 1
+            best = GraphedPredictor(self.model, sizes, self.bd_dim, self.min_similarity,
+                                    max(self.max_graphs, int(getattr(batch, "num_graphs", 1))))
+            self.buckets.append(best)
+        return best
+
+    def predict(self, batch):
+        return self._pick(batch).predict(batch)
+
+    def predict_device(self, batch):
+        return self._pick(batch).predict_device(batch)

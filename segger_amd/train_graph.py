@@ -14,6 +14,11 @@ counter value of its own forward; the CSR views are rebuilt eagerly per batch in
 Constraint inherited from PyTorch: when the first call of a bucket captures the backward, no autograd graph
 from an earlier eager step may still be alive (e.g. a retained loss tensor): its AccumulateGrad nodes force a
 cross-stream sync inside the capture, which aborts it.  Keep only detached values between steps.
+
+Superseded for training loops by ``segger_amd.train_step_graph`` (round 2): the WHOLE step -- losses and Adam included --
+as one graph, one-launch staging instead of a per-batch re-sort, and a captured forward that runs on parameter aliases
+and is therefore immune to the constraint above.  This module remains for callers that want eager losses on the real
+batch around a replayed encoder.
 """
 from __future__ import annotations
 

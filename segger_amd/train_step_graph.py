@@ -39,7 +39,7 @@ import torch
 from torch import Tensor
 
 from . import ops
-from .graph import EdgeCSR, EdgeGraph, batch_cache, edge_graph
+from .graph import EdgeCSR, EdgeGraph, batch_cache, edge_graph, padded_view_segments
 from .hetero import TX_BD, TX_TX
 
 
@@ -140,18 +140,6 @@ class GraphedTrainStep:
         return max(s["e_tt"] / max(int(batch[TX_TX].edge_index.shape[1]), 1), s["tx"] / max(batch["tx"].num_nodes, 1))
 
     # ------------------------------------------------------------------------------------------- staging
-    @staticmethod
-    def _view_segments(dst: EdgeCSR, src: EdgeCSR, n_real: int, pad_cols) -> list:
-        """Real rows / slots from ``src``; padding edges spread evenly over the dummy rows n_real .. n_rows-1 (q each),
-        their columns = the row itself (``pad_cols`` None) or ``pad_cols`` = (fill, a, b)."""
-        e = src.n_edges
-        pad, n_dummy = dst.n_edges - e, dst.n_rows - n_real
-        q = max(-(-pad // n_dummy), 1)
-        col_fill = ("div", n_real, q) if pad_cols is None else pad_cols
-        return [(dst.indptr, src.indptr, "ramp", e, q, pad),
-                (dst.col, src.col, *col_fill, 0),
-                (dst.eid, src.eid, "div", e, 1, 0)]
-
     def _sampler_segments(self, dst: dict, ix: dict, n_total: int) -> list:
         n = int(ix["lab"].numel())
         return [(dst["lab"], ix["lab"], "const", dst["n_clusters"], 0, 0),          # padding: the masked-out cluster
@@ -212,9 +200,9 @@ class GraphedTrainStep:
             (self.scal[3:4], None, "const", fb(w[0]), 0, 0), (self.scal[4:5], None, "const", fb(w[1]), 0, 0),
             (self.scal[5:6], None, "const", fb(w[2]), 0, 0),
         ]
-        segs += self._view_segments(self.g_tt.by_dst, g_tt.by_dst, n_tx, None)
-        segs += self._view_segments(self.g_tt.by_src, g_tt.require_by_src(), n_tx, None)
-        segs += self._view_segments(self.g_tb.by_dst, g_tb.by_dst, n_bd, dummies)
+        segs += padded_view_segments(self.g_tt.by_dst, g_tt.by_dst, n_tx, None)
+        segs += padded_view_segments(self.g_tt.by_src, g_tt.require_by_src(), n_tx, None)
+        segs += padded_view_segments(self.g_tb.by_dst, g_tb.by_dst, n_bd, dummies)
         segs += self._sampler_segments(self.ix_tx, ix_tx, nt)
         segs += self._sampler_segments(self.ix_bd, ix_bd, s["bd"])
         ops.stage(segs, self.dev)
