@@ -294,13 +294,30 @@ def main():
             for i in range(len(pti)):
                 outs.append(model.predict_step(pti[i], i))
         rows = sum(int(o[0].numel()) for o in outs)
+        # the same sweep through the hipGraph predictor pool: no per-tile sync, one mask compaction at the end
+        from segger_amd.inference import GraphedPredictorPool
+        opool = GraphedPredictorPool(model, spec.bd_dim)
+        for phase in ("overlap_graphed_capture_s", "overlap_graphed_predict_s"):
+            with Phase(phase, times):
+                dev_out = [opool.predict_device(pti[i]) for i in range(len(pti))]
+                mask = torch.cat([o[4] for o in dev_out])
+                outs_g = [tuple(torch.cat([o[i] for o in dev_out])[mask] for i in range(4))]
+                rows_g = int(outs_g[0][0].numel())
+                del dev_out, mask
+        same = rows_g == rows and all(
+            torch.equal(torch.cat([o[i] for o in outs]).to(dev), outs_g[0][i]) for i in (0, 3))
+        del outs_g
         with Phase("overlap_postprocess_s", times):
             seg = assign_transcripts_to_cells(outs, device=dev)
         overlap = {"tiles": len(pti), "margin_um": args.margin, "dtype": "f16", "predict_seconds": times["overlap_predict_s"],
                    "rows_from_tiles": rows, "transcripts": int(seg["row_index"].numel()),
                    "assigned": int((seg["cell_encoding"] >= 0).sum()),
                    "postprocess_seconds": times["overlap_postprocess_s"], "global_threshold": seg["global_threshold"],
-                   "transcripts_per_s": int(seg["row_index"].numel()) / times["overlap_predict_s"]}
+                   "transcripts_per_s": int(seg["row_index"].numel()) / times["overlap_predict_s"],
+                   "graphed": {"predict_seconds": times["overlap_graphed_predict_s"],
+                               "capture_sweep_seconds": times["overlap_graphed_capture_s"], "buckets": len(opool.buckets),
+                               "same_rows_as_eager": bool(same),
+                               "transcripts_per_s": int(seg["row_index"].numel()) / times["overlap_graphed_predict_s"]}}
         if args.segmentation_parquet:
             from segger_amd.postprocess import to_frame
             with Phase("write_parquet_s", times):
