@@ -306,6 +306,40 @@ def test_graphed_predictor_matches_eager_predict_step(cuda, dtype):
     assert n_checked >= 3 and gp.graph is not None
 
 
+def test_predictor_pool_on_partition_batches_without_sync(cuda):
+    """GraphedPredictorPool on batches of a TilePartition with slide-level CSR views (staged from slices, no per-batch
+    sort): predict_device returns unmasked device tensors; masking after the loop gives predict_step's rows."""
+    from segger_amd import tiles as T
+    from segger_amd.inference import GraphedPredictorPool
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=20000, n_bd=500, k_tx=7, seed=33)
+    m, _, b, _ = build(spec, cuda, dtype=torch.float16)
+    m.eval()
+    for nt in ("tx", "bd"):
+        del b[nt]["mask"]
+    bg = b.to(cuda)
+    tiling = T.SquareTiling(torch.cat([b["tx"].pos, b["bd"].pos]), 55.0)
+    part = T.partition_by_tiling(bg, tiling, margin=3.0)
+    part.add_node_attr("tx", "predict_mask", torch.rand(spec.n_tx, device=cuda) < 0.9, permuted=True)
+    part.build_csr()
+    sampler = T.TileBatchSampler(part, max_num=max(part.weights("edge")) * 2, mode="edge", skip_too_big=True)
+    batches = [ids for ids in sampler if all(part.node_sizes["bd"][t] > 1 for t in ids)]
+    batches = batches + [[ids[0]] for ids in batches[:3]]             # packed batches (sorted per batch) and single
+    assert len(batches) >= 6                                          # tiles (views sliced from the slide-level sort)
+    pool = GraphedPredictorPool(m, spec.bd_dim, granularity=1.3)
+    dev_out = [pool.predict_device(part.batch(ids)) for ids in batches]
+    mask = torch.cat([o[4] for o in dev_out])
+    got = tuple(torch.cat([o[i] for o in dev_out])[mask].cpu() for i in range(4))
+    want = [m.predict_step(part.batch(ids), 0) for ids in batches]
+    want = tuple(torch.cat([w[i] for w in want]) for i in range(4))
+    assert len(pool.buckets) < len(batches)
+    assert torch.equal(got[0], want[0]) and torch.equal(got[3], want[3])
+    assert torch.allclose(got[2], want[2], atol=2e-3)
+    assert (got[1] == want[1]).float().mean() > 0.98
+    one = pool.predict(part.batch(batches[0]))                       # the reference-shaped call: CPU, masked
+    assert all(torch.equal(a, w) for a, w in zip((one[0], one[3]), (m.predict_step(part.batch(batches[0]), 0)[i] for i in (0, 3))))
+
+
 def test_graphed_encoder_matches_eager_forward_and_backward(cuda):
     """Encoder fwd+bwd as hipGraph replays (torch.cuda.make_graphed_callables over bucket-padded tiles):
     same embeddings and same parameter gradients as the eager path, for tiles of different sizes; with
