@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEGGER_ABI_VERSION 6
+#define SEGGER_ABI_VERSION 7
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -446,6 +446,20 @@ int segger_linear_wgrad(const void* dy, int64_t ld_dy, const void* x, int64_t ld
  * ---------------------------------------------------------------------- */
 int segger_posfreq(const float* pos, const int64_t* batch, const float* mins, const float* maxs, int64_t n,
                    int32_t freq_dim, float eps, float max_period, void* out, int32_t dtype, segger_stream_t stream);
+/*
+ * segger_posmlp_fwd: the whole Positional2dEmbedder (ist_encoder.py:33-79) in one kernel -- normalisation, the
+ * 256-wide sinusoid, Linear(256 -> 64), SiLU, Linear(64 -> 64) -- with the sinusoid features generated in registers as
+ * MFMA operand fragments instead of written to / read from HBM (segger_posfreq + two segger_linear_fwd otherwise).
+ *   w0 [64, 256], w2 [64, 64] row-major in `dtype` (bf16 / f16), b0 / b2 fp32 [64]
+ *   pe   [2n, 64] in `dtype` (= the embedder's [n, 128] output, x half then y half per node)
+ *   z1   [2n, 64], feat [2n, 256] in `dtype`: the pre-activation of the first layer and the sinusoid features, stored
+ *        for the backward (dW0 = dz1^T feat via segger_linear_wgrad); both NULL for inference.
+ * Covered: frequency_embedding_size 256, hidden_size 128 (segger's in_channels default): segger_posmlp_supported.
+ */
+int segger_posmlp_supported(int32_t freq_dim, int32_t dim, int32_t dtype);
+int segger_posmlp_fwd(const float* pos, const int64_t* batch, const float* mins, const float* maxs, int64_t n, float eps,
+                      float max_period, const void* w0, const float* b0, const void* w2, const float* b2, void* pe,
+                      void* z1, void* feat, int32_t dtype, segger_stream_t stream);
 int segger_embed_gelu_fwd(const float* table, const int32_t* ids, const void* pe, int64_t ld_pe, int64_t n,
                           int32_t n_rows_table, int32_t D, void* out, int64_t ld_out, int32_t dtype,
                           segger_stream_t stream);

@@ -69,6 +69,7 @@ class Positional2dEmbedder(Module):
             Linear(self.dim, self.dim, bias=True),
         )
         self.frequency_embedding_size = frequency_embedding_size
+        self.fused = True            # one-kernel route (ops.posmlp) where it applies; False: posfreq + linear + SiLU + linear
 
     @staticmethod
     def normalize(pos: Tensor, batch: Optional[Tensor], num_graphs: Optional[int] = None) -> Tensor:
@@ -91,6 +92,13 @@ class Positional2dEmbedder(Module):
             if num_graphs is None:
                 num_graphs = int(batch.max()) + 1 if batch.numel() else 0
             mins, maxs = ops.segment_minmax(pos, batch, num_graphs)
+            l0, l2 = self.mlp[0], self.mlp[2]
+            if (self.fused and pos.is_cuda and l0.bias is not None and l2.bias is not None
+                    and ops.posmlp_supported(fd, self.dim, dtype)):
+                # sinusoid + Linear + SiLU + Linear in one kernel: the [2n, 256] feature matrix is generated in
+                # registers (and stored once for the weight gradient when training) instead of written and re-read
+                return ops.posmlp(pos, batch, mins, maxs, l0.weight, l0.bias, l2.weight, l2.bias, dtype,
+                                  eps=1e-8, max_period=10000.0)
             freq = ops.posfreq(pos, batch, mins, maxs, fd, dtype, eps=1e-8, max_period=10000.0)
         else:
             pos = self.normalize(pos, batch, num_graphs)

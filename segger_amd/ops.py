@@ -910,6 +910,72 @@ def posfreq(pos: Tensor, batch: Optional[Tensor], mins: Tensor, maxs: Tensor, fr
     return out
 
 
+def posmlp_supported(freq_dim: int, dim: int, dtype: torch.dtype) -> bool:
+    return dtype in (torch.bfloat16, torch.float16) and bool(
+        _lib.load().segger_posmlp_supported(int(freq_dim), int(dim), DTYPE_CODE[dtype]))
+
+
+class _PosMlp(torch.autograd.Function):
+    """Positional2dEmbedder in one kernel (``segger_posmlp_fwd``): [n, 2] positions -> [n, 128].  With gradients the
+    kernel also stores the first layer's pre-activation and the sinusoid features, and the backward is assembled from
+    the projection kernels: dW2 / db2 and dW0 / db0 by ``segger_linear_wgrad``, dh1 by ``segger_linear_fwd``."""
+
+    @staticmethod
+    def forward(ctx, pos, batch, mins, maxs, eps, max_period, dtype, train, w0, b0, w2, b2):
+        _lib.require_cuda(pos, w0)
+        lib = _lib.load()
+        dev = pos.device
+        pos = pos.to(torch.float32).contiguous()
+        n = int(pos.shape[0])
+        if batch is not None:
+            batch = batch.to(device=dev, dtype=torch.int64).contiguous()
+        pk0 = _pack_for((w0,), (b0,)).get(dtype, dev)
+        pk2 = _pack_for((w2,), (b2,)).get(dtype, dev)
+        pe = torch.empty((n, 2 * w2.shape[0]), dtype=dtype, device=dev)
+        z1 = torch.empty((2 * n, w0.shape[0]), dtype=dtype, device=dev) if train else None
+        feat = torch.empty((2 * n, w0.shape[1]), dtype=dtype, device=dev) if train else None
+        with _lib.on_device(dev):
+            rc = lib.segger_posmlp_fwd(pos.data_ptr(), _lib.ptr(batch), mins.data_ptr(), maxs.data_ptr(), n, float(eps),
+                                       float(max_period), pk0.w.data_ptr(), pk0.b.data_ptr(), pk2.w.data_ptr(),
+                                       pk2.b.data_ptr(), pe.data_ptr(), _lib.ptr(z1), _lib.ptr(feat), DTYPE_CODE[dtype],
+                                       _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_posmlp_fwd")
+        if train:
+            ctx.save_for_backward(z1, feat)
+            ctx.pk2, ctx.key2 = pk2, pk2.key
+        return pe
+
+    @staticmethod
+    def backward(ctx, gpe):
+        z1, feat = ctx.saved_tensors
+        dt = z1.dtype
+        d = z1.shape[1]
+        g = gpe.to(dt).reshape(-1, d)
+        if g.shape[0] > 1 and g.stride(1) != 1:
+            g = g.contiguous()
+        if ctx.pk2.key != ctx.key2:
+            raise RuntimeError("the positional MLP's weights changed between this forward and its backward")
+        h1 = torch.nn.functional.silu(z1)
+        gw2, gb2 = linear_wgrad_launch(g, h1)
+        dh1 = linear_fwd_launch(g, ctx.pk2.wt, None)                          # [2n, 64] @ W2
+        dz1 = torch.ops.aten.silu_backward(dh1, z1)
+        gw0, gb0 = linear_wgrad_launch(dz1, feat)
+        need = ctx.needs_input_grad
+        return (None, None, None, None, None, None, None, None, gw0 if need[8] else None, gb0 if need[9] else None,
+                gw2 if need[10] else None, gb2 if need[11] else None)
+
+
+def posmlp(pos: Tensor, batch: Optional[Tensor], mins: Tensor, maxs: Tensor, w0: Tensor, b0: Tensor, w2: Tensor,
+           b2: Tensor, dtype: torch.dtype, eps: float = 1e-8, max_period: float = 10000.0) -> Tensor:
+    """``Positional2dEmbedder.forward`` (reference ist_encoder.py:33-79) for bf16 / f16 activations."""
+    if not posmlp_supported(w0.shape[1], w0.shape[0], dtype) or tuple(w2.shape) != (w0.shape[0], w0.shape[0]):
+        raise ValueError("posmlp: unsupported shapes (see segger_posmlp_supported)")
+    if b0 is None or b2 is None:
+        raise ValueError("posmlp: the embedder's Linear layers carry biases")
+    train = torch.is_grad_enabled() and any(t.requires_grad for t in (w0, b0, w2, b2))   # else nothing is stored
+    return _PosMlp.apply(pos, batch, mins, maxs, eps, max_period, dtype, train, w0, b0, w2, b2)
+
+
 class _EmbedGelu(torch.autograd.Function):
     """gelu(cat(table[ids], pe)): table fp32 [G, D] (embedding weight), ids int32 [n], pe [n, D] -> [n, 2D]."""
 

@@ -317,3 +317,49 @@ def test_stage_segments_copy_and_fill(cuda):
     many = [(torch.zeros(5, dtype=torch.int64, device=cuda), None, "div", i, 1, 0) for i in range(101)]   # > one launch
     ops.stage(many, cuda)
     assert all(torch.equal(t[0], i + k[:5]) for i, t in enumerate(many))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("n", [1, 31, 1000, 40_003])
+def test_fused_positional_embedder_matches_unfused_route(cuda, dtype, n):
+    """segger_posmlp_fwd (sinusoid generated as MFMA fragments, both Linear layers and SiLU fused) against fp64
+    arithmetic of ist_encoder.py:33-79 on the same rounded weights, and its gradients against autograd of the unfused
+    route (posfreq + linear + SiLU + linear).  Tolerances: one rounding of a 64-term dot product of O(1) values to the
+    16-bit output (2^-8 / 2^-10 relative + the rounding of h1)."""
+    from segger_amd import ops
+    from segger_amd.ist_encoder import Positional2dEmbedder
+    g = torch.Generator().manual_seed(n)
+    pos = (torch.rand(n, 2, generator=g) * 700 + 3).to(cuda)
+    batch = torch.sort(torch.randint(0, 3, (n,), generator=g)).values.to(cuda)
+    emb = Positional2dEmbedder(128).to(cuda)
+    with torch.no_grad():
+        for p_ in emb.parameters():
+            p_.mul_(3.0)                                     # bigger activations than the default init gives
+    pe = emb(pos, batch, num_graphs=3, dtype=dtype)          # fused (CUDA, 16-bit, 256 -> 64 -> 64)
+    assert pe.shape == (n, 128) and pe.dtype == dtype
+    # fp64 reference on the weights as the kernel sees them (rounded to dtype)
+    mins, maxs = ops.segment_minmax(pos, batch, 3)
+    p = ((pos - mins[batch]) / (maxs[batch] - mins[batch] + 1e-8)).double().flatten()
+    j = torch.arange(128, device=cuda, dtype=torch.float64)
+    ang = p[:, None] * torch.exp(-torch.log(torch.tensor(10000.0, dtype=torch.float64)) * j / 128)[None]
+    feat = torch.cat([ang.cos(), ang.sin()], 1).to(dtype).double()
+    l0, l2 = emb.mlp[0], emb.mlp[2]
+    z1 = feat @ l0.weight.detach().to(dtype).double().t() + l0.bias.detach().double()
+    h1 = (z1 * torch.sigmoid(z1)).to(dtype).double()
+    ref = (h1 @ l2.weight.detach().to(dtype).double().t() + l2.bias.detach().double()).reshape(n, 128)
+    rel = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert bool(((pe.double() - ref).abs() <= 2 * rel * ref.abs() + 4 * rel).all())
+    # gradients: fused forward + assembled backward vs autograd through the unfused ops
+    gy = torch.randn(n, 128, device=cuda, generator=torch.Generator(device=cuda).manual_seed(1)).to(dtype)
+    emb.zero_grad()
+    emb(pos, batch, num_graphs=3, dtype=dtype).backward(gy)
+    got = [p_.grad.clone() for p_ in emb.parameters()]
+    emb.zero_grad()
+    freq = ops.posfreq(pos, batch, mins, maxs, 256, dtype)
+    h = torch.nn.functional.silu(ops.linear(freq, l0.weight, l0.bias))
+    ops.linear(h, l2.weight, l2.bias).flatten(-2).backward(gy)
+    for a, p_ in zip(got, emb.parameters()):
+        scale = p_.grad.abs().max().item() + 1e-6
+        assert (a - p_.grad).abs().max().item() <= 3e-2 * scale
+    with torch.no_grad():                                    # inference: same values, nothing stored
+        assert torch.equal(emb(pos, batch, num_graphs=3, dtype=dtype), pe)
