@@ -452,14 +452,20 @@ int segger_posfreq(const float* pos, const int64_t* batch, const float* mins, co
  * MFMA operand fragments instead of written to / read from HBM (segger_posfreq + two segger_linear_fwd otherwise).
  *   w0 [64, 256], w2 [64, 64] row-major in `dtype` (bf16 / f16), b0 / b2 fp32 [64]
  *   pe   [2n, 64] in `dtype` (= the embedder's [n, 128] output, x half then y half per node)
- *   z1   [2n, 64], feat [2n, 256] in `dtype`: the pre-activation of the first layer and the sinusoid features, stored
- *        for the backward (dW0 = dz1^T feat via segger_linear_wgrad); both NULL for inference.
+ *   z1   [2n, 64] in `dtype`, pn [2n] fp32: the pre-activation of the first layer and the normalised coordinate per
+ *        row, stored for the backward; both NULL for inference.
+ * segger_posmlp_wgrad: dW0 [64, 256] = dz1^T F and db0 [64] = sum dz1 with F regenerated from pn inside the weight-
+ *   gradient kernel (one float per row read instead of a 512-byte feature row); workspace as
+ *   segger_linear_wgrad_workspace_bytes(n_rows, 64, 256); n_rows = 2n.
  * Covered: frequency_embedding_size 256, hidden_size 128 (segger's in_channels default): segger_posmlp_supported.
  */
 int segger_posmlp_supported(int32_t freq_dim, int32_t dim, int32_t dtype);
 int segger_posmlp_fwd(const float* pos, const int64_t* batch, const float* mins, const float* maxs, int64_t n, float eps,
                       float max_period, const void* w0, const float* b0, const void* w2, const float* b2, void* pe,
-                      void* z1, void* feat, int32_t dtype, segger_stream_t stream);
+                      void* z1, float* pn, int32_t dtype, segger_stream_t stream);
+int segger_posmlp_wgrad(const void* dz1, int64_t ld_dz1, const float* pn, int64_t n_rows, float max_period,
+                        int32_t dtype, float* grad_w0, float* grad_b0, void* workspace, size_t workspace_bytes,
+                        segger_stream_t stream);
 int segger_embed_gelu_fwd(const float* table, const int32_t* ids, const void* pe, int64_t ld_pe, int64_t n,
                           int32_t n_rows_table, int32_t D, void* out, int64_t ld_out, int32_t dtype,
                           segger_stream_t stream);

@@ -127,6 +127,7 @@ EXPORTS = {
     "segger_stage": (C.c_int, [C.POINTER(StageSeg), C.c_int32, vp]),
     "segger_posmlp_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "segger_posmlp_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp]),
+    "segger_posmlp_wgrad": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_float, C.c_int32, vp, vp, vp, C.c_size_t, vp]),
     "segger_sample_negatives": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_uint64, vp, vp, vp]),
     "segger_edge_cos_argmax": (C.c_int, [C.POINTER(EdgeArgmaxArgs), vp]),
     "segger_triplet_sample": (C.c_int, [vp, C.c_int64, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp, vp, vp, vp, vp]),

@@ -64,6 +64,8 @@ struct WgradParams {
   int64_t n_stages;          // ceil(n_rows / 16)
   int64_t stages_per_block;
   float* partial;            // [gridDim.x][M*K + M]
+  const float* pn;           // GEN: normalised coordinate per row (x is not read: its rows are sinusoid features of pn)
+  float log_max_period;
 };
 
 // One LDS-DMA wave-instruction: every lane fetches 16 bytes at rsrc + voffset + soffset (zeros when that is past
@@ -86,17 +88,20 @@ constexpr int kNBuf = 4;                   // LDS ring: stages s .. s+2 in fligh
 constexpr int kAhead = kNBuf - 1;
 constexpr int kOutOfRange = 0x40000000;    // byte offset past every slab (host checks slabs < 1 GiB): reads as zeros
 
-template <int M, int K, int NW> struct WgGeo {
+// GEN: the X operand is not staged but generated from one float per row (the positional embedder's sinusoid features,
+// X[row][f] = cos / sin(pn[row] * w_f)): the stage image is the dY rows followed by the 16 coordinates
+template <int M, int K, int NW, bool GEN = false> struct WgGeo {
   static constexpr int SY = M * 2 + 64, SX = K * 2 + 64;          // LDS row strides in bytes
-  static constexpr int IMG = kStageRows * (SY + SX);              // one stage: dY rows, then X rows
+  static constexpr int IMG = GEN ? kStageRows * SY + kStageRows * 4
+                                 : kStageRows * (SY + SX);         // one stage: dY rows, then X rows
   static constexpr int P = ((IMG + 1023) / 1024 + NW - 1) / NW;   // 1 KiB DMA chunks per wave per stage
   static constexpr int BUF = P * NW * 1024;                       // ring slot (chunks past IMG receive zeros)
   static constexpr int LDS = kNBuf * BUF;
 };
 
-template <typename T, int M, int K, int NW>
+template <typename T, int M, int K, int NW, bool GEN = false>
 __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
-  using G = WgGeo<M, K, NW>;
+  using G = WgGeo<M, K, NW, GEN>;
   constexpr int WM = NW == 8 ? 4 : 2, WK = 2;          // wave grid over (M tiles, K tiles)
   static_assert(M * K / (64 * NW) <= 192, "accumulator does not fit the register file");
   constexpr int TM = M / 32, TK = K / 32;
@@ -123,8 +128,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
   int64_t span_rows = p.n_rows > row_beg ? p.n_rows - row_beg : 0;             // valid rows from row_beg on ...
   if (span_rows > (int64_t)n_local * kStageRows) span_rows = (int64_t)n_local * kStageRows;   // ... inside this slab
   const i32x4 ry = make_rsrc(dy + row_beg * p.ld_dy, span_rows * p.ld_dy * 2);
-  const i32x4 rx = make_rsrc(x + row_beg * p.ld_x, span_rows * p.ld_x * 2);
-  const int stage_bytes_y = kStageRows * (int)p.ld_dy * 2, stage_bytes_x = kStageRows * (int)p.ld_x * 2;
+  const i32x4 rx = GEN ? make_rsrc(p.pn + row_beg, span_rows * 4) : make_rsrc(x + row_beg * p.ld_x, span_rows * p.ld_x * 2);
+  const int stage_bytes_y = kStageRows * (int)p.ld_dy * 2;
+  const int stage_bytes_x = GEN ? kStageRows * 4 : kStageRows * (int)p.ld_x * 2;
   int voff[P];
 #pragma unroll
   for (int j = 0; j < P; ++j) {
@@ -134,8 +140,12 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
       voff[j] = row * (int)p.ld_dy * 2 + (w < M * 2 ? w : 0);      // a row's 64 pad bytes re-read its first bytes
     } else if (o < G::IMG) {
       const int oo = o - kStageRows * SY;
-      const int row = oo / SX, w = oo % SX;
-      voff[j] = row * (int)p.ld_x * 2 + (w < K * 2 ? w : 0);
+      if (GEN) {
+        voff[j] = oo;                                      // the stage's 16 coordinates, contiguous
+      } else {
+        const int row = oo / SX, w = oo % SX;
+        voff[j] = row * (int)p.ld_x * 2 + (w < K * 2 ? w : 0);
+      }
     } else {
       voff[j] = kOutOfRange;
     }
@@ -167,6 +177,18 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
   float dbias[MT];
 #pragma unroll
   for (int a = 0; a < MT; ++a) dbias[a] = 0.f;
+  // GEN: this lane's feature columns f = 32 * (wk*KT + b) + (lane & 31): frequency in revolutions per unit coordinate,
+  // cos for the first half of the columns, sin for the second (wave-uniform: a wave's K tiles lie in one half)
+  float omega[KT];
+  const bool gen_sin = GEN && (32 * wk * KT >= K / 2);
+  if (GEN) {
+    static_assert(!GEN || (K / 2) % (32 * KT) == 0, "a wave's feature tiles must not straddle the cos / sin halves");
+#pragma unroll
+    for (int b = 0; b < KT; ++b) {
+      const int f = (32 * (wk * KT + b) + (lane & 31)) % (K / 2);
+      omega[b] = expf(-p.log_max_period * (float)f / (float)(K / 2)) * 0.15915494309189535f;
+    }
+  }
 
   for (int d = 0; d < kAhead; ++d) issue(d);
   for (int s = 0; s < n_local; ++s) {
@@ -193,13 +215,33 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
         dbias[a] = d;
       }
     }
+    if constexpr (GEN) {
+      // B fragment of tile b: lane (n = lane & 31, h = lane >> 5) supplies X[row 8h + i][column n], i = 0..7
+      const float* pr = reinterpret_cast<const float*>(base + kStageRows * SY) + 8 * (lane >> 5);
+      const f32x4 pa = *reinterpret_cast<const f32x4*>(pr), pb = *reinterpret_cast<const f32x4*>(pr + 4);
+      const float pv[8] = {pa.x, pa.y, pa.z, pa.w, pb.x, pb.y, pb.z, pb.w};
 #pragma unroll
-    for (int b = 0; b < KT; ++b) {
-      const u32x2 lo = lds_read_tr(base + off_x + b * 64);
-      const u32x2 hi = lds_read_tr(base + off_x + b * 64 + 4 * SX);
-      const u32x4 fb = u32x4{lo.x, lo.y, hi.x, hi.y};
+      for (int b = 0; b < KT; ++b) {
+        float v[8];
 #pragma unroll
-      for (int a = 0; a < MT; ++a) acc[a][b] = WgMfma<T>::run(fa[a], fb, acc[a][b]);
+        for (int i = 0; i < 8; ++i) {
+          const float rev = pv[i] * omega[b];
+          v[i] = gen_sin ? __builtin_amdgcn_sinf(rev) : __builtin_amdgcn_cosf(rev);
+        }
+        const u32x4 fb = u32x4{Vec8<T>::pack(v[0], v[1]), Vec8<T>::pack(v[2], v[3]), Vec8<T>::pack(v[4], v[5]),
+                               Vec8<T>::pack(v[6], v[7])};
+#pragma unroll
+        for (int a = 0; a < MT; ++a) acc[a][b] = WgMfma<T>::run(fa[a], fb, acc[a][b]);
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < KT; ++b) {
+        const u32x2 lo = lds_read_tr(base + off_x + b * 64);
+        const u32x2 hi = lds_read_tr(base + off_x + b * 64 + 4 * SX);
+        const u32x4 fb = u32x4{lo.x, lo.y, hi.x, hi.y};
+#pragma unroll
+        for (int a = 0; a < MT; ++a) acc[a][b] = WgMfma<T>::run(fa[a], fb, acc[a][b]);
+      }
     }
   }
   // the ring ran kAhead stages past the slab (zero reads): let them land before the wave ends
@@ -310,6 +352,8 @@ void launch_wgrad(const WgradParams& p, int64_t grid, hipStream_t stream) {
   hipLaunchKernelGGL((wgrad_kernel<T, M, K, NW>), dim3((unsigned)grid), dim3(NW * 64), 0, stream, p);
 }
 
+int reduce_partials(float* partial, int64_t grid, int m_out, int k_in, float* grad_w, float* grad_b, hipStream_t stream);
+
 template <typename T>
 int dispatch_wgrad(const WgradParams& p, int m, int k, int64_t grid, hipStream_t stream) {
 #define CASE(MM, KK) if (m == MM && k == KK) { launch_wgrad<T, MM, KK>(p, grid, stream); return SEGGER_OK; }
@@ -374,18 +418,62 @@ extern "C" int segger_linear_wgrad(const void* dy, int64_t ld_dy, const void* x,
                                       : dispatch_wgrad<f16_t>(p, m_out, k_in, grid, stream);
   if (rc != SEGGER_OK) return rc;
   SEGGER_LAUNCH_CHECK("wgrad_kernel");
+  return reduce_partials(p.partial, grid, m_out, k_in, grad_w, grad_b, stream);
+}
+
+namespace segger {
+namespace {
+int reduce_partials(float* partial, int64_t grid, int m_out, int k_in, float* grad_w, float* grad_b, hipStream_t stream) {
   const int64_t width = (int64_t)m_out * k_in + m_out;
   if (grid <= kSinglePassSlabs) {
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, stream, p.partial, grid,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, stream, partial, grid,
                        width, (int64_t)m_out * k_in, grad_w, grad_b);
     SEGGER_LAUNCH_CHECK("wgrad_reduce_kernel");
     return SEGGER_OK;
   }
-  float* part2 = p.partial + grid * width;             // behind the per-workgroup partials
+  float* part2 = partial + grid * width;               // behind the per-workgroup partials
   hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3((unsigned)((width + 255) / 256), kRedGroups), dim3(256), 0, stream,
-                     p.partial, grid, width, part2);
+                     partial, grid, width, part2);
   hipLaunchKernelGGL(wgrad_reduce2_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, stream,
                      part2, width, (int64_t)m_out * k_in, grad_w, grad_b);
   SEGGER_LAUNCH_CHECK("wgrad_reduce_kernel");
   return SEGGER_OK;
+}
+}  // namespace
+}  // namespace segger
+
+extern "C" int segger_posmlp_wgrad(const void* dz1, int64_t ld_dz1, const float* pn, int64_t n_rows, float max_period,
+                                   int32_t dtype, float* grad_w0, float* grad_b0, void* workspace, size_t workspace_bytes,
+                                   segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  constexpr int M = 64, K = 256;
+  SEGGER_REQUIRE(n_rows >= 0, "segger_posmlp_wgrad: negative size");
+  SEGGER_REQUIRE(dtype == SEGGER_BF16 || dtype == SEGGER_F16, "segger_posmlp_wgrad: bf16 / f16 only");
+  SEGGER_REQUIRE(grad_w0 != nullptr, "segger_posmlp_wgrad: grad_w0 is NULL");
+  if (n_rows == 0) {
+    SEGGER_HIP(hipMemsetAsync(grad_w0, 0, (size_t)M * K * sizeof(float), stream));
+    if (grad_b0) SEGGER_HIP(hipMemsetAsync(grad_b0, 0, (size_t)M * sizeof(float), stream));
+    return SEGGER_OK;
+  }
+  SEGGER_REQUIRE(dz1 && pn, "segger_posmlp_wgrad: NULL input");
+  SEGGER_REQUIRE(aligned16(dz1) && aligned16(pn) && ld_dz1 >= M && (ld_dz1 * 2) % 16 == 0,
+                 "segger_posmlp_wgrad: dz1 rows and pn must be 16-byte aligned");
+  const size_t need = segger_linear_wgrad_workspace_bytes(n_rows, M, K);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("segger_posmlp_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
+    return SEGGER_EWORKSPACE;
+  }
+  const int64_t grid = grid_for(n_rows, M, K);
+  const int64_t stages = (n_rows + kStageRows - 1) / kStageRows;
+  SEGGER_REQUIRE(((stages + grid - 1) / grid) * kStageRows * ld_dz1 * 2 < (int64_t)kOutOfRange,
+                 "segger_posmlp_wgrad: a workgroup's row slab exceeds 1 GiB");
+  WgradParams p{dz1, ld_dz1, nullptr, 0, n_rows, stages, (stages + grid - 1) / grid, static_cast<float*>(workspace), pn,
+                logf(max_period)};
+  if (dtype == SEGGER_BF16)
+    hipLaunchKernelGGL((wgrad_kernel<bf16_t, M, K, 4, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<f16_t, M, K, 4, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  SEGGER_LAUNCH_CHECK("wgrad_kernel (generated operand)");
+  return reduce_partials(p.partial, grid, M, K, grad_w0, grad_b0, stream);
+
 }

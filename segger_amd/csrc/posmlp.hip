@@ -6,8 +6,8 @@
 // The unfused route writes F -- [2 Nt, 256], 1 GB at C2 -- to HBM and reads it back for the first GEMM.  Here a lane
 // GENERATES its rows' features directly in the register layout of the MFMA B operand (lane (r, h) of a
 // v_mfma_f32_32x32x16 supplies 8 consecutive k for data row r: 8 frequencies of one coordinate), so F never exists in
-// memory at inference; for training the same fragments are also stored once (16 B per lane) because the weight
-// gradient dW0 = dz1^T F reads them back.  The second GEMM consumes the first one's accumulators without a transpose:
+// memory; for training the kernel stores the normalised coordinate (4 bytes per row) and the weight gradient
+// dW0 = dz1^T F regenerates F the same way (segger_posmlp_wgrad: linear_wgrad.hip's kernel with a generated operand).  The second GEMM consumes the first one's accumulators without a transpose:
 // the k order of a GEMM is free, so the A operand (W2) is read from LDS in the order the accumulator lanes hold h1.
 #include "common.h"
 
@@ -39,7 +39,7 @@ struct PosMlpParams {
   const float* pos; const int64_t* batch; const float* mins; const float* maxs;
   int64_t n; float eps; float log_max_period;
   const void* w0; const float* b0; const void* w2; const float* b2;
-  void* pe; void* z1; void* feat;
+  void* pe; void* z1; float* pn;
 };
 
 // sin / cos on the hardware units (v_sin_f32 / v_cos_f32 take revolutions and reduce the range themselves; absolute
@@ -131,6 +131,8 @@ __global__ __launch_bounds__(256, 2) void posmlp_fwd_kernel(PosMlpParams p) {
     const float pn = pn_n;
     if (t + t_step < n_tiles) pn_n = coord(t + t_step, valid_n, row_n);
 
+    if (TRAIN && valid && h == 0) p.pn[row] = pn;        // all the weight gradient needs to regenerate the features
+
     // ---- GEMM 1: z1[m][row] = sum_k W0[m][k] F[row][k], F generated as B fragments ---------------------------------
     f32x16 acc[2];
 #pragma unroll
@@ -148,11 +150,6 @@ __global__ __launch_bounds__(256, 2) void posmlp_fwd_kernel(PosMlpParams p) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) sincos_hw(pn * w[j], &sn[j], &cs[j]);
       const u32x4 bc = pack8<T>(cs), bs = pack8<T>(sn);
-      if (TRAIN && valid) {
-        T* f = static_cast<T*>(p.feat) + row * kFreq + k0;
-        *reinterpret_cast<u32x4*>(f) = bc;
-        *reinterpret_cast<u32x4*>(f + kHalf) = bs;
-      }
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
         const unsigned char* wr = lw0 + (ct * 32 + r) * kW0Stride + k0 * 2;
@@ -240,16 +237,16 @@ extern "C" int segger_posmlp_supported(int32_t freq_dim, int32_t dim, int32_t dt
 
 extern "C" int segger_posmlp_fwd(const float* pos, const int64_t* batch, const float* mins, const float* maxs, int64_t n,
                                  float eps, float max_period, const void* w0, const float* b0, const void* w2,
-                                 const float* b2, void* pe, void* z1, void* feat, int32_t dtype, segger_stream_t stream_) {
+                                 const float* b2, void* pe, void* z1, float* pn, int32_t dtype, segger_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SEGGER_REQUIRE(n >= 0, "segger_posmlp_fwd: negative size");
   SEGGER_REQUIRE(dtype == SEGGER_BF16 || dtype == SEGGER_F16, "segger_posmlp_fwd: bf16 / f16 only");
   if (n == 0) return SEGGER_OK;
   SEGGER_REQUIRE(pos && mins && maxs && w0 && b0 && w2 && b2 && pe, "segger_posmlp_fwd: NULL pointer");
-  SEGGER_REQUIRE(!z1 == !feat, "segger_posmlp_fwd: z1 and feat go together (both for training, neither for inference)");
-  SEGGER_REQUIRE(aligned16(w0) && aligned16(w2) && aligned16(pe) && aligned16(z1) && aligned16(feat),
+  SEGGER_REQUIRE(!z1 == !pn, "segger_posmlp_fwd: z1 and pn go together (both for training, neither for inference)");
+  SEGGER_REQUIRE(aligned16(w0) && aligned16(w2) && aligned16(pe) && aligned16(z1) && aligned16(pn),
                  "segger_posmlp_fwd: matrices must be 16-byte aligned");
-  PosMlpParams p{pos, batch, mins, maxs, n, eps, logf(max_period), w0, b0, w2, b2, pe, z1, feat};
+  PosMlpParams p{pos, batch, mins, maxs, n, eps, logf(max_period), w0, b0, w2, b2, pe, z1, pn};
   const int64_t n_tiles = (2 * n + 31) / 32;
   int64_t blocks = (n_tiles + 3) / 4;
   if (blocks > 512) blocks = 512;                          // persistent: 2 workgroups per CU

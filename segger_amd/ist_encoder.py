@@ -57,6 +57,9 @@ def sinusoidal_embedding(x: Tensor, dim: int, max_period: float = 1000) -> Tenso
     return emb
 
 
+FUSED_POSMLP = True      # default of Positional2dEmbedder.fused (tools flip it for A/B runs)
+
+
 class Positional2dEmbedder(Module):
     """Per-graph min-max normalised (x, y) -> 2 x sinusoid(256) -> shared MLP -> concat."""
 
@@ -69,7 +72,7 @@ class Positional2dEmbedder(Module):
             Linear(self.dim, self.dim, bias=True),
         )
         self.frequency_embedding_size = frequency_embedding_size
-        self.fused = True            # one-kernel route (ops.posmlp) where it applies; False: posfreq + linear + SiLU + linear
+        self.fused = FUSED_POSMLP    # one-kernel route (ops.posmlp) where it applies; False: posfreq + linear + SiLU + linear
 
     @staticmethod
     def normalize(pos: Tensor, batch: Optional[Tensor], num_graphs: Optional[int] = None) -> Tensor:

@@ -917,8 +917,9 @@ def posmlp_supported(freq_dim: int, dim: int, dtype: torch.dtype) -> bool:
 
 class _PosMlp(torch.autograd.Function):
     """Positional2dEmbedder in one kernel (``segger_posmlp_fwd``): [n, 2] positions -> [n, 128].  With gradients the
-    kernel also stores the first layer's pre-activation and the sinusoid features, and the backward is assembled from
-    the projection kernels: dW2 / db2 and dW0 / db0 by ``segger_linear_wgrad``, dh1 by ``segger_linear_fwd``."""
+    kernel also stores the first layer's pre-activation and the normalised coordinates (4 bytes per row), and the
+    backward is assembled from the projection kernels: dW2 / db2 by ``segger_linear_wgrad``, dh1 by
+    ``segger_linear_fwd``, dW0 / db0 by ``segger_posmlp_wgrad`` (the sinusoid features regenerated in the kernel)."""
 
     @staticmethod
     def forward(ctx, pos, batch, mins, maxs, eps, max_period, dtype, train, w0, b0, w2, b2):
@@ -933,21 +934,21 @@ class _PosMlp(torch.autograd.Function):
         pk2 = _pack_for((w2,), (b2,)).get(dtype, dev)
         pe = torch.empty((n, 2 * w2.shape[0]), dtype=dtype, device=dev)
         z1 = torch.empty((2 * n, w0.shape[0]), dtype=dtype, device=dev) if train else None
-        feat = torch.empty((2 * n, w0.shape[1]), dtype=dtype, device=dev) if train else None
+        pn = torch.empty(2 * n, dtype=torch.float32, device=dev) if train else None
         with _lib.on_device(dev):
             rc = lib.segger_posmlp_fwd(pos.data_ptr(), _lib.ptr(batch), mins.data_ptr(), maxs.data_ptr(), n, float(eps),
                                        float(max_period), pk0.w.data_ptr(), pk0.b.data_ptr(), pk2.w.data_ptr(),
-                                       pk2.b.data_ptr(), pe.data_ptr(), _lib.ptr(z1), _lib.ptr(feat), DTYPE_CODE[dtype],
+                                       pk2.b.data_ptr(), pe.data_ptr(), _lib.ptr(z1), _lib.ptr(pn), DTYPE_CODE[dtype],
                                        _lib.stream_ptr(dev))
         _lib.check(rc, "segger_posmlp_fwd")
         if train:
-            ctx.save_for_backward(z1, feat)
-            ctx.pk2, ctx.key2 = pk2, pk2.key
+            ctx.save_for_backward(z1, pn)
+            ctx.pk2, ctx.key2, ctx.max_period = pk2, pk2.key, float(max_period)
         return pe
 
     @staticmethod
     def backward(ctx, gpe):
-        z1, feat = ctx.saved_tensors
+        z1, pn = ctx.saved_tensors
         dt = z1.dtype
         d = z1.shape[1]
         g = gpe.to(dt).reshape(-1, d)
@@ -959,7 +960,18 @@ class _PosMlp(torch.autograd.Function):
         gw2, gb2 = linear_wgrad_launch(g, h1)
         dh1 = linear_fwd_launch(g, ctx.pk2.wt, None)                          # [2n, 64] @ W2
         dz1 = torch.ops.aten.silu_backward(dh1, z1)
-        gw0, gb0 = linear_wgrad_launch(dz1, feat)
+        # dW0 = dz1^T F with the sinusoid features F regenerated from one float per row inside the kernel
+        lib = _lib.load()
+        dev = z1.device
+        gw0 = torch.empty((d, 4 * d), dtype=torch.float32, device=dev)
+        gb0 = torch.empty(d, dtype=torch.float32, device=dev)
+        ws_bytes = lib.segger_linear_wgrad_workspace_bytes(int(dz1.shape[0]), d, 4 * d)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        dp, ldd = _rows(dz1, d, "dz1")
+        with _lib.on_device(dev):
+            rc = lib.segger_posmlp_wgrad(dp, ldd, pn.data_ptr(), int(dz1.shape[0]), ctx.max_period, DTYPE_CODE[dt],
+                                         gw0.data_ptr(), gb0.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_posmlp_wgrad")
         need = ctx.needs_input_grad
         return (None, None, None, None, None, None, None, None, gw0 if need[8] else None, gb0 if need[9] else None,
                 gw2 if need[10] else None, gb2 if need[11] else None)
