@@ -102,7 +102,8 @@ template <int M, int K, int NW, bool GEN = false> struct WgGeo {
 template <typename T, int M, int K, int NW, bool GEN = false>
 __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
   using G = WgGeo<M, K, NW, GEN>;
-  constexpr int WM = NW == 8 ? 4 : 2, WK = 2;          // wave grid over (M tiles, K tiles)
+  // wave grid over (M tiles, K tiles); GEN: every wave its own K tiles, so no generated fragment is computed twice
+  constexpr int WM = GEN ? 1 : (NW == 8 ? 4 : 2), WK = GEN ? NW : 2;
   static_assert(M * K / (64 * NW) <= 192, "accumulator does not fit the register file");
   constexpr int TM = M / 32, TK = K / 32;
   static_assert(TM % WM == 0 && TK % WK == 0, "tile grid does not split over the waves");
