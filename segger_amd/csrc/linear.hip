@@ -45,9 +45,12 @@ struct LinearParams {
   void* y; int64_t ldy;
   int64_t n_rows;
   int m_out;
+  // optional per-row additive term: y[row, :] += rowbias[rowidx[row], :] (fp32 table, row stride ld_rb elements) -- the
+  // part of a projection that depends on a row only through a small categorical id (ist_encoder's gene embedding)
+  const float* rowbias; const int32_t* rowidx; int64_t ld_rb;
 };
 
-template <typename T, int K>
+template <typename T, int K, bool RB = false>
 __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
   constexpr int NK = K / 16;                       // k-steps
   constexpr int WSTRIDE = K * 2 + 16;              // bytes per LDS row of W
@@ -96,12 +99,26 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
   };
 
   const int n_chunks = p.m_out / kChunk;
+  // per-row additive table row of this lane's data row (its columns are fetched per chunk, ahead of the MFMAs)
+  const float* rb_row = nullptr;
+  if (RB) {
+    int64_t row = row0 + r;
+    if (row >= p.n_rows) row = p.n_rows - 1;
+    rb_row = p.rowbias + (int64_t)p.rowidx[row] * p.ld_rb + 4 * h;
+  }
   w_fetch(0);
   for (int c = 0; c < n_chunks; ++c) {
     const int c0 = c * kChunk;
     w_commit();                                    // all waves left the previous chunk's MFMA loop (epilogue barrier)
     __syncthreads();
     if (c + 1 < n_chunks) w_fetch(c0 + kChunk);    // prefetch under the MFMAs
+    f32x4 rbv[RB ? 2 : 1][RB ? 4 : 1];
+    if (RB) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) rbv[ct][g] = *reinterpret_cast<const f32x4*>(rb_row + c0 + ct * 32 + 8 * g);
+    }
 
     f32x16 acc[2];
 #pragma unroll
@@ -120,6 +137,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
 
     // ---- epilogue: lane owns data row r and output columns ct*32 + 8g + 4h + {0..3} -------------
     unsigned char* et = lds_e + wave * 32 * ESTRIDE;
+
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
@@ -128,6 +146,10 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
         float v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[ct][4 * g + j] + (p.bias ? p.bias[c0 + col + j] : 0.f);
+        if (RB) {
+          const f32x4 t4 = rbv[RB ? ct : 0][RB ? g : 0];
+          v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+        }
         uint2 pk;
         pk.x = Vec8<T>::pack(v[0], v[1]);
         pk.y = Vec8<T>::pack(v[2], v[3]);
@@ -150,6 +172,17 @@ int launch_linear(const LinearParams& p, int k_in, hipStream_t stream) {
   const int64_t nb = (p.n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
   if (nb > 0x7fffffffLL) { set_error("segger_linear_fwd: too many rows"); return SEGGER_EUNSUPPORTED; }
   dim3 grid((unsigned)nb), block(256);
+  if (p.rowbias) {
+    switch (k_in) {
+      case 64:  hipLaunchKernelGGL((linear_fwd_kernel<T, 64, true>), grid, block, 0, stream, p); break;
+      case 128: hipLaunchKernelGGL((linear_fwd_kernel<T, 128, true>), grid, block, 0, stream, p); break;
+      default:
+        set_error("segger_linear_fwd_rowbias: k_in=%d not supported (64, 128)", k_in);
+        return SEGGER_EUNSUPPORTED;
+    }
+    SEGGER_LAUNCH_CHECK("linear_fwd_kernel (row bias)");
+    return SEGGER_OK;
+  }
   switch (k_in) {
     case 64:  hipLaunchKernelGGL((linear_fwd_kernel<T, 64>), grid, block, 0, stream, p); break;
     case 128: hipLaunchKernelGGL((linear_fwd_kernel<T, 128>), grid, block, 0, stream, p); break;
@@ -175,6 +208,13 @@ extern "C" int segger_linear_supported(int32_t k_in, int32_t m_out, int32_t dtyp
 
 extern "C" int segger_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy,
                                  int64_t n_rows, int32_t k_in, int32_t m_out, int32_t dtype, segger_stream_t stream) {
+  return segger_linear_fwd_rowbias(x, ldx, w, bias, nullptr, 0, nullptr, y, ldy, n_rows, k_in, m_out, dtype, stream);
+}
+
+extern "C" int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void* w, const float* bias,
+                                         const float* rowbias, int64_t ld_rb, const int32_t* rowidx, void* y, int64_t ldy,
+                                         int64_t n_rows, int32_t k_in, int32_t m_out, int32_t dtype,
+                                         segger_stream_t stream) {
   SEGGER_REQUIRE(n_rows >= 0 && k_in > 0 && m_out > 0, "segger_linear_fwd: bad sizes");
   if (n_rows == 0) return SEGGER_OK;
   if (!segger_linear_supported(k_in, m_out, dtype)) {
@@ -186,7 +226,10 @@ extern "C" int segger_linear_fwd(const void* x, int64_t ldx, const void* w, cons
   SEGGER_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), "segger_linear_fwd: pointers must be 16-byte aligned");
   SEGGER_REQUIRE(ldx >= k_in && ldy >= m_out && (ldx * 2) % 16 == 0 && (ldy * 2) % 16 == 0,
                  "segger_linear_fwd: bad leading dimension");
-  LinearParams p{x, ldx, w, bias, y, ldy, n_rows, m_out};
+  SEGGER_REQUIRE(!rowbias == !rowidx, "segger_linear_fwd_rowbias: rowbias and rowidx go together");
+  SEGGER_REQUIRE(!rowbias || (aligned16(rowbias) && ld_rb >= m_out && ld_rb % 4 == 0),
+                 "segger_linear_fwd_rowbias: the table needs 16-byte aligned rows of at least m_out floats");
+  LinearParams p{x, ldx, w, bias, y, ldy, n_rows, m_out, rowbias, rowidx, ld_rb};
   return dtype == SEGGER_BF16 ? launch_linear<bf16_t>(p, k_in, (hipStream_t)stream)
                               : launch_linear<f16_t>(p, k_in, (hipStream_t)stream);
 }

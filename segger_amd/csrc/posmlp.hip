@@ -40,6 +40,7 @@ struct PosMlpParams {
   int64_t n; float eps; float log_max_period;
   const void* w0; const float* b0; const void* w2; const float* b2;
   void* pe; void* z1; float* pn;
+  void* pe_pre;            // GELU && TRAIN: the embedder's own output; `pe` then receives gelu(pe_pre)
 };
 
 // sin / cos on the hardware units (v_sin_f32 / v_cos_f32 take revolutions and reduce the range themselves; absolute
@@ -69,7 +70,7 @@ __device__ __forceinline__ void store_tile(const unsigned char* et, T* dst, int6
   }
 }
 
-template <typename T, bool TRAIN>
+template <typename T, bool TRAIN, bool GELU>
 __global__ __launch_bounds__(256, 2) void posmlp_fwd_kernel(PosMlpParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kDim * kW0Stride + kDim * kW2Stride + 4 * 32 * kEStride + kHalf * 4];
   unsigned char* lw0 = lds;
@@ -212,15 +213,31 @@ __global__ __launch_bounds__(256, 2) void posmlp_fwd_kernel(PosMlpParams p) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
-      for (int gq = 0; gq < 4; ++gq) {
-        const int col = ct * 32 + 8 * gq + 4 * h;
-        uint2 pk;
-        pk.x = Vec8<T>::pack(acc2[ct][4 * gq + 0] + b2v[ct][4 * gq + 0], acc2[ct][4 * gq + 1] + b2v[ct][4 * gq + 1]);
-        pk.y = Vec8<T>::pack(acc2[ct][4 * gq + 2] + b2v[ct][4 * gq + 2], acc2[ct][4 * gq + 3] + b2v[ct][4 * gq + 3]);
-        *reinterpret_cast<uint2*>(et + r * kEStride + col * 2) = pk;
-      }
+      for (int i = 0; i < 16; ++i) acc2[ct][i] += b2v[ct][i];
     }
-    __builtin_amdgcn_wave_barrier();
+    auto put_tile = [&](bool act) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          const int col = ct * 32 + 8 * gq + 4 * h;
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = act ? gelu_erf(acc2[ct][4 * gq + j]) : acc2[ct][4 * gq + j];
+          uint2 pk;
+          pk.x = Vec8<T>::pack(v[0], v[1]);
+          pk.y = Vec8<T>::pack(v[2], v[3]);
+          *reinterpret_cast<uint2*>(et + r * kEStride + col * 2) = pk;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    };
+    if (GELU && TRAIN) {                                  // the backward needs the pre-activation for gelu'
+      put_tile(false);
+      store_tile<T>(et, static_cast<T*>(p.pe_pre), row0, n_rows, lane);
+      __builtin_amdgcn_wave_barrier();
+    }
+    put_tile(GELU);
     store_tile<T>(et, pe, row0, n_rows, lane);
     __builtin_amdgcn_wave_barrier();
   }
@@ -237,7 +254,8 @@ extern "C" int segger_posmlp_supported(int32_t freq_dim, int32_t dim, int32_t dt
 
 extern "C" int segger_posmlp_fwd(const float* pos, const int64_t* batch, const float* mins, const float* maxs, int64_t n,
                                  float eps, float max_period, const void* w0, const float* b0, const void* w2,
-                                 const float* b2, void* pe, void* z1, float* pn, int32_t dtype, segger_stream_t stream_) {
+                                 const float* b2, void* pe, void* z1, float* pn, void* pe_pre, int32_t gelu,
+                                 int32_t dtype, segger_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SEGGER_REQUIRE(n >= 0, "segger_posmlp_fwd: negative size");
   SEGGER_REQUIRE(dtype == SEGGER_BF16 || dtype == SEGGER_F16, "segger_posmlp_fwd: bf16 / f16 only");
@@ -246,15 +264,20 @@ extern "C" int segger_posmlp_fwd(const float* pos, const int64_t* batch, const f
   SEGGER_REQUIRE(!z1 == !pn, "segger_posmlp_fwd: z1 and pn go together (both for training, neither for inference)");
   SEGGER_REQUIRE(aligned16(w0) && aligned16(w2) && aligned16(pe) && aligned16(z1) && aligned16(pn),
                  "segger_posmlp_fwd: matrices must be 16-byte aligned");
-  PosMlpParams p{pos, batch, mins, maxs, n, eps, logf(max_period), w0, b0, w2, b2, pe, z1, pn};
+  SEGGER_REQUIRE(!pe_pre || (gelu && z1), "segger_posmlp_fwd: pe_pre is the training output of the gelu variant");
+  SEGGER_REQUIRE(!(gelu && z1) || pe_pre, "segger_posmlp_fwd: training with gelu needs pe_pre");
+  SEGGER_REQUIRE(aligned16(pe_pre), "segger_posmlp_fwd: pe_pre must be 16-byte aligned");
+  PosMlpParams p{pos, batch, mins, maxs, n, eps, logf(max_period), w0, b0, w2, b2, pe, z1, pn, pe_pre};
   const int64_t n_tiles = (2 * n + 31) / 32;
   int64_t blocks = (n_tiles + 3) / 4;
   if (blocks > 512) blocks = 512;                          // persistent: 2 workgroups per CU
   const bool train = z1 != nullptr;
-#define GO(T)                                                                                              \
-  do {                                                                                                     \
-    if (train) hipLaunchKernelGGL((posmlp_fwd_kernel<T, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p);   \
-    else hipLaunchKernelGGL((posmlp_fwd_kernel<T, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p);        \
+#define GO(T)                                                                                                    \
+  do {                                                                                                           \
+    if (train && gelu) hipLaunchKernelGGL((posmlp_fwd_kernel<T, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p);        \
+    else if (train) hipLaunchKernelGGL((posmlp_fwd_kernel<T, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p);          \
+    else if (gelu) hipLaunchKernelGGL((posmlp_fwd_kernel<T, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p);           \
+    else hipLaunchKernelGGL((posmlp_fwd_kernel<T, false, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p);                    \
   } while (0)
   if (dtype == SEGGER_BF16) GO(bf16_t); else GO(f16_t);
 #undef GO

@@ -87,7 +87,8 @@ class Positional2dEmbedder(Module):
         return (pos - lo) / (hi - lo + 1e-8)                # ist_encoder.py:74
 
     def forward(self, pos: Tensor, batch: Optional[Tensor] = None, *, num_graphs: Optional[int] = None,
-                dtype: torch.dtype = torch.float32) -> Tensor:
+                dtype: torch.dtype = torch.float32, gelu: bool = False) -> Tensor:
+        """``gelu`` (not in the reference): also apply the GELU that ISTEncoder puts on its concatenated input."""
         n = pos.shape[0]
         fd = self.frequency_embedding_size
         if batch is not None and fd % 16 == 0:
@@ -101,15 +102,15 @@ class Positional2dEmbedder(Module):
                 # sinusoid + Linear + SiLU + Linear in one kernel: the [2n, 256] feature matrix is generated in
                 # registers (and stored once for the weight gradient when training) instead of written and re-read
                 return ops.posmlp(pos, batch, mins, maxs, l0.weight, l0.bias, l2.weight, l2.bias, dtype,
-                                  eps=1e-8, max_period=10000.0)
+                                  eps=1e-8, max_period=10000.0, gelu=gelu)
             freq = ops.posfreq(pos, batch, mins, maxs, fd, dtype, eps=1e-8, max_period=10000.0)
         else:
             pos = self.normalize(pos, batch, num_graphs)
             freq = sinusoidal_embedding(pos.flatten(), fd, max_period=10000).reshape(n, 2, fd).to(dtype)
         l0, l2 = self.mlp[0], self.mlp[2]
         h = F.silu(ops.linear(freq, l0.weight, l0.bias))
-        h = ops.linear(h, l2.weight, l2.bias)
-        return h.flatten(-2)
+        h = ops.linear(h, l2.weight, l2.bias).flatten(-2)
+        return F.gelu(h) if gelu else h
 
 
 class GATv2Conv(Module):
@@ -194,8 +195,9 @@ class SkipGAT(Module):
         tt, tb = self.conv[TX_TX], self.conv[TX_BD]
         dt = x_tx.dtype
         # one fused projection for the three linear maps that read x_tx (stacked and cast once per optimizer step)
-        xp_tx = ops.linear(x_tx, (tt.lin_l.weight, tt.lin_r.weight, tb.lin_l.weight),
-                           (tt.lin_l.bias, tt.lin_r.bias, tb.lin_l.bias))
+        proj = ops.embed_linear if isinstance(x_tx, ops.EmbedInput) else ops.linear
+        xp_tx = proj(x_tx, (tt.lin_l.weight, tt.lin_r.weight, tb.lin_l.weight),
+                     (tt.lin_l.bias, tt.lin_r.bias, tb.lin_l.bias))
         xp_bd = ops.linear(x_bd, tb.lin_r.weight, tb.lin_r.bias)
         p = tt.dropout if self.training else 0.0
         y_tx, y_bd, alpha = ops.hetero_gat_layer(
@@ -252,6 +254,7 @@ class ISTEncoder(Module):
                             normalize_embeddings=normalize_embeddings,
                             use_positional_embeddings=use_positional_embeddings)
         self.in_channels, self.n_heads = in_channels, n_heads
+        self.split_first_layer = True       # 16-bit compute: first-layer projections as per-gene table + positional GEMM
         self.lin_first = ModuleDict({"tx": Embedding(n_genes, in_channels)})
         if bd_in_channels is not None:
             self.lin_first["bd"] = Linear(bd_in_channels, in_channels)
@@ -330,7 +333,16 @@ class ISTEncoder(Module):
                         by_gene = ops.rows_by_id(ids, emb.weight.shape[0])
                         if cache is not None:
                             cache[key] = by_gene
-                x_tx = ops.embed_gelu(emb.weight, ids, pe("tx"), by_gene)
+                first = self.conv_layers[0].conv
+                m_first = sum(int(w.shape[0]) for w in (first[TX_TX].lin_l.weight, first[TX_TX].lin_r.weight,
+                                                        first[TX_BD].lin_l.weight))
+                probe = ops.EmbedInput(emb.weight, ids, x_bd[:0, : self.in_channels], None)
+                if self.split_first_layer and dt != torch.float32 and ops.embed_linear_supported(probe, m_first):
+                    # keep gelu(cat(E[g], pe)) as its parts: the first layer projects it as T[g] + W_pe gelu(pe)
+                    act_pe = self.pos_emb(pos_dict["tx"], batch_dict.get("tx"), num_graphs=num_graphs, dtype=dt, gelu=True)
+                    x_tx = ops.EmbedInput(emb.weight, ids.to(torch.int32).contiguous(), act_pe, by_gene)
+                else:
+                    x_tx = ops.embed_gelu(emb.weight, ids, pe("tx"), by_gene)
             else:
                 x_tx = F.gelu(torch.cat((emb(x_dict["tx"].long()).to(dt), pe("tx")), -1))
         else:

@@ -922,7 +922,7 @@ class _PosMlp(torch.autograd.Function):
     ``segger_linear_fwd``, dW0 / db0 by ``segger_posmlp_wgrad`` (the sinusoid features regenerated in the kernel)."""
 
     @staticmethod
-    def forward(ctx, pos, batch, mins, maxs, eps, max_period, dtype, train, w0, b0, w2, b2):
+    def forward(ctx, pos, batch, mins, maxs, eps, max_period, dtype, train, gelu, w0, b0, w2, b2):
         _lib.require_cuda(pos, w0)
         lib = _lib.load()
         dev = pos.device
@@ -935,22 +935,26 @@ class _PosMlp(torch.autograd.Function):
         pe = torch.empty((n, 2 * w2.shape[0]), dtype=dtype, device=dev)
         z1 = torch.empty((2 * n, w0.shape[0]), dtype=dtype, device=dev) if train else None
         pn = torch.empty(2 * n, dtype=torch.float32, device=dev) if train else None
+        pre = torch.empty_like(pe) if (train and gelu) else None
         with _lib.on_device(dev):
             rc = lib.segger_posmlp_fwd(pos.data_ptr(), _lib.ptr(batch), mins.data_ptr(), maxs.data_ptr(), n, float(eps),
                                        float(max_period), pk0.w.data_ptr(), pk0.b.data_ptr(), pk2.w.data_ptr(),
-                                       pk2.b.data_ptr(), pe.data_ptr(), _lib.ptr(z1), _lib.ptr(pn), DTYPE_CODE[dtype],
+                                       pk2.b.data_ptr(), pe.data_ptr(), _lib.ptr(z1), _lib.ptr(pn), _lib.ptr(pre), int(bool(gelu)),
+                                       DTYPE_CODE[dtype],
                                        _lib.stream_ptr(dev))
         _lib.check(rc, "segger_posmlp_fwd")
         if train:
-            ctx.save_for_backward(z1, pn)
+            ctx.save_for_backward(z1, pn, pre)
             ctx.pk2, ctx.key2, ctx.max_period = pk2, pk2.key, float(max_period)
         return pe
 
     @staticmethod
     def backward(ctx, gpe):
-        z1, pn = ctx.saved_tensors
+        z1, pn, pre = ctx.saved_tensors
         dt = z1.dtype
         d = z1.shape[1]
+        if pre is not None:                                  # the output was gelu(embedder output)
+            gpe = torch.ops.aten.gelu_backward(gpe.to(dt), pre)
         g = gpe.to(dt).reshape(-1, d)
         if g.shape[0] > 1 and g.stride(1) != 1:
             g = g.contiguous()
@@ -973,19 +977,94 @@ class _PosMlp(torch.autograd.Function):
                                          gw0.data_ptr(), gb0.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
         _lib.check(rc, "segger_posmlp_wgrad")
         need = ctx.needs_input_grad
-        return (None, None, None, None, None, None, None, None, gw0 if need[8] else None, gb0 if need[9] else None,
-                gw2 if need[10] else None, gb2 if need[11] else None)
+        return (None, None, None, None, None, None, None, None, None, gw0 if need[9] else None,
+                gb0 if need[10] else None, gw2 if need[11] else None, gb2 if need[12] else None)
 
 
 def posmlp(pos: Tensor, batch: Optional[Tensor], mins: Tensor, maxs: Tensor, w0: Tensor, b0: Tensor, w2: Tensor,
-           b2: Tensor, dtype: torch.dtype, eps: float = 1e-8, max_period: float = 10000.0) -> Tensor:
-    """``Positional2dEmbedder.forward`` (reference ist_encoder.py:33-79) for bf16 / f16 activations."""
+           b2: Tensor, dtype: torch.dtype, eps: float = 1e-8, max_period: float = 10000.0, gelu: bool = False) -> Tensor:
+    """``Positional2dEmbedder.forward`` (reference ist_encoder.py:33-79) for bf16 / f16 activations; ``gelu``: the GELU
+    that ISTEncoder applies to the concatenated input (ist_encoder.py:324-325) on top, in the same kernel."""
     if not posmlp_supported(w0.shape[1], w0.shape[0], dtype) or tuple(w2.shape) != (w0.shape[0], w0.shape[0]):
         raise ValueError("posmlp: unsupported shapes (see segger_posmlp_supported)")
     if b0 is None or b2 is None:
         raise ValueError("posmlp: the embedder's Linear layers carry biases")
     train = torch.is_grad_enabled() and any(t.requires_grad for t in (w0, b0, w2, b2))   # else nothing is stored
-    return _PosMlp.apply(pos, batch, mins, maxs, eps, max_period, dtype, train, w0, b0, w2, b2)
+    return _PosMlp.apply(pos, batch, mins, maxs, eps, max_period, dtype, train, bool(gelu), w0, b0, w2, b2)
+
+
+class EmbedInput:
+    """The transcripts' first-layer input ``gelu(cat(table[ids], pe))`` (ist_encoder.py:312-325) kept as its parts:
+    ``table`` fp32 [G, D] (the gene embedding), ``ids`` int32 [n], ``act_pe`` = gelu(positional embedding) [n, D] in the
+    compute dtype, ``by_gene`` = rows grouped by id.  :func:`embed_linear` projects it without materialising the
+    concatenation."""
+
+    def __init__(self, table: Tensor, ids: Tensor, act_pe: Tensor, by_gene: Optional[EdgeCSR]):
+        self.table, self.ids, self.act_pe, self.by_gene = table, ids, act_pe, by_gene
+        self.shape = (int(act_pe.shape[0]), int(table.shape[1]) + int(act_pe.shape[1]))
+        self.dtype, self.device = act_pe.dtype, act_pe.device
+
+
+class _RowBiasLinear(torch.autograd.Function):
+    """y = c @ Wc^T + T[ids]  (``segger_linear_fwd_rowbias``).  Backward: dc = dY Wc, dWc = dY^T c (MFMA kernels),
+    dT = rows of dY summed by id (``segger_segment_rowsum`` over the rows-by-gene grouping)."""
+
+    @staticmethod
+    def forward(ctx, c, wc, tab, ids, by_gene):
+        lib = _lib.load()
+        dev, dt = c.device, c.dtype
+        n, k = c.shape
+        m = wc.shape[0]
+        w16 = wc.detach().to(dt).contiguous()
+        tab32 = tab.detach().to(torch.float32).contiguous()
+        y = torch.empty((n, m), dtype=dt, device=dev)
+        cp, ldc = _rows(c, k, "c")
+        with _lib.on_device(dev):
+            rc = lib.segger_linear_fwd_rowbias(cp, ldc, w16.data_ptr(), None, tab32.data_ptr(), m, ids.data_ptr(),
+                                               y.data_ptr(), m, n, k, m, DTYPE_CODE[dt], _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_linear_fwd_rowbias")
+        ctx.save_for_backward(c, w16)
+        ctx.by_gene, ctx.ids, ctx.n_ids = by_gene, ids, int(tab.shape[0])
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        c, w16 = ctx.saved_tensors
+        dt = c.dtype
+        gy = gy.to(dt)
+        if gy.shape[0] > 1 and gy.stride(1) != 1:
+            gy = gy.contiguous()
+        gc = gw = gt = None
+        if ctx.needs_input_grad[0]:
+            gc = linear_fwd_launch(gy, w16.t().contiguous(), None)              # [n, M] @ Wc -> [n, K]
+        if ctx.needs_input_grad[1]:
+            gw, _ = linear_wgrad_launch(gy, c, want_bias=False)
+        if ctx.needs_input_grad[2]:
+            by_gene = ctx.by_gene if ctx.by_gene is not None else rows_by_id(ctx.ids, ctx.n_ids)
+            gt = segment_rowsum(gy, by_gene)
+        return gc, gw, gt, None, None
+
+
+def embed_linear_supported(x: "EmbedInput", m_out: int) -> bool:
+    k = int(x.act_pe.shape[1])
+    return (x.act_pe.is_cuda and x.table.dtype == torch.float32 and m_out % 4 == 0 and k in (64, 128)
+            and linear_supported(k, m_out, x.dtype)
+            and linear_supported(m_out, k, x.dtype) and linear_wgrad_supported(m_out, k, x.dtype))
+
+
+def embed_linear(x: "EmbedInput", weight, bias) -> Tensor:
+    """``linear(gelu(cat(table[ids], pe)), W, b)`` for the stacked first-layer projections without the concatenated
+    [n, 2D] input: the embedding half depends on a row only through its gene, so it is a per-gene table
+    ``T = gelu(table) Wa^T + b`` ([G, M], a tiny GEMM) added in the epilogue of the GEMM over the positional half
+    (K: 2D -> D).  Autograd: T's gradient is the by-gene row sum of dY; table, Wa and b receive theirs through T."""
+    weights = tuple(weight) if isinstance(weight, (list, tuple)) else (weight,)
+    biases = tuple(bias) if isinstance(bias, (list, tuple)) else (bias,)
+    d = int(x.table.shape[1])
+    w = weights[0] if len(weights) == 1 else torch.cat(weights, 0)                # [M, 2D] fp32 master weights
+    tab = torch.nn.functional.gelu(x.table) @ w[:, :d].t()                         # [G, M]
+    if any(b is not None for b in biases):
+        tab = tab + torch.cat([b if b is not None else ww.new_zeros(ww.shape[0]) for ww, b in zip(weights, biases)], 0)
+    return _RowBiasLinear.apply(x.act_pe, w[:, d:], tab, x.ids, x.by_gene)
 
 
 class _EmbedGelu(torch.autograd.Function):

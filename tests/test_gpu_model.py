@@ -455,3 +455,30 @@ def test_c2_scale_backward_properties(cuda):
         res.append((a.float(), b.float(), ga.clone(), gb.clone()))
     for one, two in zip(*res):
         assert torch.equal(one * 2.0, two)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_split_first_layer_projection_matches_concatenated_input(cuda, dtype):
+    """16-bit compute keeps gelu(cat(E[g], pe)) as its parts and projects it as  T[g] + W_pe gelu(pe)  (per-gene table
+    + a GEMM over the positional half, ops.embed_linear): same embeddings and same parameter gradients as the route
+    that materialises the concatenated input, up to the rounding of a 16-bit activation."""
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=6000, n_bd=200, k_tx=7, seed=47)
+    m, _, b, _ = build(spec, cuda, dtype=dtype)
+    m.eval()                                                   # no dropout: the two routes must agree deterministically
+    bg = b.to(cuda)
+    out = {}
+    for split in (True, False):
+        m.model.split_first_layer = split
+        m.zero_grad(set_to_none=True)
+        z = m(bg)
+        (z["tx"].float().square().sum() * 0.3 + z["bd"].float().sum()).backward()
+        out[split] = (z["tx"].detach().float(), z["bd"].detach().float(),
+                      {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    tol = 3e-2 if dtype == torch.bfloat16 else 6e-3
+    assert torch.allclose(out[True][0], out[False][0], atol=tol) and torch.allclose(out[True][1], out[False][1], atol=tol)
+    assert out[True][2].keys() == out[False][2].keys()
+    gmax = max(g.abs().max().item() for g in out[False][2].values())
+    rel = 0.15 if dtype == torch.bfloat16 else 0.04          # sums of ~1e6 rounded terms that largely cancel
+    for k, g in out[False][2].items():
+        assert (out[True][2][k] - g).abs().max().item() <= rel * g.abs().max().item() + 2e-3 * rel * gmax, k
