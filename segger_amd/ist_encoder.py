@@ -254,7 +254,10 @@ class ISTEncoder(Module):
                             normalize_embeddings=normalize_embeddings,
                             use_positional_embeddings=use_positional_embeddings)
         self.in_channels, self.n_heads = in_channels, n_heads
-        self.split_first_layer = True       # 16-bit compute: first-layer projections as per-gene table + positional GEMM
+        # 16-bit compute: first-layer projections as per-gene table + positional GEMM (ops.embed_linear); its ~15 extra
+        # tiny launches (table GEMM, weight slices) only pay for themselves on large batches
+        self.split_first_layer = True
+        self.split_first_layer_min_rows = 200_000
         self.lin_first = ModuleDict({"tx": Embedding(n_genes, in_channels)})
         if bd_in_channels is not None:
             self.lin_first["bd"] = Linear(bd_in_channels, in_channels)
@@ -337,7 +340,8 @@ class ISTEncoder(Module):
                 m_first = sum(int(w.shape[0]) for w in (first[TX_TX].lin_l.weight, first[TX_TX].lin_r.weight,
                                                         first[TX_BD].lin_l.weight))
                 probe = ops.EmbedInput(emb.weight, ids, x_bd[:0, : self.in_channels], None)
-                if self.split_first_layer and dt != torch.float32 and ops.embed_linear_supported(probe, m_first):
+                if (self.split_first_layer and dt != torch.float32 and ids.shape[0] >= self.split_first_layer_min_rows
+                        and ops.embed_linear_supported(probe, m_first)):
                     # keep gelu(cat(E[g], pe)) as its parts: the first layer projects it as T[g] + W_pe gelu(pe)
                     act_pe = self.pos_emb(pos_dict["tx"], batch_dict.get("tx"), num_graphs=num_graphs, dtype=dt, gelu=True)
                     x_tx = ops.EmbedInput(emb.weight, ids.to(torch.int32).contiguous(), act_pe, by_gene)

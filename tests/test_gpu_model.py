@@ -466,6 +466,7 @@ def test_split_first_layer_projection_matches_concatenated_input(cuda, dtype):
     spec = SyntheticSpec(n_tx=6000, n_bd=200, k_tx=7, seed=47)
     m, _, b, _ = build(spec, cuda, dtype=dtype)
     m.eval()                                                   # no dropout: the two routes must agree deterministically
+    m.model.split_first_layer_min_rows = 0                    # (the default reserves the split for large batches)
     bg = b.to(cuda)
     out = {}
     for split in (True, False):
