@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEGGER_ABI_VERSION 8
+#define SEGGER_ABI_VERSION 9
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -204,6 +204,12 @@ typedef struct segger_gatv2_bwd_args {
                              segger_coo_unique).  grad_xl[i] then has a single term, the destination-side pass
                              stores it itself and by_src is ignored (may be all zero): no by-source sort, no
                              source-side pass.  Needs a specialised geometry (segger_gatv2_has_specialised). */
+  void* zero_rows_out;    /* optional, two-pass form only: a second [n_src, H*C] matrix (row stride ld_zero) that the
+                             source pass zero-fills row by row while it writes grad_xl -- the grad_xl of ANOTHER edge
+                             type over the same source nodes whose one-pass backward runs next (segger: tx-neighbors-tx
+                             fills the tx-belongs-bd window of the stacked projection gradient) */
+  int64_t ld_zero;
+  int32_t grad_xl_zeroed; /* one-pass form (src_unique): grad_xl already holds zeros (see zero_rows_out): skip the fill */
 } segger_gatv2_bwd_args;
 
 size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads, int32_t channels);

@@ -222,7 +222,10 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
   p.n_rows = n_dst; p.n_edges = n_edges; p.rows_per_wave_iter = bwd_row_iters(n_dst);
   p.bits = a->keep_bits_dst;
   p.direct_gxl = direct ? 1 : 0;
-  if (direct && n_src > 0) {
+  SEGGER_REQUIRE(!a->zero_rows_out || (!direct && specialised),
+                 "segger_gatv2_bwd: zero_rows_out needs the two-pass backward of a specialised geometry");
+  if (a->zero_rows_out && n_src > 0) CHECK_RC(check_rows("zero_rows_out", a->zero_rows_out, a->ld_zero, a->dtype, hc));
+  if (direct && n_src > 0 && !a->grad_xl_zeroed) {
     // sources without an out-edge keep a zero gradient; the others are stored by the destination pass
     // (rows are 16-byte aligned multiples of 16 bytes: checked above.  hipMemset2DAsync measured 0.19 ms for
     // 1M x 256 B at pitch 768; this kernel 0.05 ms)
@@ -254,6 +257,7 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
   p.indptr = a->by_src.indptr; p.col = a->by_src.col; p.eid = a->by_src.eid; p.order = a->by_src.row_order;
   p.bits = a->keep_bits_src;
   p.n_rows = n_src; p.rows_per_wave_iter = 1;
+  p.zero_rows = a->zero_rows_out; p.ld_zero = a->ld_zero;
   if (n_src > 0) CHECK_RC(launch(Pass::BwdSrc, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_src), stream));
   return SEGGER_OK;
 }

@@ -77,6 +77,7 @@ struct GatParams {
   const void* gout; int64_t ld_go;
   void* gpre; int64_t ld_gp;     // dst pass: output; src pass: input
   float* dsum;                   // [n_dst, H, 2] = (lse, D) pairs -- dst pass: output; src pass: input
+  void* zero_rows; int64_t ld_zero;   // src pass, optional: a [n_src, HC] matrix whose rows it zero-fills on the way
   void* gxl; int64_t ld_gxl;
   void* gxr; int64_t ld_gxr;
   float* slab;                   // [nblocks][2][HC] partial grad_att | grad_bias
@@ -643,8 +644,10 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
   if (row_ok) { beg = p.indptr[row]; end = p.indptr[row + 1]; }
   // tx-belongs-bd by source: most transcripts have no out-edge; such waves only write zeros
   if (__all(beg == end)) {
-    if (row_ok && L.lane_on && (!WPR || L.grp == 0))
+    if (row_ok && L.lane_on && (!WPR || L.grp == 0)) {
       store_pairs(static_cast<T*>(p.gxl) + row * p.ld_gxl + ch0, acc);
+      if (p.zero_rows) store_pairs(static_cast<T*>(p.zero_rows) + row * p.ld_zero + ch0, acc);     // (acc is zero here)
+    }
     return;
   }
   load_att(p.att, ch0, p.slope, kLog2e, a1, a2);
@@ -718,8 +721,15 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
       }
     }
   }
-  if (row_ok && L.lane_on && (!WPR || L.grp == 0))
+  if (row_ok && L.lane_on && (!WPR || L.grp == 0)) {
     store_pairs(static_cast<T*>(p.gxl) + row * p.ld_gxl + ch0, acc);
+    if (p.zero_rows) {                                     // zero row of another matrix indexed by the same sources
+      f32x2 z[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) z[i] = splat(0.f);
+      store_pairs(static_cast<T*>(p.zero_rows) + row * p.ld_zero + ch0, z);
+    }
+  }
 }
 
 }  // namespace segger

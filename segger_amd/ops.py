@@ -109,8 +109,12 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
 def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optional[Tensor],
                      heads: int, channels: int, grad_out: Tensor, pre: Tensor, lse: Tensor,
                      grad_xl: Tensor, grad_xr: Tensor, *, apply_gelu: bool, negative_slope: float = 0.2,
-                     dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tuple] = None) -> Tuple[Tensor, Tensor]:
-    """Writes grad_xl / grad_xr (views allowed); returns (grad_att[HC], grad_bias[HC]) fp32."""
+                     dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tuple] = None,
+                     zero_rows_out: Optional[Tensor] = None, grad_xl_zeroed: bool = False) -> Tuple[Tensor, Tensor]:
+    """Writes grad_xl / grad_xr (views allowed); returns (grad_att[HC], grad_bias[HC]) fp32.  ``zero_rows_out``: a
+    second [n_src, HC] matrix the source pass zero-fills on its way (ignored -> ``False`` comes back in
+    ``gatv2_bwd_launch.zero_filled`` when this edge type runs the one-pass form or the generic kernels);
+    ``grad_xl_zeroed``: the one-pass form may skip its own zero fill."""
     _lib.require_cuda(xl, xr, grad_out)
     lib = _lib.load()
     hc = heads * channels
@@ -118,10 +122,15 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
     n_dst = g.n_dst
     a = _lib.GatBwdArgs()
     a.by_dst = g.by_dst.c_struct()
+    gatv2_bwd_launch.zero_filled = False
     if g.by_src is None and g.src_unique() and lib.segger_gatv2_has_specialised(heads, channels):
         a.src_unique = 1          # every source has at most one out-edge: the destination pass stores grad_xl itself
+        a.grad_xl_zeroed = int(bool(grad_xl_zeroed))
     else:
         a.by_src = g.require_by_src().c_struct()
+        if zero_rows_out is not None and lib.segger_gatv2_has_specialised(heads, channels) and g.n_src > 0:
+            a.zero_rows_out, a.ld_zero = _rows(zero_rows_out, hc, "zero_rows_out")
+            gatv2_bwd_launch.zero_filled = True
     a.x_l, a.ld_xl = _rows(xl, hc, "x_l")
     a.x_r, a.ld_xr = _rows(xr, hc, "x_r")
     keep = (_f32_vec(att, hc, "att"), _f32_vec(bias, hc, "bias"))
@@ -261,14 +270,17 @@ class _HeteroGatLayer(torch.autograd.Function):
             gy_tx = torch.zeros_like(pre_tx)
         if gy_bd is None:
             gy_bd = torch.zeros_like(pre_bd)
+        # tx-neighbors-tx first: its source pass visits every transcript row and zero-fills the tx-belongs-bd window of
+        # the stacked projection gradient on the way, so the one-pass tx-belongs-bd backward needs no fill of its own
         gatt_tt, gbias_tt = gatv2_bwd_launch(
             g_tt, xp_tx[:, :hc], xp_tx[:, hc:2 * hc], att_tt, bias_tt, heads, channels, gy_tx, pre_tx, lse_tx,
             gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc], apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tt,
-            keep_bits=ctx.bits[0])
+            keep_bits=ctx.bits[0], zero_rows_out=gxp_tx[:, 2 * hc:])
+        zeroed = gatv2_bwd_launch.zero_filled
         gatt_tb, gbias_tb = gatv2_bwd_launch(
             g_tb, xp_tx[:, 2 * hc:], xp_bd, att_tb, bias_tb, heads, channels, gy_bd, pre_bd, lse_bd,
             gxp_tx[:, 2 * hc:], gxp_bd, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb,
-            keep_bits=ctx.bits[1])
+            keep_bits=ctx.bits[1], grad_xl_zeroed=zeroed)
         r = lambda gt, ref: gt.reshape(ref.shape).to(ref.dtype) if ref is not None else None
         return (gxp_tx, gxp_bd, r(gatt_tt, att_tt), r(gbias_tt, bias_tt), r(gatt_tb, att_tb), r(gbias_tb, bias_tb),
                 None, None, None, None, None, None, None, None, None, None, None, None)
