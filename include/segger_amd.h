@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEGGER_ABI_VERSION 9
+#define SEGGER_ABI_VERSION 10
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -410,6 +410,12 @@ int segger_segment_minmax(const float* pos, const int64_t* batch, int64_t n, int
 int segger_linear_supported(int32_t k_in, int32_t m_out, int32_t dtype);
 int segger_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy,
                       int64_t n_rows, int32_t k_in, int32_t m_out, int32_t dtype, segger_stream_t stream);
+/* segger_linear_fwd_silu_grad: y = (x @ w^T) * silu'(gate), gate [n_rows, m_out] in `dtype`: the data gradient through
+ * Linear -> SiLU (the positional MLP, ist_encoder.py:45-49) with torch's separate silu_backward pass folded into the
+ * GEMM epilogue.  k_in = 64. */
+int segger_linear_fwd_silu_grad(const void* x, int64_t ldx, const void* w, const void* gate, int64_t ld_gate, void* y,
+                                int64_t ldy, int64_t n_rows, int32_t k_in, int32_t m_out, int32_t dtype,
+                                segger_stream_t stream);
 /* segger_linear_fwd_rowbias: the same with  y[row, :] += rowbias[rowidx[row], :]  added in the epilogue (fp32 table
  * [n_ids, ld_rb >= m_out], int32 ids in range -- not checked): the gene-embedding half of the first layer's projections
  * collapses to a per-gene table T = gelu(E) Wa^T + b ([n_genes, 384]), so the GEMM runs over the positional half only
@@ -465,8 +471,8 @@ int segger_posfreq(const float* pos, const int64_t* batch, const float* mins, co
  * MFMA operand fragments instead of written to / read from HBM (segger_posfreq + two segger_linear_fwd otherwise).
  *   w0 [64, 256], w2 [64, 64] row-major in `dtype` (bf16 / f16), b0 / b2 fp32 [64]
  *   pe   [2n, 64] in `dtype` (= the embedder's [n, 128] output, x half then y half per node)
- *   z1   [2n, 64] in `dtype`, pn [2n] fp32: the pre-activation of the first layer and the normalised coordinate per
- *        row, stored for the backward; both NULL for inference.
+ *   z1, h1 [2n, 64] in `dtype`, pn [2n] fp32: the pre-activation of the first layer, its SiLU and the normalised
+ *        coordinate per row, stored for the backward; all NULL for inference.
  *   gelu != 0: pe receives gelu(embedder output) -- the positional half of ISTEncoder's gelu(cat(...)),
  *        ist_encoder.py:324-325 -- and, when training, pe_pre [2n, 64] the output itself (for gelu'); else pe_pre NULL.
  * segger_posmlp_wgrad: dW0 [64, 256] = dz1^T F and db0 [64] = sum dz1 with F regenerated from pn inside the weight-
@@ -477,7 +483,7 @@ int segger_posfreq(const float* pos, const int64_t* batch, const float* mins, co
 int segger_posmlp_supported(int32_t freq_dim, int32_t dim, int32_t dtype);
 int segger_posmlp_fwd(const float* pos, const int64_t* batch, const float* mins, const float* maxs, int64_t n, float eps,
                       float max_period, const void* w0, const float* b0, const void* w2, const float* b2, void* pe,
-                      void* z1, float* pn, void* pe_pre, int32_t gelu, int32_t dtype, segger_stream_t stream);
+                      void* z1, float* pn, void* h1, void* pe_pre, int32_t gelu, int32_t dtype, segger_stream_t stream);
 int segger_posmlp_wgrad(const void* dz1, int64_t ld_dz1, const float* pn, int64_t n_rows, float max_period,
                         int32_t dtype, float* grad_w0, float* grad_b0, void* workspace, size_t workspace_bytes,
                         segger_stream_t stream);

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
@@ -127,8 +127,8 @@ EXPORTS = {
     "segger_coo_unique": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
     "segger_stage": (C.c_int, [C.POINTER(StageSeg), C.c_int32, vp]),
     "segger_posmlp_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
-    "segger_posmlp_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int32,
-                                    C.c_int32, vp]),
+    "segger_posmlp_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                    C.c_int32, C.c_int32, vp]),
     "segger_posmlp_wgrad": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_float, C.c_int32, vp, vp, vp, C.c_size_t, vp]),
     "segger_sample_negatives": (C.c_int, [vp, C.c_int64, C.c_int64, vp, C.c_uint64, vp, vp, vp]),
     "segger_edge_cos_argmax": (C.c_int, [C.POINTER(EdgeArgmaxArgs), vp]),
@@ -142,6 +142,8 @@ EXPORTS = {
     "segger_segment_minmax": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp, vp]),
     "segger_linear_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "segger_linear_fwd": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "segger_linear_fwd_silu_grad": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                              C.c_int32, vp]),
     "segger_linear_fwd_rowbias": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                             C.c_int32, vp]),
     "segger_linear_wgrad_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),

@@ -87,6 +87,9 @@ template <> struct Vec8<bf16_t> {
     f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
     f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
   }
+  static __device__ __forceinline__ void unpack2(uint32_t w, float& a, float& b) {
+    a = __uint_as_float(w << 16); b = __uint_as_float(w & 0xffff0000u);
+  }
   static __device__ __forceinline__ uint32_t pack(float a, float b) {
     // plain cast: hipcc emits v_cvt_pk_bf16_f32 (RNE, NaN-preserving) on gfx950
     typedef float v2f __attribute__((ext_vector_type(2)));
@@ -105,6 +108,7 @@ template <> struct Vec8<f16_t> {
     h16x2 h = __builtin_bit_cast(h16x2, w);
     a = static_cast<float>(h.x); b = static_cast<float>(h.y);
   }
+  static __device__ __forceinline__ void unpack2(uint32_t w, float& a, float& b) { unpack(w, a, b); }
   static __device__ __forceinline__ void load(const f16_t* p, float (&f)[8]) {
     u32x4 r = *reinterpret_cast<const u32x4*>(p);
     unpack(r.x, f[0], f[1]); unpack(r.y, f[2], f[3]);

@@ -48,9 +48,12 @@ struct LinearParams {
   // optional per-row additive term: y[row, :] += rowbias[rowidx[row], :] (fp32 table, row stride ld_rb elements) -- the
   // part of a projection that depends on a row only through a small categorical id (ist_encoder's gene embedding)
   const float* rowbias; const int32_t* rowidx; int64_t ld_rb;
+  // optional epilogue factor: y[row, c] *= silu'(gate[row, c]) (gate in the activation dtype, row stride ld_gate) -- the
+  // backward of Linear -> SiLU without a separate elementwise pass over dX
+  const void* gate; int64_t ld_gate;
 };
 
-template <typename T, int K, bool RB = false>
+template <typename T, int K, bool RB = false, bool SG = false>
 __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
   constexpr int NK = K / 16;                       // k-steps
   constexpr int WSTRIDE = K * 2 + 16;              // bytes per LDS row of W
@@ -150,6 +153,19 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
           const f32x4 t4 = rbv[RB ? ct : 0][RB ? g : 0];
           v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
         }
+        if (SG) {
+          int64_t grow = row0 + r;
+          if (grow >= p.n_rows) grow = p.n_rows - 1;
+          const uint2 zz = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.gate) + grow * p.ld_gate + c0 + col);
+          float z[4];
+          Vec8<T>::unpack2(zz.x, z[0], z[1]);
+          Vec8<T>::unpack2(zz.y, z[2], z[3]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z[j]));
+            v[j] *= sg * (1.0f + z[j] * (1.0f - sg));         // d/dz [z sigmoid(z)]
+          }
+        }
         uint2 pk;
         pk.x = Vec8<T>::pack(v[0], v[1]);
         pk.y = Vec8<T>::pack(v[2], v[3]);
@@ -172,6 +188,15 @@ int launch_linear(const LinearParams& p, int k_in, hipStream_t stream) {
   const int64_t nb = (p.n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
   if (nb > 0x7fffffffLL) { set_error("segger_linear_fwd: too many rows"); return SEGGER_EUNSUPPORTED; }
   dim3 grid((unsigned)nb), block(256);
+  if (p.gate) {
+    if (k_in != 64) {
+      set_error("segger_linear_fwd_silu_grad: k_in=%d not supported (64)", k_in);
+      return SEGGER_EUNSUPPORTED;
+    }
+    hipLaunchKernelGGL((linear_fwd_kernel<T, 64, false, true>), grid, block, 0, stream, p);
+    SEGGER_LAUNCH_CHECK("linear_fwd_kernel (silu')");
+    return SEGGER_OK;
+  }
   if (p.rowbias) {
     switch (k_in) {
       case 64:  hipLaunchKernelGGL((linear_fwd_kernel<T, 64, true>), grid, block, 0, stream, p); break;
@@ -211,6 +236,23 @@ extern "C" int segger_linear_fwd(const void* x, int64_t ldx, const void* w, cons
   return segger_linear_fwd_rowbias(x, ldx, w, bias, nullptr, 0, nullptr, y, ldy, n_rows, k_in, m_out, dtype, stream);
 }
 
+extern "C" int segger_linear_fwd_silu_grad(const void* x, int64_t ldx, const void* w, const void* gate, int64_t ld_gate,
+                                           void* y, int64_t ldy, int64_t n_rows, int32_t k_in, int32_t m_out,
+                                           int32_t dtype, segger_stream_t stream) {
+  SEGGER_REQUIRE(n_rows >= 0 && k_in > 0 && m_out > 0, "segger_linear_fwd_silu_grad: bad sizes");
+  if (n_rows == 0) return SEGGER_OK;
+  SEGGER_REQUIRE(segger_linear_supported(k_in, m_out, dtype) && k_in == 64,
+                 "segger_linear_fwd_silu_grad: k_in 64, m_out %% 64 == 0, bf16 / f16");
+  SEGGER_REQUIRE(x && w && y && gate, "segger_linear_fwd_silu_grad: NULL pointer");
+  SEGGER_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && aligned16(gate),
+                 "segger_linear_fwd_silu_grad: pointers must be 16-byte aligned");
+  SEGGER_REQUIRE(ldx >= k_in && ldy >= m_out && ld_gate >= m_out && (ldx * 2) % 16 == 0 && (ldy * 2) % 16 == 0 &&
+                     (ld_gate * 2) % 8 == 0, "segger_linear_fwd_silu_grad: bad leading dimension");
+  LinearParams p{x, ldx, w, nullptr, y, ldy, n_rows, m_out, nullptr, nullptr, 0, gate, ld_gate};
+  return dtype == SEGGER_BF16 ? launch_linear<bf16_t>(p, k_in, (hipStream_t)stream)
+                              : launch_linear<f16_t>(p, k_in, (hipStream_t)stream);
+}
+
 extern "C" int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void* w, const float* bias,
                                          const float* rowbias, int64_t ld_rb, const int32_t* rowidx, void* y, int64_t ldy,
                                          int64_t n_rows, int32_t k_in, int32_t m_out, int32_t dtype,
@@ -229,7 +271,7 @@ extern "C" int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void*
   SEGGER_REQUIRE(!rowbias == !rowidx, "segger_linear_fwd_rowbias: rowbias and rowidx go together");
   SEGGER_REQUIRE(!rowbias || (aligned16(rowbias) && ld_rb >= m_out && ld_rb % 4 == 0),
                  "segger_linear_fwd_rowbias: the table needs 16-byte aligned rows of at least m_out floats");
-  LinearParams p{x, ldx, w, bias, y, ldy, n_rows, m_out, rowbias, rowidx, ld_rb};
+  LinearParams p{x, ldx, w, bias, y, ldy, n_rows, m_out, rowbias, rowidx, ld_rb, nullptr, 0};
   return dtype == SEGGER_BF16 ? launch_linear<bf16_t>(p, k_in, (hipStream_t)stream)
                               : launch_linear<f16_t>(p, k_in, (hipStream_t)stream);
 }

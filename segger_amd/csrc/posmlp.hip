@@ -41,6 +41,7 @@ struct PosMlpParams {
   const void* w0; const float* b0; const void* w2; const float* b2;
   void* pe; void* z1; float* pn;
   void* pe_pre;            // GELU && TRAIN: the embedder's own output; `pe` then receives gelu(pe_pre)
+  void* h1;                // TRAIN: SiLU(z1), the second layer's input (its weight gradient reads it)
 };
 
 // sin / cos on the hardware units (v_sin_f32 / v_cos_f32 take revolutions and reduce the range themselves; absolute
@@ -184,6 +185,19 @@ __global__ __launch_bounds__(256, 2) void posmlp_fwd_kernel(PosMlpParams p) {
       __builtin_amdgcn_wave_barrier();                    // the tile is wave-private: one wave's LDS ops stay in order
       store_tile<T>(et, static_cast<T*>(p.z1), row0, n_rows, lane);
       __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+          uint2 pk;
+          pk.x = Vec8<T>::pack(h1[ct][4 * gq + 0], h1[ct][4 * gq + 1]);
+          pk.y = Vec8<T>::pack(h1[ct][4 * gq + 2], h1[ct][4 * gq + 3]);
+          *reinterpret_cast<uint2*>(et + r * kEStride + (ct * 32 + 8 * gq + 4 * h) * 2) = pk;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      store_tile<T>(et, static_cast<T*>(p.h1), row0, n_rows, lane);
+      __builtin_amdgcn_wave_barrier();
     }
 
     // ---- GEMM 2: pe[m2][row] = sum_m W2[m2][m] h1[m][row]; k-step (ct, gp) covers m = ct*32 + 16gp + {0..15} in the
@@ -254,20 +268,22 @@ extern "C" int segger_posmlp_supported(int32_t freq_dim, int32_t dim, int32_t dt
 
 extern "C" int segger_posmlp_fwd(const float* pos, const int64_t* batch, const float* mins, const float* maxs, int64_t n,
                                  float eps, float max_period, const void* w0, const float* b0, const void* w2,
-                                 const float* b2, void* pe, void* z1, float* pn, void* pe_pre, int32_t gelu,
+                                 const float* b2, void* pe, void* z1, float* pn, void* h1, void* pe_pre, int32_t gelu,
                                  int32_t dtype, segger_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SEGGER_REQUIRE(n >= 0, "segger_posmlp_fwd: negative size");
   SEGGER_REQUIRE(dtype == SEGGER_BF16 || dtype == SEGGER_F16, "segger_posmlp_fwd: bf16 / f16 only");
   if (n == 0) return SEGGER_OK;
   SEGGER_REQUIRE(pos && mins && maxs && w0 && b0 && w2 && b2 && pe, "segger_posmlp_fwd: NULL pointer");
-  SEGGER_REQUIRE(!z1 == !pn, "segger_posmlp_fwd: z1 and pn go together (both for training, neither for inference)");
+  SEGGER_REQUIRE(!z1 == !pn && !z1 == !h1,
+                 "segger_posmlp_fwd: z1, pn and h1 go together (all for training, none for inference)");
+  SEGGER_REQUIRE(aligned16(h1), "segger_posmlp_fwd: h1 must be 16-byte aligned");
   SEGGER_REQUIRE(aligned16(w0) && aligned16(w2) && aligned16(pe) && aligned16(z1) && aligned16(pn),
                  "segger_posmlp_fwd: matrices must be 16-byte aligned");
   SEGGER_REQUIRE(!pe_pre || (gelu && z1), "segger_posmlp_fwd: pe_pre is the training output of the gelu variant");
   SEGGER_REQUIRE(!(gelu && z1) || pe_pre, "segger_posmlp_fwd: training with gelu needs pe_pre");
   SEGGER_REQUIRE(aligned16(pe_pre), "segger_posmlp_fwd: pe_pre must be 16-byte aligned");
-  PosMlpParams p{pos, batch, mins, maxs, n, eps, logf(max_period), w0, b0, w2, b2, pe, z1, pn, pe_pre};
+  PosMlpParams p{pos, batch, mins, maxs, n, eps, logf(max_period), w0, b0, w2, b2, pe, z1, pn, pe_pre, h1};
   const int64_t n_tiles = (2 * n + 31) / 32;
   int64_t blocks = (n_tiles + 3) / 4;
   if (blocks > 512) blocks = 512;                          // persistent: 2 workgroups per CU

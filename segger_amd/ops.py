@@ -948,21 +948,23 @@ class _PosMlp(torch.autograd.Function):
         z1 = torch.empty((2 * n, w0.shape[0]), dtype=dtype, device=dev) if train else None
         pn = torch.empty(2 * n, dtype=torch.float32, device=dev) if train else None
         pre = torch.empty_like(pe) if (train and gelu) else None
+        h1 = torch.empty_like(z1) if train else None
         with _lib.on_device(dev):
             rc = lib.segger_posmlp_fwd(pos.data_ptr(), _lib.ptr(batch), mins.data_ptr(), maxs.data_ptr(), n, float(eps),
                                        float(max_period), pk0.w.data_ptr(), pk0.b.data_ptr(), pk2.w.data_ptr(),
-                                       pk2.b.data_ptr(), pe.data_ptr(), _lib.ptr(z1), _lib.ptr(pn), _lib.ptr(pre), int(bool(gelu)),
+                                       pk2.b.data_ptr(), pe.data_ptr(), _lib.ptr(z1), _lib.ptr(pn), _lib.ptr(h1), _lib.ptr(pre),
+                                       int(bool(gelu)),
                                        DTYPE_CODE[dtype],
                                        _lib.stream_ptr(dev))
         _lib.check(rc, "segger_posmlp_fwd")
         if train:
-            ctx.save_for_backward(z1, pn, pre)
+            ctx.save_for_backward(z1, pn, pre, h1)
             ctx.pk2, ctx.key2, ctx.max_period = pk2, pk2.key, float(max_period)
         return pe
 
     @staticmethod
     def backward(ctx, gpe):
-        z1, pn, pre = ctx.saved_tensors
+        z1, pn, pre, h1 = ctx.saved_tensors
         dt = z1.dtype
         d = z1.shape[1]
         if pre is not None:                                  # the output was gelu(embedder output)
@@ -972,10 +974,16 @@ class _PosMlp(torch.autograd.Function):
             g = g.contiguous()
         if ctx.pk2.key != ctx.key2:
             raise RuntimeError("the positional MLP's weights changed between this forward and its backward")
-        h1 = torch.nn.functional.silu(z1)
         gw2, gb2 = linear_wgrad_launch(g, h1)
-        dh1 = linear_fwd_launch(g, ctx.pk2.wt, None)                          # [2n, 64] @ W2
-        dz1 = torch.ops.aten.silu_backward(dh1, z1)
+        # dz1 = (g @ W2) * silu'(z1): the SiLU derivative is applied in the GEMM's epilogue
+        lib0 = _lib.load()
+        dz1 = torch.empty_like(z1)
+        wt = ctx.pk2.wt
+        gp, ldg = _rows(g, d, "g")
+        with _lib.on_device(z1.device):
+            rc = lib0.segger_linear_fwd_silu_grad(gp, ldg, wt.data_ptr(), z1.data_ptr(), d, dz1.data_ptr(), d,
+                                                  int(g.shape[0]), d, d, DTYPE_CODE[dt], _lib.stream_ptr(z1.device))
+        _lib.check(rc, "segger_linear_fwd_silu_grad")
         # dW0 = dz1^T F with the sinusoid features F regenerated from one float per row inside the kernel
         lib = _lib.load()
         dev = z1.device
