@@ -416,11 +416,11 @@ int segger_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bi
 int segger_linear_fwd_silu_grad(const void* x, int64_t ldx, const void* w, const void* gate, int64_t ld_gate, void* y,
                                 int64_t ldy, int64_t n_rows, int32_t k_in, int32_t m_out, int32_t dtype,
                                 segger_stream_t stream);
-/* segger_linear_fwd_rowbias: the same with  y[row, :] += rowbias[rowidx[row], :]  added in the epilogue (fp32 table
- * [n_ids, ld_rb >= m_out], int32 ids in range -- not checked): the gene-embedding half of the first layer's projections
+/* segger_linear_fwd_rowbias: the same with  y[row, :] += rowbias[rowidx[row], :]  added in the epilogue (table
+ * [n_ids, ld_rb >= m_out] in `dtype`, added in fp32; int32 ids in range -- not checked): the gene-embedding half of the first layer's projections
  * collapses to a per-gene table T = gelu(E) Wa^T + b ([n_genes, 384]), so the GEMM runs over the positional half only
  * (K 256 -> 128) and gelu(cat(E[g], pe)) is never materialised (ist_encoder.py:312-325 + GATv2Conv.lin_l / lin_r). */
-int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void* w, const float* bias, const float* rowbias,
+int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void* w, const float* bias, const void* rowbias,
                               int64_t ld_rb, const int32_t* rowidx, void* y, int64_t ldy, int64_t n_rows, int32_t k_in,
                               int32_t m_out, int32_t dtype, segger_stream_t stream);
 

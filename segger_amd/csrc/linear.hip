@@ -47,7 +47,7 @@ struct LinearParams {
   int m_out;
   // optional per-row additive term: y[row, :] += rowbias[rowidx[row], :] (fp32 table, row stride ld_rb elements) -- the
   // part of a projection that depends on a row only through a small categorical id (ist_encoder's gene embedding)
-  const float* rowbias; const int32_t* rowidx; int64_t ld_rb;
+  const void* rowbias; const int32_t* rowidx; int64_t ld_rb;      // (table in the activation dtype)
   // optional epilogue factor: y[row, c] *= silu'(gate[row, c]) (gate in the activation dtype, row stride ld_gate) -- the
   // backward of Linear -> SiLU without a separate elementwise pass over dX
   const void* gate; int64_t ld_gate;
@@ -103,11 +103,17 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
 
   const int n_chunks = p.m_out / kChunk;
   // per-row additive table row of this lane's data row (its columns are fetched per chunk, ahead of the MFMAs)
-  const float* rb_row = nullptr;
+  const T* rb_row = nullptr;
+  const T* gate_row = nullptr;
   if (RB) {
     int64_t row = row0 + r;
     if (row >= p.n_rows) row = p.n_rows - 1;
-    rb_row = p.rowbias + (int64_t)p.rowidx[row] * p.ld_rb + 4 * h;
+    rb_row = static_cast<const T*>(p.rowbias) + (int64_t)p.rowidx[row] * p.ld_rb + 4 * h;
+  }
+  if (SG) {
+    int64_t row = row0 + r;
+    if (row >= p.n_rows) row = p.n_rows - 1;
+    gate_row = static_cast<const T*>(p.gate) + row * p.ld_gate + 4 * h;
   }
   w_fetch(0);
   for (int c = 0; c < n_chunks; ++c) {
@@ -115,12 +121,14 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
     w_commit();                                    // all waves left the previous chunk's MFMA loop (epilogue barrier)
     __syncthreads();
     if (c + 1 < n_chunks) w_fetch(c0 + kChunk);    // prefetch under the MFMAs
-    f32x4 rbv[RB ? 2 : 1][RB ? 4 : 1];
-    if (RB) {
+    // this lane's 4-column groups of the table row / the gate row, requested ahead of the MFMAs
+    uint2 rbv[(RB || SG) ? 2 : 1][(RB || SG) ? 4 : 1];
+    if (RB || SG) {
+      const T* src = RB ? rb_row : gate_row;
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) rbv[ct][g] = *reinterpret_cast<const f32x4*>(rb_row + c0 + ct * 32 + 8 * g);
+        for (int g = 0; g < 4; ++g) rbv[ct][g] = *reinterpret_cast<const uint2*>(src + c0 + ct * 32 + 8 * g);
     }
 
     f32x16 acc[2];
@@ -150,13 +158,14 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[ct][4 * g + j] + (p.bias ? p.bias[c0 + col + j] : 0.f);
         if (RB) {
-          const f32x4 t4 = rbv[RB ? ct : 0][RB ? g : 0];
-          v[0] += t4.x; v[1] += t4.y; v[2] += t4.z; v[3] += t4.w;
+          const uint2 tt = rbv[RB ? ct : 0][RB ? g : 0];
+          float t4[4];
+          Vec8<T>::unpack2(tt.x, t4[0], t4[1]);
+          Vec8<T>::unpack2(tt.y, t4[2], t4[3]);
+          v[0] += t4[0]; v[1] += t4[1]; v[2] += t4[2]; v[3] += t4[3];
         }
         if (SG) {
-          int64_t grow = row0 + r;
-          if (grow >= p.n_rows) grow = p.n_rows - 1;
-          const uint2 zz = *reinterpret_cast<const uint2*>(static_cast<const T*>(p.gate) + grow * p.ld_gate + c0 + col);
+          const uint2 zz = rbv[SG ? ct : 0][SG ? g : 0];
           float z[4];
           Vec8<T>::unpack2(zz.x, z[0], z[1]);
           Vec8<T>::unpack2(zz.y, z[2], z[3]);
@@ -254,7 +263,7 @@ extern "C" int segger_linear_fwd_silu_grad(const void* x, int64_t ldx, const voi
 }
 
 extern "C" int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void* w, const float* bias,
-                                         const float* rowbias, int64_t ld_rb, const int32_t* rowidx, void* y, int64_t ldy,
+                                         const void* rowbias, int64_t ld_rb, const int32_t* rowidx, void* y, int64_t ldy,
                                          int64_t n_rows, int32_t k_in, int32_t m_out, int32_t dtype,
                                          segger_stream_t stream) {
   SEGGER_REQUIRE(n_rows >= 0 && k_in > 0 && m_out > 0, "segger_linear_fwd: bad sizes");
@@ -270,7 +279,7 @@ extern "C" int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void*
                  "segger_linear_fwd: bad leading dimension");
   SEGGER_REQUIRE(!rowbias == !rowidx, "segger_linear_fwd_rowbias: rowbias and rowidx go together");
   SEGGER_REQUIRE(!rowbias || (aligned16(rowbias) && ld_rb >= m_out && ld_rb % 4 == 0),
-                 "segger_linear_fwd_rowbias: the table needs 16-byte aligned rows of at least m_out floats");
+                 "segger_linear_fwd_rowbias: the table needs 8-byte aligned rows of at least m_out elements");
   LinearParams p{x, ldx, w, bias, y, ldy, n_rows, m_out, rowbias, rowidx, ld_rb, nullptr, 0};
   return dtype == SEGGER_BF16 ? launch_linear<bf16_t>(p, k_in, (hipStream_t)stream)
                               : launch_linear<f16_t>(p, k_in, (hipStream_t)stream);

@@ -1036,11 +1036,11 @@ class _RowBiasLinear(torch.autograd.Function):
         n, k = c.shape
         m = wc.shape[0]
         w16 = wc.detach().to(dt).contiguous()
-        tab32 = tab.detach().to(torch.float32).contiguous()
+        tab16 = tab.detach().to(dt).contiguous()             # the table is added in fp32 but travels in the compute dtype
         y = torch.empty((n, m), dtype=dt, device=dev)
         cp, ldc = _rows(c, k, "c")
         with _lib.on_device(dev):
-            rc = lib.segger_linear_fwd_rowbias(cp, ldc, w16.data_ptr(), None, tab32.data_ptr(), m, ids.data_ptr(),
+            rc = lib.segger_linear_fwd_rowbias(cp, ldc, w16.data_ptr(), None, tab16.data_ptr(), m, ids.data_ptr(),
                                                y.data_ptr(), m, n, k, m, DTYPE_CODE[dt], _lib.stream_ptr(dev))
         _lib.check(rc, "segger_linear_fwd_rowbias")
         ctx.save_for_backward(c, w16)
