@@ -233,3 +233,73 @@ def test_assign_tiles_balances_load():
     loads = [sum(w[i] for i in p) for p in parts]
     assert max(loads) - min(loads) <= 2
     assert assign_tiles(w, 3) == parts and assign_tiles([], 2) == [[], []]
+
+
+def _emulate_stage(segments):
+    """CPU restatement of segger_stage (include/segger_amd.h) for the host-logic tests: copy the source to the front
+    of the destination, fill the rest by the segment's formula."""
+    for dst, src, fill, a, b, c in segments:
+        n_copy = 0 if src is None else src.numel()
+        flat = dst.view(-1)
+        if n_copy:
+            flat[:n_copy] = src.reshape(-1).to(flat.dtype)
+        k = torch.arange(flat.numel() - n_copy)
+        if fill == "const":
+            flat[n_copy:] = a
+        elif fill == "tile":
+            flat[n_copy:] = src.reshape(-1)[k % a].to(flat.dtype)
+        elif fill == "div":
+            flat[n_copy:] = (a + k // b).to(flat.dtype)
+        elif fill == "mod":
+            flat[n_copy:] = (a + k % b).to(flat.dtype)
+        elif fill == "ramp":
+            flat[n_copy:] = (a + torch.clamp((k + 1) * b, max=c)).to(flat.dtype)
+        else:
+            raise AssertionError(fill)
+
+
+@pytest.mark.parametrize("pad_cols", [None, "mod"])
+@pytest.mark.parametrize("n_real,n_rows,e_pad_extra", [(7, 9, 5), (7, 8, 40), (1, 4, 0), (20, 33, 13)])
+def test_padded_view_segments_build_a_valid_csr_without_sorting(n_real, n_rows, e_pad_extra, pad_cols):
+    """graph.padded_view_segments (how a batch's CSR view is written into the static buffers of a captured step):
+    the padded view must be a CSR of the real edges plus padding edges that touch dummy rows / columns only, slots in
+    row order, edge ids a permutation of 0..E_pad-1 with the real ones unchanged."""
+    from segger_amd.graph import EdgeCSR, padded_view_segments
+    g = torch.Generator().manual_seed(n_real + e_pad_extra)
+    n_cols_real, n_cols = 11, 15
+    deg = torch.randint(0, 5, (n_real,), generator=g)
+    e = int(deg.sum())
+    src = EdgeCSR(torch.cat([torch.zeros(1, dtype=torch.long), deg.cumsum(0)]),
+                  torch.randint(0, n_real if pad_cols is None else n_cols_real, (e,), generator=g).int(),
+                  torch.randperm(e, generator=g).int(), n_real, n_real if pad_cols is None else n_cols_real)
+    e_pad = e + e_pad_extra
+    dst = EdgeCSR(torch.full((n_rows + 1,), -1, dtype=torch.long), torch.full((e_pad,), -1, dtype=torch.int32),
+                  torch.full((e_pad,), -1, dtype=torch.int32), n_rows, n_rows if pad_cols is None else n_cols)
+    fill = None if pad_cols is None else ("mod", n_cols_real, n_cols - n_cols_real)
+    _emulate_stage(padded_view_segments(dst, src, n_real, fill))
+    ip = dst.indptr
+    assert ip[0] == 0 and ip[-1] == e_pad and bool((ip[1:] >= ip[:-1]).all())
+    assert torch.equal(ip[: n_real + 1], src.indptr) and torch.equal(dst.col[:e], src.col) and torch.equal(dst.eid[:e], src.eid)
+    assert torch.equal(torch.sort(dst.eid.long()).values, torch.arange(e_pad))
+    rows = torch.repeat_interleave(torch.arange(n_rows), ip[1:] - ip[:-1])
+    assert bool((rows[e:] >= n_real).all())                               # padding edges hang on dummy rows ...
+    if pad_cols is None:
+        assert torch.equal(dst.col[e:].long(), rows[e:])                  # ... as self-loops
+    else:
+        assert bool(((dst.col[e:] >= n_cols_real) & (dst.col[e:] < n_cols)).all())    # ... or point at dummy columns
+    with pytest.raises(ValueError):
+        padded_view_segments(EdgeCSR(ip[: n_real + 1].clone(), dst.col[:e], dst.eid[:e], n_real, n_real), src, n_real)
+
+
+def test_step_bucket_sizes_leave_a_dummy_of_every_kind():
+    from segger_amd.hetero import HeteroBatch, TX_BD, TX_TX
+    from segger_amd.train_step_graph import step_bucket
+    b = HeteroBatch(num_graphs=3)
+    b["tx"]["x"] = torch.zeros(50_000, dtype=torch.long)
+    b["bd"]["x"] = torch.zeros(512, 4)
+    b[TX_TX]["edge_index"] = torch.zeros(2, 730_000, dtype=torch.long)
+    b[TX_BD]["edge_index"] = torch.zeros(2, 19_000, dtype=torch.long)
+    s = step_bucket(b, granularity=1.06)
+    assert s["tx"] > 50_000 and s["bd"] > 512 and s["e_tt"] >= 730_000 and s["e_tb"] >= 19_000 and s["graphs"] >= 3
+    assert s["tx"] <= 50_000 * 1.07 and s["e_tt"] <= 730_000 * 1.07          # one granule at most on the transcript side
+    assert step_bucket(b, granularity=1.06) == s

@@ -21,7 +21,8 @@ def t(fn, it=20):
     for _ in range(it): fn()
     e.record(); torch.cuda.synchronize(); return a.elapsed_time(e) / it
 for name, g in (("lazy", build_edge_graph(ei, n, nb, need_by_src="lazy")), ("full", build_edge_graph(ei, n, nb))):
-    ops.gatv2_fwd_launch(g.by_dst, xp[:, 2*hc:], xb, att, bias, H, C, out, pre=pre, lse=lse, apply_gelu=True, dropout_p=0.2, seed=5)
+    fwd = lambda: ops.gatv2_fwd_launch(g.by_dst, xp[:, 2*hc:], xb, att, bias, H, C, out, pre=pre, lse=lse, apply_gelu=True, dropout_p=0.2, seed=5)
+    print(name, "fwd %.3f ms" % t(fwd))
     bwd = lambda: ops.gatv2_bwd_launch(g, xp[:, 2*hc:], xb, att, bias, H, C, gy, pre, lse, gxp[:, 2*hc:], gxb, apply_gelu=True, dropout_p=0.2, seed=5)
     print(name, "unique", g.src_unique(), "bwd %.3f ms" % t(bwd))
 z = torch.empty_like(gxp)
