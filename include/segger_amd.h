@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEGGER_ABI_VERSION 10
+#define SEGGER_ABI_VERSION 11
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -259,6 +259,15 @@ typedef struct {
   int32_t reserved_;
 } segger_stage_seg;
 int segger_stage(const segger_stage_seg* segs, int32_t n_segs, segger_stream_t stream);
+
+/* segger_transpose_many: dst [cols, rows] = src [rows, cols]^T for n_segs contiguous 16-bit matrices in one launch:
+ * the W^T copies the data-gradient GEMMs (dX = dY W on segger_linear_fwd) need after every optimizer step. */
+typedef struct {
+  void* dst;
+  const void* src;
+  int32_t rows, cols;
+} segger_transpose_seg;
+int segger_transpose_many(const segger_transpose_seg* segs, int32_t n_segs, segger_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Prediction head: cosine similarity on tx->bd candidate edges + per-transcript

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
@@ -82,6 +82,10 @@ class StageSeg(C.Structure):
     ]
 
 
+class TransposeSeg(C.Structure):
+    _fields_ = [("dst", vp), ("src", vp), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
 FILL_CONST, FILL_TILE, FILL_DIV, FILL_MOD, FILL_RAMP = range(5)
 
 
@@ -126,6 +130,7 @@ EXPORTS = {
     "segger_gatv2_has_specialised": (C.c_int, [C.c_int32, C.c_int32]),
     "segger_coo_unique": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
     "segger_stage": (C.c_int, [C.POINTER(StageSeg), C.c_int32, vp]),
+    "segger_transpose_many": (C.c_int, [C.POINTER(TransposeSeg), C.c_int32, vp]),
     "segger_posmlp_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "segger_posmlp_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                     C.c_int32, C.c_int32, vp]),

@@ -92,3 +92,59 @@ extern "C" int segger_stage(const segger_stage_seg* segs, int32_t n_segs, segger
   }
   return SEGGER_OK;
 }
+
+// ---- many small 2-D transposes of 16-bit matrices in one launch -------------------------------------------------------
+// The data gradient dX = dY W runs on the projection kernel with W^T as its weight: every optimizer step the compute-
+// dtype copies of ~12 weight matrices are re-transposed.  One launch (blockIdx.y = matrix) instead of one per matrix.
+namespace segger {
+constexpr int kTrMaxSegs = 32;
+struct TrBatch { segger_transpose_seg s[kTrMaxSegs]; };
+
+__global__ __launch_bounds__(256) void transpose_many_kernel(TrBatch b) {
+  __shared__ uint16_t tile[32][33];
+  const segger_transpose_seg& g = b.s[blockIdx.y];
+  const uint16_t* __restrict__ src = static_cast<const uint16_t*>(g.src);
+  uint16_t* __restrict__ dst = static_cast<uint16_t*>(g.dst);
+  const int tr = (g.rows + 31) / 32, tc = (g.cols + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8 threads
+  for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+    const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + ty + 8 * i, c = c0 + tx;
+      tile[ty + 8 * i][tx] = (r < g.rows && c < g.cols) ? src[(int64_t)r * g.cols + c] : (uint16_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + ty + 8 * i, r = r0 + tx;                      // dst is [cols, rows]
+      if (c < g.cols && r < g.rows) dst[(int64_t)c * g.rows + r] = tile[tx][ty + 8 * i];
+    }
+    __syncthreads();
+  }
+}
+}  // namespace segger
+
+extern "C" int segger_transpose_many(const segger_transpose_seg* segs, int32_t n_segs, segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGGER_REQUIRE(n_segs >= 0, "segger_transpose_many: negative segment count");
+  SEGGER_REQUIRE(n_segs == 0 || segs != nullptr, "segger_transpose_many: segs is NULL");
+  for (int32_t s0 = 0; s0 < n_segs; s0 += kTrMaxSegs) {
+    TrBatch b;
+    const int n = (n_segs - s0 < kTrMaxSegs) ? (n_segs - s0) : kTrMaxSegs;
+    int most = 0;
+    for (int i = 0; i < n; ++i) {
+      const segger_transpose_seg& g = segs[s0 + i];
+      SEGGER_REQUIRE(g.rows >= 0 && g.cols >= 0 && (g.rows == 0 || g.cols == 0 || (g.src && g.dst)),
+                     "segger_transpose_many: segment %d: bad shape or NULL pointer", s0 + i);
+      b.s[i] = g;
+      const int tiles = ((g.rows + 31) / 32) * ((g.cols + 31) / 32);
+      if (tiles > most) most = tiles;
+    }
+    if (most == 0) continue;
+    if (most > 64) most = 64;
+    hipLaunchKernelGGL(transpose_many_kernel, dim3((unsigned)most, (unsigned)n), dim3(256), 0, stream, b);
+    SEGGER_LAUNCH_CHECK("transpose_many_kernel");
+  }
+  return SEGGER_OK;
+}

@@ -802,6 +802,19 @@ def _refresh_all_packs() -> None:
         _copy_groups(dsts, srcs)
     for pk, key in live:
         pk.key, pk._wt_fresh = (gen, key), False
+    # the transposed copies the data gradients stream (every pack that has been through a backward): one launch
+    tr = [pk for pk, _ in live if pk._wt is not None and pk.w.element_size() == 2 and pk.w.is_cuda]
+    if tr:
+        arr = (_lib.TransposeSeg * len(tr))()
+        for i, pk in enumerate(tr):
+            arr[i].dst, arr[i].src = pk._wt.data_ptr(), pk.w.data_ptr()
+            arr[i].rows, arr[i].cols = int(pk.w.shape[0]), int(pk.w.shape[1])
+        dev = tr[0].w.device
+        with _lib.on_device(dev):
+            rc = _lib.load().segger_transpose_many(arr, len(tr), _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_transpose_many")
+        for pk in tr:
+            pk._wt_fresh = True
     _REFRESHED_GENERATION[0] = gen
 
 
