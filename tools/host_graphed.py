@@ -1,4 +1,5 @@
-"""Host-side time per phase of the graphed training step (no device sync inside the loop)."""
+"""Host-side time per phase of the graphed training step (batch assembly, bucket pick, staging, replay), no device sync
+inside the loop, followed by a cProfile of the same loop:  python tools/host_graphed.py"""
 import sys, time
 sys.path.insert(0, '.')
 import torch
