@@ -507,9 +507,12 @@ class PredictTiles:
 
 
 class PredictTileIndex(PredictTiles):
-    """``PredictTiles`` over the tiles of a :class:`SquareTiling` with work per tile proportional to the tile's
-    3 x 3 neighbourhood instead of the whole slide: nodes are binned by tile once (one stable sort), edges by the
-    tile of their source, and a prediction tile only looks at the 9 slices around it.  Returns exactly what
+    """``PredictTiles`` over the tiles of a :class:`SquareTiling` with work per tile proportional to what the tile
+    can contain instead of the whole slide: nodes are binned once (one stable sort), edges by the bin of their source,
+    and a prediction tile only looks at the bins its margin can reach.  With ``2 * margin <= side`` every tile is
+    binned into 3 x 3 sub-cells -- border strips of the margin's width around an interior -- and a prediction tile takes
+    its own nine plus the strips of its eight neighbours that face it (~1.2x its own content for segger's 10 um margin
+    on ~220 um tiles); wider margins fall back to whole 3 x 3 tile neighbourhoods (9x).  Returns exactly what
     ``PredictTiles.__getitem__`` returns (same node and edge order).  Needs ``margin <= side_length``."""
 
     def __init__(self, data: HeteroBatch, tiling: SquareTiling, margin: float = 0.0):
@@ -518,36 +521,66 @@ class PredictTileIndex(PredictTiles):
             raise ValueError(f"margin ({margin}) must not exceed the tile side ({tiling.side_length})")
         self.nx, self.ny = tiling.nx, tiling.ny
         T = len(tiling)
+        self.strips = 2.0 * margin <= tiling.side_length
+        self._sub = 9 if self.strips else 1                  # bins per tile
         self._nperm: Dict[str, Tensor] = {}
         self._nptr: Dict[str, List[int]] = {}
         self._new_id: Dict[str, Tensor] = {}
-        tile_of: Dict[str, Tensor] = {}
+        bin_of: Dict[str, Tensor] = {}
+        tiles_t = tiling.tiles
         for nt, store in data._nodes.items():
-            ix, iy = tiling._cell(store["pos"])            # clamped: nodes outside the extent go to a border tile
+            pos = store["pos"]
+            ix, iy = tiling._cell(pos)                        # clamped: nodes outside the extent go to a border tile
             lab = ix * tiling.ny + iy
-            tile_of[nt] = lab
+            if self.strips:
+                # strip index inside the node's own tile: 0 / 2 = within the margin of the low / high border (a hair
+                # wider than the margin: the exact box test in __getitem__ decides, this only has to be a superset)
+                box = tiles_t.to(pos.device)[lab]
+                w = margin * (1.0 + 1e-6) + 1e-6 * tiling.side_length
+                sx = (pos[:, 0] >= box[:, 2] - w).long() * 2
+                sx = torch.where(pos[:, 0] < box[:, 0] + w, torch.zeros_like(sx), torch.where(sx == 2, sx, torch.ones_like(sx)))
+                sy = (pos[:, 1] >= box[:, 3] - w).long() * 2
+                sy = torch.where(pos[:, 1] < box[:, 1] + w, torch.zeros_like(sy), torch.where(sy == 2, sy, torch.ones_like(sy)))
+                # a tile narrower than two margins cannot happen here (2 * margin <= side), but low wins on a tie
+                lab = lab * 9 + sx * 3 + sy
+            bin_of[nt] = lab
             self._nperm[nt] = torch.argsort(lab, stable=True)
-            sizes = torch.bincount(lab, minlength=T)
+            sizes = torch.bincount(lab, minlength=T * self._sub)
             self._nptr[nt] = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)]).tolist()
-            self._new_id[nt] = torch.full((store["pos"].shape[0],), -1, dtype=torch.long, device=store["pos"].device)
+            self._new_id[nt] = torch.full((pos.shape[0],), -1, dtype=torch.long, device=pos.device)
         self._edges: Dict[EdgeType, Tensor] = {}
         self._eptr: Dict[EdgeType, List[int]] = {}
         for et, store in data._edges.items():
             ei = store["edge_index"].long()
-            lab = tile_of[et[0]][ei[0]]
+            lab = bin_of[et[0]][ei[0]]
             order = torch.argsort(lab, stable=True)
             self._edges[et] = torch.cat([ei[:, order], order[None]], 0)      # rows: src, dst, original edge id
-            sizes = torch.bincount(lab, minlength=T)
+            sizes = torch.bincount(lab, minlength=T * self._sub)
             self._eptr[et] = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)]).tolist()
+
+    def _bins(self, idx: int) -> List[int]:
+        """Bins a node of prediction tile ``idx`` can lie in (a node of a neighbouring tile must be within the margin of
+        the shared border, i.e. in the strip facing this tile)."""
+        ix, iy = idx // self.ny, idx % self.ny
+        out: List[int] = []
+        for jx in range(max(ix - 1, 0), min(ix + 2, self.nx)):
+            for jy in range(max(iy - 1, 0), min(iy + 2, self.ny)):
+                t = jx * self.ny + jy
+                if not self.strips:
+                    out.append(t)
+                    continue
+                dx, dy = jx - ix, jy - iy
+                xs = (2,) if dx < 0 else (0,) if dx > 0 else (0, 1, 2)
+                ys = (2,) if dy < 0 else (0,) if dy > 0 else (0, 1, 2)
+                out.extend(t * 9 + sx * 3 + sy for sx in xs for sy in ys)
+        return out
 
     def __getitem__(self, idx: int) -> HeteroBatch:
         if idx < 0 or idx >= len(self):
             raise IndexError(f"Requested {idx}, but tiling only contains {len(self)} tiles.")
         x0, y0, x1, y1 = (float(v) for v in self.tiles[idx])
         m = self.margin
-        ix, iy = idx // self.ny, idx % self.ny
-        neigh = [jx * self.ny + jy for jx in range(max(ix - 1, 0), min(ix + 2, self.nx))
-                 for jy in range(max(iy - 1, 0), min(iy + 2, self.ny))]
+        neigh = self._bins(idx)
         out = HeteroBatch(num_graphs=1)
         subs: Dict[str, Tensor] = {}
         for nt, store in self.data._nodes.items():
@@ -570,9 +603,9 @@ class PredictTileIndex(PredictTiles):
             ptr, tab = self._eptr[et], self._edges[et]
             e = torch.cat([tab[:, ptr[t]:ptr[t + 1]] for t in neigh], 1)
             a, b = self._new_id[s][e[0]], self._new_id[d][e[1]]
-            ok = (a >= 0) & (b >= 0)
-            order = torch.argsort(e[2][ok])                 # back to the original edge order
-            out[et]["edge_index"] = torch.stack([a[ok][order], b[ok][order]])
+            kept = ((a >= 0) & (b >= 0)).nonzero(as_tuple=False).squeeze(1)      # one compaction (one sync) per type
+            kept = kept[torch.argsort(e[2][kept])]                                # back to the original edge order
+            out[et]["edge_index"] = torch.stack([a[kept], b[kept]])
         for nt, sub in subs.items():
             self._new_id[nt][sub] = -1
         return out

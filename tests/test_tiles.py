@@ -151,9 +151,10 @@ def test_predict_tiles_subgraph(graph):
         ds[len(ds)]
 
 
-@pytest.mark.parametrize("side,margin", [(30.0, 4.0), (17.0, 17.0), (1000.0, 5.0)])
+@pytest.mark.parametrize("side,margin", [(30.0, 4.0), (17.0, 17.0), (1000.0, 5.0), (20.0, 10.0), (25.0, 9.9), (12.0, 0.0)])
 def test_predict_tile_index_equals_predict_tiles(graph, side, margin):
-    """The 3 x 3-neighbourhood index returns exactly the whole-slide subgraph of PredictTiles."""
+    """The binned index (border strips for margins up to half a tile, whole 3 x 3 neighbourhoods beyond) returns
+    exactly the whole-slide subgraph of PredictTiles."""
     tiling = T.SquareTiling(all_pos(graph), side)
     slow = T.PredictTiles(graph, tiling.tiles, margin=margin)
     fast = T.PredictTileIndex(graph, tiling, margin=margin)
