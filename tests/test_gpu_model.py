@@ -58,11 +58,18 @@ def test_encoder_without_positional_embeddings_and_normalisation(oracle, cuda):
         assert torch.allclose(z[k].double().cpu(), ref, atol=2e-5 * max(1.0, ref.abs().max().item()), rtol=1e-4)
 
 
-def test_encoder_bf16_close_to_oracle_and_auroc(oracle, cuda):
+@pytest.mark.parametrize("front_end", ["fused", "fused+split", "unfused"])
+def test_encoder_bf16_close_to_oracle_and_auroc(oracle, cuda, front_end):
+    """bf16 compute against the float32 oracle through each front-end route: the one-kernel positional embedder
+    (default), plus the first layer as per-gene table + positional GEMM (default from 200k rows up), and the
+    reference's op sequence (posfreq + linear + SiLU + linear, concatenated input)."""
     from segger_amd.synthetic import SyntheticSpec
     spec = SyntheticSpec(n_tx=20000, n_bd=400, k_tx=15, seed=7)
     m, sd, b, aux = build(spec, cuda, dtype=torch.bfloat16)
     m.eval()
+    m.model.pos_emb.fused = front_end != "unfused"
+    m.model.split_first_layer = front_end == "fused+split"
+    m.model.split_first_layer_min_rows = 0
     z = m(b.to(cuda))
     z_ref = oracle.ist_encoder_forward({k: v.float() for k, v in sd.items()}, b.x_dict, b.edge_index_dict,
                                        b.pos_dict, b.batch_dict, n_heads=2)
