@@ -11,7 +11,6 @@ kernel into one HIP graph per *shape bucket* and replays it for every batch padd
   views, padding by index arithmetic) into the captured buffers -- no per-batch sort or concatenation;
 * masks (``predict_mask``) and the device->host copy stay outside the graph, as in the reference; ``predict_device``
   defers both to the caller so that a loop over batches never waits for the GPU.
-(:func:`pad_batch` builds an explicitly padded batch; ``train_graph.GraphedEncoder`` still uses it.)
 
 hipGraph capture works because every C-ABI entry point only enqueues on the caller's stream and never
 allocates or synchronises (include/segger_amd.h conventions).
@@ -41,41 +40,6 @@ def bucket_sizes(batch, granularity: float = 1.25, floor: int = 1024) -> Dict[st
     for et in _EDGE_TYPES:
         sizes["__".join(et)] = up(int(batch[et].edge_index.shape[1]))
     return sizes
-
-
-def pad_batch(batch, sizes: Dict[str, int]) -> HeteroBatch:
-    """Pad to ``sizes``: dummy nodes copy node 0's attributes (positions included, so per-graph min/max
-    are unchanged), get ``predict_mask`` False, and padding edges connect the LAST dummy tx to the last dummy
-    tx / bd only (spread round-robin over the dummies)."""
-    out = HeteroBatch(num_graphs=getattr(batch, "num_graphs", 1))
-    n = {}
-    for nt in ("tx", "bd"):
-        cur = batch[nt].num_nodes
-        tgt = sizes[nt]
-        if tgt <= cur:
-            raise ValueError(f"bucket for '{nt}' ({tgt}) must exceed the batch size ({cur})")
-        n[nt] = tgt
-        for a, v in batch[nt].items():
-            if a == "num_nodes" or not isinstance(v, Tensor):
-                continue
-            fill = v[:1].expand(tgt - cur, *v.shape[1:])
-            if a in ("predict_mask", "mask"):
-                fill = torch.zeros_like(fill)
-            out[nt][a] = torch.cat([v, fill], 0)
-    for et in _EDGE_TYPES:
-        s, _, d = et
-        ei = batch[et].edge_index.long()
-        tgt = sizes["__".join(et)]
-        pad = tgt - ei.shape[1]
-        if pad <= 0:
-            raise ValueError(f"bucket for {et} ({tgt}) must exceed the edge count ({ei.shape[1]})")
-        # spread the padding edges round-robin over the dummy nodes: one dummy hub with ~25 % of all edges
-        # would serialise a whole kernel on a single row
-        k = torch.arange(pad, device=ei.device, dtype=ei.dtype)
-        n_ds, n_dd = n[s] - batch[s].num_nodes, n[d] - batch[d].num_nodes
-        fill = torch.stack([batch[s].num_nodes + k % n_ds, batch[d].num_nodes + k % n_dd])
-        out[et]["edge_index"] = torch.cat([ei, fill], 1)
-    return out
 
 
 class GraphedPredictor:

@@ -183,7 +183,7 @@ class LitISTEncoder(_Base):
     def get_losses(self, batch, dst_neg: Optional[Tensor] = None, embeddings: Optional[dict] = None,
                    uniforms: Optional[tuple] = None):
         """(loss_tx, loss_bd, loss_sg, loss), lightning_model.py:151-213.  ``embeddings`` lets a caller supply
-        the encoder output it already has (e.g. from a hipGraph replay, ``train_graph.GraphedEncoder``);
+        the encoder output it already has;
         ``dst_neg`` / ``uniforms`` = (per-transcript, per-boundary) selector draws replace the random numbers
         (replaying recorded vectors)."""
         if self.loss_tx is None or self.loss_bd is None:

@@ -689,19 +689,67 @@ def _weight_grad_gemm(gy: Tensor, x: Tensor) -> Tensor:
 
 # Parameters change between forwards in ways their version counters do not always show: torch's FUSED optimizers
 # update them in place without bumping ``_version`` (measured: fused Adam 0 -> 0, foreach Adam 0 -> 1).  Every
-# optimizer step therefore advances a global generation through torch's optimizer post-step hook; anything else that
-# writes parameters behind autograd's back (``p.data`` arithmetic) must call :func:`invalidate_weight_cache`.
-_WEIGHT_GENERATION = [0]
+# optimizer step therefore advances a generation counter ON THE PARAMETERS IT STEPPED (torch's optimizer post-step
+# hook); anything else that writes parameters behind autograd's back (``p.data`` arithmetic, a hipGraph replay) must
+# call :func:`invalidate_weights` on them, or :func:`invalidate_weight_cache` (everything).  The generation is per
+# parameter so that one model's optimizer step does not re-key another model's packs: a pending backward of the other
+# model must not see "weights changed" (and its packs are not re-copied for nothing).
+_GLOBAL_GENERATION = [0]
+_GEN_ATTR = "_segger_weight_gen"
+_BASE_ATTR = "_segger_weight_base"      # an alias (detached view) of a parameter names it here: it ages with its base
+
+
+def alias_of(p: Tensor) -> Tensor:
+    """A distinct autograd leaf over the storage of parameter ``p`` whose cached copies follow ``p``'s generation."""
+    a = p.detach().requires_grad_(p.requires_grad)
+    setattr(a, _BASE_ATTR, p)
+    return a
+
+
+def _gen_of(p) -> tuple:
+    base = getattr(p, _BASE_ATTR, None)
+    return (getattr(p, _GEN_ATTR, 0), 0 if base is None else getattr(base, _GEN_ATTR, 0))
+
+
+def invalidate_weights(params) -> None:
+    """The given parameters were written in place: their cached compute-dtype copies are rebuilt on next use."""
+    for p in params:
+        if p is not None:
+            setattr(p, _GEN_ATTR, getattr(p, _GEN_ATTR, 0) + 1)
 
 
 def invalidate_weight_cache(*_args, **_kwargs) -> None:
     """Forget every cached compute-dtype copy of the projection weights (they are rebuilt on next use)."""
-    _WEIGHT_GENERATION[0] += 1
+    _GLOBAL_GENERATION[0] += 1
+
+
+def _optimizer_stepped(optimizer, *_args, **_kwargs) -> None:
+    for group in optimizer.param_groups:
+        invalidate_weights(group["params"])
 
 
 from torch.optim.optimizer import register_optimizer_step_post_hook as _register_step_hook  # noqa: E402
 
-_register_step_hook(invalidate_weight_cache)
+_register_step_hook(_optimizer_stepped)
+
+# While a hipGraph is being captured, a refresh must only touch buffers the captured step owns: a multi-tensor copy
+# over every pack of the process would bake pointers to OTHER models' packs (and their source parameters) into the
+# graph, and replays would write through them after those models are gone.  ``pack_scope(params)`` names the
+# parameters of the step being captured; outside a scope a capturing refresh is limited to the requesting pack.
+_PACK_SCOPE: list = []
+
+
+class pack_scope:
+    def __init__(self, params):
+        self.ids = frozenset(id(p) for p in params)
+
+    def __enter__(self):
+        _PACK_SCOPE.append(self.ids)
+        return self
+
+    def __exit__(self, *exc):
+        _PACK_SCOPE.pop()
+        return False
 
 
 class _Pack:
@@ -709,12 +757,13 @@ class _Pack:
     copy the data gradient streams), refreshed only when a parameter changed (optimizer step, load_state_dict, .to()):
     the three projections that read x_tx (lin_l / lin_r of tx-neighbors-tx, lin_l of tx-belongs-bd) are ONE GEMM
     without a per-forward cat + cast + transpose (and without autograd's slice-copies on the way back).  The copies
-    live in persistent buffers; after an optimizer step ALL packs of the process are refreshed by one multi-tensor
+    live in persistent buffers; after an optimizer step ALL stale packs of the process are refreshed by one multi-tensor
     copy (``torch._foreach_copy_`` casts fp32 -> bf16 into row windows of the stacked buffers in a single launch)."""
 
     def __init__(self, weights, biases):
         import weakref
         self.params = [weakref.ref(p) for p in tuple(weights) + tuple(b for b in biases if b is not None)]
+        self.param_ids = frozenset(id(p) for p in tuple(weights) + tuple(b for b in biases if b is not None))
         self.rows = [int(w.shape[0]) for w in weights]
         self.has_bias = [b is not None for b in biases]
         self.k = int(weights[0].shape[1])
@@ -742,21 +791,20 @@ class _Pack:
         ps = [r() for r in self.params]
         if any(p is None for p in ps):
             return None, ps
-        return tuple((p.data_ptr(), p._version) for p in ps), ps
+        return (_GLOBAL_GENERATION[0],) + tuple((p.data_ptr(), p._version) + _gen_of(p) for p in ps), ps
 
     def get(self, dtype, device):
         key, ps = self._current_key()
-        gen = _WEIGHT_GENERATION[0]
         if self.w is None or self.dtype != dtype or self.w.device != device:
             self._alloc(dtype, device)
             self.key = None
-        if self.key != (gen, key):
-            if _REFRESHED_GENERATION[0] != gen and self.key is not None:
-                _refresh_all_packs()                         # one launch for every pack of the process
-            if self.key != (gen, key):                       # (first use, or a change outside an optimizer step)
+        if self.key != key:
+            if self.key is not None:
+                _refresh_stale_packs(self)                   # one launch for every stale pack (of the scope)
+            if self.key != key:                              # (first use, or skipped by the scope)
                 with torch.no_grad():
                     _copy_groups(self.views, [p.detach() for p in ps])
-                self.key, self._wt_fresh = (gen, key), False
+                self.key, self._wt_fresh = key, False
         return self
 
     @property
@@ -770,7 +818,6 @@ class _Pack:
 
 
 _PACKS: dict = {}
-_REFRESHED_GENERATION = [-1]
 
 
 def _copy_groups(dsts, srcs) -> None:
@@ -786,14 +833,23 @@ def _copy_groups(dsts, srcs) -> None:
 
 
 @torch.no_grad()
-def _refresh_all_packs() -> None:
-    gen = _WEIGHT_GENERATION[0]
+def _refresh_stale_packs(requester: "_Pack") -> None:
+    """Refresh every pack whose parameters changed since it was filled, in one multi-tensor copy per dtype (+ one
+    launch for the transposed copies).  During a hipGraph capture only the packs of the active :class:`pack_scope`
+    (or, without one, only ``requester``) are touched: see ``_PACK_SCOPE``."""
+    scope = _PACK_SCOPE[-1] if _PACK_SCOPE else None
+    capturing = requester.w.is_cuda and torch.cuda.is_current_stream_capturing()
     dsts, srcs, live = [], [], []
     for pk in _PACKS.values():
-        if pk.w is None:
+        if pk.w is None or pk.w.device != requester.w.device:
+            continue
+        if scope is not None:
+            if not pk.param_ids <= scope:
+                continue
+        elif capturing and pk is not requester:
             continue
         key, ps = pk._current_key()
-        if key is None:
+        if key is None or key == pk.key:
             continue
         dsts += pk.views
         srcs += [p.detach() for p in ps]
@@ -801,7 +857,7 @@ def _refresh_all_packs() -> None:
     if dsts:
         _copy_groups(dsts, srcs)
     for pk, key in live:
-        pk.key, pk._wt_fresh = (gen, key), False
+        pk.key, pk._wt_fresh = key, False
     # the transposed copies the data gradients stream (every pack that has been through a backward): one launch
     tr = [pk for pk, _ in live if pk._wt is not None and pk.w.element_size() == 2 and pk.w.is_cuda]
     if tr:
@@ -815,7 +871,13 @@ def _refresh_all_packs() -> None:
         _lib.check(rc, "segger_transpose_many")
         for pk in tr:
             pk._wt_fresh = True
-    _REFRESHED_GENERATION[0] = gen
+
+
+def packs_of(params) -> list:
+    """The live packs built over (a subset of) ``params``: a captured step keeps them -- and so their buffers -- alive
+    for as long as its graph may replay."""
+    ids = frozenset(id(p) for p in params)
+    return [pk for pk in _PACKS.values() if pk.param_ids <= ids]
 
 
 def _pack_for(weights, biases) -> _Pack:

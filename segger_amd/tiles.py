@@ -171,12 +171,31 @@ class TilePartition:
         return torch.tensor(values, dtype=torch.long).pin_memory().to(device, non_blocking=True)
 
     # ---- sorted edge views, once per slide ----------------------------------------------------------
+    # one `segger_csr_from_coo` call sorts fewer than 2^31 edges (int32 slot / edge ids); a slide-level edge store can be
+    # larger (reference _patches.py:1-9 documents >INT_MAX edge masks; neighbors.py:159: "600M transcripts" = 9G kNN edges)
+    csr_sort_max_edges = (1 << 31) - (1 << 20)
+
+    def _sort_chunks(self, et: EdgeType) -> List[tuple]:
+        """Consecutive tile ranges [t0, t1) whose edges of ``et`` fit one sort.  Tiles are independent graphs with
+        contiguous nodes and edges, so the sorted views of a range are the sorted views of its tiles back to back."""
+        eptr, cap = self._eptr[et], int(self.csr_sort_max_edges)
+        chunks, t0 = [], 0
+        for t in range(self.num_tiles):
+            if eptr[t + 1] - eptr[t] > cap:
+                raise ValueError(f"tile {t} alone holds {eptr[t + 1] - eptr[t]} edges of {et}: more than one sort "
+                                 f"takes ({cap}); use smaller tiles")
+            if eptr[t + 1] - eptr[t0] > cap:
+                chunks.append((t0, t)); t0 = t
+        chunks.append((t0, self.num_tiles))
+        return chunks
+
     def build_csr(self, edge_types: Optional[Sequence[EdgeType]] = None) -> None:
         """Sort every edge store ONCE for the whole slide (``segger_csr_from_coo``: by destination and by source)
         and keep the result in tile-local coordinates.  Tiles are independent graphs whose nodes and edges are
         contiguous, so the CSR views of any batch of tiles are concatenations of per-tile slices plus one offset
         per tile: :meth:`batch` then hands the encoder ready-made views and no batch is ever sorted again
-        (5 radix sorts per batch otherwise).  Needs the partition on the GPU."""
+        (5 radix sorts per batch otherwise).  An edge store of 2^31 edges or more is sorted in ranges of whole tiles
+        (``csr_sort_max_edges``).  Needs the partition on the GPU."""
         from .graph import csr_from_coo, sources_unique
         self.csr_max_tiles = 1
         self._csr: Dict[EdgeType, Dict[str, Dict[str, Tensor]]] = {}
@@ -187,23 +206,30 @@ class TilePartition:
             # once per slide (one sync here, none per batch): does every source have at most one out-edge?  Then the
             # backward of this edge type needs no by-source view (graph.EdgeGraph, segger_gatv2_bwd_args.src_unique)
             self._src_unique[et] = bool(int(sources_unique(ei[0], self.data[s].num_nodes))) if ei.is_cuda else False
-            n = {"by_dst": (self.data[d].num_nodes, self.data[s].num_nodes), "by_src": (self.data[s].num_nodes, self.data[d].num_nodes)}
-            tile_of_edge = torch.repeat_interleave(torch.arange(self.num_tiles, device=ei.device), self.edge_sizes[et])
+            eptr = self._eptr[et]
+            tile_ids = torch.arange(self.num_tiles, device=ei.device)
             views = {}
             for side, (row_t, col_t, row, col) in {"by_dst": (d, s, ei[1], ei[0]), "by_src": (s, d, ei[0], ei[1])}.items():
-                csr = csr_from_coo(row, col, n[side][0], n[side][1], validate=False)
-                # tile-local coordinates (edges of a tile stay contiguous under the sort: all of them are intra-tile)
-                eid_tile = tile_of_edge[csr.eid.long()]
-                col_local = (csr.col.long() - self.node_indptr[col_t][:-1][eid_tile]).to(torch.int32)
-                eid_local = (csr.eid.long() - self.edge_indptr[et][:-1][eid_tile]).to(torch.int32)
-                tile_of_row = torch.repeat_interleave(torch.arange(self.num_tiles, device=ei.device), self.node_sizes[row_t])
-                ptr_local = csr.indptr[:-1] - self.edge_indptr[et][:-1][tile_of_row]   # row start inside its tile
-                views[side] = {"ptr": ptr_local, "col": col_local, "eid": eid_local}
+                rptr, cptr = self._nptr[row_t], self._nptr[col_t]
+                parts = {"ptr": [], "col": [], "eid": []}
+                for t0, t1 in self._sort_chunks(et):
+                    e0, e1, r0, r1, c0, c1 = eptr[t0], eptr[t1], rptr[t0], rptr[t1], cptr[t0], cptr[t1]
+                    csr = csr_from_coo(row[e0:e1] - r0, col[e0:e1] - c0, r1 - r0, max(c1 - c0, 1), validate=False)
+                    # tile-local coordinates (edges of a tile stay contiguous under the sort: all of them are intra-tile)
+                    tile_of_edge = torch.repeat_interleave(tile_ids[t0:t1], self.edge_sizes[et][t0:t1], output_size=e1 - e0)
+                    eid_tile = tile_of_edge[csr.eid.long()]
+                    parts["col"].append((csr.col.long() + c0 - self.node_indptr[col_t][:-1][eid_tile]).to(torch.int32))
+                    parts["eid"].append((csr.eid.long() + e0 - self.edge_indptr[et][:-1][eid_tile]).to(torch.int32))
+                    tile_of_row = torch.repeat_interleave(tile_ids[t0:t1], self.node_sizes[row_t][t0:t1], output_size=r1 - r0)
+                    parts["ptr"].append(csr.indptr[:-1] + e0 - self.edge_indptr[et][:-1][tile_of_row])   # row start inside its tile
+                views[side] = {k: (v[0] if len(v) == 1 else torch.cat(v)) for k, v in parts.items()}
             self._csr[et] = views
 
     def _batch_graph(self, et: EdgeType, tile_ids: Sequence[int], base: Dict[str, List[int]], n_nodes: Dict[str, int],
-                     need_by_dst: bool = True, need_by_src: bool = True):
-        """Sorted views of one edge type for a batch of tiles, sliced from the slide-level sort."""
+                     need_by_dst: bool = True, need_by_src: bool = True, edge_index: Optional[Tensor] = None):
+        """Sorted views of one edge type for a batch of tiles, sliced from the slide-level sort.  ``edge_index`` (the
+        batch's COO list) rides along so that a consumer that does need the skipped by-source view -- the generic
+        GATv2 kernels have no one-pass backward -- can still sort it on demand (``EdgeGraph.require_by_src``)."""
         from .graph import EdgeCSR, EdgeGraph
         s, _, d = et
         eptr = self._eptr[et]
@@ -242,7 +268,24 @@ class TilePartition:
             indptr[:-1] = ptr
             indptr[-1:] = n_edges
             out[side] = EdgeCSR(indptr, col, eid, n_nodes[row_t], n_nodes[col_t]).balanced_order()
-        return EdgeGraph(out["by_dst"], out["by_src"], n_nodes[s], n_nodes[d], n_edges, None, unique)
+        return EdgeGraph(out["by_dst"], out["by_src"], n_nodes[s], n_nodes[d], n_edges, edge_index, unique)
+
+    def _persistent_store(self, key: tuple) -> dict:
+        """Per-tile-set scratch that survives the batch object (sampler indices, rows-by-gene grouping), kept in an
+        LRU of ``persist_max`` entries: a shuffling sampler re-packs the tiles every epoch (``TileBatchSampler``,
+        reference data_module.py:344), so almost every tile set is new each epoch and an unbounded store would grow by
+        one batch-sized entry per step.  Default bound: two epochs' worth of single-tile batches."""
+        from collections import OrderedDict
+        store = self.__dict__.setdefault("_persist", OrderedDict())
+        cap = getattr(self, "persist_max", None) or max(64, 2 * self.num_tiles)
+        entry = store.get(key)
+        if entry is None:
+            entry = store[key] = {}
+            while len(store) > cap:
+                store.popitem(last=False)
+        else:
+            store.move_to_end(key)
+        return entry
 
     def add_node_attr(self, node_type: str, name: str, value: Tensor, permuted: bool = False) -> None:
         self.data[node_type][name] = value if permuted else value.index_select(0, self.node_perm[node_type])
@@ -308,7 +351,7 @@ class TilePartition:
                 out[et]["edge_index"] = ei[:, :0]
         from .graph import batch_cache
         # what never changes for this set of tiles (labels, masks -> the loss samplers' indices) survives the batch object
-        batch_cache(out)["persistent"] = self.__dict__.setdefault("_persist", {}).setdefault(tuple(tile_ids), {})
+        batch_cache(out)["persistent"] = self._persistent_store(tuple(tile_ids))
         if getattr(self, "_csr", None) and tile_ids:
             # graph.edge_graph() asks this factory before it sorts a batch's edge store itself
             n_nodes = {nt: out[nt].num_nodes for nt in self.data._nodes}
@@ -319,7 +362,7 @@ class TilePartition:
                 # single-tile batches are pure slices; for many tiles one radix sort of the batch measured faster
                 # than concatenating + re-basing 3 arrays x 18 tile slices per view (50M-tx FOV, 16M-edge batches)
                 if len(ids) <= self.csr_max_tiles and mine.get(key) == (edge_index.data_ptr(), int(edge_index.shape[1])):
-                    return self._batch_graph(key, ids, base, n_nodes, need_by_dst, need_by_src)
+                    return self._batch_graph(key, ids, base, n_nodes, need_by_dst, need_by_src, edge_index)
                 return None
             batch_cache(out)["graph_factory"] = factory
             batch_cache(out)["src_unique"] = self._src_unique      # slide-level: holds for every subset of its edges

@@ -23,8 +23,10 @@ batch padded into the bucket's static buffers:
 
 What it computes is ``LitISTEncoder.training_step`` + ``optimizer.step()`` (reference lightning_model.py:151-231 with
 Lightning's automatic optimisation), for the default ``sg_loss_type='triplet'``.  The optimizer must be capturable
-(``LitISTEncoder.configure_optimizers(capturable=True)``); ``ops.invalidate_weight_cache()`` is called after every
-replay because the parameters change without Python noticing.
+(``LitISTEncoder.configure_optimizers(capturable=True)``); ``ops.invalidate_weights(params)`` is called after every
+replay because the parameters change without Python noticing.  The capture runs inside ``ops.pack_scope(aliases)``: the
+weight refresh baked into the graph touches only the compute-dtype copies of THIS step's parameter aliases, which the
+step keeps alive (``_pack_refs``), never another model's.
 
 Data parallelism (``GraphedTrainer(..., grad_sync=bucket.all_reduce_mean)``): the step is captured as TWO graphs --
 forward + backward, and Adam -- with the gradient exchange between them run eagerly (one collective per step on every
@@ -121,7 +123,7 @@ class GraphedTrainStep:
         # crashes).  The aliases' sinks are born inside the capture; the gradients are handed to the optimizer's
         # parameters by assignment.
         lit_model.model._materialize_bd(int(template["bd"]["x"].shape[1]), dev)
-        self._alias = {n: p.detach().requires_grad_(p.requires_grad) for n, p in lit_model.model.named_parameters()}
+        self._alias = {n: ops.alias_of(p) for n, p in lit_model.model.named_parameters()}
         by_id = {id(p): self._alias[n] for n, p in lit_model.model.named_parameters()}
         self._params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad and id(p) in by_id]
         self._leaves = [by_id[id(p)] for p in self._params]
@@ -283,24 +285,32 @@ class GraphedTrainStep:
                 self._run()
             torch.cuda.current_stream().wait_stream(side)
             self._restore(keep)                               # ... which must not count as a training step
-            ops.invalidate_weight_cache()                     # the captured step starts with the weight refresh
+            aliases = list(self._alias.values())
+            ops.invalidate_weights(aliases)                   # the captured step starts with the weight refresh ...
             self.graph = torch.cuda.CUDAGraph()
-            if self.grad_sync is None:
-                with torch.cuda.graph(self.graph):
-                    self._run()
-            else:                                             # forward + backward | <gradient exchange> | Adam
-                with torch.cuda.graph(self.graph):
-                    self._run_grads()
-                self.graph_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
-                    self.opt.step()
+            with ops.pack_scope(aliases):                     # ... of this step's own packs only
+                if self.grad_sync is None:
+                    with torch.cuda.graph(self.graph):
+                        self._run()
+                else:                                         # forward + backward | <gradient exchange> | Adam
+                    with torch.cuda.graph(self.graph):
+                        self._run_grads()
+                    self.graph_opt = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
+                        self.opt.step()
+            # the graph holds raw pointers into these buffers: they must outlive it whatever happens to the cache
+            self._pack_refs = [(pk, pk.w, pk.b, pk._wt) for pk in ops.packs_of(aliases)]
             self._grads = [p.grad for p in self._params]
             self._training = lit.model.training
             self._replay()                                    # (capturing runs nothing)
         else:
             self._replay()
-        ops.invalidate_weight_cache()                         # parameters changed behind Python's back
+        self._params_changed()
         return self.out
+
+    def _params_changed(self) -> None:
+        """The replay stepped the parameters behind Python's back: eager users' compute-dtype copies are stale."""
+        ops.invalidate_weights(p for g in self.opt.param_groups for p in g["params"])
 
     def _replay(self, empty: bool = False) -> None:
         """Fused mode: one replay.  Split mode: replay forward + backward (``empty``: zero the gradients instead -- this
@@ -321,7 +331,7 @@ class GraphedTrainStep:
 
     def empty_step(self) -> None:
         self._replay(empty=True)
-        ops.invalidate_weight_cache()
+        self._params_changed()
 
 
 class GraphedTrainer:
@@ -352,7 +362,6 @@ class GraphedTrainer:
                     p.grad = torch.zeros_like(p)
         self.grad_sync()
         self.opt.step()
-        ops.invalidate_weight_cache()
 
     def step(self, batch) -> Optional[Tensor]:
         if batch is None:

@@ -347,50 +347,6 @@ def test_predictor_pool_on_partition_batches_without_sync(cuda):
     assert all(torch.equal(a, w) for a, w in zip((one[0], one[3]), (m.predict_step(part.batch(batches[0]), 0)[i] for i in (0, 3))))
 
 
-def test_graphed_encoder_matches_eager_forward_and_backward(cuda):
-    """Encoder fwd+bwd as hipGraph replays (torch.cuda.make_graphed_callables over bucket-padded tiles):
-    same embeddings and same parameter gradients as the eager path, for tiles of different sizes; with
-    attention dropout the replays draw a new mask each time (device-side seed counter)."""
-    from segger_amd import tiles as T
-    from segger_amd.inference import bucket_sizes
-    from segger_amd.train_graph import GraphedEncoder
-    from segger_amd.synthetic import SyntheticSpec
-    spec = SyntheticSpec(n_tx=8000, n_bd=200, k_tx=8, seed=37)
-    m, _, b, _ = build(spec, cuda)
-    for nt in ("tx", "bd"):
-        del b[nt]["mask"]
-    bg = b.to(cuda)
-    part = T.partition_by_tiling(bg, T.SquareTiling(torch.cat([b["tx"].pos, b["bd"].pos]), 50.0), margin=3.0)
-    tiles = [part.tile(t) for t in range(len(part)) if part.node_sizes["bd"][t] > 1 and part.node_sizes["tx"][t] > 200]
-    sizes = {}
-    for t in tiles:
-        for k, v in bucket_sizes(t, floor=256).items():
-            sizes[k] = max(sizes.get(k, 0), v)
-    m.eval()                                       # deterministic comparison first (no dropout)
-    ge = GraphedEncoder(m, sizes, bd_dim=spec.bd_dim, max_graphs=4)
-    ge(tiles[0])                                   # capture now: no eager autograd graph may be alive at capture time
-    for t in tiles[:4]:
-        w = torch.randn(t["tx"].num_nodes, 64, device=cuda)
-        m.zero_grad(set_to_none=True)
-        z_e = m(t)
-        (z_e["tx"] * w).sum().backward()
-        g_e = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
-        m.zero_grad(set_to_none=True)
-        z_g = ge(t)
-        (z_g["tx"] * w).sum().backward()
-        assert torch.allclose(z_g["tx"], z_e["tx"], atol=2e-6) and torch.allclose(z_g["bd"], z_e["bd"], atol=2e-6)
-        for k, p in m.named_parameters():
-            if k in g_e:
-                scale = g_e[k].abs().max().item() + 1e-12
-                assert (p.grad - g_e[k]).abs().max().item() < 2e-4 * scale, k
-        del z_e, z_g
-    m.zero_grad(set_to_none=True)
-    m.train()                                      # training mode: re-captured, dropout masks differ between replays
-    z1 = ge(tiles[0])["tx"].detach().clone()
-    z2 = ge(tiles[0])["tx"].detach().clone()
-    assert torch.isfinite(z1).all() and (z1 - z2).abs().max() > 1e-4
-
-
 def test_bad_edge_index_is_reported_without_a_mid_step_sync(cuda):
     """Deferred validation: a model forward over an edge_index with out-of-range node ids does not fault (ids are
     clamped) and the IndexError surfaces from a later graph build, flush_validation() or predict_step."""

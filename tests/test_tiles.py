@@ -204,3 +204,20 @@ def test_bin_packers_reproduce_reference_vectors():
     with pytest.raises(ValueError) as e:
         T.harmonic_k([1.0], 10.0, k=1)
     assert str(e.value) == err["harmonic_k_k1"][1]
+
+
+def test_persistent_store_is_bounded(graph):
+    """The per-tile-set store behind ``batch_cache(batch)['persistent']`` is an LRU: a shuffling sampler makes new tile
+    tuples every epoch (reference data_module.py:344) and must not grow it without bound (round-2 advice)."""
+    from segger_amd.graph import batch_cache
+    part = T.partition_by_tiling(graph, T.SquareTiling(all_pos(graph), 25.0), margin=2.0)
+    part.persist_max = 4
+    first = batch_cache(part.batch([0]))["persistent"]
+    first["marker"] = 1
+    assert batch_cache(part.batch([0]))["persistent"] is first               # same tile set -> same entry
+    for i in range(1, 4):
+        batch_cache(part.batch([i]))["persistent"]["marker"] = i
+    assert batch_cache(part.batch([0]))["persistent"] is first               # still there (4 entries) and now most recent
+    batch_cache(part.batch([0, 1]))                                          # 5th entry evicts the least recently used: [1]
+    assert len(part._persist) == 4 and (1,) not in part._persist and (0,) in part._persist
+    assert "marker" not in batch_cache(part.batch([1]))["persistent"]
