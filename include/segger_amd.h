@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEGGER_ABI_VERSION 11
+#define SEGGER_ABI_VERSION 12
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -449,6 +449,17 @@ size_t segger_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t m_out, int32_
 int segger_linear_wgrad(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, int64_t n_rows,
                         int32_t m_out, int32_t k_in, int32_t dtype, float* grad_w, float* grad_b,
                         void* workspace, size_t workspace_bytes, segger_stream_t stream);
+/* segger_linear_wgrad_dx: the WHOLE backward of one projection in one pass over dY:
+ *     grad_w, grad_b as above, and    dx[n, K] = dY[n, M] * W[M, K]
+ * (autograd's `grad @ weight` for the same nn.Linear / PyG Linear call sites).  dY [n, 3*HC] of the stacked
+ * lin_l | lin_r | lin_l projections is the widest matrix of a layer's backward; the separate data-gradient GEMM
+ * (segger_linear_fwd on W^T) read it a second time.  w_t = W^T, [k_in, m_out] contiguous in `dtype`; dx row stride
+ * ld_dx (elements, 16-byte aligned rows); covered: k_in == 128, m_out in {64,128,192,384}, bf16 / f16
+ * (segger_linear_wgrad_dx_supported); workspace as for segger_linear_wgrad. */
+int segger_linear_wgrad_dx_supported(int32_t m_out, int32_t k_in, int32_t dtype);
+int segger_linear_wgrad_dx(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, const void* w_t, int64_t n_rows,
+                           int32_t m_out, int32_t k_in, int32_t dtype, float* grad_w, float* grad_b, void* dx,
+                           int64_t ld_dx, void* workspace, size_t workspace_bytes, segger_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Encoder front end / tail as fused row-wise kernels.

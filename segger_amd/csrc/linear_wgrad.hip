@@ -15,6 +15,15 @@
 //     per fragment, fp32 accumulate), by the waves that own the first K tiles;
 //   * every workgroup writes its partial [M*K + M] to the workspace; a second kernel sums the partials in slab
 //     order (deterministic, no atomics).
+//
+// DX variant (segger_linear_wgrad_dx): the DATA gradient dX[n, K] = dY[n, M] * W[M, K] of the same projection from the
+// same LDS stage, so that dY -- the widest matrix of a layer's backward, [n, 3*HC] for the stacked projections -- is
+// read from HBM once instead of twice (once by the dX GEMM, once here).  The staged dY rows are read a second time,
+// row-major (ds_read_b128), as the B operand of v_mfma_f32_16x16x32 against W^T fragments that stay in registers for
+// the whole kernel (wave w owns output columns 16*CT*w .. of dX: M/32 x CT fragments of 4 VGPRs); the 16 x K result of
+// a stage goes through a double-buffered LDS tile so that it leaves as full rows, one 8- or 16-byte store per lane,
+// issued one stage later (after the ring's barrier).  The stores share vmcnt with the LDS-DMA loads: the counted
+// waits below include them.
 #include "common.h"
 
 namespace segger {
@@ -36,6 +45,9 @@ template <> struct WgMfma<bf16_t> {
   static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
   }
+  static __device__ __forceinline__ f32x4 run16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
   // c + lo(a) + hi(a)
   static __device__ __forceinline__ float sum2(uint32_t a, float c) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2v, a), __builtin_bit_cast(bf16x2v, 0x3f803f80u), c, false);
@@ -44,6 +56,9 @@ template <> struct WgMfma<bf16_t> {
 template <> struct WgMfma<f16_t> {
   static __device__ __forceinline__ f32x16 run(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 run16(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
   }
   static __device__ __forceinline__ float sum2(uint32_t a, float c) {
     return __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2v, a), __builtin_bit_cast(f16x2v, 0x3c003c00u), c, false);
@@ -66,6 +81,8 @@ struct WgradParams {
   float* partial;            // [gridDim.x][M*K + M]
   const float* pn;           // GEN: normalised coordinate per row (x is not read: its rows are sinusoid features of pn)
   float log_max_period;
+  const void* wt;            // DX: W^T [K, M] row-major in the activation dtype
+  void* dx; int64_t ld_dx;   // DX: dX [n_rows, K]
 };
 
 // One LDS-DMA wave-instruction: every lane fetches 16 bytes at rsrc + voffset + soffset (zeros when that is past
@@ -97,11 +114,18 @@ template <int M, int K, int NW, bool GEN = false> struct WgGeo {
   static constexpr int P = ((IMG + 1023) / 1024 + NW - 1) / NW;   // 1 KiB DMA chunks per wave per stage
   static constexpr int BUF = P * NW * 1024;                       // ring slot (chunks past IMG receive zeros)
   static constexpr int LDS = kNBuf * BUF;
+  static constexpr int SO = K * 2 + 16;                           // DX: row stride of the dX stage tile
+  static constexpr int OUT = kStageRows * SO;                     // DX: one dX stage tile (two of them behind the ring)
 };
 
-template <typename T, int M, int K, int NW, bool GEN = false>
+template <int N> __device__ __forceinline__ void wait_vmcnt() {   // lgkmcnt / expcnt untouched
+  __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
+}
+
+template <typename T, int M, int K, int NW, bool GEN = false, bool DX = false>
 __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
   using G = WgGeo<M, K, NW, GEN>;
+  static_assert(!(GEN && DX), "the generated-operand form has no data gradient");
   // wave grid over (M tiles, K tiles); GEN: every wave its own K tiles, so no generated fragment is computed twice
   constexpr int WM = GEN ? 1 : (NW == 8 ? 4 : 2), WK = GEN ? NW : 2;
   static_assert(M * K / (64 * NW) <= 192, "accumulator does not fit the register file");
@@ -110,7 +134,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
   constexpr int MT = TM / WM, KT = TK / WK;            // 32x32 tiles per wave
   constexpr int SY = G::SY, SX = G::SX, P = G::P, BUF = G::BUF;
   static_assert((kStageRows * SY) % 1024 == 0, "the dY / X boundary must fall on a DMA chunk boundary");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS];
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS + (DX ? 2 * G::OUT : 0)];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -191,14 +215,66 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
     }
   }
 
+  // ---- DX: this wave's W^T fragments (A operand of the 16x16x32 MFMA: lane (i, q) holds W^T[c0 + i][32 ks + 8 q ..+8)),
+  //      resident for the whole kernel, and the addresses of its pieces of the dX stage tile
+  constexpr int CT = DX ? (K / 16) / NW : 1;                // 16-column tiles of dX per wave
+  constexpr int KS = DX ? M / 32 : 1;                       // k-steps of the dX product
+  static_assert(!DX || ((K / 16) % NW == 0 && CT * KS * 4 <= 64), "dX tiles do not split over the waves");
+  constexpr int SO = G::SO;
+  constexpr int PB = kStageRows * K * 2 / (NW * 64);        // bytes of a dX stage tile per thread (8 or 16)
+  static_assert(!DX || PB == 8 || PB == 16, "dX store width");
+  u32x4 wf[CT][KS];
+  unsigned char* lds_out = lds + G::LDS;
+  const int dq = lane >> 4, dj = lane & 15;
+  T* __restrict__ dxp = static_cast<T*>(p.dx);
+  if constexpr (DX) {
+    const T* wt = static_cast<const T*>(p.wt);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        wf[ct][ks] = *reinterpret_cast<const u32x4*>(wt + (int64_t)(16 * (wave * CT + ct) + dj) * M + 32 * ks + 8 * dq);
+  }
+  // stage t's dX tile (LDS, written by all waves before the last barrier) -> global memory, full rows
+  auto store_dx = [&](int t, bool check_rows) {
+    const int o = tid * PB, row = o / (K * 2), colb = o % (K * 2);
+    const unsigned char* src = lds_out + (t & 1) * G::OUT + row * SO + colb;
+    const int64_t grow = row_beg + (int64_t)t * kStageRows + row;
+    unsigned char* dst = reinterpret_cast<unsigned char*>(dxp + grow * p.ld_dx) + colb;
+    if (PB == 8) {
+      const u32x2 v = *reinterpret_cast<const u32x2*>(src);
+      if (!check_rows || grow < p.n_rows) *reinterpret_cast<u32x2*>(dst) = v;
+    } else {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src);
+      if (!check_rows || grow < p.n_rows) *reinterpret_cast<u32x4*>(dst) = v;
+    }
+  };
+
   for (int d = 0; d < kAhead; ++d) issue(d);
   for (int s = 0; s < n_local; ++s) {
     // this wave's pieces of stage s have landed once at most (kAhead - 1) * P of its loads are outstanding;
     // the barrier then makes every wave's pieces visible and retires all reads of stage s - 1, whose ring slot
     // the next issue overwrites
-    __builtin_amdgcn_s_waitcnt(0x0F70 | (((kAhead - 1) * P) & 15) | ((((kAhead - 1) * P) >> 4) << 14));
-    __syncthreads();
+    if constexpr (!DX) {
+      wait_vmcnt<(kAhead - 1) * P>();
+      __syncthreads();
+    } else {
+      // the dX stores of earlier iterations sit between the loads in vmcnt's (in-order) queue: per wave the stream
+      // is L0 L1 L2 | L3 | L4 S0 | L5 S1 | ..., so behind the loads of stage s there are 2 P loads and min(s - 1, 3)
+      // stores (every in-loop store is unconditional: one instruction per wave and iteration, see store_dx)
+      if (s < 2) wait_vmcnt<(kAhead - 1) * P>();
+      else if (s == 2) wait_vmcnt<(kAhead - 1) * P + 1>();
+      else if (s == 3) wait_vmcnt<(kAhead - 1) * P + 2>();
+      else wait_vmcnt<(kAhead - 1) * P + 3>();
+      // a bare barrier (+ the LDS writes of the previous iteration's dX tile drained): __syncthreads() would add a
+      // release fence, i.e. vmcnt(0) -- the loads in flight are the pipelining this kernel lives on
+      __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
+      __builtin_amdgcn_s_barrier();
+    }
     issue(s + kAhead);
+    if constexpr (DX) {
+      if (s > 0) store_dx(s - 1, false);
+    }
     const unsigned char* base = lds + (s % kNBuf) * BUF;
     u32x4 fa[MT];
 #pragma unroll
@@ -243,6 +319,32 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
 #pragma unroll
         for (int a = 0; a < MT; ++a) acc[a][b] = WgMfma<T>::run(fa[a], fb, acc[a][b]);
       }
+    }
+    if constexpr (DX) {
+      // dX^T tile = W^T[16 columns of dX, M] * dY^T[M, 16 rows]: B operand lane (j, q) = dY[row j][32 ks + 8 q ..+8),
+      // a row-major 16-byte read of the staged rows; D lane (j, q) = dX[row j][c0 + 4 q + e], e = 0..3
+      f32x4 dacc[CT];
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) dacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4 fy = *reinterpret_cast<const u32x4*>(base + dj * SY + (32 * ks + 8 * dq) * 2);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) dacc[ct] = WgMfma<T>::run16(wf[ct][ks], fy, dacc[ct]);
+      }
+      unsigned char* ot = lds_out + (s & 1) * G::OUT + dj * SO;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const u32x2 pk = u32x2{Vec8<T>::pack(dacc[ct].x, dacc[ct].y), Vec8<T>::pack(dacc[ct].z, dacc[ct].w)};
+        *reinterpret_cast<u32x2*>(ot + (16 * (wave * CT + ct) + 4 * dq) * 2) = pk;
+      }
+    }
+  }
+  if constexpr (DX) {
+    if (n_local > 0) {                                       // the last stage's tile (the only one that may be partial)
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      __builtin_amdgcn_s_barrier();
+      store_dx(n_local - 1, true);
     }
   }
   // the ring ran kAhead stages past the slab (zero reads): let them land before the wave ends
@@ -329,20 +431,24 @@ bool shape_ok(int m, int k) {
 int waves_for(int m) { return m % 128 == 0 ? 8 : 4; }
 // workgroups per CU the register and LDS footprints allow (accumulator registers per lane = M*K / (64*NW);
 // LDS = 4 ring slots of the stage image rounded up to whole 1 KiB chunks per wave)
-int blocks_per_cu(int m, int k) {
+int blocks_per_cu(int m, int k, bool dx = false) {
   const int nw = waves_for(m);
-  const int acc = m * k / (64 * nw);
+  int acc = m * k / (64 * nw);
   const int img = kStageRows * (m * 2 + 64 + k * 2 + 64);
-  const int lds = kNBuf * (((img + 1023) / 1024 + nw - 1) / nw) * nw * 1024;
+  int lds = kNBuf * (((img + 1023) / 1024 + nw - 1) / nw) * nw * 1024;
+  if (dx) {                                            // + the W^T fragments and the two dX stage tiles
+    acc += (k / 16 / nw) * (m / 32) * 4;
+    lds += 2 * kStageRows * (k * 2 + 16);
+  }
   int by_regs = acc > 64 ? 1 : (acc > 32 ? 2 : 4);
   if (nw == 4 && by_regs < 4) by_regs *= 2;           // 4-wave workgroups: one wave per SIMD each
   const int by_lds = (160 * 1024) / lds;
   const int b = by_regs < by_lds ? by_regs : by_lds;
   return b < 1 ? 1 : b;
 }
-int64_t grid_for(int64_t n_rows, int m, int k) {
+int64_t grid_for(int64_t n_rows, int m, int k, bool dx = false) {
   const int64_t stages = (n_rows + kStageRows - 1) / kStageRows;
-  const int64_t cap = (int64_t)kNumCu * blocks_per_cu(m, k);
+  const int64_t cap = (int64_t)kNumCu * blocks_per_cu(m, k, dx);
   const int64_t want = (stages + kMinStagesPerBlock - 1) / kMinStagesPerBlock;
   return want < cap ? (want < 1 ? 1 : want) : cap;
 }
@@ -354,6 +460,26 @@ void launch_wgrad(const WgradParams& p, int64_t grid, hipStream_t stream) {
 }
 
 int reduce_partials(float* partial, int64_t grid, int m_out, int k_in, float* grad_w, float* grad_b, hipStream_t stream);
+
+template <typename T, int M, int K>
+void launch_wgrad_dx(const WgradParams& p, int64_t grid, hipStream_t stream) {
+  constexpr int NW = M % 128 == 0 ? 8 : 4;
+  hipLaunchKernelGGL((wgrad_kernel<T, M, K, NW, false, true>), dim3((unsigned)grid), dim3(NW * 64), 0, stream, p);
+}
+
+bool dx_shape_ok(int m, int k) { return k == 128 && (m == 384 || m == 192 || m == 128 || m == 64); }
+
+template <typename T>
+int dispatch_wgrad_dx(const WgradParams& p, int m, int64_t grid, hipStream_t stream) {
+  switch (m) {
+    case 384: launch_wgrad_dx<T, 384, 128>(p, grid, stream); return SEGGER_OK;
+    case 192: launch_wgrad_dx<T, 192, 128>(p, grid, stream); return SEGGER_OK;
+    case 128: launch_wgrad_dx<T, 128, 128>(p, grid, stream); return SEGGER_OK;
+    case 64:  launch_wgrad_dx<T, 64, 128>(p, grid, stream); return SEGGER_OK;
+  }
+  set_error("segger_linear_wgrad_dx: m_out=%d not supported", m);
+  return SEGGER_EUNSUPPORTED;
+}
 
 template <typename T>
 int dispatch_wgrad(const WgradParams& p, int m, int k, int64_t grid, hipStream_t stream) {
@@ -379,6 +505,52 @@ extern "C" int segger_linear_wgrad_supported(int32_t m_out, int32_t k_in, int32_
 extern "C" size_t segger_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t m_out, int32_t k_in) {
   if (n_rows <= 0 || !shape_ok(m_out, k_in)) return 16;
   return (size_t)(grid_for(n_rows, m_out, k_in) + kRedGroups) * ((size_t)m_out * k_in + m_out) * sizeof(float);
+}
+
+extern "C" int segger_linear_wgrad_dx_supported(int32_t m_out, int32_t k_in, int32_t dtype) {
+  return dx_shape_ok(m_out, k_in) && (dtype == SEGGER_BF16 || dtype == SEGGER_F16);
+}
+
+extern "C" int segger_linear_wgrad_dx(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, const void* w_t,
+                                      int64_t n_rows, int32_t m_out, int32_t k_in, int32_t dtype, float* grad_w,
+                                      float* grad_b, void* dx, int64_t ld_dx, void* workspace, size_t workspace_bytes,
+                                      segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGGER_REQUIRE(n_rows >= 0 && m_out > 0 && k_in > 0, "segger_linear_wgrad_dx: bad sizes");
+  SEGGER_REQUIRE(grad_w != nullptr, "segger_linear_wgrad_dx: grad_w is NULL");
+  if (!segger_linear_wgrad_dx_supported(m_out, k_in, dtype)) {
+    set_error("segger_linear_wgrad_dx: m_out=%d k_in=%d dtype=%d not supported (m_out in {64,128,192,384}, k_in 128, "
+              "bf16/f16)", m_out, k_in, dtype);
+    return SEGGER_EUNSUPPORTED;
+  }
+  if (n_rows == 0) {
+    SEGGER_HIP(hipMemsetAsync(grad_w, 0, (size_t)m_out * k_in * sizeof(float), stream));
+    if (grad_b) SEGGER_HIP(hipMemsetAsync(grad_b, 0, (size_t)m_out * sizeof(float), stream));
+    return SEGGER_OK;
+  }
+  SEGGER_REQUIRE(dy && x && w_t && dx, "segger_linear_wgrad_dx: NULL pointer");
+  SEGGER_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(w_t) && aligned16(dx),
+                 "segger_linear_wgrad_dx: pointers must be 16-byte aligned");
+  SEGGER_REQUIRE(ld_dy >= m_out && ld_x >= k_in && ld_dx >= k_in && (ld_dy * 2) % 16 == 0 && (ld_x * 2) % 16 == 0 &&
+                     (ld_dx * 2) % 16 == 0, "segger_linear_wgrad_dx: bad leading dimension");
+  const size_t need = segger_linear_wgrad_workspace_bytes(n_rows, m_out, k_in);     // (the dX form never uses more slabs)
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("segger_linear_wgrad_dx: workspace %zu < %zu bytes", workspace_bytes, need);
+    return SEGGER_EWORKSPACE;
+  }
+  const int64_t grid = grid_for(n_rows, m_out, k_in, true);
+  const int64_t stages = (n_rows + kStageRows - 1) / kStageRows;
+  {
+    const int64_t span = ((stages + grid - 1) / grid) * kStageRows * (ld_dy > ld_x ? ld_dy : ld_x) * 2;
+    SEGGER_REQUIRE(span < (int64_t)kOutOfRange, "segger_linear_wgrad_dx: a workgroup's row slab exceeds 1 GiB");
+  }
+  WgradParams p{dy, ld_dy, x, ld_x, n_rows, stages, (stages + grid - 1) / grid, static_cast<float*>(workspace), nullptr, 0.f,
+                w_t, dx, ld_dx};
+  const int rc = dtype == SEGGER_BF16 ? dispatch_wgrad_dx<bf16_t>(p, m_out, grid, stream)
+                                      : dispatch_wgrad_dx<f16_t>(p, m_out, grid, stream);
+  if (rc != SEGGER_OK) return rc;
+  SEGGER_LAUNCH_CHECK("wgrad_kernel (dX)");
+  return reduce_partials(p.partial, grid, m_out, k_in, grad_w, grad_b, stream);
 }
 
 extern "C" int segger_linear_wgrad(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, int64_t n_rows,

@@ -681,6 +681,38 @@ def linear_wgrad_launch(gy: Tensor, x: Tensor, want_bias: bool = True) -> Tuple[
     return gw, gb
 
 
+def linear_wgrad_dx_supported(m_out: int, k_in: int, dtype: torch.dtype) -> bool:
+    return dtype in (torch.bfloat16, torch.float16) and bool(
+        _lib.load().segger_linear_wgrad_dx_supported(int(m_out), int(k_in), DTYPE_CODE[dtype]))
+
+
+FUSED_WGRAD_DX = True        # tools flip it for A/B runs: False = separate data-gradient GEMM + weight-gradient kernel
+
+
+def linear_wgrad_dx_launch(gy: Tensor, x: Tensor, wt: Tensor, want_bias: bool = True
+                           ) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
+    """(dX[n, K], dW[M, K], db[M]) of ``y = x @ W.T + b`` in ONE pass over ``gy`` [n, M] (``segger_linear_wgrad_dx``):
+    ``wt`` = W^T [K, M] contiguous in the activation dtype; dX in the activation dtype, dW / db fp32."""
+    _lib.require_cuda(gy, x, wt)
+    lib = _lib.load()
+    n, m = gy.shape
+    k = x.shape[1]
+    if x.shape[0] != n or gy.dtype != x.dtype or wt.dtype != x.dtype or tuple(wt.shape) != (k, m) or not wt.is_contiguous():
+        raise ValueError("linear_wgrad_dx: gy [n, M], x [n, K] and a contiguous W^T [K, M] of one dtype")
+    gp, ldg = _rows(gy, m, "gy")
+    xp, ldx = _rows(x, k, "x")
+    gx = torch.empty((n, k), dtype=x.dtype, device=x.device)
+    gw = torch.empty((m, k), dtype=torch.float32, device=x.device)
+    gb = torch.empty(m, dtype=torch.float32, device=x.device) if want_bias else None
+    ws_bytes = lib.segger_linear_wgrad_workspace_bytes(n, m, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    with _lib.on_device(x.device):
+        rc = lib.segger_linear_wgrad_dx(gp, ldg, xp, ldx, wt.data_ptr(), n, m, k, DTYPE_CODE[x.dtype], gw.data_ptr(),
+                                        _lib.ptr(gb), gx.data_ptr(), k, ws.data_ptr(), ws_bytes, _lib.stream_ptr(x.device))
+    _lib.check(rc, "segger_linear_wgrad_dx")
+    return gx, gw, gb
+
+
 def _weight_grad_gemm(gy: Tensor, x: Tensor) -> Tensor:
     """dW[M, K] = gy^T x as a plain library GEMM: shapes the MFMA weight-gradient kernel does not cover
     (``linear_wgrad_supported``).  fp32 result."""
@@ -922,19 +954,23 @@ class _Linear(torch.autograd.Function):
         w = ctx.w
         m, k = w.shape
         gx = None
+        want_w = any(ctx.needs_input_grad[2:2 + n_w])
+        want_b = any(h and g for h, g in zip(ctx.has_bias, ctx.needs_input_grad[2 + n_w:]))
+        gw = gb = None
         if ctx.needs_input_grad[0]:
             if ctx.wt_of.key != ctx.w_key:
                 raise RuntimeError("the projection weights changed between this forward and its backward "
                                    "(optimizer step in between?): run backward before stepping")
             wt = ctx.wt_of.wt                                                   # [K, M]: dX = dY @ W
-            if linear_supported(m, k, dt):
+            if (FUSED_WGRAD_DX and (want_w or want_b) and x.shape[0] > 0 and linear_wgrad_dx_supported(m, k, dt)):
+                gx, gw, gb = linear_wgrad_dx_launch(gy, x, wt, want_bias=want_b)    # dY read ONCE for dX, dW and db
+            elif linear_supported(m, k, dt):
                 gx = linear_fwd_launch(gy, wt, None)
             else:
                 gx = gy @ w
-        want_w = any(ctx.needs_input_grad[2:2 + n_w])
-        want_b = any(h and g for h, g in zip(ctx.has_bias, ctx.needs_input_grad[2 + n_w:]))
-        gw = gb = None
-        if (want_w or want_b) and x.shape[0] > 0 and linear_wgrad_supported(m, k, dt):
+        if gw is not None:
+            pass
+        elif (want_w or want_b) and x.shape[0] > 0 and linear_wgrad_supported(m, k, dt):
             gw, gb = linear_wgrad_launch(gy, x, want_bias=want_b)       # dY and X read once for both
         else:
             if want_w:
@@ -1130,10 +1166,15 @@ class _RowBiasLinear(torch.autograd.Function):
         if gy.shape[0] > 1 and gy.stride(1) != 1:
             gy = gy.contiguous()
         gc = gw = gt = None
-        if ctx.needs_input_grad[0]:
-            gc = linear_fwd_launch(gy, w16.t().contiguous(), None)              # [n, M] @ Wc -> [n, K]
-        if ctx.needs_input_grad[1]:
-            gw, _ = linear_wgrad_launch(gy, c, want_bias=False)
+        m, k = w16.shape
+        if (FUSED_WGRAD_DX and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and c.shape[0] > 0
+                and linear_wgrad_dx_supported(m, k, dt)):
+            gc, gw, _ = linear_wgrad_dx_launch(gy, c, w16.t().contiguous(), want_bias=False)   # dY read once for both
+        else:
+            if ctx.needs_input_grad[0]:
+                gc = linear_fwd_launch(gy, w16.t().contiguous(), None)          # [n, M] @ Wc -> [n, K]
+            if ctx.needs_input_grad[1]:
+                gw, _ = linear_wgrad_launch(gy, c, want_bias=False)
         if ctx.needs_input_grad[2]:
             by_gene = ctx.by_gene if ctx.by_gene is not None else rows_by_id(ctx.ids, ctx.n_ids)
             gt = segment_rowsum(gy, by_gene)

@@ -87,6 +87,83 @@ def test_linear_wgrad_matches_fp64(cuda, dtype, m, k, n):
     assert none is None and torch.equal(gw3, gw)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m", [384, 192, 128, 64])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 31, 33, 1000, 8193, 70_001])
+def test_linear_wgrad_dx_matches_fp64(cuda, dtype, m, n):
+    """segger_linear_wgrad_dx: dX = dY W, dW = dY^T X and db = sum dY in ONE pass over dY (K = 128) against float64 on
+    the same rounded inputs.  dW / db: as test_linear_wgrad_matches_fp64 (and bit-identical to the separate kernel: the
+    same accumulation order).  dX: fp32 accumulation of M <= 384 products, one rounding to the storage dtype."""
+    from segger_amd import ops
+    k = 128
+    assert ops.linear_wgrad_dx_supported(m, k, dtype) and not ops.linear_wgrad_dx_supported(m, 256, dtype)
+    g = torch.Generator(device=cuda).manual_seed(n + m)
+    gy = (torch.randn(n, m, device=cuda, generator=g) + 0.1).to(dtype)
+    x = torch.randn(n, k, device=cuda, generator=g).to(dtype)
+    w = (torch.randn(m, k, device=cuda, generator=g) / m ** 0.5).to(dtype)
+    gx, gw, gb = ops.linear_wgrad_dx_launch(gy, x, w.t().contiguous())
+    assert gx.shape == (n, k) and gx.dtype == dtype and gw.shape == (m, k) and gb.shape == (m,)
+    ref_w = gy.double().t() @ x.double()
+    bound_w = 1e-5 * (gy.double().abs().t() @ x.double().abs()) + 1e-6
+    assert bool(((gw.double() - ref_w).abs() <= bound_w).all())
+    assert bool(((gb.double() - gy.double().sum(0)).abs() <= 1e-5 * gy.double().abs().sum(0) + 1e-6).all())
+    gw1, gb1 = ops.linear_wgrad_launch(gy, x)
+    assert torch.equal(gw, gw1) and torch.equal(gb, gb1)
+    ref_x = gy.double() @ w.double()
+    rel = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert bool(((gx.double() - ref_x).abs() <= rel * ref_x.abs() + 1e-3).all())
+    gx2, gw2, gb2 = ops.linear_wgrad_dx_launch(gy, x, w.t().contiguous())
+    assert torch.equal(gx, gx2) and torch.equal(gw, gw2) and torch.equal(gb, gb2)   # deterministic
+    gx3, gw3, none = ops.linear_wgrad_dx_launch(gy, x, w.t().contiguous(), want_bias=False)
+    assert none is None and torch.equal(gx3, gx) and torch.equal(gw3, gw)
+
+
+def test_linear_wgrad_dx_operand_maps_exact_and_strided(cuda):
+    """Small exact integers: dX and dW must equal the integer matmuls bit for bit, for asymmetric patterns, with dY / X
+    given as column windows of wider matrices, over a row count that leaves a partial last stage and several slabs."""
+    from segger_amd import ops
+    for n in (37, 16 * 32 * 3 + 5):
+        m, k = 384, 128
+        r = torch.arange(n, device=cuda)
+        big_y = ((r[:, None] * 3 + torch.arange(3 * m, device=cuda)[None] * 5) % 7 - 3).to(torch.bfloat16)
+        big_x = ((r[:, None] * 2 + torch.arange(2 * k, device=cuda)[None] * 11) % 5 - 2).to(torch.bfloat16)
+        w = ((torch.arange(m, device=cuda)[:, None] * 7 + torch.arange(k, device=cuda)[None] * 3) % 5 - 2).to(torch.bfloat16)
+        gy, x = big_y[:, m:2 * m], big_x[:, k:]
+        gx, gw, gb = ops.linear_wgrad_dx_launch(gy, x, w.t().contiguous())
+        assert torch.equal(gw, gy.float().t() @ x.float())
+        assert torch.equal(gb, gy.float().sum(0))
+        want = gy.float() @ w.float()                       # |values| <= 3 * 2 * 384: exact in fp32, and in bf16 up to 256
+        assert torch.equal(gx.float(), want.to(torch.bfloat16).float())
+    gx0, gw0, gb0 = ops.linear_wgrad_dx_launch(gy[:0], x[:0], w.t().contiguous())
+    assert gx0.shape == (0, k) and not gw0.any() and not gb0.any()
+
+
+@pytest.mark.parametrize("m", [384, 64])
+def test_linear_autograd_fused_equals_separate_kernels(cuda, m):
+    """ops.linear's backward through the one-pass kernel == through the separate dX GEMM + weight-gradient kernel:
+    parameter gradients bit for bit (same kernel arithmetic), dX within one rounding of the storage dtype."""
+    from segger_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(m)
+    n, k = 50_003, 128
+    x = torch.randn(n, k, device=cuda, generator=g).to(torch.bfloat16)
+    w = torch.nn.Parameter(torch.randn(m, k, device=cuda, generator=g) / k ** 0.5)
+    b = torch.nn.Parameter(torch.randn(m, device=cuda, generator=g))
+    gy = torch.randn(n, m, device=cuda, generator=g).to(torch.bfloat16)
+    out = {}
+    for fused in (True, False):
+        ops.FUSED_WGRAD_DX = fused
+        try:
+            xi = x.clone().requires_grad_(True)
+            w.grad = b.grad = None
+            ops.linear(xi, w, b).backward(gy)
+            out[fused] = (xi.grad.clone(), w.grad.clone(), b.grad.clone())
+        finally:
+            ops.FUSED_WGRAD_DX = True
+    assert torch.equal(out[True][1], out[False][1]) and torch.equal(out[True][2], out[False][2])
+    a, r = out[True][0].float(), out[False][0].float()
+    assert bool(((a - r).abs() <= 2.0 ** -7 * r.abs() + 1e-3).all())
+
+
 def test_linear_wgrad_operand_maps_exact_and_strided(cuda):
     """Small exact integers (every product and sum representable): dW must equal the integer matmul bit for bit, for
     an asymmetric pattern, with dY / X given as column windows of wider matrices (row stride != width)."""

@@ -21,7 +21,11 @@ for m, k in ((384, 256), (384, 128), (64, 128), (64, 256), (64, 64), (128, 128))
     ms_f = t(lambda: ops.linear_fwd_launch(x, w, None))
     ms_dx = t(lambda: ops.linear_fwd_launch(gy, wt, None)) if ops.linear_supported(m, k, torch.bfloat16) else float('nan')
     ms_w = t(lambda: ops.linear_wgrad_launch(gy, x))
+    ms_fused = (t(lambda: ops.linear_wgrad_dx_launch(gy, x, wt)) if ops.linear_wgrad_dx_supported(m, k, torch.bfloat16)
+                else float('nan'))
+    gb_fused = (rows * (m + 2 * k) * 2) / 1e9
     ms_old = t(lambda: ((gy.t() @ x).float(), ops.colsum(gy)))
     print(f"rows {rows} M {m} K {k}: fwd {ms_f:.3f} ms ({gb / ms_f:.2f} TB/s)  dX {ms_dx:.3f} ms  "
           f"wgrad {ms_w:.3f} ms ({gb / ms_w:.2f} TB/s, {2 * rows * m * k / ms_w / 1e9:.0f} TFLOP/s)  "
+          f"dX+dW+db in one pass {ms_fused:.3f} ms ({gb_fused / ms_fused:.2f} TB/s; separate {ms_dx + ms_w:.3f})  "
           f"gemm+colsum {ms_old:.3f} ms", flush=True)
