@@ -78,7 +78,10 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
                      heads: int, channels: int, out: Tensor, *, pre: Optional[Tensor] = None,
                      lse: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
                      apply_gelu: bool = False, negative_slope: float = 0.2,
-                     dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tensor] = None) -> None:
+                     dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tensor] = None,
+                     stream: Optional["torch.cuda.Stream"] = None, keep: Optional[list] = None) -> None:
+    """``stream``: launch there instead of on torch's current stream (the caller orders it against the current stream
+    and keeps every tensor alive until it has joined: temporaries made here are appended to ``keep``)."""
     _lib.require_cuda(xl, xr, att, out)
     lib = _lib.load()
     hc = heads * channels
@@ -90,8 +93,10 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
     a.x_r, a.ld_xr = _rows(xr, hc, "x_r")
     if xl.shape[0] != by_dst.n_cols or xr.shape[0] != by_dst.n_rows or out.shape[0] != by_dst.n_rows:
         raise ValueError("gatv2: feature row counts do not match the graph")
-    keep = (_f32_vec(att, hc, "att"), _f32_vec(bias, hc, "bias"))
-    a.att, a.bias = keep[0].data_ptr(), _lib.ptr(keep[1])
+    vecs = (_f32_vec(att, hc, "att"), _f32_vec(bias, hc, "bias"))
+    if keep is not None:
+        keep.append(vecs)
+    a.att, a.bias = vecs[0].data_ptr(), _lib.ptr(vecs[1])
     a.heads, a.channels, a.dtype, a.apply_gelu = heads, channels, DTYPE_CODE[xl.dtype], int(apply_gelu)
     a.negative_slope, a.dropout_p = negative_slope, dropout_p
     a.seed, a.seed_dev = _seed_parts(seed)
@@ -102,7 +107,7 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
     if keep_bits is not None and dropout_p > 0.0:
         a.keep_bits = _bits_ptr(keep_bits, by_dst.n_edges)
     with _lib.on_device(xl.device):
-        rc = lib.segger_gatv2_fwd(C.byref(a), _lib.stream_ptr(xl.device))
+        rc = lib.segger_gatv2_fwd(C.byref(a), _lib.stream_ptr(xl.device) if stream is None else stream.cuda_stream)
     _lib.check(rc, "segger_gatv2_fwd")
 
 
@@ -110,11 +115,13 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
                      heads: int, channels: int, grad_out: Tensor, pre: Tensor, lse: Tensor,
                      grad_xl: Tensor, grad_xr: Tensor, *, apply_gelu: bool, negative_slope: float = 0.2,
                      dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tuple] = None,
-                     zero_rows_out: Optional[Tensor] = None, grad_xl_zeroed: bool = False) -> Tuple[Tensor, Tensor]:
+                     zero_rows_out: Optional[Tensor] = None, grad_xl_zeroed: bool = False,
+                     stream: Optional["torch.cuda.Stream"] = None, keep: Optional[list] = None) -> Tuple[Tensor, Tensor]:
     """Writes grad_xl / grad_xr (views allowed); returns (grad_att[HC], grad_bias[HC]) fp32.  ``zero_rows_out``: a
     second [n_src, HC] matrix the source pass zero-fills on its way (ignored -> ``False`` comes back in
     ``gatv2_bwd_launch.zero_filled`` when this edge type runs the one-pass form or the generic kernels);
-    ``grad_xl_zeroed``: the one-pass form may skip its own zero fill."""
+    ``grad_xl_zeroed``: the one-pass form may skip its own zero fill.  ``stream`` / ``keep``: as in
+    :func:`gatv2_fwd_launch`."""
     _lib.require_cuda(xl, xr, grad_out)
     lib = _lib.load()
     hc = heads * channels
@@ -133,8 +140,8 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
             gatv2_bwd_launch.zero_filled = True
     a.x_l, a.ld_xl = _rows(xl, hc, "x_l")
     a.x_r, a.ld_xr = _rows(xr, hc, "x_r")
-    keep = (_f32_vec(att, hc, "att"), _f32_vec(bias, hc, "bias"))
-    a.att, a.bias = keep[0].data_ptr(), _lib.ptr(keep[1])
+    vecs = (_f32_vec(att, hc, "att"), _f32_vec(bias, hc, "bias"))
+    a.att, a.bias = vecs[0].data_ptr(), _lib.ptr(vecs[1])
     a.heads, a.channels, a.dtype, a.apply_gelu = heads, channels, DTYPE_CODE[dt], int(apply_gelu)
     a.negative_slope, a.dropout_p = negative_slope, dropout_p
     a.seed, a.seed_dev = _seed_parts(seed)
@@ -161,8 +168,10 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
     ws_bytes = lib.segger_gatv2_bwd_workspace_bytes(n_dst, heads, channels)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
+    if keep is not None:
+        keep.append((vecs, grad_out, grad_pre, dsum, ws, gparams))
     with _lib.on_device(dev):
-        rc = lib.segger_gatv2_bwd(C.byref(a), _lib.stream_ptr(dev))
+        rc = lib.segger_gatv2_bwd(C.byref(a), _lib.stream_ptr(dev) if stream is None else stream.cuda_stream)
     _lib.check(rc, "segger_gatv2_bwd")
     return gparams[0], gparams[1]
 
@@ -218,6 +227,26 @@ def gatv2_aggregate(xl: Tensor, xr: Tensor, att: Tensor, bias: Optional[Tensor],
     return (out, alpha) if return_alpha else out
 
 
+# The two edge types of a hetero layer are independent given the projections: tx-belongs-bd (10^4 rows of 40-400 edges,
+# latency-bound, a few dozen microseconds that leave most of the chip idle) runs on a side stream beside the
+# tx-neighbors-tx aggregation and joins before the layer returns -- in a captured step the fork / join become parallel
+# branches of the hipGraph.  Eager small batches are host-bound: there the extra event calls cost more than they hide.
+SIDE_STREAM = True
+SIDE_STREAM_MIN_EDGES = 2_000_000
+_SIDE_STREAMS: dict = {}
+
+
+def _side_stream(dev, n_edges: int) -> Optional["torch.cuda.Stream"]:
+    if not SIDE_STREAM or dev.type != "cuda":
+        return None
+    if n_edges < SIDE_STREAM_MIN_EDGES and not torch.cuda.is_current_stream_capturing():
+        return None
+    s = _SIDE_STREAMS.get(dev.index)
+    if s is None:
+        s = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
+    return s
+
+
 class _HeteroGatLayer(torch.autograd.Function):
     """segger's HeteroConv layer as one autograd node.
 
@@ -242,12 +271,19 @@ class _HeteroGatLayer(torch.autograd.Function):
         lse_tx = torch.empty((nt, heads), dtype=torch.float32, device=dev) if need_grad else None
         lse_bd = torch.empty((nb, heads), dtype=torch.float32, device=dev) if need_grad else None
         alpha = torch.empty((g_tt.n_edges, heads), dtype=torch.float32, device=dev) if want_alpha else None
+        side = _side_stream(dev, g_tt.n_edges)
+        keep: list = []
+        if side is not None:                                 # fork: everything queued so far precedes the side branch
+            side.wait_stream(torch.cuda.current_stream(dev))
+        gatv2_fwd_launch(g_tb.by_dst, xl_tb, xp_bd, att_tb, bias_tb, heads, channels, y_bd, pre=pre_bd, lse=lse_bd,
+                         apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tb,
+                         keep_bits=None if bits_tb is None else bits_tb[0], stream=side, keep=keep)
         gatv2_fwd_launch(g_tt.by_dst, xl_tt, xr_tt, att_tt, bias_tt, heads, channels, y_tx, pre=pre_tx, lse=lse_tx,
                          alpha=alpha, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tt,
                          keep_bits=None if bits_tt is None else bits_tt[0])
-        gatv2_fwd_launch(g_tb.by_dst, xl_tb, xp_bd, att_tb, bias_tb, heads, channels, y_bd, pre=pre_bd, lse=lse_bd,
-                         apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tb,
-                         keep_bits=None if bits_tb is None else bits_tb[0])
+        if side is not None:                                 # join (``keep`` dies after this point)
+            torch.cuda.current_stream(dev).wait_stream(side)
+        del keep
         if need_grad:
             ctx.save_for_backward(xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb,
                                   pre_tx if apply_gelu else y_tx, pre_bd if apply_gelu else y_bd, lse_tx, lse_bd)
@@ -270,17 +306,37 @@ class _HeteroGatLayer(torch.autograd.Function):
             gy_tx = torch.zeros_like(pre_tx)
         if gy_bd is None:
             gy_bd = torch.zeros_like(pre_bd)
-        # tx-neighbors-tx first: its source pass visits every transcript row and zero-fills the tx-belongs-bd window of
-        # the stacked projection gradient on the way, so the one-pass tx-belongs-bd backward needs no fill of its own
-        gatt_tt, gbias_tt = gatv2_bwd_launch(
-            g_tt, xp_tx[:, :hc], xp_tx[:, hc:2 * hc], att_tt, bias_tt, heads, channels, gy_tx, pre_tx, lse_tx,
-            gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc], apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tt,
-            keep_bits=ctx.bits[0], zero_rows_out=gxp_tx[:, 2 * hc:])
-        zeroed = gatv2_bwd_launch.zero_filled
-        gatt_tb, gbias_tb = gatv2_bwd_launch(
-            g_tb, xp_tx[:, 2 * hc:], xp_bd, att_tb, bias_tb, heads, channels, gy_bd, pre_bd, lse_bd,
-            gxp_tx[:, 2 * hc:], gxp_bd, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb,
-            keep_bits=ctx.bits[1], grad_xl_zeroed=zeroed)
+        dev = xp_tx.device
+        side = _side_stream(dev, g_tt.n_edges)
+        if side is not None:
+            # the two backward passes write disjoint column windows of the stacked gradient: tx-belongs-bd (with its
+            # own zero fill) runs on the side stream beside the tx-neighbors-tx pair
+            keep: list = []
+            if gy_bd.dtype != xp_tx.dtype or (gy_bd.shape[0] > 1 and gy_bd.stride(1) != 1):
+                gy_bd = gy_bd.to(xp_tx.dtype).contiguous()   # (on the current stream, BEFORE the fork)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            gatt_tb, gbias_tb = gatv2_bwd_launch(
+                g_tb, xp_tx[:, 2 * hc:], xp_bd, att_tb, bias_tb, heads, channels, gy_bd, pre_bd, lse_bd,
+                gxp_tx[:, 2 * hc:], gxp_bd, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb,
+                keep_bits=ctx.bits[1], stream=side, keep=keep)
+            gatt_tt, gbias_tt = gatv2_bwd_launch(
+                g_tt, xp_tx[:, :hc], xp_tx[:, hc:2 * hc], att_tt, bias_tt, heads, channels, gy_tx, pre_tx, lse_tx,
+                gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc], apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p,
+                seed=seed_tt, keep_bits=ctx.bits[0])
+            torch.cuda.current_stream(dev).wait_stream(side)
+            del keep
+        else:
+            # tx-neighbors-tx first: its source pass visits every transcript row and zero-fills the tx-belongs-bd window
+            # of the stacked projection gradient on the way, so the one-pass tx-belongs-bd backward needs no fill of its own
+            gatt_tt, gbias_tt = gatv2_bwd_launch(
+                g_tt, xp_tx[:, :hc], xp_tx[:, hc:2 * hc], att_tt, bias_tt, heads, channels, gy_tx, pre_tx, lse_tx,
+                gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc], apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p,
+                seed=seed_tt, keep_bits=ctx.bits[0], zero_rows_out=gxp_tx[:, 2 * hc:])
+            zeroed = gatv2_bwd_launch.zero_filled
+            gatt_tb, gbias_tb = gatv2_bwd_launch(
+                g_tb, xp_tx[:, 2 * hc:], xp_bd, att_tb, bias_tb, heads, channels, gy_bd, pre_bd, lse_bd,
+                gxp_tx[:, 2 * hc:], gxp_bd, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb,
+                keep_bits=ctx.bits[1], grad_xl_zeroed=zeroed)
         r = lambda gt, ref: gt.reshape(ref.shape).to(ref.dtype) if ref is not None else None
         return (gxp_tx, gxp_bd, r(gatt_tt, att_tt), r(gbias_tt, bias_tt), r(gatt_tb, att_tb), r(gbias_tb, bias_tb),
                 None, None, None, None, None, None, None, None, None, None, None, None)
