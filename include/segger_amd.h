@@ -461,6 +461,22 @@ int segger_linear_wgrad_dx(const void* dy, int64_t ld_dy, const void* x, int64_t
                            int32_t m_out, int32_t k_in, int32_t dtype, float* grad_w, float* grad_b, void* dx,
                            int64_t ld_dx, void* workspace, size_t workspace_bytes, segger_stream_t stream);
 
+/*
+ * Deferred partial sums.  segger_linear_wgrad / _wgrad_dx / segger_posmlp_wgrad and segger_gatv2_bwd finish with a small
+ * kernel that sums per-workgroup partials from their workspace into grad_w / grad_b / grad_att / grad_bias.  Between
+ *     segger_reductions_defer_begin()  ...  segger_reductions_flush(stream)
+ * (calling thread only) those sums of at most 128 partials are queued instead of launched and the flush runs them all
+ * as ONE grid -- autograd hands every parameter gradient of a backward pass (ist_encoder.py:289-333 under
+ * lightning_model.py:215-237) to the optimizer at the same time anyway.  Contract while deferring: the outputs are
+ * undefined and the workspaces must stay untouched until the flush has been enqueued on the same stream (or one
+ * ordered after the producers); at most 64 sums are queued, further ones run immediately.  The table travels as a
+ * kernel argument: no allocation, no synchronisation, capturable.  segger_reductions_pending(): queued sums, -1 when
+ * not deferring.
+ */
+int segger_reductions_defer_begin(void);
+int segger_reductions_pending(void);
+int segger_reductions_flush(segger_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Encoder front end / tail as fused row-wise kernels.
  *

@@ -34,6 +34,17 @@ int hip_fail(hipError_t e, const char* what);
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ------------------------------------------------- deferred partial sums ---
+// out0[e] (e < split) / out1[e - split] (e >= split; out1 may be NULL) = sum_s partial[s * width + e], slabs in order.
+// Between segger_reductions_defer_begin() and segger_reductions_flush() (csrc/reduce.hip) the kernels that leave
+// per-workgroup partial sums (weight gradients, grad_att / grad_bias slabs) queue their final sum here instead of
+// launching it; defer_reduce() returns false when nothing is being deferred (or the sum is too long for one pass,
+// or the table is full) and the caller launches its own reduction as usual.
+struct ReduceSeg {
+  const float* partial; int64_t n_slabs; int64_t width; int64_t split; float* out0; float* out1;
+};
+bool defer_reduce(const ReduceSeg& seg);
+
 constexpr int kWave = 64;
 constexpr int kNumXcd = 8;
 

@@ -1,0 +1,72 @@
+// All final sums of a step's per-workgroup partials in ONE launch.
+//
+// The weight-gradient kernels (csrc/linear_wgrad.hip) and the destination pass of the GATv2 backward (csrc/gatv2.hip)
+// leave [n_slabs][width] fp32 partials that a small kernel sums in slab order.  At segger's default batch budget
+// (1M edges: ~50k transcripts) a training step holds ~30 such sums of 4-8 us each -- a quarter of the kernel nodes of
+// the captured step (segger_amd/train_step_graph.py) for 2 % of its arithmetic.  A caller that can wait for the sums
+// until the end of the backward pass brackets it with segger_reductions_defer_begin() / segger_reductions_flush():
+// the producers then only queue their sum (thread-local table, passed to the kernel by value: nothing to allocate,
+// capturable) and the flush runs them all as one grid.  Deterministic: every column is summed by one thread in slab
+// order, exactly as the per-producer kernels do.
+#include "common.h"
+
+namespace segger {
+namespace {
+
+constexpr int kMaxSegs = 64;
+constexpr int64_t kMaxDeferredSlabs = 128;      // longer sums keep their two-stage kernels (a serial chain per thread)
+
+struct ReduceBatch { int n; ReduceSeg seg[kMaxSegs]; };
+static thread_local ReduceBatch g_batch;
+static thread_local bool g_active = false;
+
+__global__ __launch_bounds__(256) void reduce_many_kernel(ReduceBatch b) {
+  const ReduceSeg g = b.seg[blockIdx.y];
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= g.width) return;
+  const float* __restrict__ p = g.partial + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t s = 0;
+  for (; s + 3 < g.n_slabs; s += 4) {
+    s0 += p[s * g.width];       s1 += p[(s + 1) * g.width];
+    s2 += p[(s + 2) * g.width]; s3 += p[(s + 3) * g.width];
+  }
+  for (; s < g.n_slabs; ++s) s0 += p[s * g.width];
+  const float t = (s0 + s1) + (s2 + s3);
+  if (e < g.split) g.out0[e] = t;
+  else if (g.out1) g.out1[e - g.split] = t;
+}
+
+}  // namespace
+
+bool defer_reduce(const ReduceSeg& seg) {
+  if (!g_active || g_batch.n >= kMaxSegs || seg.n_slabs > kMaxDeferredSlabs) return false;
+  g_batch.seg[g_batch.n++] = seg;
+  return true;
+}
+
+}  // namespace segger
+
+using namespace segger;
+
+extern "C" int segger_reductions_defer_begin(void) {
+  SEGGER_REQUIRE(!g_active, "segger_reductions_defer_begin: already deferring (flush first)");
+  g_active = true;
+  g_batch.n = 0;
+  return SEGGER_OK;
+}
+
+extern "C" int segger_reductions_pending(void) { return g_active ? g_batch.n : -1; }
+
+extern "C" int segger_reductions_flush(segger_stream_t stream) {
+  SEGGER_REQUIRE(g_active, "segger_reductions_flush: nothing is being deferred");
+  g_active = false;
+  if (g_batch.n == 0) return SEGGER_OK;
+  int64_t width = 0;
+  for (int i = 0; i < g_batch.n; ++i) width = g_batch.seg[i].width > width ? g_batch.seg[i].width : width;
+  hipLaunchKernelGGL(reduce_many_kernel, dim3((unsigned)((width + 255) / 256), (unsigned)g_batch.n), dim3(256), 0,
+                     (hipStream_t)stream, g_batch);
+  g_batch.n = 0;
+  SEGGER_LAUNCH_CHECK("reduce_many_kernel");
+  return SEGGER_OK;
+}

@@ -62,6 +62,44 @@ def dropout_bits(csr: EdgeCSR, heads: int, dropout_p: float, seeds, seed_dev: Op
     return out
 
 
+# ---- deferred partial sums (csrc/reduce.hip) ----------------------------------------------------------------
+_DEFER_KEEP: Optional[list] = None
+
+
+class deferred_reductions:
+    """Inside this context the final sums of per-workgroup partials (weight / bias gradients of every projection,
+    grad_att / grad_bias of every conv) are queued instead of launched; leaving it runs them all as ONE kernel
+    (``segger_reductions_flush``).  The gradient TENSORS handed out meanwhile are placeholders: nothing may read them
+    before the context exits, so this is for callers that hold the gradients themselves (``torch.autograd.grad`` in
+    ``train_step_graph``), not for ``loss.backward()`` into ``.grad`` accumulators.  Workspaces are kept alive here."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        global _DEFER_KEEP
+        if _DEFER_KEEP is not None:
+            raise RuntimeError("deferred_reductions does not nest")
+        _lib.check(_lib.load().segger_reductions_defer_begin(), "segger_reductions_defer_begin")
+        _DEFER_KEEP = []
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFER_KEEP
+        try:
+            with _lib.on_device(self.device):
+                rc = _lib.load().segger_reductions_flush(_lib.stream_ptr(self.device))
+            _lib.check(rc, "segger_reductions_flush")
+        finally:
+            _DEFER_KEEP = None
+        return False
+
+
+def _defer_keep(*tensors) -> None:
+    if _DEFER_KEEP is not None:
+        _DEFER_KEEP.append(tensors)
+
+
 def _f32_vec(t: Optional[Tensor], n: int, name: str) -> Optional[Tensor]:
     if t is None:
         return None
@@ -170,6 +208,7 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
     if keep is not None:
         keep.append((vecs, grad_out, grad_pre, dsum, ws, gparams))
+    _defer_keep(ws, gparams)
     with _lib.on_device(dev):
         rc = lib.segger_gatv2_bwd(C.byref(a), _lib.stream_ptr(dev) if stream is None else stream.cuda_stream)
     _lib.check(rc, "segger_gatv2_bwd")
@@ -734,6 +773,7 @@ def linear_wgrad_launch(gy: Tensor, x: Tensor, want_bias: bool = True) -> Tuple[
         rc = lib.segger_linear_wgrad(gp, ldg, xp, ldx, n, m, k, DTYPE_CODE[x.dtype], gw.data_ptr(), _lib.ptr(gb),
                                      ws.data_ptr(), ws_bytes, _lib.stream_ptr(x.device))
     _lib.check(rc, "segger_linear_wgrad")
+    _defer_keep(ws, gw, gb)
     return gw, gb
 
 
@@ -766,6 +806,7 @@ def linear_wgrad_dx_launch(gy: Tensor, x: Tensor, wt: Tensor, want_bias: bool = 
         rc = lib.segger_linear_wgrad_dx(gp, ldg, xp, ldx, wt.data_ptr(), n, m, k, DTYPE_CODE[x.dtype], gw.data_ptr(),
                                         _lib.ptr(gb), gx.data_ptr(), k, ws.data_ptr(), ws_bytes, _lib.stream_ptr(x.device))
     _lib.check(rc, "segger_linear_wgrad_dx")
+    _defer_keep(ws, gw, gb)
     return gx, gw, gb
 
 
@@ -1163,6 +1204,7 @@ class _PosMlp(torch.autograd.Function):
             rc = lib.segger_posmlp_wgrad(dp, ldd, pn.data_ptr(), int(dz1.shape[0]), ctx.max_period, DTYPE_CODE[dt],
                                          gw0.data_ptr(), gb0.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
         _lib.check(rc, "segger_posmlp_wgrad")
+        _defer_keep(ws, gw0, gb0)
         need = ctx.needs_input_grad
         return (None, None, None, None, None, None, None, None, None, gw0 if need[9] else None,
                 gb0 if need[10] else None, gw2 if need[11] else None, gb2 if need[12] else None)

@@ -128,6 +128,10 @@ class GraphedTrainStep:
         self._params = [p for g in optimizer.param_groups for p in g["params"] if p.requires_grad and id(p) in by_id]
         self._leaves = [by_id[id(p)] for p in self._params]
         self.draws = None                                     # tests: fixed (tx pos/neg, bd pos/neg/dp/dn, dst_neg)
+        # queue the backward's partial sums and run them as one launch (ops.deferred_reductions).  Only sound when no
+        # autograd node READS a parameter gradient before the backward ends (a parameter used by two nodes has its two
+        # gradients added on the spot): verified numerically during the warm-up of every capture, see _warm_up
+        self.defer_sums = True
 
     def fits(self, batch) -> bool:
         s = self.sizes
@@ -244,10 +248,44 @@ class GraphedTrainStep:
                                      pos_groups=self.g_tb.by_dst)
         terms = torch.stack([l_tx.float(), l_bd.float(), l_sg.float()]) * self._unit * self.scal[0:3]
         loss = (terms * self.scal[3:6]).sum()
-        grads = torch.autograd.grad(loss, self._leaves, allow_unused=True)
+        if self.defer_sums:                                   # ~30 partial sums of the backward as one launch
+            with ops.deferred_reductions(self.dev):
+                grads = torch.autograd.grad(loss, self._leaves, allow_unused=True)
+        else:
+            grads = torch.autograd.grad(loss, self._leaves, allow_unused=True)
         for p, g in zip(self._params, grads):
             p.grad = g
         self.out = torch.cat([terms.detach(), loss.detach().reshape(1)])
+
+    def _warm_up(self, keep) -> None:
+        """One eager step before the capture.  With deferred partial sums it is run twice from the same random
+        streams -- sums launched where they are produced, then queued -- and the two sets of parameter gradients must
+        agree (up to the order of float atomics in the loss kernels); if they do not, some autograd node consumed a
+        gradient before the queued sums ran, and this step falls back to immediate sums."""
+        if self.defer_sums:
+            self.defer_sums = False
+            self._run_grads()
+            ref = [None if p.grad is None else p.grad.detach().clone() for p in self._params]
+            with torch.no_grad():
+                self.lit.model._step_dev.copy_(keep[3])       # same dropout masks and sampler draws again
+            self.defer_sums = True
+            self._run_grads()
+            for p, r in zip(self._params, ref):
+                g = p.grad
+                if (g is None) != (r is None):
+                    self.defer_sums = False
+                elif g is not None:
+                    scale = float(r.abs().max())
+                    if not bool(torch.isfinite(g).all()) or float((g - r).abs().max()) > 1e-3 * scale + 1e-7:
+                        self.defer_sums = False
+            if not self.defer_sums:
+                import warnings
+                warnings.warn("GraphedTrainStep: a parameter gradient is consumed inside the backward pass; "
+                              "partial sums are launched where they are produced (more kernel nodes)")
+                self._run_grads()
+            self.opt.step()
+        else:
+            self._run()
 
     @torch.no_grad()
     def _snapshot(self):
@@ -282,7 +320,7 @@ class GraphedTrainStep:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                     # warm-up: lazy inits, allocator, optimizer state
-                self._run()
+                self._warm_up(keep)
             torch.cuda.current_stream().wait_stream(side)
             self._restore(keep)                               # ... which must not count as a training step
             aliases = list(self._alias.values())
