@@ -256,7 +256,8 @@ typedef struct {
   int64_t a, b, c;           /* fill parameters */
   int32_t dst_bytes, src_bytes;
   int32_t fill;
-  int32_t reserved_;
+  int32_t copy_add;          /* added to every copied and TILE-replicated element (INTEGER segments only), e.g. to
+                                rebase ids while they are copied; 0 for float segments */
 } segger_stage_seg;
 int segger_stage(const segger_stage_seg* segs, int32_t n_segs, segger_stream_t stream);
 
@@ -465,7 +466,7 @@ int segger_linear_wgrad_dx(const void* dy, int64_t ld_dy, const void* x, int64_t
  * Deferred partial sums.  segger_linear_wgrad / _wgrad_dx / segger_posmlp_wgrad and segger_gatv2_bwd finish with a small
  * kernel that sums per-workgroup partials from their workspace into grad_w / grad_b / grad_att / grad_bias.  Between
  *     segger_reductions_defer_begin()  ...  segger_reductions_flush(stream)
- * (calling thread only) those sums of at most 128 partials are queued instead of launched and the flush runs them all
+ * (process-wide: autograd queues from its own device thread) those sums of at most 128 partials are queued instead of launched and the flush runs them all
  * as ONE grid -- autograd hands every parameter gradient of a backward pass (ist_encoder.py:289-333 under
  * lightning_model.py:215-237) to the optimizer at the same time anyway.  Contract while deferring: the outputs are
  * undefined and the workspaces must stay untouched until the flush has been enqueued on the same stream (or one

@@ -78,7 +78,7 @@ class StageSeg(C.Structure):
         ("n_copy", C.c_int64), ("n_total", C.c_int64),
         ("a", C.c_int64), ("b", C.c_int64), ("c", C.c_int64),
         ("dst_bytes", C.c_int32), ("src_bytes", C.c_int32),
-        ("fill", C.c_int32), ("reserved_", C.c_int32),
+        ("fill", C.c_int32), ("copy_add", C.c_int32),
     ]
 
 

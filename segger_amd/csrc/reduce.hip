@@ -5,10 +5,13 @@
 // (1M edges: ~50k transcripts) a training step holds ~30 such sums of 4-8 us each -- a quarter of the kernel nodes of
 // the captured step (segger_amd/train_step_graph.py) for 2 % of its arithmetic.  A caller that can wait for the sums
 // until the end of the backward pass brackets it with segger_reductions_defer_begin() / segger_reductions_flush():
-// the producers then only queue their sum (thread-local table, passed to the kernel by value: nothing to allocate,
-// capturable) and the flush runs them all as one grid.  Deterministic: every column is summed by one thread in slab
+// the producers then only queue their sum (a process-wide table, passed to the kernel by value: nothing to allocate,
+// capturable) and the flush runs them all as one grid.  Process-wide, not thread-local: torch's autograd engine runs
+// the backward nodes that queue the sums on its own device thread, not on the thread that brackets the pass; one
+// process drives one GPU stream here, so a mutex around the table is all the protection it needs.  Deterministic: every column is summed by one thread in slab
 // order, exactly as the per-producer kernels do.
 #include "common.h"
+#include <mutex>
 
 namespace segger {
 namespace {
@@ -17,8 +20,9 @@ constexpr int kMaxSegs = 64;
 constexpr int64_t kMaxDeferredSlabs = 128;      // longer sums keep their two-stage kernels (a serial chain per thread)
 
 struct ReduceBatch { int n; ReduceSeg seg[kMaxSegs]; };
-static thread_local ReduceBatch g_batch;
-static thread_local bool g_active = false;
+static ReduceBatch g_batch;
+static bool g_active = false;
+static std::mutex g_mu;
 
 __global__ __launch_bounds__(256) void reduce_many_kernel(ReduceBatch b) {
   const ReduceSeg g = b.seg[blockIdx.y];
@@ -40,6 +44,7 @@ __global__ __launch_bounds__(256) void reduce_many_kernel(ReduceBatch b) {
 }  // namespace
 
 bool defer_reduce(const ReduceSeg& seg) {
+  std::lock_guard<std::mutex> lock(g_mu);
   if (!g_active || g_batch.n >= kMaxSegs || seg.n_slabs > kMaxDeferredSlabs) return false;
   g_batch.seg[g_batch.n++] = seg;
   return true;
@@ -50,15 +55,20 @@ bool defer_reduce(const ReduceSeg& seg) {
 using namespace segger;
 
 extern "C" int segger_reductions_defer_begin(void) {
+  std::lock_guard<std::mutex> lock(g_mu);
   SEGGER_REQUIRE(!g_active, "segger_reductions_defer_begin: already deferring (flush first)");
   g_active = true;
   g_batch.n = 0;
   return SEGGER_OK;
 }
 
-extern "C" int segger_reductions_pending(void) { return g_active ? g_batch.n : -1; }
+extern "C" int segger_reductions_pending(void) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  return g_active ? g_batch.n : -1;
+}
 
 extern "C" int segger_reductions_flush(segger_stream_t stream) {
+  std::lock_guard<std::mutex> lock(g_mu);
   SEGGER_REQUIRE(g_active, "segger_reductions_flush: nothing is being deferred");
   g_active = false;
   if (g_batch.n == 0) return SEGGER_OK;

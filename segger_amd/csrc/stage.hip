@@ -40,11 +40,11 @@ __global__ __launch_bounds__(256) void stage_kernel(StageBatch b) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < g.n_total; i += stride) {
     int64_t v;
     if (i < g.n_copy) {
-      v = load_elem(g.src, i, g.src_bytes);
+      v = load_elem(g.src, i, g.src_bytes) + g.copy_add;
     } else {
       const int64_t k = i - g.n_copy;
       switch (g.fill) {
-        case SEGGER_FILL_TILE: v = load_elem(g.src, k % g.a, g.src_bytes); break;
+        case SEGGER_FILL_TILE: v = load_elem(g.src, k % g.a, g.src_bytes) + g.copy_add; break;
         case SEGGER_FILL_DIV:  v = g.a + k / g.b; break;
         case SEGGER_FILL_MOD:  v = g.a + k % g.b; break;
         case SEGGER_FILL_RAMP: { const int64_t t = (k + 1) * g.b; v = g.a + (t < g.c ? t : g.c); break; }

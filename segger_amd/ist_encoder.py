@@ -113,6 +113,30 @@ class Positional2dEmbedder(Module):
         return F.gelu(h) if gelu else h
 
 
+class _SplitRows(torch.autograd.Function):
+    """[n_a + n_b, D] -> ([n_a, D], [n_b, D]) as views; backward = one ``cat`` (autograd's own slicing would zero-fill
+    and add a full-size matrix per slice)."""
+
+    @staticmethod
+    def forward(ctx, x, n_a):
+        ctx.n = (int(n_a), int(x.shape[0]) - int(n_a))
+        return x[:n_a], x[n_a:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        ref = ga if ga is not None else gb
+        if ga is None:
+            ga = ref.new_zeros((ctx.n[0],) + tuple(ref.shape[1:]))
+        if gb is None:
+            gb = ref.new_zeros((ctx.n[1],) + tuple(ref.shape[1:]))
+        return torch.cat((ga, gb), 0), None
+
+
+MERGED_POS_EMBED = True     # one embedder call for both node types (tools flip it for A/B runs)
+
+
 class GATv2Conv(Module):
     """Parameter holder with torch_geometric.nn.GATv2Conv's names and shapes
     (``lin_l``, ``lin_r``: [H*C, in] + bias; ``att``: [1, H, C]; ``bias``: [H*C]).
@@ -308,6 +332,23 @@ class ISTEncoder(Module):
             out[et] = (d, s_)
         return out
 
+    def _pos_embed_pair(self, pos_dict, batch_dict, num_graphs, dt, gelu: bool, graphs):
+        """(pe_tx, pe_bd): ``pos_emb`` of both node types, in one call where the batch vectors allow it."""
+        b_tx, b_bd = batch_dict.get("tx"), batch_dict.get("bd")
+        staged = graphs.get("pos_all") if graphs is not None else None
+        # (large batches -- the `split` route -- keep one call per type: there the launches do not matter, and joining
+        # the two gradients of the embedder's output would copy a [n_tx, D] matrix)
+        if staged is None and (not MERGED_POS_EMBED or gelu or b_tx is None or b_bd is None or num_graphs is None):
+            one = lambda k: self.pos_emb(pos_dict[k], batch_dict.get(k), num_graphs=num_graphs, dtype=dt, gelu=gelu)
+            return one("tx"), one("bd")
+        if staged is not None:                               # a captured step stages the concatenation itself
+            pos_all, batch_all = staged
+        else:
+            pos_all = torch.cat((pos_dict["tx"].float(), pos_dict["bd"].float()), 0)
+            batch_all = torch.cat((b_tx.long(), b_bd.long() + int(num_graphs)), 0)
+        pe = self.pos_emb(pos_all, batch_all, num_graphs=2 * int(num_graphs), dtype=dt, gelu=gelu)
+        return _SplitRows.apply(pe, int(pos_dict["tx"].shape[0]))
+
     def _materialize_bd(self, d_in: int, device) -> None:
         if "bd" not in self.lin_first:
             self.lin_first["bd"] = Linear(d_in, self.in_channels).to(device)
@@ -320,11 +361,26 @@ class ISTEncoder(Module):
         self._materialize_bd(x_dict["bd"].shape[-1], x_dict["bd"].device)
         bd_lin = self.lin_first["bd"]
         emb = self.lin_first["tx"]
-        pe = (lambda k: self.pos_emb(pos_dict[k], batch_dict.get(k), num_graphs=num_graphs, dtype=dt))
         x_bd = ops.linear(x_dict["bd"].to(dt), bd_lin.weight, bd_lin.bias)
         if self.use_positional_embeddings:
-            x_bd = F.gelu(torch.cat((x_bd, pe("bd")), -1))
-            if self.in_channels % 32 == 0 and emb.weight.dtype == torch.float32:
+            fused_tx = self.in_channels % 32 == 0 and emb.weight.dtype == torch.float32
+            split = False
+            if fused_tx:
+                first = self.conv_layers[0].conv
+                m_first = sum(int(w.shape[0]) for w in (first[TX_TX].lin_l.weight, first[TX_TX].lin_r.weight,
+                                                        first[TX_BD].lin_l.weight))
+                probe = ops.EmbedInput(emb.weight, x_dict["tx"], x_bd[:0, : self.in_channels], None)
+                split = (self.split_first_layer and dt != torch.float32
+                         and x_dict["tx"].shape[0] >= self.split_first_layer_min_rows
+                         and ops.embed_linear_supported(probe, m_first))
+            # ONE embedder call for both node types (the reference calls it per type, ist_encoder.py:314-318): graph ids
+            # of the boundaries are offset by num_graphs, so the per-graph min / max stay per type.  Half the launches
+            # of the front end, and the embedder's parameters receive ONE gradient each (what lets a captured step
+            # postpone its partial sums, ops.deferred_reductions).  `split`: the GELU of ist_encoder.py:320 comes
+            # applied (gelu(cat(a, b)) = cat(gelu(a), gelu(b))).
+            pe_tx, pe_bd = self._pos_embed_pair(pos_dict, batch_dict, num_graphs, dt, split, graphs)
+            x_bd = torch.cat((F.gelu(x_bd), pe_bd), -1) if split else F.gelu(torch.cat((x_bd, pe_bd), -1))
+            if fused_tx:
                 # gather + concat + GELU in one kernel; its table gradient sums over rows grouped by gene id: one
                 # sort per batch (not needed without grad), cached with the batch or supplied with `graphs`
                 ids = x_dict["tx"]
@@ -336,19 +392,13 @@ class ISTEncoder(Module):
                         by_gene = ops.rows_by_id(ids, emb.weight.shape[0])
                         if cache is not None:
                             cache[key] = by_gene
-                first = self.conv_layers[0].conv
-                m_first = sum(int(w.shape[0]) for w in (first[TX_TX].lin_l.weight, first[TX_TX].lin_r.weight,
-                                                        first[TX_BD].lin_l.weight))
-                probe = ops.EmbedInput(emb.weight, ids, x_bd[:0, : self.in_channels], None)
-                if (self.split_first_layer and dt != torch.float32 and ids.shape[0] >= self.split_first_layer_min_rows
-                        and ops.embed_linear_supported(probe, m_first)):
+                if split:
                     # keep gelu(cat(E[g], pe)) as its parts: the first layer projects it as T[g] + W_pe gelu(pe)
-                    act_pe = self.pos_emb(pos_dict["tx"], batch_dict.get("tx"), num_graphs=num_graphs, dtype=dt, gelu=True)
-                    x_tx = ops.EmbedInput(emb.weight, ids.to(torch.int32).contiguous(), act_pe, by_gene)
+                    x_tx = ops.EmbedInput(emb.weight, ids.to(torch.int32).contiguous(), pe_tx, by_gene)
                 else:
-                    x_tx = ops.embed_gelu(emb.weight, ids, pe("tx"), by_gene)
+                    x_tx = ops.embed_gelu(emb.weight, ids, pe_tx, by_gene)
             else:
-                x_tx = F.gelu(torch.cat((emb(x_dict["tx"].long()).to(dt), pe("tx")), -1))
+                x_tx = F.gelu(torch.cat((emb(x_dict["tx"].long()).to(dt), pe_tx), -1))
         else:
             x_bd = F.gelu(x_bd)
             x_tx = F.gelu(emb(x_dict["tx"].long()).to(dt))

@@ -116,10 +116,7 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
                      heads: int, channels: int, out: Tensor, *, pre: Optional[Tensor] = None,
                      lse: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
                      apply_gelu: bool = False, negative_slope: float = 0.2,
-                     dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tensor] = None,
-                     stream: Optional["torch.cuda.Stream"] = None, keep: Optional[list] = None) -> None:
-    """``stream``: launch there instead of on torch's current stream (the caller orders it against the current stream
-    and keeps every tensor alive until it has joined: temporaries made here are appended to ``keep``)."""
+                     dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tensor] = None) -> None:
     _lib.require_cuda(xl, xr, att, out)
     lib = _lib.load()
     hc = heads * channels
@@ -132,8 +129,6 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
     if xl.shape[0] != by_dst.n_cols or xr.shape[0] != by_dst.n_rows or out.shape[0] != by_dst.n_rows:
         raise ValueError("gatv2: feature row counts do not match the graph")
     vecs = (_f32_vec(att, hc, "att"), _f32_vec(bias, hc, "bias"))
-    if keep is not None:
-        keep.append(vecs)
     a.att, a.bias = vecs[0].data_ptr(), _lib.ptr(vecs[1])
     a.heads, a.channels, a.dtype, a.apply_gelu = heads, channels, DTYPE_CODE[xl.dtype], int(apply_gelu)
     a.negative_slope, a.dropout_p = negative_slope, dropout_p
@@ -145,7 +140,7 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
     if keep_bits is not None and dropout_p > 0.0:
         a.keep_bits = _bits_ptr(keep_bits, by_dst.n_edges)
     with _lib.on_device(xl.device):
-        rc = lib.segger_gatv2_fwd(C.byref(a), _lib.stream_ptr(xl.device) if stream is None else stream.cuda_stream)
+        rc = lib.segger_gatv2_fwd(C.byref(a), _lib.stream_ptr(xl.device))
     _lib.check(rc, "segger_gatv2_fwd")
 
 
@@ -153,13 +148,11 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
                      heads: int, channels: int, grad_out: Tensor, pre: Tensor, lse: Tensor,
                      grad_xl: Tensor, grad_xr: Tensor, *, apply_gelu: bool, negative_slope: float = 0.2,
                      dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tuple] = None,
-                     zero_rows_out: Optional[Tensor] = None, grad_xl_zeroed: bool = False,
-                     stream: Optional["torch.cuda.Stream"] = None, keep: Optional[list] = None) -> Tuple[Tensor, Tensor]:
+                     zero_rows_out: Optional[Tensor] = None, grad_xl_zeroed: bool = False) -> Tuple[Tensor, Tensor]:
     """Writes grad_xl / grad_xr (views allowed); returns (grad_att[HC], grad_bias[HC]) fp32.  ``zero_rows_out``: a
     second [n_src, HC] matrix the source pass zero-fills on its way (ignored -> ``False`` comes back in
     ``gatv2_bwd_launch.zero_filled`` when this edge type runs the one-pass form or the generic kernels);
-    ``grad_xl_zeroed``: the one-pass form may skip its own zero fill.  ``stream`` / ``keep``: as in
-    :func:`gatv2_fwd_launch`."""
+    ``grad_xl_zeroed``: the one-pass form may skip its own zero fill."""
     _lib.require_cuda(xl, xr, grad_out)
     lib = _lib.load()
     hc = heads * channels
@@ -206,11 +199,9 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
     ws_bytes = lib.segger_gatv2_bwd_workspace_bytes(n_dst, heads, channels)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
-    if keep is not None:
-        keep.append((vecs, grad_out, grad_pre, dsum, ws, gparams))
     _defer_keep(ws, gparams)
     with _lib.on_device(dev):
-        rc = lib.segger_gatv2_bwd(C.byref(a), _lib.stream_ptr(dev) if stream is None else stream.cuda_stream)
+        rc = lib.segger_gatv2_bwd(C.byref(a), _lib.stream_ptr(dev))
     _lib.check(rc, "segger_gatv2_bwd")
     return gparams[0], gparams[1]
 
@@ -266,26 +257,6 @@ def gatv2_aggregate(xl: Tensor, xr: Tensor, att: Tensor, bias: Optional[Tensor],
     return (out, alpha) if return_alpha else out
 
 
-# The two edge types of a hetero layer are independent given the projections: tx-belongs-bd (10^4 rows of 40-400 edges,
-# latency-bound, a few dozen microseconds that leave most of the chip idle) runs on a side stream beside the
-# tx-neighbors-tx aggregation and joins before the layer returns -- in a captured step the fork / join become parallel
-# branches of the hipGraph.  Eager small batches are host-bound: there the extra event calls cost more than they hide.
-SIDE_STREAM = True
-SIDE_STREAM_MIN_EDGES = 2_000_000
-_SIDE_STREAMS: dict = {}
-
-
-def _side_stream(dev, n_edges: int) -> Optional["torch.cuda.Stream"]:
-    if not SIDE_STREAM or dev.type != "cuda":
-        return None
-    if n_edges < SIDE_STREAM_MIN_EDGES and not torch.cuda.is_current_stream_capturing():
-        return None
-    s = _SIDE_STREAMS.get(dev.index)
-    if s is None:
-        s = _SIDE_STREAMS[dev.index] = torch.cuda.Stream(device=dev)
-    return s
-
-
 class _HeteroGatLayer(torch.autograd.Function):
     """segger's HeteroConv layer as one autograd node.
 
@@ -310,19 +281,12 @@ class _HeteroGatLayer(torch.autograd.Function):
         lse_tx = torch.empty((nt, heads), dtype=torch.float32, device=dev) if need_grad else None
         lse_bd = torch.empty((nb, heads), dtype=torch.float32, device=dev) if need_grad else None
         alpha = torch.empty((g_tt.n_edges, heads), dtype=torch.float32, device=dev) if want_alpha else None
-        side = _side_stream(dev, g_tt.n_edges)
-        keep: list = []
-        if side is not None:                                 # fork: everything queued so far precedes the side branch
-            side.wait_stream(torch.cuda.current_stream(dev))
-        gatv2_fwd_launch(g_tb.by_dst, xl_tb, xp_bd, att_tb, bias_tb, heads, channels, y_bd, pre=pre_bd, lse=lse_bd,
-                         apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tb,
-                         keep_bits=None if bits_tb is None else bits_tb[0], stream=side, keep=keep)
         gatv2_fwd_launch(g_tt.by_dst, xl_tt, xr_tt, att_tt, bias_tt, heads, channels, y_tx, pre=pre_tx, lse=lse_tx,
                          alpha=alpha, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tt,
                          keep_bits=None if bits_tt is None else bits_tt[0])
-        if side is not None:                                 # join (``keep`` dies after this point)
-            torch.cuda.current_stream(dev).wait_stream(side)
-        del keep
+        gatv2_fwd_launch(g_tb.by_dst, xl_tb, xp_bd, att_tb, bias_tb, heads, channels, y_bd, pre=pre_bd, lse=lse_bd,
+                         apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tb,
+                         keep_bits=None if bits_tb is None else bits_tb[0])
         if need_grad:
             ctx.save_for_backward(xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb,
                                   pre_tx if apply_gelu else y_tx, pre_bd if apply_gelu else y_bd, lse_tx, lse_bd)
@@ -345,37 +309,19 @@ class _HeteroGatLayer(torch.autograd.Function):
             gy_tx = torch.zeros_like(pre_tx)
         if gy_bd is None:
             gy_bd = torch.zeros_like(pre_bd)
-        dev = xp_tx.device
-        side = _side_stream(dev, g_tt.n_edges)
-        if side is not None:
-            # the two backward passes write disjoint column windows of the stacked gradient: tx-belongs-bd (with its
-            # own zero fill) runs on the side stream beside the tx-neighbors-tx pair
-            keep: list = []
-            if gy_bd.dtype != xp_tx.dtype or (gy_bd.shape[0] > 1 and gy_bd.stride(1) != 1):
-                gy_bd = gy_bd.to(xp_tx.dtype).contiguous()   # (on the current stream, BEFORE the fork)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            gatt_tb, gbias_tb = gatv2_bwd_launch(
-                g_tb, xp_tx[:, 2 * hc:], xp_bd, att_tb, bias_tb, heads, channels, gy_bd, pre_bd, lse_bd,
-                gxp_tx[:, 2 * hc:], gxp_bd, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb,
-                keep_bits=ctx.bits[1], stream=side, keep=keep)
-            gatt_tt, gbias_tt = gatv2_bwd_launch(
-                g_tt, xp_tx[:, :hc], xp_tx[:, hc:2 * hc], att_tt, bias_tt, heads, channels, gy_tx, pre_tx, lse_tx,
-                gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc], apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p,
-                seed=seed_tt, keep_bits=ctx.bits[0])
-            torch.cuda.current_stream(dev).wait_stream(side)
-            del keep
-        else:
-            # tx-neighbors-tx first: its source pass visits every transcript row and zero-fills the tx-belongs-bd window
-            # of the stacked projection gradient on the way, so the one-pass tx-belongs-bd backward needs no fill of its own
-            gatt_tt, gbias_tt = gatv2_bwd_launch(
-                g_tt, xp_tx[:, :hc], xp_tx[:, hc:2 * hc], att_tt, bias_tt, heads, channels, gy_tx, pre_tx, lse_tx,
-                gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc], apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p,
-                seed=seed_tt, keep_bits=ctx.bits[0], zero_rows_out=gxp_tx[:, 2 * hc:])
-            zeroed = gatv2_bwd_launch.zero_filled
-            gatt_tb, gbias_tb = gatv2_bwd_launch(
-                g_tb, xp_tx[:, 2 * hc:], xp_bd, att_tb, bias_tb, heads, channels, gy_bd, pre_bd, lse_bd,
-                gxp_tx[:, 2 * hc:], gxp_bd, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb,
-                keep_bits=ctx.bits[1], grad_xl_zeroed=zeroed)
+        # tx-neighbors-tx first: its source pass visits every transcript row and zero-fills the tx-belongs-bd window of
+        # the stacked projection gradient on the way, so the one-pass tx-belongs-bd backward needs no fill of its own.
+        # (Running tx-belongs-bd on a second stream beside it was measured in round 3: the kernels do overlap, but the
+        # small one then takes 10x longer and the big ones 3-7 % longer -- same total)
+        gatt_tt, gbias_tt = gatv2_bwd_launch(
+            g_tt, xp_tx[:, :hc], xp_tx[:, hc:2 * hc], att_tt, bias_tt, heads, channels, gy_tx, pre_tx, lse_tx,
+            gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc], apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tt,
+            keep_bits=ctx.bits[0], zero_rows_out=gxp_tx[:, 2 * hc:])
+        zeroed = gatv2_bwd_launch.zero_filled
+        gatt_tb, gbias_tb = gatv2_bwd_launch(
+            g_tb, xp_tx[:, 2 * hc:], xp_bd, att_tb, bias_tb, heads, channels, gy_bd, pre_bd, lse_bd,
+            gxp_tx[:, 2 * hc:], gxp_bd, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb,
+            keep_bits=ctx.bits[1], grad_xl_zeroed=zeroed)
         r = lambda gt, ref: gt.reshape(ref.shape).to(ref.dtype) if ref is not None else None
         return (gxp_tx, gxp_bd, r(gatt_tt, att_tt), r(gbias_tt, bias_tt), r(gatt_tb, att_tb), r(gbias_tb, bias_tb),
                 None, None, None, None, None, None, None, None, None, None, None, None)
@@ -634,13 +580,18 @@ def float_bits(x: float) -> int:
 
 @torch.no_grad()
 def stage(segments, device) -> None:
-    """``segger_stage``: all of ``segments`` in one launch.  A segment is ``(dst, src, fill, a, b, c)``: ``dst`` a
+    """``segger_stage``: all of ``segments`` in one launch.  A segment is ``(dst, src, fill, a, b, c[, add])``: ``dst`` a
     contiguous tensor written in full; ``src`` a contiguous tensor (or None) copied to its front; the rest filled by
-    ``fill`` in ("const", "tile", "div", "mod", "ramp") with integer parameters a, b, c (see include/segger_amd.h)."""
+    ``fill`` in ("const", "tile", "div", "mod", "ramp") with integer parameters a, b, c (see include/segger_amd.h);
+    ``add`` (integer segments only) is added to every copied / tile-replicated element."""
     lib = _lib.load()
     n = len(segments)
     arr = (_lib.StageSeg * n)()
-    for i, (dst, src, fill, a, b, c) in enumerate(segments):
+    for i, seg in enumerate(segments):
+        dst, src, fill, a, b, c = seg[:6]
+        add = int(seg[6]) if len(seg) > 6 else 0
+        if add and dst.is_floating_point():
+            raise TypeError(f"stage: segment {i}: `add` is for integer segments")
         if not dst.is_contiguous() or (src is not None and not src.is_contiguous()):
             raise ValueError("stage: tensors must be contiguous")
         n_copy = 0 if src is None else int(src.numel())
@@ -650,6 +601,7 @@ def stage(segments, device) -> None:
         g.a, g.b, g.c = int(a), int(b), int(c)
         g.dst_bytes, g.src_bytes = dst.element_size(), (src.element_size() if src is not None else dst.element_size())
         g.fill = _FILLS[fill]
+        g.copy_add = add
         if n_copy > g.n_total:
             raise ValueError(f"stage: segment {i}: source longer than destination")
         if src is not None and src.is_floating_point() != dst.is_floating_point():

@@ -87,9 +87,12 @@ class GraphedTrainStep:
         z = lambda *shape, dtype=torch.float32: torch.zeros(*shape, dtype=dtype, device=dev)
         i32, i64 = torch.int32, torch.int64
         self.n_genes = int(lit_model.model.lin_first["tx"].weight.shape[0])
-        self.nodes = {"tx": {"x": z(nt, dtype=i32), "pos": z(nt, 2), "batch": z(nt, dtype=i64)},
+        # positions / graph ids of both node types back to back: the encoder runs its positional embedder once over
+        # the concatenation (boundary graph ids offset by the bucket's graph count), staged here without a launch
+        self.pos_all, self.batch_all = z(nt + nb, 2), z(nt + nb, dtype=i64)
+        self.nodes = {"tx": {"x": z(nt, dtype=i32), "pos": self.pos_all[:nt], "batch": self.batch_all[:nt]},
                       "bd": {"x": z(nb, *template["bd"]["x"].shape[1:], dtype=template["bd"]["x"].dtype),
-                             "pos": z(nb, 2), "batch": z(nb, dtype=i64)}}
+                             "pos": self.pos_all[nt:], "batch": z(nb, dtype=i64)}}
 
         def csr(n_rows, n_cols, n_edges):
             return EdgeCSR(z(n_rows + 1, dtype=i64), z(n_edges, dtype=i32), z(n_edges, dtype=i32), n_rows, n_cols)
@@ -195,6 +198,7 @@ class GraphedTrainStep:
             (N["tx"]["pos"], tx["pos"], "tile", 2, 0, 0), (N["tx"]["batch"], tx["batch"], "tile", 1, 0, 0),
             (N["bd"]["x"], bd["x"], "tile", max(int(bd["x"][0].numel()), 1), 0, 0),
             (N["bd"]["pos"], bd["pos"], "tile", 2, 0, 0), (N["bd"]["batch"], bd["batch"], "tile", 1, 0, 0),
+            (self.batch_all[nt:], bd["batch"], "tile", 1, 0, 0, s["graphs"]),
             (self.by_gene.indptr, by_gene.indptr[: self.n_genes], "const", nt, 0, 0),
             (self.by_gene.col, by_gene.col, "div", n_tx, 1, 0),
             # segmentation triplets: padded ones carry -1 and are skipped by the kernels
@@ -226,7 +230,8 @@ class GraphedTrainStep:
             enc, self._alias,
             ({"tx": tx["x"], "bd": bd["x"]}, {TX_TX: None, TX_BD: None}, {"tx": tx["pos"], "bd": bd["pos"]},
              {"tx": tx["batch"], "bd": bd["batch"]}),
-            dict(num_graphs=s["graphs"], graphs={TX_TX: self.g_tt, TX_BD: self.g_tb, "tx_by_gene": self.by_gene}))
+            dict(num_graphs=s["graphs"], graphs={TX_TX: self.g_tt, TX_BD: self.g_tb, "tx_by_gene": self.by_gene,
+                                                 "pos_all": (self.pos_all, self.batch_all)}))
         step = enc._step_dev                                  # advanced by the forward: a fresh stream per replay
         fixed = self.draws
         # loss_tx / loss_bd: the masked forms of triplet_loss.py on the staged sampler indices; means are taken over

@@ -1,6 +1,6 @@
 """A/B of the C2 training step (bench.py's timed region) under switches of segger_amd.ops:
-    FUSED_DX=0|1 (one-pass projection backward)   SIDE=0|1 (tx-belongs-bd on a side stream)   STEPS, WARMUP, N_TX
-Alternates the variants in one process (same box, same clocks): VARIANTS="base:FUSED_DX=0,SIDE=0;new:FUSED_DX=1,SIDE=1"."""
+    FUSED_DX=0|1 (one-pass projection backward), any other integer attribute of segger_amd.ops by name;   STEPS, WARMUP, N_TX
+Alternates the variants in one process (same box, same clocks): VARIANTS="base:FUSED_DX=0;new:FUSED_DX=1"."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from segger_amd import LitISTEncoder, ops
@@ -32,14 +32,13 @@ def step():
 
 def apply(flags):
     ops.FUSED_WGRAD_DX = bool(int(flags.get("FUSED_DX", 1)))
-    ops.SIDE_STREAM = bool(int(flags.get("SIDE", 1)))
     for k, v in flags.items():
-        if k not in ("FUSED_DX", "SIDE") and hasattr(ops, k):
+        if k != "FUSED_DX" and hasattr(ops, k):
             setattr(ops, k, type(getattr(ops, k))(int(v)))
 
 
 variants = []
-for item in os.environ.get("VARIANTS", "base:FUSED_DX=0,SIDE=0;fused:FUSED_DX=1,SIDE=0;side:FUSED_DX=0,SIDE=1;both:FUSED_DX=1,SIDE=1").split(";"):
+for item in os.environ.get("VARIANTS", "base:FUSED_DX=0;fused:FUSED_DX=1").split(";"):
     name, _, fl = item.partition(":")
     variants.append((name, dict(kv.split("=") for kv in fl.split(",") if kv)))
 steps, warm = int(os.environ.get("STEPS", 15)), int(os.environ.get("WARMUP", 3))
