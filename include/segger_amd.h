@@ -346,6 +346,17 @@ typedef struct segger_triplet_args {
 } segger_triplet_args;
 
 /*
+ * segger_loss_combine_fwd / _bwd: the loss combination of LitISTEncoder.get_losses (lightning_model.py:136-149,
+ * 210-211: scheduled weights, weighted sum) on DEVICE scalars, one launch each way instead of a chain of 0-dim torch ops:
+ *   out[i] = raw[i] * a[i]  (the logged losses; a = per-loss rescaling, e.g. padded -> masked means),
+ *   out[n] = sum_i out[i] * b[i]  (b = scheduled weights);    grad_raw[i] = (grad_out[n] * b[i] + grad_out[i]) * a[i].
+ * raw / a / b: float[n] on the device, n <= 16; grad_raw feeds grad_scale_dev of the loss kernels' backward.
+ */
+int segger_loss_combine_fwd(const float* raw, const float* a, const float* b, int32_t n, float* out, segger_stream_t stream);
+int segger_loss_combine_bwd(const float* grad_out, const float* a, const float* b, int32_t n, float* grad_raw,
+                            segger_stream_t stream);
+
+/*
  * segger_triplet_sample: FastTripletSelector.sample_triplets (src/segger/models/triplet_loss.py:83-125) for all
  * nodes in one launch: per node i with cluster r = lab[i], draw the positive cluster from row r of cdf_pos and the
  * negative cluster from row r of cdf_neg (first column whose cumulative probability >= u, as torch.searchsorted),
@@ -466,11 +477,11 @@ int segger_linear_wgrad_dx(const void* dy, int64_t ld_dy, const void* x, int64_t
  * Deferred partial sums.  segger_linear_wgrad / _wgrad_dx / segger_posmlp_wgrad and segger_gatv2_bwd finish with a small
  * kernel that sums per-workgroup partials from their workspace into grad_w / grad_b / grad_att / grad_bias.  Between
  *     segger_reductions_defer_begin()  ...  segger_reductions_flush(stream)
- * (process-wide: autograd queues from its own device thread) those sums of at most 128 partials are queued instead of launched and the flush runs them all
- * as ONE grid -- autograd hands every parameter gradient of a backward pass (ist_encoder.py:289-333 under
+ * (process-wide: autograd queues from its own device thread) those sums are queued instead of launched and the flush runs them
+ * all as ONE grid (two when a sum has more than 128 partials: those fold into 32 groups first) -- autograd hands every parameter gradient of a backward pass (ist_encoder.py:289-333 under
  * lightning_model.py:215-237) to the optimizer at the same time anyway.  Contract while deferring: the outputs are
  * undefined and the workspaces must stay untouched until the flush has been enqueued on the same stream (or one
- * ordered after the producers); at most 64 sums are queued, further ones run immediately.  The table travels as a
+ * ordered after the producers); at most 56 sums are queued, further ones run immediately.  The table travels as a
  * kernel argument: no allocation, no synchronisation, capturable.  segger_reductions_pending(): queued sums, -1 when
  * not deferring.
  */

@@ -155,6 +155,8 @@ EXPORTS = {
     "segger_linear_wgrad_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "segger_linear_wgrad": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp, vp,
                                       vp, C.c_size_t, vp]),
+    "segger_loss_combine_fwd": (C.c_int, [vp, vp, vp, C.c_int32, vp, vp]),
+    "segger_loss_combine_bwd": (C.c_int, [vp, vp, vp, C.c_int32, vp, vp]),
     "segger_reductions_defer_begin": (C.c_int, []),
     "segger_reductions_pending": (C.c_int, []),
     "segger_reductions_flush": (C.c_int, [vp]),

@@ -42,7 +42,9 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // or the table is full) and the caller launches its own reduction as usual.
 struct ReduceSeg {
   const float* partial; int64_t n_slabs; int64_t width; int64_t split; float* out0; float* out1;
+  float* scratch;      // >= kReduceGroups * width floats behind the partials (sums longer than one pass go through it)
 };
+constexpr int kReduceGroups = 32;
 bool defer_reduce(const ReduceSeg& seg);
 
 constexpr int kWave = 64;

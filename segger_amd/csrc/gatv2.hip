@@ -240,7 +240,7 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
     CHECK_RC(launch(Pass::BwdDst, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), stream, gen));
     if (specialised) {
     const int width = 2 * hc;
-    if (!defer_reduce(ReduceSeg{p.slab, p.nblocks, width, hc, a->grad_att, a->grad_bias})) {
+    if (!defer_reduce(ReduceSeg{p.slab, p.nblocks, width, hc, a->grad_att, a->grad_bias, p.slab + p.nblocks * width})) {
     float* part = p.slab + p.nblocks * width;          // behind the per-block slabs
     hipLaunchKernelGGL(slab_reduce_stage1, dim3((width + 63) / 64, kSlabSplits), dim3(256), 0, stream,
                        p.slab, p.nblocks, width, part);

@@ -639,6 +639,43 @@ static int triplet_common(const segger_triplet_args* a, bool bwd, hipStream_t st
   return SEGGER_OK;
 }
 
+// ---- the weighted sum of the step's losses and its gradient, as one tiny launch each way --------------------------------
+namespace segger {
+namespace {
+__global__ void loss_combine_kernel(const float* __restrict__ raw, const float* __restrict__ a, const float* __restrict__ b,
+                                    int n, float* __restrict__ out, const float* __restrict__ gout, float* __restrict__ graw) {
+  if (threadIdx.x != 0) return;
+  if (gout == nullptr) {
+    float total = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float t = raw[i] * a[i];
+      out[i] = t;
+      total = fmaf(t, b[i], total);
+    }
+    out[n] = total;
+  } else {
+    for (int i = 0; i < n; ++i) graw[i] = (gout[n] * b[i] + gout[i]) * a[i];
+  }
+}
+}  // namespace
+}  // namespace segger
+
+extern "C" int segger_loss_combine_fwd(const float* raw, const float* a, const float* b, int32_t n, float* out,
+                                       segger_stream_t stream) {
+  SEGGER_REQUIRE(n > 0 && n <= 16 && raw && a && b && out, "segger_loss_combine_fwd: 1..16 terms, no NULL pointer");
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, raw, a, b, n, out, nullptr, nullptr);
+  SEGGER_LAUNCH_CHECK("loss_combine_kernel");
+  return SEGGER_OK;
+}
+extern "C" int segger_loss_combine_bwd(const float* grad_out, const float* a, const float* b, int32_t n, float* grad_raw,
+                                       segger_stream_t stream) {
+  SEGGER_REQUIRE(n > 0 && n <= 16 && grad_out && a && b && grad_raw, "segger_loss_combine_bwd: 1..16 terms, no NULL pointer");
+  hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, nullptr, a, b, n, nullptr, grad_out,
+                     grad_raw);
+  SEGGER_LAUNCH_CHECK("loss_combine_kernel");
+  return SEGGER_OK;
+}
+
 extern "C" int segger_triplet_fwd(const segger_triplet_args* a, segger_stream_t stream) {
   return triplet_common(a, false, (hipStream_t)stream);
 }

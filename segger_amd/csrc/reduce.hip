@@ -16,8 +16,8 @@
 namespace segger {
 namespace {
 
-constexpr int kMaxSegs = 64;
-constexpr int64_t kMaxDeferredSlabs = 128;      // longer sums keep their two-stage kernels (a serial chain per thread)
+constexpr int kMaxSegs = 56;                    // 56 x 56 B + 8 by value in the kernel arguments (< 4 KiB)
+constexpr int64_t kOnePassSlabs = 128;          // longer sums first fold into kReduceGroups interleaved groups
 
 struct ReduceBatch { int n; ReduceSeg seg[kMaxSegs]; };
 static ReduceBatch g_batch;
@@ -41,11 +41,28 @@ __global__ __launch_bounds__(256) void reduce_many_kernel(ReduceBatch b) {
   else if (g.out1) g.out1[e - g.split] = t;
 }
 
+// long sums, first level: scratch[g][e] = sum of the slabs g, g + G, g + 2 G, ... (grid: columns x segments x groups)
+__global__ __launch_bounds__(256) void reduce_many_fold_kernel(ReduceBatch b) {
+  const ReduceSeg g = b.seg[blockIdx.y];
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= g.width) return;
+  const float* __restrict__ p = g.partial + e;
+  const int grp = blockIdx.z;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int64_t s = grp;
+  for (; s + 3 * kReduceGroups < g.n_slabs; s += 4 * kReduceGroups) {
+    s0 += p[s * g.width];                       s1 += p[(s + kReduceGroups) * g.width];
+    s2 += p[(s + 2 * kReduceGroups) * g.width]; s3 += p[(s + 3 * kReduceGroups) * g.width];
+  }
+  for (; s < g.n_slabs; s += kReduceGroups) s0 += p[s * g.width];
+  g.scratch[(int64_t)grp * g.width + e] = (s0 + s1) + (s2 + s3);
+}
+
 }  // namespace
 
 bool defer_reduce(const ReduceSeg& seg) {
   std::lock_guard<std::mutex> lock(g_mu);
-  if (!g_active || g_batch.n >= kMaxSegs || seg.n_slabs > kMaxDeferredSlabs) return false;
+  if (!g_active || g_batch.n >= kMaxSegs || (seg.n_slabs > kOnePassSlabs && seg.scratch == nullptr)) return false;
   g_batch.seg[g_batch.n++] = seg;
   return true;
 }
@@ -72,6 +89,22 @@ extern "C" int segger_reductions_flush(segger_stream_t stream) {
   SEGGER_REQUIRE(g_active, "segger_reductions_flush: nothing is being deferred");
   g_active = false;
   if (g_batch.n == 0) return SEGGER_OK;
+  // sums of more than kOnePassSlabs partials: one launch folds them all into kReduceGroups groups each (their scratch),
+  // and the final launch sums those groups like any short sum
+  ReduceBatch longs; longs.n = 0;
+  int64_t long_width = 0;
+  for (int i = 0; i < g_batch.n; ++i) {
+    ReduceSeg& g = g_batch.seg[i];
+    if (g.n_slabs <= kOnePassSlabs) continue;
+    longs.seg[longs.n++] = g;
+    long_width = g.width > long_width ? g.width : long_width;
+    g.partial = g.scratch; g.n_slabs = kReduceGroups;
+  }
+  if (longs.n > 0) {
+    hipLaunchKernelGGL(reduce_many_fold_kernel, dim3((unsigned)((long_width + 255) / 256), (unsigned)longs.n, kReduceGroups),
+                       dim3(256), 0, (hipStream_t)stream, longs);
+    if (hipGetLastError() != hipSuccess) { g_batch.n = 0; set_error("reduce_many_fold_kernel: launch failed"); return SEGGER_EHIP; }
+  }
   int64_t width = 0;
   for (int i = 0; i < g_batch.n; ++i) width = g_batch.seg[i].width > width ? g_batch.seg[i].width : width;
   hipLaunchKernelGGL(reduce_many_kernel, dim3((unsigned)((width + 255) / 256), (unsigned)g_batch.n), dim3(256), 0,

@@ -193,6 +193,9 @@ class LitISTEncoder(_Base):
         tx_mask = batch['tx']['mask']
         bd_mask = batch['bd']['mask'] & (batch['bd']['cluster'] >= 0)
         u_tx, u_bd = uniforms if uniforms is not None else (None, None)
+        if (self.fused_loss_head and self._sg_loss_type == 'triplet' and embeddings['tx'].is_cuda
+                and embeddings['tx'].shape[0] > 0 and embeddings['bd'].shape[0] > 0):
+            return self._losses_fused(batch, embeddings, tx_mask, bd_mask, u_tx, u_bd, dst_neg)
         loss_tx = self.loss_tx.forward_masked(embeddings['tx'], batch['tx']['cluster'], tx_mask, batch_cache(batch),
                                               uniforms=u_tx)
         loss_bd = self.loss_bd.forward_masked(embeddings['bd'], batch['bd']['cluster'], bd_mask, uniforms=u_bd,
@@ -201,6 +204,49 @@ class LitISTEncoder(_Base):
         w_tx, w_bd, w_sg = (float(v) for v in self._scheduled_weights(self._w_start, self._w_end))
         loss = w_tx * loss_tx + w_bd * loss_bd + w_sg * loss_sg
         return loss_tx, loss_bd, loss_sg, loss
+
+    fused_loss_head = True      # the three losses + their weighted sum as one autograd node (ops.loss_head) on the GPU
+
+    def _losses_fused(self, batch, embeddings, tx_mask, bd_mask, u_tx, u_bd, dst_neg):
+        """The same four values through ``ops.loss_head``: samplers as in the unfused route (same draws from the same
+        generators, in the same order), then ONE node for the three loss kernels and the weighted sum."""
+        from .triplet_loss import _cached_index, _masked_count
+        cache = batch_cache(batch)
+        z_tx, z_bd = embeddings['tx'], embeddings['bd']
+        dev = z_tx.device
+        n_tx, n_bd = z_tx.shape[0], z_bd.shape[0]
+        tx_lab, bd_lab = batch['tx']['cluster'], batch['bd']['cluster']
+        ix_tx = _cached_index(self.loss_tx.selector, "tx_triplet_index", tx_lab, tx_mask, cache)
+        if "anchors" not in ix_tx:
+            ix_tx["anchors"] = torch.arange(n_tx, device=dev)
+            ix_tx["rescale"] = float(n_tx) / _masked_count(tx_mask)
+        if "head_a" not in ix_tx:               # per-loss rescaling: loss_tx from a mean over all rows to the masked ones
+            ix_tx["head_a"] = torch.cat([ix_tx["rescale"].reshape(1).float(), torch.ones(2, device=dev)])
+        pos, neg, _, _ = self.loss_tx.selector.sample_triplets(tx_lab, u_tx, index=ix_tx)
+        ix_bd = _cached_index(self.loss_bd.selector, "bd_metric_index", bd_lab, bd_mask, cache)
+        if "weight" not in ix_bd:
+            ix_bd["weight"] = bd_mask.float() / _masked_count(bd_mask)
+        bpos, bneg, dp, dn = self.loss_bd.selector.sample_triplets(bd_lab, u_bd, index=ix_bd)
+        sg = None
+        if n_bd > 1:                                                         # :173-175
+            src_pos, dst_pos = batch[TX_BD].edge_index
+            if dst_neg is None:
+                dst_neg = ops.sample_negatives(dst_pos, n_bd)                # :178-180, one launch
+            g = edge_graph(cache, TX_BD, batch[TX_BD].edge_index, n_tx, n_bd,
+                           need_by_src="lazy" if torch.is_grad_enabled() else False, validate="deferred")
+            sg = (src_pos, dst_pos, dst_neg, self._sg_margin, 1e-6, g.by_dst)
+        w = self._scheduled_weights(self._w_start, self._w_end)
+        key = tuple(float(v) for v in w)
+        wdev = self.__dict__.setdefault("_head_weights", {})
+        b = wdev.get((key, dev))
+        if b is None:
+            if len(wdev) > 64:
+                wdev.clear()
+            b = wdev[(key, dev)] = torch.tensor(key, dtype=torch.float32, device=dev)
+        spec = ops.LossHeadSpec((ix_tx["anchors"], pos, neg, self.loss_tx.margin, self.loss_tx.eps),
+                                (bpos, bneg, dp, dn, ix_bd["weight"], 1e-8), sg)
+        out = ops.loss_head(z_tx, z_bd, ix_tx["head_a"], b, spec)
+        return out[0], out[1], out[2], out[3]
 
     def _step(self, batch, prefix: str) -> Tensor:
         loss_tx, loss_bd, loss_sg, loss = self.get_losses(batch)

@@ -516,6 +516,124 @@ def metric_loss(z: Tensor, pos: Tensor, neg: Tensor, d_pos: Tensor, d_neg: Tenso
     return _MetricLoss.apply(z, pos, neg, d_pos, d_neg, w, float(eps))
 
 
+class LossHeadSpec:
+    """What :func:`loss_head` needs besides the embeddings.  ``tx`` = (anchors, positives, negatives, margin, eps) of
+    loss_tx (rows of z_tx; ``-1`` = skip); ``bd`` = (positives, negatives, d_pos, d_neg, weights, eps) of loss_bd (rows
+    of z_bd); ``sg`` = (src, pos, neg, margin, eps, pos_groups | None) of the segmentation triplets, or None when the
+    batch has at most one boundary (lightning_model.py:173-175: that loss is then 0)."""
+
+    def __init__(self, tx, bd, sg):
+        self.tx, self.bd, self.sg = tx, bd, sg
+
+
+class _LossHead(torch.autograd.Function):
+    """``LitISTEncoder.get_losses`` (lightning_model.py:151-213) after the sampling, as ONE autograd node:
+    out = [a0 * loss_tx, a1 * loss_bd, a2 * loss_sg, sum_i b_i * out_i].  Forward: the three loss kernels write their
+    means side by side and one launch combines them.  Backward: one launch turns the incoming gradient into the three
+    scale factors (device scalars), then the three backward kernels accumulate into ONE gradient buffer per embedding
+    matrix -- no per-loss zero fill, cast and add, and no chain of 0-dim torch ops around the weighted sum."""
+
+    @staticmethod
+    def forward(ctx, z_tx, z_bd, a, b, spec: LossHeadSpec):
+        _lib.require_cuda(z_tx, z_bd, a, b)
+        lib = _lib.load()
+        dev, dt = z_tx.device, z_tx.dtype
+        if z_bd.dtype != dt or dt not in DTYPE_CODE:
+            raise TypeError("loss_head: z_tx / z_bd must share a supported dtype")
+        c = int(z_tx.shape[1])
+        if z_bd.shape[1] != c:
+            raise ValueError("loss_head: z_tx / z_bd must have the same width")
+        a = a.detach().to(torch.float32).contiguous()
+        b = b.detach().to(torch.float32).contiguous()
+        i64 = lambda t: t.to(torch.int64).contiguous()
+        raw = torch.zeros(3, dtype=torch.float32, device=dev)
+        keep = []
+        stream = _lib.stream_ptr(dev)
+        with _lib.on_device(dev):
+            anchors, pos, neg, margin, eps = spec.tx
+            tx = tuple(i64(t) for t in (anchors, pos, neg))
+            ta = _triplet_args(*tx, z_tx, z_tx, float(margin), float(eps))
+            ws = torch.empty(lib.segger_triplet_workspace_bytes(ta.n_edges), dtype=torch.uint8, device=dev)
+            ta.loss, ta.workspace, ta.workspace_bytes = raw[0:1].data_ptr(), ws.data_ptr(), ws.numel()
+            _lib.check(lib.segger_triplet_fwd(C.byref(ta), stream), "segger_triplet_fwd")
+            keep.append(ws)
+            bpos, bneg, dp, dn, w, beps = spec.bd
+            bd = (i64(bpos), i64(bneg)) + tuple(t.to(torch.float32).contiguous() for t in (dp, dn, w))
+            nb = int(z_bd.shape[0])
+            zp, ld = _rows(z_bd, c, "z_bd")
+            ws = torch.empty(lib.segger_triplet_workspace_bytes(nb), dtype=torch.uint8, device=dev)
+            _lib.check(lib.segger_metric_fwd(zp, ld, nb, c, DTYPE_CODE[dt], bd[0].data_ptr(), bd[1].data_ptr(),
+                                             bd[2].data_ptr(), bd[3].data_ptr(), bd[4].data_ptr(), float(beps),
+                                             raw[1:2].data_ptr(), ws.data_ptr(), ws.numel(), stream), "segger_metric_fwd")
+            keep.append(ws)
+            sg = None
+            if spec.sg is not None:
+                src, spos, sneg, smargin, seps, pg = spec.sg
+                sg = tuple(i64(t) for t in (src, spos, sneg))
+                if pg is not None and (pg.n_rows != nb or pg.n_edges != sg[0].numel()):
+                    raise ValueError("loss_head: pos_groups does not describe the segmentation triplets")
+                sa = _triplet_args(*sg, z_tx, z_bd, float(smargin), float(seps))
+                ws = torch.empty(lib.segger_triplet_workspace_bytes(sa.n_edges), dtype=torch.uint8, device=dev)
+                sa.loss, sa.workspace, sa.workspace_bytes = raw[2:3].data_ptr(), ws.data_ptr(), ws.numel()
+                _lib.check(lib.segger_triplet_fwd(C.byref(sa), stream), "segger_triplet_fwd")
+                keep.append(ws)
+            out = torch.empty(4, dtype=torch.float32, device=dev)
+            _lib.check(lib.segger_loss_combine_fwd(raw.data_ptr(), a.data_ptr(), b.data_ptr(), 3, out.data_ptr(), stream),
+                       "segger_loss_combine_fwd")
+        ctx.save_for_backward(z_tx, z_bd, a, b, *tx, *bd, *(sg or ()))
+        ctx.spec = spec
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        z_tx, z_bd, a, b = ctx.saved_tensors[:4]
+        tx = ctx.saved_tensors[4:7]
+        bd = ctx.saved_tensors[7:12]
+        sg = ctx.saved_tensors[12:15] if ctx.spec.sg is not None else None
+        spec = ctx.spec
+        lib = _lib.load()
+        dev, dt = z_tx.device, z_tx.dtype
+        c = int(z_tx.shape[1])
+        nb = int(z_bd.shape[0])
+        g_out = g_out.detach().to(torch.float32).contiguous()
+        graw = torch.empty(3, dtype=torch.float32, device=dev)
+        # transcript rows collect a handful of terms (once as anchor of either loss, ~2 as positive / negative): packed
+        # 16-bit atomics straight into a gradient of the embeddings' dtype on large batches; boundary rows sum dozens
+        # of terms and stay fp32 (+ one cast)
+        packed = dt in (torch.bfloat16, torch.float16) and c % 2 == 0 and tx[0].numel() >= _CONTRIB_MIN_EDGES
+        ga = torch.zeros(z_tx.shape, dtype=dt if packed else torch.float32, device=dev)
+        pg = spec.sg[5] if spec.sg is not None else None
+        gb = (torch.empty if pg is not None else torch.zeros)(z_bd.shape, dtype=torch.float32, device=dev)
+        stream = _lib.stream_ptr(dev)
+        with _lib.on_device(dev):
+            _lib.check(lib.segger_loss_combine_bwd(g_out.data_ptr(), a.data_ptr(), b.data_ptr(), 3, graw.data_ptr(), stream),
+                       "segger_loss_combine_bwd")
+            if sg is not None:          # first: with pos_groups its positive side WRITES every row of gb
+                sa = _triplet_args(*sg, z_tx, z_bd, float(spec.sg[3]), float(spec.sg[4]))
+                sa.grad_a, sa.grad_a_packed, sa.grad_b, sa.grad_b_packed = ga.data_ptr(), int(packed), gb.data_ptr(), 0
+                if pg is not None:
+                    sa.pos_indptr, sa.pos_eid = pg.indptr.data_ptr(), (pg.eid.data_ptr() if pg.n_edges else None)
+                sa.grad_scale, sa.grad_scale_dev = 1.0, graw[2:3].data_ptr()
+                _lib.check(lib.segger_triplet_bwd(C.byref(sa), stream), "segger_triplet_bwd")
+            zp, ld = _rows(z_bd, c, "z_bd")
+            _lib.check(lib.segger_metric_bwd(zp, ld, nb, c, DTYPE_CODE[dt], bd[0].data_ptr(), bd[1].data_ptr(),
+                                             bd[2].data_ptr(), bd[3].data_ptr(), bd[4].data_ptr(), float(spec.bd[5]),
+                                             graw[1:2].data_ptr(), gb.data_ptr(), stream), "segger_metric_bwd")
+            ta = _triplet_args(*tx, z_tx, z_tx, float(spec.tx[3]), float(spec.tx[4]))
+            ta.grad_a = ta.grad_b = ga.data_ptr()
+            ta.grad_a_packed = ta.grad_b_packed = int(packed)
+            ta.grad_scale, ta.grad_scale_dev = 1.0, graw[0:1].data_ptr()
+            _lib.check(lib.segger_triplet_bwd(C.byref(ta), stream), "segger_triplet_bwd")
+        return (ga if packed else ga.to(dt)), gb.to(dt), None, None, None
+
+
+def loss_head(z_tx: Tensor, z_bd: Tensor, a: Tensor, b: Tensor, spec: LossHeadSpec) -> Tensor:
+    """-> float32[4] = (a0 * loss_tx, a1 * loss_bd, a2 * loss_sg, sum_i b_i * (the three)): the three losses of
+    ``LitISTEncoder.get_losses`` and their weighted sum as one autograd node (see :class:`_LossHead`).  ``a`` / ``b``:
+    float32[3] on the device."""
+    return _LossHead.apply(z_tx, z_bd, a, b, spec)
+
+
 @torch.no_grad()
 def triplet_sample(index: dict, uniforms=None, seed_dev: Optional[Tensor] = None, seed: Optional[int] = None):
     """``FastTripletSelector.sample_triplets`` in one launch (``segger_triplet_sample``) from the selector's index

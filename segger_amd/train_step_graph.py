@@ -111,8 +111,10 @@ class GraphedTrainStep:
         self.ix_bd = sampler_index(lit_model.loss_bd.selector, nb)
         self.bd_weight = z(nb)
         self.n_bd = z(1, dtype=i64)                           # real boundary count of the staged batch
-        self.scal = z(6)                      # 1 / masked tx count, 1, e_tb_pad / e_tb_real (0: <= 1 boundary), loss weights
-        self._unit = torch.tensor([float(nt), 1.0, 1.0], device=dev)
+        # padded -> masked means (padded rows / masked tx count, 1, e_tb_pad / e_tb_real or 0 for <= 1 boundary), loss weights
+        self.scal = z(6)
+        self.head_a = self.scal[0:3]
+        self._e_loss = torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev)          # d / d out of out[3], the total loss
         self.out: Optional[Tensor] = None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.graph_opt: Optional[torch.cuda.CUDAGraph] = None      # split mode (grad_sync): Adam as a graph of its own
@@ -176,8 +178,9 @@ class GraphedTrainStep:
         ix_tx = keep.get("tx_triplet_index") if store is not None else None
         if ix_tx is None:
             ix_tx = _cached_index(lit.loss_tx.selector, "tx_triplet_index", tx["cluster"], tx["mask"], cache)
-        if "inv_count" not in ix_tx:
-            ix_tx["inv_count"] = (1.0 / _masked_count(ix_tx["mask"])).reshape(1)
+        a0 = ("rows_over_masked", nt)                         # loss_tx: mean over the padded rows -> mean over the masked real ones
+        if a0 not in ix_tx:
+            ix_tx[a0] = (float(nt) / _masked_count(ix_tx["mask"])).reshape(1)
         ix_bd = keep.get("bd_metric_index") if store is not None else None
         if ix_bd is None:
             ix_bd = _cached_index(lit.loss_bd.selector, "bd_metric_index", bd["cluster"],
@@ -205,7 +208,7 @@ class GraphedTrainStep:
             (self.sg_src, ei[0], *dummies, 0), (self.sg_pos, ei[1], "const", -1, 0, 0),
             (self.bd_weight, ix_bd["weight"], "const", 0, 0, 0),
             (self.n_bd, None, "const", n_bd, 0, 0),
-            (self.scal[0:1], ix_tx["inv_count"], "const", 0, 0, 0), (self.scal[1:2], None, "const", fb(1.0), 0, 0),
+            (self.scal[0:1], ix_tx[a0], "const", 0, 0, 0), (self.scal[1:2], None, "const", fb(1.0), 0, 0),
             (self.scal[2:3], None, "const", fb(s["e_tb"] / max(e_tb, 1) if n_bd > 1 else 0.0), 0, 0),   # :173-175
             (self.scal[3:4], None, "const", fb(w[0]), 0, 0), (self.scal[4:5], None, "const", fb(w[1]), 0, 0),
             (self.scal[5:6], None, "const", fb(w[2]), 0, 0),
@@ -234,33 +237,27 @@ class GraphedTrainStep:
                                                  "pos_all": (self.pos_all, self.batch_all)}))
         step = enc._step_dev                                  # advanced by the forward: a fresh stream per replay
         fixed = self.draws
-        # loss_tx / loss_bd: the masked forms of triplet_loss.py on the staged sampler indices; means are taken over
-        # the padded rows by the kernels and rescaled to the masked real ones here
+        # the three losses on the staged sampler indices and their weighted sum as one autograd node (ops.loss_head):
+        # means are taken over the padded rows by the kernels and rescaled to the masked real ones by `head_a`
         if fixed is None:
             pos, neg, _, _ = ops.triplet_sample(self.ix_tx, seed=0x7478, seed_dev=step)
+            bpos, bneg, dp, dn = ops.triplet_sample(self.ix_bd, seed=0x6264, seed_dev=step)
+            # segmentation loss over the real tx-belongs-bd edges (lightning_model.py:167-189): negatives in [0, n_bd_real)
+            dst_neg = ops.sample_negatives(self.sg_pos, 0, self.n_bd, seed=0x7367, seed_dev=step)
         else:
-            pos, neg = fixed["tx"]
-        l_tx = ops.triplet_edge_loss(z["tx"], None, self._iota, pos, neg, lit.loss_tx.margin, eps=lit.loss_tx.eps)
-        if fixed is None:
-            pos, neg, dp, dn = ops.triplet_sample(self.ix_bd, seed=0x6264, seed_dev=step)
-        else:
-            pos, neg, dp, dn = fixed["bd"]
-        l_bd = ops.metric_loss(z["bd"], pos, neg, dp, dn, self.bd_weight)
-        # segmentation loss over the real tx-belongs-bd edges (lightning_model.py:167-189): negatives in [0, n_bd_real)
-        dst_neg = (ops.sample_negatives(self.sg_pos, 0, self.n_bd, seed=0x7367, seed_dev=step) if fixed is None
-                   else fixed["dst_neg"])
-        l_sg = ops.triplet_edge_loss(z["tx"], z["bd"], self.sg_src, self.sg_pos, dst_neg, lit._sg_margin, eps=1e-6,
-                                     pos_groups=self.g_tb.by_dst)
-        terms = torch.stack([l_tx.float(), l_bd.float(), l_sg.float()]) * self._unit * self.scal[0:3]
-        loss = (terms * self.scal[3:6]).sum()
+            (pos, neg), (bpos, bneg, dp, dn), dst_neg = fixed["tx"], fixed["bd"], fixed["dst_neg"]
+        spec = ops.LossHeadSpec((self._iota, pos, neg, lit.loss_tx.margin, lit.loss_tx.eps),
+                                (bpos, bneg, dp, dn, self.bd_weight, 1e-8),
+                                (self.sg_src, self.sg_pos, dst_neg, lit._sg_margin, 1e-6, self.g_tb.by_dst))
+        out = ops.loss_head(z["tx"], z["bd"], self.head_a, self.scal[3:6], spec)
         if self.defer_sums:                                   # ~30 partial sums of the backward as one launch
             with ops.deferred_reductions(self.dev):
-                grads = torch.autograd.grad(loss, self._leaves, allow_unused=True)
+                grads = torch.autograd.grad(out, self._leaves, self._e_loss, allow_unused=True)
         else:
-            grads = torch.autograd.grad(loss, self._leaves, allow_unused=True)
+            grads = torch.autograd.grad(out, self._leaves, self._e_loss, allow_unused=True)
         for p, g in zip(self._params, grads):
             p.grad = g
-        self.out = torch.cat([terms.detach(), loss.detach().reshape(1)])
+        self.out = out.detach()
 
     def _warm_up(self, keep) -> None:
         """One eager step before the capture.  With deferred partial sums it is run twice from the same random
