@@ -16,10 +16,20 @@ JSON line:
   vs_baseline / dtype / data / config {workload, tiles_per_step, parallelism}      -- the task contract
   mp_edges_per_s, loss                                                              -- message-passing edges / s
   roofline {bound, kernel, achieved, peak, unit, frac, traffic, algorithmic_bytes_per_launch, ms_per_launch}
-  roofline_other {gatv2_bwd_tx_tx, gatv2_fwd_tx_tx_eval}                            -- the other aggregation kernels
+  roofline_other {gatv2_bwd_tx_tx, gatv2_fwd_tx_tx_eval,                            -- the other kernel classes of the step,
+                  projection_fwd, projection_bwd_one_pass, projection_bwd_two_kernels,  each {achieved GB/s, frac of 8 TB/s,
+                  first_layer_rowbias_fwd, positional_embedder_fwd, triplet_bwd_loss_tx} algorithmic_bytes_per_launch, ms_per_launch}
+      algorithmic bytes (s = element size, n = rows):  projection fwd  n (K + M) s ;  its whole backward (dX, dW, db)
+      n (M + 2 K) s -- dY and X read once, dX written once ;  first layer (row-bias form)  n (K + M) s + 4 n ids ;
+      positional embedder (training forward)  n (8 + D s) + stored activations 2 n (2 Dh s + 4) ;  triplet backward
+      E (3 C s) reads + 3 E C s atomic adds
+  step_algorithmic_frac = 55.4 GB (the aggregation of all 4 layers, fwd + bwd) / ms_per_step / 8 TB/s
   predict {ms_per_batch, edges_scored_per_s}                                        -- inference on the same tile
   f32 {ms_per_step, value}          (N = 1)  the same step at the reference's own arithmetic width (fp32 storage)
-  cpu_baseline {value, unit, cores, kind, sample, ...}   (N = 1)  the oracle on the host cores, C2/10 tile
+  cpu_baseline {value, unit, cores, kind, sample, ..., default_batch {value, ...}}
+      (N = 1)  the oracle on the host cores: C2/10 tile, 2 warm-ups + median of 5; `default_batch` = the
+      same on one packed 1M-edge batch, the CPU figure that belongs next to `strong`
+  strong_value, strong_graphed_value   -- copies of strong.value / strong.graphed.value at the top level
   strong {scaling: "strong", workload, n_gpus, world_size, n_ranks_seen, census, batches, steps_per_rank,
           epoch_s, value, unit, mp_edges_per_s}
       BASELINE config 4 as SURVEY.md 8(d) defines it: ONE fixed synthetic FOV (seed 0; every rank builds the same
@@ -76,6 +86,82 @@ def time_kernel(fn, iters=20, warm=3):
     return t0.elapsed_time(t1) / iters
 
 
+def other_kernel_classes(dev, n, etb, hc, elem, gen, ops, batch):
+    """HBM-roofline entries of the step's non-aggregation kernel classes at C2 size (bytes formulas: module docstring)."""
+    import torch
+    dt = torch.bfloat16
+    k, m = hc, 3 * hc
+    x = torch.randn(n, k, device=dev, generator=gen).to(dt)
+    w = (torch.randn(m, k, device=dev, generator=gen) / k ** 0.5).to(dt)
+    wt = w.t().contiguous()
+    gy = torch.randn(n, m, device=dev, generator=gen).to(dt)
+    out = {}
+
+    def entry(name, nbytes, fn, note=None):
+        ms = time_kernel(fn, iters=10, warm=2)
+        ach = nbytes / (ms * 1e-3) / 1e9
+        out[name] = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "unit": "GB/s", "algorithmic_bytes_per_launch": nbytes,
+                     "ms_per_launch": ms}
+        if note:
+            out[name]["note"] = note
+    y = torch.empty(n, m, dtype=dt, device=dev)
+    entry("projection_fwd", n * (k + m) * elem, lambda: ops.linear_fwd_launch(x, w, None, out=y),
+          "stacked lin_l | lin_r | lin_l projection of one layer: [n,128] -> [n,384]")
+    entry("projection_bwd_one_pass", n * (m + 2 * k) * elem, lambda: ops.linear_wgrad_dx_launch(gy, x, wt),
+          "dX, dW and db of that projection from ONE read of dY (segger_linear_wgrad_dx)")
+    entry("projection_bwd_two_kernels", n * (m + 2 * k) * elem,
+          lambda: (ops.linear_fwd_launch(gy, wt, None), ops.linear_wgrad_launch(gy, x)),
+          "the same result by the separate dX GEMM + weight-gradient kernel (dY read twice); same algorithmic bytes")
+    # first layer: per-gene table + positional GEMM
+    ids = batch["tx"]["x"].to(torch.int32).contiguous()
+    n_genes = int(ids.max()) + 1
+    tab = torch.randn(n_genes, m, device=dev, generator=gen).to(dt)
+    lib = _lib_handle()
+
+    def rowbias():
+        rc = lib.segger_linear_fwd_rowbias(x.data_ptr(), k, w.data_ptr(), None, tab.data_ptr(), m, ids.data_ptr(), y.data_ptr(),
+                                           m, n, k, m, _dtype_code(dt), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+    entry("first_layer_rowbias_fwd", n * (k + m) * elem + 4 * n, rowbias, "y = c Wc^T + T[gene] (segger_linear_fwd_rowbias)")
+    pos = batch["tx"]["pos"]
+    bvec = batch["tx"]["batch"]
+    mins, maxs = ops.segment_minmax(pos, bvec, 1)
+    l0 = torch.nn.Linear(256, 64).to(dev)
+    l2 = torch.nn.Linear(64, 64).to(dev)
+    entry("positional_embedder_fwd", n * (8 + hc * elem) + 2 * n * (2 * 64 * elem + 4),
+          lambda: ops.posmlp(pos, bvec, mins, maxs, l0.weight, l0.bias, l2.weight, l2.bias, dt, gelu=True),
+          "training forward (stores z1, h1, the normalised coordinates and the pre-activation)")
+    z = torch.nn.functional.normalize(torch.randn(n, 64, device=dev, generator=gen), dim=-1).to(dt).requires_grad_(True)
+    anchors = torch.arange(n, device=dev)
+    p_ = torch.randint(0, n, (n,), device=dev, generator=gen)
+    q_ = torch.randint(0, n, (n,), device=dev, generator=gen)
+
+    def trip():
+        z.grad = None
+        ops.triplet_edge_loss(z, None, anchors, p_, q_, 0.3).backward()
+    ms_fb = time_kernel(trip, iters=10, warm=2)
+    with torch.no_grad():
+        ms_f = time_kernel(lambda: ops.triplet_edge_loss(z, None, anchors, p_, q_, 0.3), iters=10, warm=2)
+    nb = n * 3 * 64 * elem * 2
+    ms = max(ms_fb - ms_f, 1e-6)
+    out["triplet_bwd_loss_tx"] = {"achieved": nb / (ms * 1e-3) / 1e9, "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
+                                  "algorithmic_bytes_per_launch": nb, "ms_per_launch": ms,
+                                  "note": "backward of loss_tx (1M triplets, zero fill + kernel; forward subtracted): 3 row "
+                                          "reads + 3 rows of float atomics per active triplet; memory-side atomics run at "
+                                          "~1.3 TB/s of added bytes on this part (MI355X_MICROARCH.md)"}
+    return out
+
+
+def _lib_handle():
+    from segger_amd import _lib
+    return _lib.load()
+
+
+def _dtype_code(dt):
+    from segger_amd import _lib
+    return _lib.DTYPE_CODE[dt]
+
+
 def host_threads():
     try:
         n = len(os.sched_getaffinity(0))
@@ -84,9 +170,10 @@ def host_threads():
     return max(1, min(n, 16))           # the GPU box gives 16 cores per GPU
 
 
-def cpu_baseline(sample_tx=100_000, sample_bd=1_000, k=15, budget_s=30.0):
+def cpu_baseline(sample_tx=100_000, sample_bd=1_000, k=15, n_warm=2, n_reps=5, label="C2/10"):
     """The oracle (pure-torch CPU restatement of the PyG path, fp32) timed on the
-    host cores over a bounded sample of the same workload (C2/10): fwd + seg loss + bwd."""
+    host cores over a bounded sample of the same workload (C2/10): fwd + seg loss + bwd,
+    2 warm-ups + the median of 5 repetitions."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import segger_oracle as O
     from segger_amd.synthetic import SyntheticSpec, make_graph
@@ -109,15 +196,13 @@ def cpu_baseline(sample_tx=100_000, sample_bd=1_000, k=15, budget_s=30.0):
         for v in sd.values():
             v.grad = None
     t_all = time.perf_counter()
-    n_warm = 1
-    for w in range(n_warm):                  # one warm-up, then the median of up to 3 steps inside the time budget
+    for w in range(n_warm):
         step()
-        log(f"[bench] cpu_baseline warm-up {w + 1}/{n_warm} done at {time.perf_counter() - t_all:.1f}s")
-    t_all = time.perf_counter()
+        log(f"[bench] cpu_baseline[{label}] warm-up {w + 1}/{n_warm} done at {time.perf_counter() - t_all:.1f}s")
     ts = []
-    while len(ts) < 3 and (not ts or time.perf_counter() - t_all + ts[-1] < budget_s):
+    for _ in range(n_reps):
         t = time.perf_counter(); step(); ts.append(time.perf_counter() - t)
-        log(f"[bench] cpu_baseline step {ts[-1]:.2f}s")
+        log(f"[bench] cpu_baseline[{label}] step {ts[-1]:.2f}s")
     reps = len(ts)
     dt = sorted(ts)[len(ts) // 2]
     etb = int(ei.shape[1])
@@ -131,9 +216,9 @@ def cpu_baseline(sample_tx=100_000, sample_bd=1_000, k=15, budget_s=30.0):
     return {
         "value": 2 * etb / dt, "unit": "edges/s", "cores": torch.get_num_threads(), "kind": "port",
         "host": {"cpu": cpu_model, "os_cpu_count": os.cpu_count(), "threads_used": torch.get_num_threads()},
-        "sample": f"oracle fp32 fwd+seg-loss+bwd on a {sample_tx}-tx/{sample_bd}-bd k={k} tile = C2/10 "
+        "sample": f"oracle fp32 fwd+seg-loss+bwd on a {sample_tx}-tx/{sample_bd}-bd k={k} tile = {label} "
                   f"(Etb={etb}; the GPU step also runs loss_tx, loss_bd and Adam), median of {reps} after "
-                  f"{n_warm} warm-up, {dt:.2f} s/step",
+                  f"{n_warm} warm-ups, {dt:.2f} s/step",
         "size_ratio_to_gpu_workload": sample_tx / 1_000_000,
         "mp_edges_per_s": mp_edges / dt,
     }
@@ -298,6 +383,8 @@ def main():
             extra["gatv2_fwd_tx_tx_eval"] = {"achieved": ach_e, "frac": ach_e / HBM_PEAK_GBS, "unit": "GB/s",
                                              "algorithmic_bytes_per_launch": b_fwd, "ms_per_launch": ms_eval}
         log(f"[bench] gatv2 fwd {ms_fwd:.3f} ms ({ach:.0f} GB/s alg.), bwd {ms_bwd:.3f} ms ({ach_b:.0f} GB/s alg.)")
+        if dtype == torch.bfloat16:
+            extra.update(other_kernel_classes(dev, n_tx, etb, hc, elem, gen, ops, batch))
 
     # ---- secondary figure: inference-only edge scoring (predict_step) on the same tile ----------------
     predict = None
@@ -400,6 +487,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline()
+            # the CPU figure for the default regime -- one packed 1M-edge batch (~50k tx, k = 15)
+            cpu["default_batch"] = cpu_baseline(sample_tx=50_000, sample_bd=500, n_warm=1, n_reps=3,
+                                                label="one 1M-edge batch (segger's edges_per_batch default)")
         except Exception as e:  # noqa: BLE001
             cpu = {"value": None, "error": repr(e)}
 
@@ -421,7 +511,14 @@ def main():
             "loss": loss_val,
             "roofline": roof, "roofline_other": extra, "cpu_baseline": cpu, "predict": predict,
             "f32": f32, "strong": strong,
+            "strong_value": None if not strong else strong.get("value"),
+            "strong_graphed_value": None if not strong or not strong.get("graphed") else strong["graphed"].get("value"),
         }
+        if args.dtype == "bf16":
+            b_step = n_layers * (gat_fwd_algorithmic_bytes(ett, args.n_tx, 128, 2) + gat_bwd_algorithmic_bytes(ett, args.n_tx, args.n_tx, 128, 2, 2)
+                                 + gat_fwd_algorithmic_bytes(etb, args.n_bd, 128, 2) + gat_bwd_algorithmic_bytes(etb, args.n_bd, args.n_tx, 128, 2, 2))
+            res["step_algorithmic_frac"] = b_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS   # per GPU (weak scaling)
+            res["step_algorithmic_bytes"] = b_step
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
