@@ -236,9 +236,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-f32", action="store_true", help="skip the fp32 secondary line")
     ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling (fixed FOV) record")
-    ap.add_argument("--strong-graphed-dp", action="store_true",
-                    help="N > 1: also run the strong epoch with captured steps (two hipGraphs around the all-reduce); "
-                         "default off until it has run over RCCL on a multi-GPU box (N = 1 always reports it)")
+    ap.add_argument("--strong-graphed-dp", action="store_true", help="(kept for old command lines; always on now)")
     ap.add_argument("--strong-n-tx", type=int, default=50_000_000, help="transcripts of the fixed FOV (BASELINE C3/C4)")
     ap.add_argument("--strong-n-bd", type=int, default=500_000)
     ap.add_argument("--strong-edges-per-batch", type=int, default=1_000_000,
@@ -296,7 +294,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         loss = model.training_step(batch, 0)
         loss.backward()
-        bucket.all_reduce_mean()           # one flat RCCL all-reduce (no-op for a single rank)
+        bucket.all_reduce_mean()           # pack + one flat RCCL all-reduce + divide (no-op for a single rank)
         opt.step()
         return loss
 
@@ -429,56 +427,95 @@ def main():
         sspec = SyntheticSpec(n_tx=args.strong_n_tx, n_bd=args.strong_n_bd, k_tx=args.k, seed=0)
         part, batches, saux, tiling = build_fov_batches(sspec, dev, edges_per_batch=args.strong_edges_per_batch)
         torch.cuda.synchronize()
-        log(f"[bench r{rank}] fixed FOV: {args.strong_n_tx} tx -> {len(tiling)} tiles, {len(batches)} batches "
+        n_tiles_all = len(tiling)
+        log(f"[bench r{rank}] fixed FOV: {args.strong_n_tx} tx -> {n_tiles_all} tiles, {len(batches)} batches "
             f"in {time.perf_counter() - t:.1f}s")
+        weights_all = batch_weights(part, batches)
+        e_tb, e_tt = part.edge_sizes[TX_BD].tolist(), part.edge_sizes[TX_TX].tolist()
+        units_of = {k: (sum(e_tb[t] for t in ids), sum(e_tt[t] for t in ids)) for k, ids in enumerate(batches)}
+        full_bytes = part.resident_bytes()
+        if world > 1:
+            # shard residency: every rank generated the same seed-0 FOV (no data-path collective), but it keeps only the
+            # tiles of the packed batches dp.rank_schedule deals to it -- "spatial tiles shard naturally" (north_star)
+            from segger_amd.dp import rank_schedule
+            mine = [k for k in rank_schedule(weights_all, world)[rank] if k is not None]
+            tiles_mine = sorted({t for k in mine for t in batches[k]})
+            remap = {t: i for i, t in enumerate(tiles_mine)}
+            local = part.shard(tiles_mine)
+            local_batches = {k: [remap[t] for t in batches[k]] for k in mine}
+            del part
+            part = local
+            torch.cuda.empty_cache()
+        else:
+            local_batches = dict(enumerate(batches))
+        torch.cuda.reset_peak_memory_stats()
+        resident = {"tiles": part.num_tiles, "tiles_total": n_tiles_all, "bytes": part.resident_bytes(),
+                    "fraction_of_fov": part.resident_bytes() / max(full_bytes, 1)}
         model.set_similarities(saux["tx_similarity"].to(dev), saux["bd_similarity"].to(dev))
         model.train(not args.no_dropout)
         seed_rank(0, rank, model.model)
-        e_tb, e_tt = part.edge_sizes[TX_BD].tolist(), part.edge_sizes[TX_TX].tolist()
 
         def strong_step(k, i):
             opt.zero_grad(set_to_none=True)
             if k is not None:
-                model.training_step(part.batch(batches[k]), i).backward()
-            bucket.all_reduce_mean()
+                model.training_step(part.batch(local_batches[k]), i).backward()
+            elif world > 1:
+                bucket.zero()                                  # an empty step sends zeros
+            bucket.all_reduce_mean(packed=(k is None))
             opt.step()
 
-        rec = strong_scaling_epoch(batch_weights(part, batches), strong_step,
-                                   lambda k: (sum(e_tb[t] for t in batches[k]), sum(e_tt[t] for t in batches[k])),
+        rec = strong_scaling_epoch(weights_all, strong_step, lambda k: units_of[k],
                                    sync=torch.cuda.synchronize, device=dev, warmup=-1)
         etb_f, ett_f = rec.pop("units_total")
         strong = dict(rec)
         strong.update({
             "workload": f"C4: fixed synthetic FOV (seed 0), {args.strong_n_tx} tx / {args.strong_n_bd} nuclei, k={args.k}, "
-                        f"{len(tiling)} tiles packed into {len(batches)} batches of <= {args.strong_edges_per_batch} edges, "
+                        f"{n_tiles_all} tiles packed into {len(batches)} batches of <= {args.strong_edges_per_batch} edges, "
                         f"one training epoch (the second over the stream: the first, untimed, builds the per-tile "
                         f"sampler indices), {args.dtype}",
             "n_gpus": world, "value": 2.0 * etb_f / rec["epoch_s"], "unit": "edges/s",
             "mp_edges_per_s": 4.0 * (ett_f + etb_f) / rec["epoch_s"],
             "ms_per_step": rec["epoch_s"] / max(rec["steps_per_rank"], 1) * 1e3,
+            "resident": resident,
             "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30})
-        if world == 1 or args.strong_graphed_dp:
-            try:
-                # the same epoch with every step replayed as ONE hipGraph (segger_amd.train_step_graph); with several
-                # ranks (opt-in) as two graphs around the eager all-reduce of the flat gradient bucket
-                from segger_amd.train_step_graph import GraphedTrainer
-                trainer = GraphedTrainer(model, model.configure_optimizers(capturable=True),
-                                         grad_sync=bucket.all_reduce_mean if world > 1 else None)
-                rec_g = strong_scaling_epoch(batch_weights(part, batches),
-                                             lambda k, i: trainer.step(part.batch(batches[k]) if k is not None else None),
-                                             lambda k: (sum(e_tb[t] for t in batches[k]), sum(e_tt[t] for t in batches[k])),
-                                             sync=torch.cuda.synchronize, device=dev, warmup=-1)
-                etb_g, ett_g = rec_g["units_total"]
-                strong["graphed"] = {
-                    "what": "the same second epoch, each training step (stage + forward + losses + backward + Adam) as one "
-                            "hipGraph replay on static buffers padded to a shape bucket",
-                    "value": 2.0 * etb_g / rec_g["epoch_s"], "unit": "edges/s", "epoch_s": rec_g["epoch_s"],
-                    "mp_edges_per_s": 4.0 * (ett_g + etb_g) / rec_g["epoch_s"],
-                    "ms_per_step": rec_g["epoch_s"] / max(rec_g["steps_per_rank"], 1) * 1e3,
-                    "shape_buckets": len(trainer.buckets)}
-                del trainer
-            except Exception as e:  # noqa: BLE001  (the eager record above stands on its own)
-                strong["graphed"] = {"value": None, "error": repr(e)}
+        # the same epoch with every step replayed as ONE hipGraph (segger_amd.train_step_graph); with several ranks as
+        # two graphs around the all-reduce of the persistent flat gradient buffer.  The ranks decide TOGETHER whether to
+        # run it: each first takes two captured steps with NO collective (pre-flight; rolled back), then all vote
+        # (dp.all_agree): one "no" and every rank skips the phase -- nobody is left alone inside an all-reduce.  A
+        # failure after the vote is not caught: the launcher tears the job down instead of deadlocking.
+        from segger_amd.dp import all_agree, restore_training_state, snapshot_training_state
+        from segger_amd.train_step_graph import GraphedTrainer
+        ok, err, trainer = True, None, None
+        try:
+            gopt = model.configure_optimizers(capturable=True)
+            snap = snapshot_training_state(model, gopt)
+            pre = GraphedTrainer(model, gopt, grad_sync=(lambda: None) if world > 1 else None)
+            own = [k for k in sorted(local_batches)][:2]
+            for k in own:
+                pre.step(part.batch(local_batches[k]))
+            torch.cuda.synchronize()
+            del pre
+            restore_training_state(model, snap, gopt)
+            trainer = GraphedTrainer(model, gopt, grad_bucket=bucket if world > 1 else None)
+        except Exception as e:  # noqa: BLE001  (local, collective-free: safe to catch)
+            ok, err = False, repr(e)
+        if all_agree(ok, device=dev):
+            rec_g = strong_scaling_epoch(weights_all,
+                                         lambda k, i: trainer.step(part.batch(local_batches[k]) if k is not None else None),
+                                         lambda k: units_of[k], sync=torch.cuda.synchronize, device=dev, warmup=-1)
+            etb_g, ett_g = rec_g["units_total"]
+            strong["graphed"] = {
+                "what": "the same second epoch, each training step (stage + forward + losses + backward + Adam) as one "
+                        "hipGraph replay on static buffers padded to a shape bucket" +
+                        ("" if world == 1 else "; N > 1: two graphs around one all-reduce of the persistent flat gradient buffer"),
+                "value": 2.0 * etb_g / rec_g["epoch_s"], "unit": "edges/s", "epoch_s": rec_g["epoch_s"],
+                "mp_edges_per_s": 4.0 * (ett_g + etb_g) / rec_g["epoch_s"],
+                "ms_per_step": rec_g["epoch_s"] / max(rec_g["steps_per_rank"], 1) * 1e3,
+                "n_ranks_seen": rec_g["n_ranks_seen"], "census": rec_g["census"],
+                "shape_buckets": len(trainer.buckets)}
+        else:
+            strong["graphed"] = {"value": None, "error": err or "another rank failed its pre-flight"}
+        del trainer
         if rank == 0:
             log(f"[bench] strong: {strong}")
         del part, batches

@@ -18,13 +18,14 @@ from torch import Tensor
 
 
 class FlatGradBucket:
-    """One flat fp32 gradient exchange per optimizer step.
+    """One flat fp32 gradient exchange per optimizer step on a PERSISTENT buffer.
 
-    Autograd leaves every parameter its own ``.grad`` tensor (with ``zero_grad(set_to_none=True)`` the
-    accumulation step is a pointer hand-over, not an add kernel per parameter).  ``all_reduce_mean`` packs
-    those ~50 tensors into ONE contiguous buffer (a single ``cat``), runs ONE collective on it, and scatters
-    the averaged slices back with one multi-tensor copy -- three launches instead of one collective per
-    parameter.  With a single rank it does nothing at all."""
+    Autograd leaves every parameter its own ``.grad`` tensor (with ``zero_grad(set_to_none=True)`` the accumulation
+    step is a pointer hand-over, not an add kernel per parameter).  ``pack`` gathers those ~50 tensors into the flat
+    buffer with ONE multi-tensor copy and re-points every ``.grad`` at its slice of it; ``all_reduce_mean`` then runs
+    ONE collective on the buffer and divides by the world size in place -- three launches, no allocation, and no copy
+    back: the optimizer reads the averaged slices.  The buffer is allocated once (same address every step; a captured
+    optimizer graph may read it).  With a single rank ``all_reduce_mean`` does nothing at all."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -35,26 +36,91 @@ class FlatGradBucket:
                 raise TypeError("parameters are kept in fp32")
         self.numel = sum(p.numel() for p in self.params)
         self.flat: torch.Tensor = torch.empty(0)
+        self.views: List[torch.Tensor] = []
 
-    def all_reduce_mean(self, group=None) -> None:
+    def _ensure(self) -> None:
+        dev = self.params[0].device
+        if self.flat.numel() != self.numel or self.flat.device != dev:
+            self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+            self.views, off = [], 0
+            for p in self.params:
+                self.views.append(self.flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+
+    def pack(self) -> None:
+        """``.grad`` tensors -> slices of the flat buffer (one multi-tensor copy), then ``.grad`` = those slices.  A
+        parameter without a gradient (a rank whose tile never touched it, an empty step) contributes zeros."""
+        self._ensure()
+        src, dst = [], []
+        for p, v in zip(self.params, self.views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                src.append(g); dst.append(v)
+            p.grad = v
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+    def zero(self) -> None:
+        """An empty step: zeros into the exchange."""
+        self._ensure()
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v
+
+    def all_reduce_mean(self, group=None, packed: bool = False) -> None:
+        """``packed``: the caller has already run :meth:`pack` / :meth:`zero` (e.g. inside a captured graph)."""
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(group)
         if world == 1:
             return
-        grads = []
-        for p in self.params:                      # a rank whose tile never touched a parameter sends zeros
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-            grads.append(p.grad)
-        self.flat = torch.cat([g.reshape(-1) for g in grads])
+        if not packed:
+            self.pack()
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         self.flat.div_(world)
-        views, off = [], 0
-        for g in grads:
-            views.append(self.flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
-        torch._foreach_copy_(grads, views)
+
+
+def all_agree(ok: bool, device=None, group=None) -> bool:
+    """True on every rank iff ``ok`` is true on every rank (one MIN all-reduce): how ranks decide TOGETHER whether to
+    enter a phase that contains collectives -- a rank that failed its local pre-flight must not leave the others
+    waiting inside an all-reduce."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return bool(ok)
+    v = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(v, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(v.item()))
+
+
+@torch.no_grad()
+def snapshot_training_state(module: torch.nn.Module, optimizer=None) -> dict:
+    """Copies of the parameters (and the optimizer's tensors) for :func:`restore_training_state`: a pre-flight that
+    takes real optimizer steps on rank-local data must not leave the replicas different."""
+    snap = {"params": [p.detach().clone() for p in module.parameters()], "opt": None}
+    if optimizer is not None:
+        snap["opt"] = {id(p): {k: (v.clone() if isinstance(v, Tensor) else v) for k, v in st.items()}
+                       for p, st in optimizer.state.items()}
+    return snap
+
+
+@torch.no_grad()
+def restore_training_state(module: torch.nn.Module, snap: dict, optimizer=None) -> None:
+    """In place (captured graphs keep their pointers): parameters back to the snapshot; optimizer tensors back to the
+    snapshot, or zeroed where the snapshot had none (Adam's initial state)."""
+    torch._foreach_copy_([p for p in module.parameters()], snap["params"])
+    if optimizer is not None:
+        old = snap["opt"] or {}
+        for p, st in optimizer.state.items():
+            for k, v in st.items():
+                if isinstance(v, Tensor):
+                    o = old.get(id(p), {}).get(k)
+                    v.zero_() if o is None else v.copy_(o)
+    try:
+        from . import ops
+        ops.invalidate_weights(module.parameters())
+    except Exception:  # noqa: BLE001  (CPU-only use)
+        pass
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> None:

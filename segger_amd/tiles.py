@@ -287,6 +287,84 @@ class TilePartition:
             store.move_to_end(key)
         return entry
 
+    def shard(self, tile_ids: Sequence[int]) -> "TilePartition":
+        """A partition holding ONLY the given tiles (renumbered 0 .. k-1 in the given order), with its own copies of
+        their node / edge slices and of the slide-level CSR slices: what a data-parallel rank keeps resident once it
+        knows which packed batches it will train on (tiles are independent graphs: ``partition/dataset.py:480-494``
+        drops every inter-tile edge).  ``shard(ids).batch([i, j])`` equals ``self.batch([ids[i], ids[j]])``."""
+        ids = [int(t) for t in tile_ids]
+        if len(set(ids)) != len(ids) or any(not 0 <= t < self.num_tiles for t in ids):
+            raise IndexError("shard: tile ids must be distinct and in range")
+        new = TilePartition.__new__(TilePartition)
+        new.num_tiles = len(ids)
+        new.node_perm, new.node_indptr, new.node_sizes = {}, {}, {}
+        new.edge_indptr, new.edge_sizes = {}, {}
+        new.data = HeteroBatch(num_graphs=1)
+        take = lambda v, ptr: (torch.cat([v[ptr[t]:ptr[t + 1]] for t in ids], 0) if ids else v[:0]).clone()
+        new_base: Dict[str, List[int]] = {}
+        for nt, store in self.data._nodes.items():
+            ptr = self._nptr[nt]
+            sizes = self.node_sizes[nt][ids] if ids else self.node_sizes[nt][:0]
+            new.node_sizes[nt] = sizes.clone()
+            new.node_indptr[nt] = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)])
+            new.node_perm[nt] = take(self.node_perm[nt], ptr)
+            for a, v in store.items():
+                new.data[nt][a] = take(v, ptr) if isinstance(v, Tensor) else v
+            run, base = 0, []
+            for t in ids:
+                base.append(run); run += ptr[t + 1] - ptr[t]
+            new_base[nt] = base
+        for et, store in self.data._edges.items():
+            s_, _, d_ = et
+            ptr = self._eptr[et]
+            sizes = self.edge_sizes[et][ids] if ids else self.edge_sizes[et][:0]
+            new.edge_sizes[et] = sizes.clone()
+            new.edge_indptr[et] = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)])
+            ei = store["edge_index"]
+            parts = []
+            for j, t in enumerate(ids):                      # endpoints move with their tile's first node
+                shift = torch.tensor([[new_base[s_][j] - self._nptr[s_][t]], [new_base[d_][j] - self._nptr[d_][t]]],
+                                     dtype=ei.dtype, device=ei.device)
+                parts.append(ei[:, ptr[t]:ptr[t + 1]] + shift)
+            new.data[et]["edge_index"] = torch.cat(parts, 1) if parts else ei[:, :0].clone()
+        new._nptr = {k: v.tolist() for k, v in new.node_indptr.items()}
+        new._eptr = {k: v.tolist() for k, v in new.edge_indptr.items()}
+        if getattr(self, "_csr", None):                     # tile-local coordinates: slices carry over unchanged
+            new.csr_max_tiles = self.csr_max_tiles
+            new._src_unique = dict(self._src_unique)
+            new._csr = {}
+            for et, views in self._csr.items():
+                s_, _, d_ = et
+                new._csr[et] = {}
+                for side, row_t in (("by_dst", d_), ("by_src", s_)):
+                    v = views[side]
+                    new._csr[et][side] = {"ptr": take(v["ptr"], self._nptr[row_t]),
+                                          "col": take(v["col"], self._eptr[et]), "eid": take(v["eid"], self._eptr[et])}
+        for k in ("persist_max", "csr_sort_max_edges"):
+            if k in self.__dict__:
+                setattr(new, k, self.__dict__[k])
+        return new
+
+    def resident_bytes(self) -> int:
+        """Bytes of every tensor this partition keeps (node / edge stores, permutations, CSR slices)."""
+        seen, total = set(), 0
+
+        def add(t):
+            nonlocal total
+            if isinstance(t, Tensor) and t.data_ptr() not in seen:
+                seen.add(t.data_ptr()); total += t.numel() * t.element_size()
+        for store in list(self.data._nodes.values()) + list(self.data._edges.values()):
+            for v in store.values():
+                add(v)
+        for d in (self.node_perm, self.node_indptr, self.edge_indptr):
+            for v in d.values():
+                add(v)
+        for views in (getattr(self, "_csr", None) or {}).values():
+            for side in views.values():
+                for v in side.values():
+                    add(v)
+        return total
+
     def add_node_attr(self, node_type: str, name: str, value: Tensor, permuted: bool = False) -> None:
         self.data[node_type][name] = value if permuted else value.index_select(0, self.node_perm[node_type])
 

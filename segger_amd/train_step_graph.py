@@ -28,10 +28,11 @@ replay because the parameters change without Python noticing.  The capture runs 
 weight refresh baked into the graph touches only the compute-dtype copies of THIS step's parameter aliases, which the
 step keeps alive (``_pack_refs``), never another model's.
 
-Data parallelism (``GraphedTrainer(..., grad_sync=bucket.all_reduce_mean)``): the step is captured as TWO graphs --
-forward + backward, and Adam -- with the gradient exchange between them run eagerly (one collective per step on every
-rank, whatever a rank is capturing; a rank that ran out of batches zeroes its gradients instead of replaying the first
-graph).  Covered by a two-rank gloo test on one GPU; not yet run over RCCL on a multi-GPU box.
+Data parallelism (``GraphedTrainer(..., grad_bucket=dp.FlatGradBucket(...))``): the step is captured as TWO graphs --
+forward + backward + the packing of the gradients into the bucket's persistent flat buffer, and Adam reading that
+buffer's slices -- with the gradient exchange between them run eagerly: one all-reduce + one divide per step on every
+rank, whatever a rank is capturing; a rank that ran out of batches zeroes the buffer instead of replaying the first
+graph.  Covered by a two-rank gloo test on one GPU; not yet run over RCCL on a multi-GPU box.
 """
 from __future__ import annotations
 
@@ -67,8 +68,13 @@ class GraphedTrainStep:
     CSR views, the rows-by-gene grouping of the embedding gradient, the segmentation triplets and the loss samplers'
     indices are all "copy the batch's own (cached) arrays, fill the padding by a formula" segments."""
 
-    def __init__(self, lit_model, optimizer, sizes: Dict[str, int], template, grad_sync=None):
-        self.grad_sync = grad_sync
+    def __init__(self, lit_model, optimizer, sizes: Dict[str, int], template, grad_sync=None, grad_bucket=None):
+        if grad_bucket is None and hasattr(getattr(grad_sync, "__self__", None), "pack"):
+            grad_bucket, grad_sync = grad_sync.__self__, None     # bucket.all_reduce_mean given as the callable
+        self.grad_sync, self.grad_bucket = grad_sync, grad_bucket
+        self.split = grad_sync is not None or grad_bucket is not None
+        if grad_bucket is not None:
+            grad_bucket._ensure()                             # the flat buffer must exist before anything is captured
         if lit_model._sg_loss_type != "triplet":
             raise NotImplementedError("the graphed step covers the (default) triplet segmentation loss")
         if lit_model.loss_tx is None or lit_model.loss_bd is None:
@@ -329,12 +335,14 @@ class GraphedTrainStep:
             ops.invalidate_weights(aliases)                   # the captured step starts with the weight refresh ...
             self.graph = torch.cuda.CUDAGraph()
             with ops.pack_scope(aliases):                     # ... of this step's own packs only
-                if self.grad_sync is None:
+                if not self.split:
                     with torch.cuda.graph(self.graph):
                         self._run()
-                else:                                         # forward + backward | <gradient exchange> | Adam
+                else:                                         # forward + backward (+ pack) | <exchange> | Adam
                     with torch.cuda.graph(self.graph):
                         self._run_grads()
+                        if self.grad_bucket is not None:      # gradients -> the bucket's flat buffer; .grad = its slices
+                            self.grad_bucket.pack()
                     self.graph_opt = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
                         self.opt.step()
@@ -357,8 +365,18 @@ class GraphedTrainStep:
         rank ran out of batches), hand this bucket's gradient tensors to the parameters, let ``grad_sync`` exchange
         them (exactly ONE collective per step on every rank: the warm-up of a capture never synchronises), replay
         Adam."""
-        if self.grad_sync is None:
+        if not self.split:
             self.graph.replay()
+            return
+        if self.grad_bucket is not None:
+            if empty:
+                self.grad_bucket.zero()
+            else:
+                self.graph.replay()                           # ends with the pack into the flat buffer
+                for p, v in zip(self.grad_bucket.params, self.grad_bucket.views):
+                    p.grad = v
+            self.grad_bucket.all_reduce_mean(packed=True)
+            self.graph_opt.replay()                           # reads the buffer's slices
             return
         if empty:
             torch._foreach_zero_([g for g in self._grads if g is not None])
@@ -366,7 +384,7 @@ class GraphedTrainStep:
             self.graph.replay()
         for p, g in zip(self._params, self._grads):
             p.grad = g
-        self.grad_sync()
+        self.grad_sync()          # must average IN PLACE: the captured optimizer reads the tensors .grad points at now
         self.graph_opt.replay()
 
     def empty_step(self) -> None:
@@ -379,28 +397,36 @@ class GraphedTrainer:
     when none fits or the tightest one would pad the transcript side by more than two granules; with ``max_buckets``
     captured, the tightest fit is used whatever it wastes, and a batch no bucket holds is an error."""
 
-    def __init__(self, lit_model, optimizer, granularity: float = 1.06, max_buckets: int = 24, grad_sync=None):
-        """``grad_sync`` (data parallelism): a callable that averages the parameters' ``.grad`` over the ranks, e.g.
-        ``dp.FlatGradBucket(model.parameters()).all_reduce_mean``.  The step is then two graphs with the exchange
-        between them, run eagerly (one collective per ``step`` call on every rank; ``step(None)`` is the empty step
-        of a rank that ran out of batches: zeros into the exchange, then Adam)."""
+    def __init__(self, lit_model, optimizer, granularity: float = 1.06, max_buckets: int = 24, grad_sync=None,
+                 grad_bucket=None):
+        """Data parallelism: ``grad_bucket`` = a ``dp.FlatGradBucket`` over the model's parameters (the captured
+        backward packs into its flat buffer, Adam reads its slices; per step one all-reduce and one divide run eagerly
+        between the two graphs), or ``grad_sync`` = any callable that averages the tensors ``.grad`` points at IN PLACE.
+        One collective per ``step`` call on every rank; ``step(None)`` is the empty step of a rank that ran out of
+        batches: zeros into the exchange, then Adam."""
         self.lit, self.opt, self.granularity, self.max_buckets = lit_model, optimizer, granularity, max_buckets
-        self.grad_sync = grad_sync
+        if grad_bucket is None and hasattr(getattr(grad_sync, "__self__", None), "pack"):
+            grad_bucket, grad_sync = grad_sync.__self__, None
+        self.grad_sync, self.grad_bucket = grad_sync, grad_bucket
         self.buckets: List[GraphedTrainStep] = []
         self.n_captures = 0
         self._last: Optional[GraphedTrainStep] = None
 
     def _empty_step(self) -> None:
-        if self.grad_sync is None:
+        if self.grad_sync is None and self.grad_bucket is None:
             return
         if self._last is not None and self._last.graph_opt is not None:
             self._last.empty_step()
             return
-        for g in self.opt.param_groups:                       # no bucket captured yet on this rank: eager
-            for p in g["params"]:
-                if p.requires_grad:
-                    p.grad = torch.zeros_like(p)
-        self.grad_sync()
+        if self.grad_bucket is not None:                      # no bucket captured yet on this rank: eager
+            self.grad_bucket.zero()
+            self.grad_bucket.all_reduce_mean(packed=True)
+        else:
+            for g in self.opt.param_groups:
+                for p in g["params"]:
+                    if p.requires_grad:
+                        p.grad = torch.zeros_like(p)
+            self.grad_sync()
         self.opt.step()
 
     def step(self, batch) -> Optional[Tensor]:
@@ -413,7 +439,8 @@ class GraphedTrainer:
             if full:
                 raise RuntimeError(f"no captured bucket holds this batch and {self.max_buckets} buckets exist: "
                                    f"raise `granularity` or `max_buckets`")
-            best = GraphedTrainStep(self.lit, self.opt, step_bucket(batch, self.granularity), batch, self.grad_sync)
+            best = GraphedTrainStep(self.lit, self.opt, step_bucket(batch, self.granularity), batch, self.grad_sync,
+                                    self.grad_bucket)
             self.buckets.append(best)
             self.n_captures += 1
         self._last = best

@@ -38,9 +38,11 @@ def main():
     seed_rank(7, rank, m.model)
     opt = m.configure_optimizers(capturable=True)
     bucket = FlatGradBucket(m.parameters())
-    trainer = GraphedTrainer(m, opt, granularity=1.4, grad_sync=bucket.all_reduce_mean)
+    trainer = GraphedTrainer(m, opt, granularity=1.4, grad_bucket=bucket)
     losses = []
     epochs = 4
+    bucket._ensure()
+    flat_ptr0 = bucket.flat.data_ptr()
     for ep in range(epochs):
         for k in sched:
             out = trainer.step(part.batch(batches[k]) if k is not None else None)
@@ -53,7 +55,9 @@ def main():
     steps = float(next(iter(opt.state.values()))["step"])
     print(json.dumps({"rank": rank, "own": sum(k is not None for k in sched), "steps_per_epoch": len(sched),
                       "adam_steps": steps, "epochs": epochs, "captures": trainer.n_captures,
-                      "finite": bool(torch.isfinite(flat).all()),
+                      "finite": bool(torch.isfinite(flat).all()), "flat_ptr_stable": bucket.flat.data_ptr() == flat_ptr0,
+                      "grads_are_views": all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                                             for p, v in zip(bucket.params, bucket.views)),
                       "max_param_diff": max(float((g - flat).abs().max()) for g in gathered),
                       "first": sum(losses[: len(losses) // epochs]), "last": sum(losses[-(len(losses) // epochs):])}),
           flush=True)

@@ -184,3 +184,98 @@ def test_strong_scaling_epoch_single_process():
     seen = []
     rec = strong_scaling_epoch([2.0, 1.0, 4.0], lambda k, i: seen.append(k), lambda k: (1.0,))
     assert seen == [2, 0, 1] and rec["units_total"] == [3.0] and rec["n_ranks_seen"] == 1 and rec["steps_per_rank"] == 3
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 3: shard residency, the persistent flat gradient buffer, and the collective vote before a phase with collectives
+def _round3_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from segger_amd import tiles as T
+    from segger_amd.dp import FlatGradBucket, all_agree, broadcast_parameters, rank_schedule
+    from segger_amd.hetero import TX_BD, TX_TX
+    from segger_amd.synthetic import SyntheticSpec, make_graph
+    res = {}
+    # (a) every rank builds the same graph, partitions it, and keeps only the tiles of its own batches
+    g = make_graph(SyntheticSpec(n_tx=4000, n_bd=120, k_tx=6, seed=9))
+    for nt in ("tx", "bd"):
+        del g[nt]["mask"]
+    part = T.partition_by_tiling(g, T.SquareTiling(torch.cat([g["tx"].pos, g["bd"].pos]), 22.0), margin=2.0)
+    sampler = T.TileBatchSampler(part, max(part.weights("edge")) * 2, mode="edge", skip_too_big=True)
+    batches = list(sampler)
+    w = part.weights("edge")
+    weights = [float(sum(w[t] for t in ids)) for ids in batches]
+    mine = [k for k in rank_schedule(weights, world)[rank] if k is not None]
+    tiles_mine = sorted({t for k in mine for t in batches[k]})
+    remap = {t: i for i, t in enumerate(tiles_mine)}
+    local = part.shard(tiles_mine)
+    same = True
+    for k in mine:
+        a, b = local.batch([remap[t] for t in batches[k]]), part.batch(batches[k])
+        same &= all(torch.equal(a[nt][key], b[nt][key]) for nt in ("tx", "bd") for key in ("x", "pos", "index", "mask", "batch"))
+        same &= all(torch.equal(a[et].edge_index, b[et].edge_index) for et in (TX_TX, TX_BD))
+    res["shard_batches_equal"] = bool(same)
+    res["resident_fraction"] = local.resident_bytes() / part.resident_bytes()
+    res["tiles"] = tiles_mine
+    # (b) persistent flat buffer: same address every step, .grad = its slices, values = the mean over the ranks
+    torch.manual_seed(3)
+    lin = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Linear(4, 2))
+    broadcast_parameters(lin)
+    bucket = FlatGradBucket(lin.parameters())
+    ptrs, views_ok, mean_ok = [], True, True
+    for step in range(3):
+        lin.zero_grad(set_to_none=True)
+        x = torch.full((3, 5), float(rank + 1 + step))
+        lin(x).sum().backward()
+        own = [p.grad.clone() for p in lin.parameters()]
+        bucket.all_reduce_mean()
+        ptrs.append(bucket.flat.data_ptr())
+        views_ok &= all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, [o.tolist() for o in own])
+        want = [sum(torch.tensor(gr[i]) for gr in gathered) / world for i in range(len(own))]
+        mean_ok &= all(torch.allclose(p.grad, w_) for p, w_ in zip(lin.parameters(), want))
+    bucket.zero()                                           # an empty step: zeros in, .grad still the slices
+    res["flat_ptr_stable"] = len(set(ptrs)) == 1 and bucket.flat.data_ptr() == ptrs[0]
+    res["grads_are_views"], res["mean_ok"] = bool(views_ok), bool(mean_ok)
+    res["zero_ok"] = bool((bucket.flat == 0).all()) and all(p.grad is not None for p in lin.parameters())
+    # (c) vote: a rank that failed its collective-free pre-flight makes EVERY rank skip the phase
+    try:
+        if rank == 1:
+            raise RuntimeError("pre-flight failed on this rank")
+        ok = True
+    except RuntimeError:
+        ok = False
+    entered = all_agree(ok)
+    if entered:                                             # would deadlock if only some ranks came here
+        dist.all_reduce(torch.ones(1))
+    res["entered_after_no_vote"] = entered
+    res["agree_when_all_ok"] = all_agree(True)
+    alive = torch.ones(1)
+    dist.all_reduce(alive)                                  # both ranks are still in step with each other
+    res["alive"] = float(alive)
+    allres = [None] * world
+    dist.all_gather_object(allres, res)
+    if rank == 0:
+        out.put(allres)
+    dist.destroy_process_group()
+
+
+def test_shard_residency_persistent_bucket_and_vote_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_round3_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r["shard_batches_equal"] for r in res)
+    assert not set(res[0]["tiles"]) & set(res[1]["tiles"])                  # disjoint tile sets ...
+    assert abs(res[0]["resident_fraction"] + res[1]["resident_fraction"] - 1.0) < 0.15   # ... that split the bytes
+    assert all(0.25 < r["resident_fraction"] < 0.75 for r in res)           # about 1 / world each
+    for r in res:
+        assert r["flat_ptr_stable"] and r["grads_are_views"] and r["mean_ok"] and r["zero_ok"]
+        assert r["entered_after_no_vote"] is False and r["agree_when_all_ok"] is True and r["alive"] == 2.0

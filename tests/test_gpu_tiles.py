@@ -178,6 +178,28 @@ def test_slide_csr_sorted_in_tile_ranges_equals_one_sort(graphs):
         many.build_csr()
 
 
+def test_shard_of_a_csr_partition_hands_out_the_same_views(graphs):
+    """``TilePartition.shard`` (a data-parallel rank's resident subset) carries the slide-level CSR slices along: batches
+    of the shard get the same sorted views as the same batches of the full partition."""
+    from segger_amd.graph import batch_cache, edge_graph
+    host, dev = graphs
+    part = T.partition_by_tiling(dev, T.SquareTiling(all_pos(dev), 25.0), margin=2.0)
+    part.build_csr()
+    part.csr_max_tiles = 8
+    mine = list(range(1, len(part), 2))
+    local = part.shard(mine)
+    assert local.resident_bytes() < 0.7 * part.resident_bytes()
+    for loc in ([0], [2, 1], [len(mine) - 1]):
+        a, b = local.batch(loc), part.batch([mine[i] for i in loc])
+        for et in ETS:
+            assert torch.equal(a[et].edge_index, b[et].edge_index)
+            ga = edge_graph(batch_cache(a), et, a[et].edge_index, a[et[0]].num_nodes, a[et[2]].num_nodes)
+            gb = edge_graph(batch_cache(b), et, b[et].edge_index, b[et[0]].num_nodes, b[et[2]].num_nodes)
+            for side in ("by_dst", "by_src"):
+                x, y = getattr(ga, side), getattr(gb, side)
+                assert torch.equal(x.indptr, y.indptr) and torch.equal(x.col, y.col) and torch.equal(x.eid, y.eid)
+
+
 def test_staged_padded_batch_equals_partition_batch(cuda):
     """The captured training step's static buffers after ONE ``segger_stage`` launch: the real prefix of every array is
     the batch ``TilePartition.batch`` assembled (node features, the three CSR views == host stable sort of the batch's

@@ -178,5 +178,6 @@ def test_graphed_trainer_data_parallel(cuda, tmp_path):
     assert {x["own"] for x in recs} == {recs[0]["steps_per_epoch"], recs[0]["steps_per_epoch"] - 1}   # one empty step
     for x in recs:
         assert x["finite"] and x["max_param_diff"] == 0.0
+        assert x["flat_ptr_stable"] and x["grads_are_views"]        # persistent flat buffer, .grad = its slices
         assert x["adam_steps"] == x["epochs"] * x["steps_per_epoch"]
         assert x["last"] < x["first"]

@@ -221,3 +221,31 @@ def test_persistent_store_is_bounded(graph):
     batch_cache(part.batch([0, 1]))                                          # 5th entry evicts the least recently used: [1]
     assert len(part._persist) == 4 and (1,) not in part._persist and (0,) in part._persist
     assert "marker" not in batch_cache(part.batch([1]))["persistent"]
+
+
+def test_shard_keeps_only_its_tiles_and_batches_match(graph):
+    """``TilePartition.shard``: a data-parallel rank's resident subset.  Batches assembled on the shard are identical to
+    the same batches assembled on the full partition; two complementary shards hold every node and edge exactly once
+    and about half the bytes each."""
+    part = T.partition_by_tiling(graph, T.SquareTiling(all_pos(graph), 25.0), margin=2.0)
+    n_t = len(part)
+    mine, theirs = list(range(0, n_t, 2)), list(range(1, n_t, 2))
+    a, b = part.shard(mine), part.shard(theirs)
+    assert len(a) == len(mine) and len(b) == len(theirs)
+    for nt in ("tx", "bd"):
+        assert int(a.node_sizes[nt].sum()) + int(b.node_sizes[nt].sum()) == int(part.node_sizes[nt].sum())
+        assert sorted(torch.cat([a.node_perm[nt], b.node_perm[nt]]).tolist()) == sorted(part.node_perm[nt].tolist())
+    for et in (TX_TX, TX_BD, TX_NB_BD):
+        assert int(a.edge_sizes[et].sum()) + int(b.edge_sizes[et].sum()) == int(part.edge_sizes[et].sum())
+    assert 0.3 * part.resident_bytes() < a.resident_bytes() < 0.7 * part.resident_bytes()
+    for local, glob in (([0], [mine[0]]), ([2, 0, 1], [mine[2], mine[0], mine[1]]), (list(range(len(mine))), mine)):
+        x, y = a.batch(local), part.batch(glob)
+        assert x.num_graphs == y.num_graphs
+        for nt in ("tx", "bd"):
+            for k in ("x", "pos", "index", "mask", "cluster", "batch"):
+                assert torch.equal(x[nt][k], y[nt][k]), (nt, k)
+        for et in (TX_TX, TX_BD, TX_NB_BD):
+            assert torch.equal(x[et].edge_index, y[et].edge_index), et
+    assert part.shard([]).num_tiles == 0
+    with pytest.raises(IndexError):
+        part.shard([0, 0])
