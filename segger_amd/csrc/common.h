@@ -34,6 +34,13 @@ int hip_fail(hipError_t e, const char* what);
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ------------------------------------------------- fp32 projections (csrc/linear_f32.hip) ---
+int linear_f32_launch(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t n_rows,
+                      int k_in, int m_out, hipStream_t stream);
+size_t wgrad_f32_workspace_bytes(int64_t n_rows, int m_out, int k_in);
+int wgrad_f32_launch(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, int64_t n_rows, int m_out, int k_in,
+                     float* partial, int64_t* n_slabs, hipStream_t stream);
+
 // ------------------------------------------------- deferred partial sums ---
 // out0[e] (e < split) / out1[e - split] (e >= split; out1 may be NULL) = sum_s partial[s * width + e], slabs in order.
 // Between segger_reductions_defer_begin() and segger_reductions_flush() (csrc/reduce.hip) the kernels that leave

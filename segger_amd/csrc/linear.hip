@@ -237,7 +237,7 @@ using namespace segger;
 
 extern "C" int segger_linear_supported(int32_t k_in, int32_t m_out, int32_t dtype) {
   const bool k_ok = k_in == 64 || k_in == 128 || k_in == 256 || k_in == 384;
-  return k_ok && m_out > 0 && m_out % kChunk == 0 && (dtype == SEGGER_BF16 || dtype == SEGGER_F16);
+  return k_ok && m_out > 0 && m_out % kChunk == 0 && (dtype == SEGGER_BF16 || dtype == SEGGER_F16 || dtype == SEGGER_F32);
 }
 
 extern "C" int segger_linear_fwd(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy,
@@ -250,7 +250,7 @@ extern "C" int segger_linear_fwd_silu_grad(const void* x, int64_t ldx, const voi
                                            int32_t dtype, segger_stream_t stream) {
   SEGGER_REQUIRE(n_rows >= 0 && k_in > 0 && m_out > 0, "segger_linear_fwd_silu_grad: bad sizes");
   if (n_rows == 0) return SEGGER_OK;
-  SEGGER_REQUIRE(segger_linear_supported(k_in, m_out, dtype) && k_in == 64,
+  SEGGER_REQUIRE(segger_linear_supported(k_in, m_out, dtype) && k_in == 64 && dtype != SEGGER_F32,
                  "segger_linear_fwd_silu_grad: k_in 64, m_out %% 64 == 0, bf16 / f16");
   SEGGER_REQUIRE(x && w && y && gate, "segger_linear_fwd_silu_grad: NULL pointer");
   SEGGER_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y) && aligned16(gate),
@@ -275,6 +275,12 @@ extern "C" int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void*
   }
   SEGGER_REQUIRE(x && w && y, "segger_linear_fwd: NULL pointer");
   SEGGER_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), "segger_linear_fwd: pointers must be 16-byte aligned");
+  if (dtype == SEGGER_F32) {       // fp32 storage: exact-fp32 MFMA kernel (csrc/linear_f32.hip); plain projection only
+    SEGGER_REQUIRE(!rowbias && !rowidx, "segger_linear_fwd_rowbias: the per-row table form is 16-bit only");
+    SEGGER_REQUIRE(ldx >= k_in && ldy >= m_out && ldx % 4 == 0 && ldy % 4 == 0 && (!bias || aligned16(bias)),
+                   "segger_linear_fwd: fp32 rows (and the bias) must be 16-byte aligned");
+    return linear_f32_launch(x, ldx, w, bias, y, ldy, n_rows, k_in, m_out, (hipStream_t)stream);
+  }
   SEGGER_REQUIRE(ldx >= k_in && ldy >= m_out && (ldx * 2) % 16 == 0 && (ldy * 2) % 16 == 0,
                  "segger_linear_fwd: bad leading dimension");
   SEGGER_REQUIRE(!rowbias == !rowidx, "segger_linear_fwd_rowbias: rowbias and rowidx go together");

@@ -1,0 +1,307 @@
+// The projections of the encoder at the REFERENCE'S arithmetic width: fp32 storage, fp32 products, fp32 accumulation
+// (segger trains with a default Trainer(), i.e. fp32: src/segger/cli/segment.py:400-405), on the matrix cores'
+// f32-input form v_mfma_f32_32x32x2_f32 -- exact fp32 (the same result as a chain of fmaf), 64 FLOP/clk/SIMD, i.e. 157
+// TFLOP/s on the chip.  At n ~ 10^6 rows and K, M <= 384 these GEMMs are MFMA-bound (0.1 TFLOP against 2 GB: 0.63 ms of
+// matrix time, 0.4 ms of traffic), unlike their bf16 forms, so the kernels below are built to keep the MFMA pipe fed and
+// to touch every matrix once; the vendor GEMM they replace re-reads the tall operand per column macro-tile.
+//
+//   segger_linear_fwd (dtype f32):   Y[n, M] = X[n, K] W[M, K]^T + b            (also dX = dY W, called with W^T)
+//   segger_linear_wgrad (dtype f32): dW[M, K] = dY[n, M]^T X[n, K],  db = sum_n dY
+//
+// Operand layout of v_mfma_f32_32x32x2_f32: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31],
+// ONE float each.  The k order of a product is free as long as A and B agree, so a lane fetches FOUR consecutive k of its
+// row with one 16-byte load (lane half h covers k = 8 t + 4 h + u, u = 0..3) and feeds them to four MFMAs.
+#include "common.h"
+
+namespace segger {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mfma_f32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ forward / dX
+struct LinF32Params {
+  const float* x; int64_t ldx;
+  const float* w;            // [m_out, K] row-major
+  const float* bias;         // [m_out] or NULL
+  float* y; int64_t ldy;
+  int64_t n_rows;
+  int m_out;
+};
+
+// A workgroup (4 waves) owns 128 rows and produces all M columns: X is read once.  A wave keeps its 32 rows as B-operand
+// fragments in registers (K / 2 VGPRs); W streams through LDS in chunks of CH output columns (row stride K + 4 floats:
+// the ds_read_b128 of 16 different rows hit 16 disjoint 4-bank groups), the next chunk prefetched under the MFMAs.
+// D = W_chunk X_tile^T: a lane owns one DATA row and 4-column groups of the output -> 16-byte stores, 32 bytes per row
+// and instruction, the four groups of a tile completing 128-byte lines.
+template <int K>
+__global__ __launch_bounds__(256, K <= 256 ? 2 : 1) void linear_f32_kernel(LinF32Params p) {
+  constexpr int CH = K <= 128 ? 64 : 32;                 // output columns per W chunk
+  constexpr int CT = CH / 32;                            // 32-column tiles per chunk
+  constexpr int NT = K / 8;                              // 16-byte k groups
+  constexpr int WS = K + 4;                              // LDS row stride (floats)
+  constexpr int PPT = CH * K / 4 / 256;                  // float4 pieces of a chunk per thread
+  static_assert((CH * K / 4) % 256 == 0, "chunk must split evenly over the block");
+  __shared__ __attribute__((aligned(16))) float lds_w[CH * WS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t row0 = (int64_t)blockIdx.x * 128 + wave * 32;
+  int64_t row = row0 + r;
+  const bool row_ok = row < p.n_rows;
+  if (!row_ok) row = p.n_rows - 1;                       // clamp: loaded, never stored
+
+  f32x4 xq[NT];
+  {
+    const float* xr = p.x + row * p.ldx + 4 * h;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xq[t] = *reinterpret_cast<const f32x4*>(xr + 8 * t);
+  }
+  f32x4 wreg[PPT];
+  auto w_fetch = [&](int c0) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int piece = tid + 256 * i, wrow = piece / (K / 4), wcol = piece % (K / 4);
+      wreg[i] = *reinterpret_cast<const f32x4*>(p.w + (int64_t)(c0 + wrow) * K + wcol * 4);
+    }
+  };
+  auto w_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int piece = tid + 256 * i, wrow = piece / (K / 4), wcol = piece % (K / 4);
+      *reinterpret_cast<f32x4*>(lds_w + wrow * WS + wcol * 4) = wreg[i];
+    }
+  };
+
+  const int n_chunks = p.m_out / CH;
+  w_fetch(0);
+  for (int c = 0; c < n_chunks; ++c) {
+    const int c0 = c * CH;
+    __syncthreads();                                     // every wave has left the previous chunk's reads
+    w_commit();
+    __syncthreads();
+    if (c + 1 < n_chunks) w_fetch(c0 + CH);
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[ct][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+        const f32x4 wq = *reinterpret_cast<const f32x4*>(lds_w + (ct * 32 + r) * WS + 8 * t + 4 * h);
+        acc[ct] = mfma_f32(wq.x, xq[t].x, acc[ct]);
+        acc[ct] = mfma_f32(wq.y, xq[t].y, acc[ct]);
+        acc[ct] = mfma_f32(wq.z, xq[t].z, acc[ct]);
+        acc[ct] = mfma_f32(wq.w, xq[t].w, acc[ct]);
+      }
+    }
+    if (row_ok) {
+      float* yr = p.y + row * p.ldy + c0;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = ct * 32 + 8 * g + 4 * h;
+          f32x4 v = f32x4{acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]};
+          if (p.bias) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + c0 + col);
+            v = v + b;
+          }
+          *reinterpret_cast<f32x4*>(yr + col) = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dW, db
+struct WgF32Params {
+  const float* dy; int64_t ld_dy;
+  const float* x;  int64_t ld_x;
+  int64_t n_rows;
+  int64_t n_steps;           // ceil(n_rows / 2): one MFMA k-step = two rows
+  int64_t steps_per_block;
+  float* partial;            // [gridDim.x][m_total * K + m_total]
+  int m_off, m_total;        // this launch covers output rows m_off .. m_off + M of an [m_total, K] gradient
+};
+
+
+// The product reduces over the rows, so the MFMA's k index IS the row: lane l supplies dY[row0 + (l >> 5)][m0 + (l & 31)]
+// and X[row0 + (l >> 5)][k0 + (l & 31)] -- 128-byte row segments straight from global memory, no transpose, no LDS.  As
+// in the 16-bit kernel a persistent workgroup owns a slab of rows and keeps the whole [M, K] accumulator in registers
+// (6 tiles of 32 x 32 per wave at most); db accumulates from the A operands on the side.
+template <int M, int K, int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad_f32_kernel(WgF32Params p) {
+  constexpr int TM = M / 32, TK = K / 32;
+  constexpr int WM = NW == 8 ? (TM % 4 == 0 ? 4 : 2) : 2, WK = NW / WM;
+  static_assert(TM % WM == 0 && TK % WK == 0, "tile grid does not split over the waves");
+  constexpr int MT = TM / WM, KT = TK / WK;
+  static_assert(MT * KT <= 12, "accumulator does not fit the register file");
+  constexpr int U = MT * KT > 6 ? 2 : 4;     // row pairs per software-pipeline stage (the next stage's operands in flight)
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave % WM, wk = wave / WM;
+  const int r = lane & 31, h = lane >> 5;
+
+  const int64_t s_beg = (int64_t)blockIdx.x * p.steps_per_block;
+  int64_t s_end = s_beg + p.steps_per_block;
+  if (s_end > p.n_steps) s_end = p.n_steps;
+
+  f32x16 acc[MT][KT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < KT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+  float dbias[MT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a) dbias[a] = 0.f;
+
+  const float* __restrict__ dyb = p.dy + 32 * wm * MT + r;
+  const float* __restrict__ xb = p.x + 32 * wk * KT + r;
+  // rows past the slab / the matrix: the loads are clamped to the last row (never out of bounds, no branch around a
+  // load) and the A operand is zeroed when it is used
+  const int64_t row_last = (2 * s_end < p.n_rows ? 2 * s_end : p.n_rows) - 1;     // last row of this slab
+  float fa[2][U][MT], fb[2][U][KT];
+  auto fetch = [&](int buf, int64_t s0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t row = 2 * (s0 + u) + h;
+      row = row < row_last ? row : row_last;
+      const float* pa = dyb + row * p.ld_dy;
+      const float* pb = xb + row * p.ld_x;
+#pragma unroll
+      for (int a = 0; a < MT; ++a) fa[buf][u][a] = pa[32 * a];
+#pragma unroll
+      for (int b = 0; b < KT; ++b) fb[buf][u][b] = pb[32 * b];
+    }
+  };
+  auto compute = [&](int buf, int64_t s0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool ok = 2 * (s0 + u) + h <= row_last;
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        const float av = ok ? fa[buf][u][a] : 0.f;
+        if (wk == 0) dbias[a] += av;
+#pragma unroll
+        for (int b = 0; b < KT; ++b) acc[a][b] = mfma_f32(av, fb[buf][u][b], acc[a][b]);
+      }
+    }
+  };
+  if (s_beg < s_end) {
+    // two register stages: the operands of rows s + 8 .. s + 15 are requested before the MFMAs of rows s .. s + 7
+    // (a stage past the slab reads nothing and holds zeros)
+    int64_t s = s_beg;
+    fetch(0, s);
+    while (true) {
+      fetch(1, s + U);
+      compute(0, s);
+      s += U;
+      if (s >= s_end) break;
+      fetch(0, s + U);
+      compute(1, s);
+      s += U;
+      if (s >= s_end) break;
+    }
+  }
+
+  // acc tile (a, b) element e of lane l is dW[m][k]: m = 32 (wm MT + a) + (e & 3) + 8 (e >> 2) + 4 (l >> 5), k = 32 (wk KT + b) + (l & 31)
+  float* out = p.partial + (int64_t)blockIdx.x * ((int64_t)p.m_total * K + p.m_total);
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < KT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = p.m_off + 32 * (wm * MT + a) + (e & 3) + 8 * (e >> 2) + 4 * h;
+        out[m * K + 32 * (wk * KT + b) + r] = acc[a][b][e];
+      }
+  if (wk == 0) {
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      const float d = dbias[a] + __shfl_xor(dbias[a], 32, 64);      // the two rows of every step
+      if (h == 0) out[p.m_total * K + p.m_off + 32 * (wm * MT + a) + r] = d;
+    }
+  }
+}
+
+constexpr int f32_waves(int m, int k) {
+  const int tiles = (m / 32) * (k / 32);
+  return tiles >= 32 ? 8 : 4;          // (1024-thread workgroups would cap a wave at 128 registers)
+}
+constexpr int kNumCuF32 = 256;
+constexpr int64_t kMinStepsPerBlock = 256;     // 512 rows per workgroup at least (cf. the 16-bit kernel)
+
+int64_t f32_grid(int64_t n_rows) {
+  const int64_t steps = (n_rows + 1) / 2;
+  const int64_t want = (steps + kMinStepsPerBlock - 1) / kMinStepsPerBlock;
+  return want < kNumCuF32 ? (want < 1 ? 1 : want) : kNumCuF32;
+}
+
+template <int M, int K>
+void launch_wgrad_f32(const WgF32Params& p, int64_t grid, hipStream_t stream) {
+  constexpr int NW = f32_waves(M, K);
+  hipLaunchKernelGGL((wgrad_f32_kernel<M, K, NW>), dim3((unsigned)grid), dim3(NW * 64), 0, stream, p);
+}
+
+}  // namespace
+
+// (declared in common.h for csrc/linear.hip and csrc/linear_wgrad.hip, which dispatch on the dtype)
+int linear_f32_launch(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t n_rows,
+                      int k_in, int m_out, hipStream_t stream) {
+  LinF32Params p{static_cast<const float*>(x), ldx, static_cast<const float*>(w), bias, static_cast<float*>(y), ldy,
+                 n_rows, m_out};
+  const int64_t nb = (n_rows + 127) / 128;
+  if (nb > 0x7fffffffLL) { set_error("segger_linear_fwd: too many rows"); return SEGGER_EUNSUPPORTED; }
+  dim3 grid((unsigned)nb), block(256);
+  switch (k_in) {
+    case 64:  hipLaunchKernelGGL((linear_f32_kernel<64>), grid, block, 0, stream, p); break;
+    case 128: hipLaunchKernelGGL((linear_f32_kernel<128>), grid, block, 0, stream, p); break;
+    case 256: hipLaunchKernelGGL((linear_f32_kernel<256>), grid, block, 0, stream, p); break;
+    case 384: hipLaunchKernelGGL((linear_f32_kernel<384>), grid, block, 0, stream, p); break;
+    default: set_error("segger_linear_fwd: k_in=%d not supported (64, 128, 256, 384)", k_in); return SEGGER_EUNSUPPORTED;
+  }
+  SEGGER_LAUNCH_CHECK("linear_f32_kernel");
+  return SEGGER_OK;
+}
+
+size_t wgrad_f32_workspace_bytes(int64_t n_rows, int m_out, int k_in) {
+  return (size_t)(f32_grid(n_rows) + kReduceGroups) * ((size_t)m_out * k_in + m_out) * sizeof(float);
+}
+
+int wgrad_f32_launch(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, int64_t n_rows, int m_out, int k_in,
+                     float* partial, int64_t* n_slabs, hipStream_t stream) {
+  const int64_t grid = f32_grid(n_rows);
+  WgF32Params p{static_cast<const float*>(dy), ld_dy, static_cast<const float*>(x), ld_x, n_rows, (n_rows + 1) / 2, 0, partial,
+                0, m_out};
+  p.steps_per_block = (p.n_steps + grid - 1) / grid;
+  *n_slabs = grid;
+  if (m_out == 384 && k_in == 256) {
+    // 96 accumulator tiles do not fit 8 waves at two waves per SIMD: two launches over the halves of dY's columns
+    // (X is read twice; this shape is the first layer's concatenated input, once per step)
+    for (int half = 0; half < 2; ++half) {
+      WgF32Params q = p;
+      q.dy = p.dy + 192 * half; q.m_off = 192 * half;
+      launch_wgrad_f32<192, 256>(q, grid, stream);
+    }
+    SEGGER_LAUNCH_CHECK("wgrad_f32_kernel");
+    return SEGGER_OK;
+  }
+#define CASE(MM, KK) if (m_out == MM && k_in == KK) { launch_wgrad_f32<MM, KK>(p, grid, stream); SEGGER_LAUNCH_CHECK("wgrad_f32_kernel"); return SEGGER_OK; }
+  CASE(384, 128) CASE(384, 64)
+  CASE(192, 256) CASE(192, 128) CASE(192, 64)
+  CASE(128, 256) CASE(128, 128) CASE(128, 64)
+  CASE(64, 256) CASE(64, 128) CASE(64, 64)
+#undef CASE
+  set_error("segger_linear_wgrad: m_out=%d k_in=%d not supported", m_out, k_in);
+  return SEGGER_EUNSUPPORTED;
+}
+
+}  // namespace segger

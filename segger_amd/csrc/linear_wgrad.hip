@@ -499,12 +499,14 @@ int dispatch_wgrad(const WgradParams& p, int m, int k, int64_t grid, hipStream_t
 using namespace segger;
 
 extern "C" int segger_linear_wgrad_supported(int32_t m_out, int32_t k_in, int32_t dtype) {
-  return shape_ok(m_out, k_in) && (dtype == SEGGER_BF16 || dtype == SEGGER_F16);
+  return shape_ok(m_out, k_in) && (dtype == SEGGER_BF16 || dtype == SEGGER_F16 || dtype == SEGGER_F32);
 }
 
 extern "C" size_t segger_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t m_out, int32_t k_in) {
   if (n_rows <= 0 || !shape_ok(m_out, k_in)) return 16;
-  return (size_t)(grid_for(n_rows, m_out, k_in) + kRedGroups) * ((size_t)m_out * k_in + m_out) * sizeof(float);
+  const size_t b16 = (size_t)(grid_for(n_rows, m_out, k_in) + kRedGroups) * ((size_t)m_out * k_in + m_out) * sizeof(float);
+  const size_t b32 = wgrad_f32_workspace_bytes(n_rows, m_out, k_in);       // (the fp32 kernel's slab count)
+  return b16 > b32 ? b16 : b32;
 }
 
 extern "C" int segger_linear_wgrad_dx_supported(int32_t m_out, int32_t k_in, int32_t dtype) {
@@ -571,13 +573,20 @@ extern "C" int segger_linear_wgrad(const void* dy, int64_t ld_dy, const void* x,
   }
   SEGGER_REQUIRE(dy && x, "segger_linear_wgrad: NULL input");
   SEGGER_REQUIRE(aligned16(dy) && aligned16(x), "segger_linear_wgrad: inputs must be 16-byte aligned");
-  SEGGER_REQUIRE(ld_dy >= m_out && ld_x >= k_in && (ld_dy * 2) % 16 == 0 && (ld_x * 2) % 16 == 0,
-                 "segger_linear_wgrad: bad leading dimension");
   const size_t need = segger_linear_wgrad_workspace_bytes(n_rows, m_out, k_in);
   if (workspace == nullptr || workspace_bytes < need) {
     set_error("segger_linear_wgrad: workspace %zu < %zu bytes", workspace_bytes, need);
     return SEGGER_EWORKSPACE;
   }
+  if (dtype == SEGGER_F32) {       // fp32 storage: exact-fp32 MFMA kernel (csrc/linear_f32.hip), same partial sums
+    SEGGER_REQUIRE(ld_dy >= m_out && ld_x >= k_in, "segger_linear_wgrad: bad leading dimension");
+    int64_t slabs = 0;
+    const int rc32 = wgrad_f32_launch(dy, ld_dy, x, ld_x, n_rows, m_out, k_in, static_cast<float*>(workspace), &slabs, stream);
+    if (rc32 != SEGGER_OK) return rc32;
+    return reduce_partials(static_cast<float*>(workspace), slabs, m_out, k_in, grad_w, grad_b, stream);
+  }
+  SEGGER_REQUIRE(ld_dy >= m_out && ld_x >= k_in && (ld_dy * 2) % 16 == 0 && (ld_x * 2) % 16 == 0,
+                 "segger_linear_wgrad: bad leading dimension");
   const int64_t grid = grid_for(n_rows, m_out, k_in);
   {
     // buffer resources address one workgroup's slab with 32-bit offsets

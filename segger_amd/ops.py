@@ -760,8 +760,7 @@ def segment_minmax(pos: Tensor, batch: Optional[Tensor], num_graphs: int) -> Tup
 # Tall-skinny projection GEMM (MFMA) with autograd
 # --------------------------------------------------------------------------
 def linear_supported(k_in: int, m_out: int, dtype: torch.dtype) -> bool:
-    return dtype in (torch.bfloat16, torch.float16) and bool(
-        _lib.load().segger_linear_supported(int(k_in), int(m_out), DTYPE_CODE[dtype]))
+    return dtype in DTYPE_CODE and bool(_lib.load().segger_linear_supported(int(k_in), int(m_out), DTYPE_CODE[dtype]))
 
 
 def linear_fwd_launch(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Optional[Tensor] = None) -> Tensor:
@@ -820,8 +819,7 @@ def segment_rowsum(x: Tensor, by_id: EdgeCSR) -> Tensor:
 
 
 def linear_wgrad_supported(m_out: int, k_in: int, dtype: torch.dtype) -> bool:
-    return dtype in (torch.bfloat16, torch.float16) and bool(
-        _lib.load().segger_linear_wgrad_supported(int(m_out), int(k_in), DTYPE_CODE[dtype]))
+    return dtype in DTYPE_CODE and bool(_lib.load().segger_linear_wgrad_supported(int(m_out), int(k_in), DTYPE_CODE[dtype]))
 
 
 def linear_wgrad_launch(gy: Tensor, x: Tensor, want_bias: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
@@ -1155,8 +1153,9 @@ class _Linear(torch.autograd.Function):
 
 def linear(x: Tensor, weight, bias) -> Tensor:
     """``F.linear`` for node-feature matrices.  ``weight`` / ``bias`` may be sequences of tensors: the maps are
-    stacked by rows into one GEMM (``[lin_l | lin_r | ...](x)``).  bf16/f16 activations with a covered (K, M) use
-    the MFMA kernels; fp32 activations (parity mode) and uncovered shapes use the vendor GEMM."""
+    stacked by rows into one GEMM (``[lin_l | lin_r | ...](x)``).  Activations with a covered (K, M) use the MFMA
+    kernels -- bf16 / f16 on v_mfma_f32_32x32x16, fp32 (the reference's arithmetic width) on the exact-fp32
+    v_mfma_f32_32x32x2_f32 -- and only uncovered shapes fall to the vendor GEMM."""
     weights = tuple(weight) if isinstance(weight, (list, tuple)) else (weight,)
     biases = tuple(bias) if isinstance(bias, (list, tuple)) else (bias,)
     if len(biases) != len(weights):

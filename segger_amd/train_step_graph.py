@@ -278,18 +278,24 @@ class GraphedTrainStep:
                 self.lit.model._step_dev.copy_(keep[3])       # same dropout masks and sampler draws again
             self.defer_sums = True
             self._run_grads()
+            names = {id(p): n for n, p in self.lit.model.named_parameters()}
+            why = None
             for p, r in zip(self._params, ref):
                 g = p.grad
                 if (g is None) != (r is None):
-                    self.defer_sums = False
+                    why = f"{names.get(id(p))}: gradient {'missing' if g is None else 'unexpected'}"
                 elif g is not None:
-                    scale = float(r.abs().max())
-                    if not bool(torch.isfinite(g).all()) or float((g - r).abs().max()) > 1e-3 * scale + 1e-7:
-                        self.defer_sums = False
-            if not self.defer_sums:
+                    scale, diff = float(r.abs().max()), float((g - r).abs().max())
+                    # (the loss kernels accumulate with float atomics: run-to-run differences of ~1e-6 are expected)
+                    if not bool(torch.isfinite(g).all()) or diff > 1e-2 * scale + 1e-6:
+                        why = f"{names.get(id(p))}: differs by {diff:.3e} (scale {scale:.3e})"
+                if why:
+                    break
+            if why:
+                self.defer_sums = False
                 import warnings
-                warnings.warn("GraphedTrainStep: a parameter gradient is consumed inside the backward pass; "
-                              "partial sums are launched where they are produced (more kernel nodes)")
+                warnings.warn("GraphedTrainStep: a parameter gradient is consumed inside the backward pass "
+                              f"({why}); partial sums are launched where they are produced (more kernel nodes)")
                 self._run_grads()
             self.opt.step()
         else:

@@ -24,6 +24,71 @@ def test_linear_forward(cuda, dtype, k, m, n):
     assert ((y.float() - ref).abs() <= rel * ref.abs() + 1e-3).all()
 
 
+@pytest.mark.parametrize("k,m", [(64, 64), (128, 64), (128, 384), (256, 384), (384, 256), (384, 128), (256, 64), (64, 128)])
+@pytest.mark.parametrize("n", [1, 127, 128, 1000, 4133])
+def test_linear_forward_fp32(cuda, k, m, n):
+    """fp32 storage on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation) against float64: the error of an
+    fp32 dot product of K <= 384 terms, <= 1e-6 * sum |x||w| (K * 2^-24 = 2.3e-5 is the worst case; sums of random signs
+    stay far below it), and the result must agree with torch's own fp32 GEMM to the same bound."""
+    from segger_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(n + k + m)
+    x = torch.randn(n, k, device=cuda, generator=g)
+    w = torch.randn(m, k, device=cuda, generator=g) / k ** 0.5
+    b = torch.randn(m, device=cuda, generator=g)
+    assert ops.linear_supported(k, m, torch.float32)
+    y = ops.linear(x, w, b)
+    assert y.dtype == torch.float32 and y.shape == (n, m)
+    ref = x.double() @ w.double().t() + b.double()
+    bound = 2e-6 * (x.double().abs() @ w.double().abs().t() + b.double().abs()) + 1e-7
+    assert bool(((y.double() - ref).abs() <= bound).all())
+    big = torch.randn(n, 3 * k, device=cuda, generator=g)          # a column window of a wider matrix
+    yv = ops.linear(big[:, k:2 * k], w, None)
+    assert torch.allclose(yv.double(), big[:, k:2 * k].double() @ w.double().t(), rtol=0, atol=float(bound.max()))
+
+
+@pytest.mark.parametrize("m,k", [(384, 256), (384, 128), (384, 64), (192, 64), (192, 256), (128, 256), (128, 128),
+                                 (128, 64), (64, 256), (64, 128), (64, 64)])
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 1000, 70_001])
+def test_linear_wgrad_fp32_matches_fp64(cuda, m, k, n):
+    """fp32 weight / bias gradients on the exact-fp32 MFMA against float64 (bound as for the 16-bit kernel: 1e-5 of
+    sum |dY||X|), exact on small integers, deterministic."""
+    from segger_amd import ops
+    assert ops.linear_wgrad_supported(m, k, torch.float32)
+    g = torch.Generator(device=cuda).manual_seed(n + m + k)
+    gy = torch.randn(n, m, device=cuda, generator=g) + 0.1
+    x = torch.randn(n, k, device=cuda, generator=g)
+    gw, gb = ops.linear_wgrad_launch(gy, x)
+    assert gw.shape == (m, k) and gb.shape == (m,)
+    ref_w = gy.double().t() @ x.double()
+    assert bool(((gw.double() - ref_w).abs() <= 1e-5 * (gy.double().abs().t() @ x.double().abs()) + 1e-6).all())
+    assert bool(((gb.double() - gy.double().sum(0)).abs() <= 1e-5 * gy.double().abs().sum(0) + 1e-6).all())
+    gw2, gb2 = ops.linear_wgrad_launch(gy, x)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
+    r = torch.arange(n, device=cuda)
+    iy = ((r[:, None] * 3 + torch.arange(m, device=cuda)[None] * 5) % 7 - 3).float()
+    ix = ((r[:, None] * 2 + torch.arange(k, device=cuda)[None] * 11) % 5 - 2).float()
+    if n <= 1000:
+        ew, eb = ops.linear_wgrad_launch(iy, ix)
+        assert torch.equal(ew, iy.t() @ ix) and torch.equal(eb, iy.sum(0))
+
+
+@pytest.mark.parametrize("k,m", [(256, 384), (128, 384), (128, 64)])
+def test_linear_autograd_fp32(cuda, k, m):
+    from segger_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(k)
+    n = 40001
+    x = torch.randn(n, k, device=cuda, generator=g).requires_grad_(True)
+    w = (torch.randn(m, k, device=cuda, generator=g) / k ** 0.5).requires_grad_(True)
+    b = torch.randn(m, device=cuda, generator=g).requires_grad_(True)
+    gy = torch.randn(n, m, device=cuda, generator=g)
+    ops.linear(x, w, b).backward(gy)
+    xr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    (xr @ wr.t() + br).backward(gy.double())
+    assert torch.allclose(x.grad.double(), xr.grad, rtol=1e-5, atol=1e-5)
+    assert (w.grad.double() - wr.grad).abs().max().item() < 1e-5 * (gy.double().abs().t() @ x.detach().double().abs()).max().item()
+    assert torch.allclose(b.grad.double(), br.grad, rtol=1e-5, atol=1e-3)
+
+
 def test_linear_strided_input_and_leading_dims(cuda):
     from segger_amd import ops
     g = torch.Generator(device=cuda).manual_seed(0)
@@ -212,7 +277,7 @@ def test_unsupported_shapes_use_vendor_gemm(cuda):
     from segger_amd import ops
     assert not ops.linear_supported(100, 64, torch.bfloat16)
     assert not ops.linear_supported(128, 96, torch.bfloat16)
-    assert not ops.linear_supported(128, 64, torch.float32)
+    assert ops.linear_supported(128, 64, torch.float32)          # fp32 storage: the exact-fp32 MFMA kernels (round 3)
     x = torch.randn(10, 100, device=cuda).to(torch.bfloat16)
     w = torch.randn(96, 100, device=cuda)
     assert ops.linear(x, w, None).shape == (10, 96)
