@@ -119,6 +119,72 @@ __global__ __launch_bounds__(256, K <= 256 ? 2 : 1) void linear_f32_kernel(LinF3
   }
 }
 
+// The data gradients dX[n, M] = dY[n, K = 3 HC] W^T have a LONG reduction and few output columns: holding all K of a row
+// in registers (192 VGPRs) leaves one wave per SIMD.  This form walks K in slices of KS instead and keeps the whole
+// [32 rows, M] output of a wave in accumulators (M / 32 tiles): per slice a wave loads KS / 2 registers of its rows and
+// the workgroup stages W[:, slice] ([M, KS], row stride KS + 4) in LDS; the output is stored once at the end.
+template <int K, int M>
+__global__ __launch_bounds__(256, 2) void linear_f32_kslice_kernel(LinF32Params p) {
+  constexpr int KS = M <= 128 ? 128 : 32;
+  constexpr int NS = K / KS, NT = KS / 8, MT = M / 32, WS = KS + 4;
+  constexpr int PPT = M * KS / 4 / 256;
+  static_assert(K % KS == 0 && (M * KS / 4) % 256 == 0, "slices must tile the operands");
+  __shared__ __attribute__((aligned(16))) float lds_w[M * WS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  int64_t row = (int64_t)blockIdx.x * 128 + wave * 32 + r;
+  const bool row_ok = row < p.n_rows;
+  if (!row_ok) row = p.n_rows - 1;
+  const float* xr = p.x + row * p.ldx + 4 * h;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
+  for (int sl = 0; sl < NS; ++sl) {
+    f32x4 xq[NT], wreg[PPT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) xq[t] = *reinterpret_cast<const f32x4*>(xr + sl * KS + 8 * t);
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int piece = tid + 256 * i, wrow = piece / (KS / 4), wcol = piece % (KS / 4);
+      wreg[i] = *reinterpret_cast<const f32x4*>(p.w + (int64_t)wrow * K + sl * KS + wcol * 4);
+    }
+    __syncthreads();                                     // the previous slice's reads are done
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int piece = tid + 256 * i, wrow = piece / (KS / 4), wcol = piece % (KS / 4);
+      *reinterpret_cast<f32x4*>(lds_w + wrow * WS + wcol * 4) = wreg[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 wq = *reinterpret_cast<const f32x4*>(lds_w + (mt * 32 + r) * WS + 8 * t + 4 * h);
+        acc[mt] = mfma_f32(wq.x, xq[t].x, acc[mt]);
+        acc[mt] = mfma_f32(wq.y, xq[t].y, acc[mt]);
+        acc[mt] = mfma_f32(wq.z, xq[t].z, acc[mt]);
+        acc[mt] = mfma_f32(wq.w, xq[t].w, acc[mt]);
+      }
+    }
+  }
+  if (row_ok) {
+    float* yr = p.y + row * p.ldy;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = mt * 32 + 8 * g + 4 * h;
+        f32x4 v = f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+        if (p.bias) v = v + *reinterpret_cast<const f32x4*>(p.bias + col);
+        *reinterpret_cast<f32x4*>(yr + col) = v;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ dW, db
 struct WgF32Params {
   const float* dy; int64_t ld_dy;
@@ -142,7 +208,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_f32_kernel(WgF32Params p) {
   static_assert(TM % WM == 0 && TK % WK == 0, "tile grid does not split over the waves");
   constexpr int MT = TM / WM, KT = TK / WK;
   static_assert(MT * KT <= 12, "accumulator does not fit the register file");
-  constexpr int U = MT * KT > 6 ? 2 : 4;     // row pairs per software-pipeline stage (the next stage's operands in flight)
+  // row pairs per software-pipeline stage (the next stage's operands are in flight under this stage's MFMAs): few tiles
+  // per wave = few MFMAs per loaded operand = a memory-bound shape that needs more bytes in flight
+  constexpr int U = MT * KT > 6 ? 2 : (MT * KT == 6 ? 4 : (MT + KT <= 2 ? 16 : 8));
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave % WM, wk = wave / WM;
@@ -239,10 +307,14 @@ constexpr int f32_waves(int m, int k) {
 constexpr int kNumCuF32 = 256;
 constexpr int64_t kMinStepsPerBlock = 256;     // 512 rows per workgroup at least (cf. the 16-bit kernel)
 
-int64_t f32_grid(int64_t n_rows) {
+// persistent workgroups: one per CU for the 8-wave shapes (their accumulators fill the register file at two waves per
+// SIMD); the 4-wave shapes with <= 128 registers of accumulator + operands run two per CU (more loads in flight)
+int64_t f32_grid(int64_t n_rows, int m, int k) {
   const int64_t steps = (n_rows + 1) / 2;
   const int64_t want = (steps + kMinStepsPerBlock - 1) / kMinStepsPerBlock;
-  return want < kNumCuF32 ? (want < 1 ? 1 : want) : kNumCuF32;
+  const int tiles_per_wave = (m / 32) * (k / 32) / f32_waves(m, k);
+  const int64_t cap = (f32_waves(m, k) == 4 && tiles_per_wave <= 4) ? 2 * kNumCuF32 : kNumCuF32;
+  return want < cap ? (want < 1 ? 1 : want) : cap;
 }
 
 template <int M, int K>
@@ -261,6 +333,12 @@ int linear_f32_launch(const void* x, int64_t ldx, const void* w, const float* bi
   const int64_t nb = (n_rows + 127) / 128;
   if (nb > 0x7fffffffLL) { set_error("segger_linear_fwd: too many rows"); return SEGGER_EUNSUPPORTED; }
   dim3 grid((unsigned)nb), block(256);
+  if (k_in == 384 && (m_out == 128 || m_out == 256)) {   // the data gradients of the stacked projections
+    if (m_out == 128) hipLaunchKernelGGL((linear_f32_kslice_kernel<384, 128>), grid, block, 0, stream, p);
+    else              hipLaunchKernelGGL((linear_f32_kslice_kernel<384, 256>), grid, block, 0, stream, p);
+    SEGGER_LAUNCH_CHECK("linear_f32_kslice_kernel");
+    return SEGGER_OK;
+  }
   switch (k_in) {
     case 64:  hipLaunchKernelGGL((linear_f32_kernel<64>), grid, block, 0, stream, p); break;
     case 128: hipLaunchKernelGGL((linear_f32_kernel<128>), grid, block, 0, stream, p); break;
@@ -273,12 +351,12 @@ int linear_f32_launch(const void* x, int64_t ldx, const void* w, const float* bi
 }
 
 size_t wgrad_f32_workspace_bytes(int64_t n_rows, int m_out, int k_in) {
-  return (size_t)(f32_grid(n_rows) + kReduceGroups) * ((size_t)m_out * k_in + m_out) * sizeof(float);
+  return (size_t)(f32_grid(n_rows, m_out, k_in) + kReduceGroups) * ((size_t)m_out * k_in + m_out) * sizeof(float);
 }
 
 int wgrad_f32_launch(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, int64_t n_rows, int m_out, int k_in,
                      float* partial, int64_t* n_slabs, hipStream_t stream) {
-  const int64_t grid = f32_grid(n_rows);
+  const int64_t grid = f32_grid(n_rows, m_out, k_in);
   WgF32Params p{static_cast<const float*>(dy), ld_dy, static_cast<const float*>(x), ld_x, n_rows, (n_rows + 1) / 2, 0, partial,
                 0, m_out};
   p.steps_per_block = (p.n_steps + grid - 1) / grid;

@@ -29,3 +29,16 @@ for m, k in ((384, 256), (384, 128), (64, 128), (64, 256), (64, 64), (128, 128))
           f"wgrad {ms_w:.3f} ms ({gb / ms_w:.2f} TB/s, {2 * rows * m * k / ms_w / 1e9:.0f} TFLOP/s)  "
           f"dX+dW+db in one pass {ms_fused:.3f} ms ({gb_fused / ms_fused:.2f} TB/s; separate {ms_dx + ms_w:.3f})  "
           f"gemm+colsum {ms_old:.3f} ms", flush=True)
+
+# fp32 storage: exact-fp32 MFMA kernels (csrc/linear_f32.hip) against the vendor GEMM they replace
+for m, k in ((384, 256), (384, 128), (64, 128), (64, 256)):
+    x = torch.randn(n, k, device=dev, generator=g)
+    gy = torch.randn(n, m, device=dev, generator=g)
+    w = torch.randn(m, k, device=dev, generator=g)
+    flops = 2 * n * m * k
+    ms_f = t(lambda: ops.linear_fwd_launch(x, w, None), it=10)
+    ms_w = t(lambda: ops.linear_wgrad_launch(gy, x), it=10)
+    ms_vf = t(lambda: torch.nn.functional.linear(x, w), it=10)
+    ms_vw = t(lambda: (gy.t() @ x, gy.sum(0)), it=10)
+    print(f"f32 rows {n} M {m} K {k}: fwd {ms_f:.3f} ms ({flops / ms_f / 1e9:.0f} TFLOP/s, {n * (m + k) * 4 / ms_f / 1e9:.2f} TB/s; "
+          f"vendor {ms_vf:.3f})  wgrad {ms_w:.3f} ms ({flops / ms_w / 1e9:.0f} TFLOP/s; vendor gemm + sum {ms_vw:.3f})", flush=True)

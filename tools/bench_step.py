@@ -14,7 +14,7 @@ batch = b.to(dev)
 torch.manual_seed(0)
 model = LitISTEncoder(n_genes=spec.n_genes, in_channels=128)
 model.model._materialize_bd(spec.bd_dim, "cpu")
-model.model.compute_dtype = torch.bfloat16
+model.model.compute_dtype = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[os.environ.get('DTYPE', 'bf16')]
 model = model.to(dev)
 model.set_similarities(aux["tx_similarity"].to(dev), aux["bd_similarity"].to(dev))
 model._max_epochs_override, model.current_epoch = 20, 10
