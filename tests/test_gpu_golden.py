@@ -73,6 +73,50 @@ def test_encoder_golden_embeddings_attention_and_predict(cuda, dtype):
         assert np.abs(pred[2].double().numpy() - z["out::pred_sim"])[diff].max(initial=0.0) < 5e-5
 
 
+def _layer_of(name: str) -> str:
+    """model.conv_layers.2.conv... -> 'conv_layers.2'; other parameters group by their module (lin_first, pos_emb, lin_last)."""
+    parts = name.split(".")
+    return ".".join(parts[1:3]) if parts[1] == "conv_layers" else parts[1]
+
+
+def _golden_grads(cuda, dtype):
+    z, sd, b = load_encoder_golden()
+    m = golden_model(sd, cuda, dtype).eval()              # dropout off, gradients flow
+    bg = b.to(cuda)
+    loss = m._segmentation_loss(m(bg), bg, torch.from_numpy(z["in::neg"]).to(cuda))
+    loss.backward()
+    return float(loss), {k: p.grad.double().cpu() for k, p in m.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("dtype,u", [(torch.bfloat16, 2.0 ** -8), (torch.float16, 2.0 ** -11)])
+def test_16bit_gradients_follow_the_fp32_hip_gradients_per_layer(cuda, dtype, u):
+    """Every parameter gradient of the 16-bit step against the SAME kernels at fp32 storage (the exact-fp32 MFMA
+    projections, fp32 aggregation), per tensor, in the Euclidean norm:
+        || g16 - g32 ||  <=  16 u || g32 ||  +  2 u G_layer ,     G_layer = max over the tensors of the same layer of || g32 ||
+    u = the storage format's unit in the last place (bf16 2^-8, f16 2^-11; one rounding costs u / 2).  Between a layer's
+    parameters and the loss lie at most 4 layers x (projection, pre-activation, activation) stored forward values and as
+    many stored gradient matrices, ~ 30 roundings of u / 2 on the longest path: 16 u.  The additive term is what a tensor
+    whose own gradient nearly cancels (lin_r / att of the late layers, the tx-belongs-bd convs of the early ones: 10^2-10^6
+    times smaller than their layer's largest tensor) inherits from the rounding of the activations it is summed over:
+    proportional to the layer's gradient flow, not to its own size.  Measured (tools output in DESIGN.md 1): the large
+    tensors differ by 1.2-2.5 % (bf16) / 0.2-0.6 % (f16), the loss by < 1e-3.  This replaces the 12 %-of-max bound the
+    bf16 run was held to against the stored oracle gradients."""
+    loss32, g32 = _golden_grads(cuda, torch.float32)
+    loss16, g16 = _golden_grads(cuda, dtype)
+    assert abs(loss16 - loss32) < (4e-3 if dtype == torch.bfloat16 else 5e-4)
+    assert set(g16) == set(g32) and len(g32) >= 40
+    layer_max: dict = {}
+    for k, g in g32.items():
+        layer_max[_layer_of(k)] = max(layer_max.get(_layer_of(k), 0.0), float(g.norm()))
+    worst = 0.0
+    for k, g in g32.items():
+        err, own, flow = float((g16[k] - g).norm()), float(g.norm()), layer_max[_layer_of(k)]
+        assert err <= 16 * u * own + 2 * u * flow, f"{k}: |dg| {err:.3e} vs |g| {own:.3e} (layer {flow:.3e})"
+        if own > 0.1 * flow:
+            worst = max(worst, err / own)
+    assert worst < 12 * u                              # the tensors that carry a layer's gradient: well inside the bound
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_encoder_golden_loss_and_parameter_gradients(cuda, dtype):
     from segger_amd import TX_BD
@@ -86,12 +130,21 @@ def test_encoder_golden_loss_and_parameter_gradients(cuda, dtype):
     assert abs(loss.item() - ref_loss) < (2e-5 if dtype == torch.float32 else 2e-2)
     named = dict(m.named_parameters())
     checked = 0
-    # fp32: every tensor within 2e-3 of its own largest entry.  bf16 (activations and their gradients rounded to 8 bits
-    # through 4 layers): 12 % of the tensor's largest entry, plus a floor of 5e-3 of the largest gradient of the whole
-    # model for tensors whose gradient is a difference of nearly cancelling terms (e.g. lin_r of a late layer, 1e-5).
-    rel = 2e-3 if dtype == torch.float32 else 0.12
-    gmax = max(np.abs(z[f"grad::{k}"]).max() for k in sd)
-    floor = 1e-7 if dtype == torch.float32 else 5e-3 * gmax
+    # fp32: every tensor within 2e-3 of its own largest entry of the STORED oracle gradient.  bf16 against the oracle:
+    # the per-layer norm bound of test_16bit_gradients_follow_the_fp32_hip_gradients_per_layer (16 u |g| + 2 u G_layer,
+    # u = 2^-8), widened by the fp32 run's own distance to the oracle
+    if dtype != torch.float32:
+        u = 2.0 ** -8
+        ref = {k: torch.from_numpy(z[f"grad::{k}"].astype(np.float64)) for k in sd if k in named and named[k].grad is not None}
+        layer_max: dict = {}
+        for k, g in ref.items():
+            layer_max[_layer_of(k)] = max(layer_max.get(_layer_of(k), 0.0), float(g.norm()))
+        for k, g in ref.items():
+            err = float((named[k].grad.double().cpu() - g).norm())
+            assert err <= (16 * u + 1e-3) * float(g.norm()) + 2 * u * layer_max[_layer_of(k)], f"{k}: {err}"
+        assert len(ref) >= 40
+        return
+    rel, floor = 2e-3, 1e-7
     for k in sd:
         ref = z[f"grad::{k}"].astype(np.float64)
         if k not in named or named[k].grad is None:

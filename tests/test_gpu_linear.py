@@ -273,6 +273,20 @@ def test_cached_weight_copies_follow_the_optimizer(cuda, fused):
     assert torch.allclose(y[:, :64].float(), x.float() @ w1.detach().to(torch.bfloat16).float().t() + b1.detach(), rtol=2 ** -7, atol=2e-2)
 
 
+def test_default_model_projections_are_all_on_the_mfma_kernels_at_every_width(cuda):
+    """CLI-default dims (in 128, hidden / out 64, 2 heads: reference lightning_model.py:30-35, segment.py:201-235): every
+    projection of a training step -- forward, data gradient, weight gradient -- is covered by the hand-written kernels
+    at bf16, f16 AND fp32 storage (the fp32 model-level parity tests of test_gpu_model.py therefore run on
+    v_mfma_f32_32x32x2_f32, not on the vendor GEMM)."""
+    from segger_amd import ops
+    fwd = [(256, 384), (128, 384), (128, 128), (256, 128), (128, 64), (256, 64), (64, 64)]     # (K, M)
+    for dt in (torch.bfloat16, torch.float16, torch.float32):
+        for k, m in fwd:
+            assert ops.linear_supported(k, m, dt), (k, m, dt)
+            assert ops.linear_supported(m, k, dt), ("dX", m, k, dt)
+            assert ops.linear_wgrad_supported(m, k, dt), ("dW", m, k, dt)
+
+
 def test_unsupported_shapes_use_vendor_gemm(cuda):
     from segger_amd import ops
     assert not ops.linear_supported(100, 64, torch.bfloat16)
