@@ -153,11 +153,6 @@ typedef struct segger_gatv2_fwd_args {
                                above, precomputed by segger_dropout_bits for this layer's seed.  The kernels then test
                                a bit instead of hashing per (edge, head); results are identical.  Ignored when alpha
                                is requested or the geometry runs on the generic kernels. */
-  void* gelu_grad;        /* optional output (apply_gelu, specialised geometries): [n_dst, H*C] in `dtype`, gelu'(pre) =
-                             Phi(pre) + pre phi(pre), evaluated while Phi is at hand for the GELU itself.  Handed to
-                             segger_gatv2_bwd it saves the destination pass a second evaluation of Phi and phi per
-                             channel (two exponentials); NULL = the backward recomputes it from pre */
-  int64_t ld_gelu_grad;
 } segger_gatv2_fwd_args;
 
 int segger_gatv2_fwd(const segger_gatv2_fwd_args* args, segger_stream_t stream);
@@ -215,8 +210,6 @@ typedef struct segger_gatv2_bwd_args {
                              fills the tx-belongs-bd window of the stacked projection gradient) */
   int64_t ld_zero;
   int32_t grad_xl_zeroed; /* one-pass form (src_unique): grad_xl already holds zeros (see zero_rows_out): skip the fill */
-  const void* gelu_grad;  /* optional: the forward's gelu_grad output (same dtype, apply_gelu only); NULL = recompute */
-  int64_t ld_gelu_grad;
 } segger_gatv2_bwd_args;
 
 size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads, int32_t channels);

@@ -46,7 +46,6 @@ class GatFwdArgs(C.Structure):
         ("pre", vp), ("ld_pre", C.c_int64),
         ("lse", vp), ("alpha", vp),
         ("keep_bits", vp),
-        ("gelu_grad", vp), ("ld_gelu_grad", C.c_int64),
     ]
 
 
@@ -70,7 +69,6 @@ class GatBwdArgs(C.Structure):
         ("keep_bits_dst", vp), ("keep_bits_src", vp),
         ("src_unique", C.c_int32),
         ("zero_rows_out", vp), ("ld_zero", C.c_int64), ("grad_xl_zeroed", C.c_int32),
-        ("gelu_grad", vp), ("ld_gelu_grad", C.c_int64),
     ]
 
 

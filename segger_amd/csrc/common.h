@@ -206,9 +206,6 @@ __device__ __forceinline__ float normal_cdf(float x) {
   const float half = 0.5f * __builtin_amdgcn_exp2f(q * s);
   return x < 0.f ? half : 1.0f - half;
 }
-__device__ __forceinline__ float normal_pdf(float x) {
-  return 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
-}
 __device__ __forceinline__ float gelu_erf(float x) { return x * normal_cdf(x); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
   const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);

@@ -153,10 +153,6 @@ extern "C" int segger_gatv2_fwd(const segger_gatv2_fwd_args* a, segger_stream_t 
   p.att = a->att; p.bias = a->bias;
   p.out = a->out; p.ld_out = a->ld_out; p.pre = a->pre; p.ld_pre = a->ld_pre;
   p.lse = a->lse; p.alpha = a->alpha;
-  if (a->gelu_grad && a->apply_gelu && gatv2_has_specialised(a->heads, a->channels)) {
-    CHECK_RC(check_rows("gelu_grad", a->gelu_grad, a->ld_gelu_grad, a->dtype, a->heads * a->channels));
-    p.gact = a->gelu_grad; p.ld_gact = a->ld_gelu_grad;
-  }
   p.bits = a->alpha ? nullptr : a->keep_bits;
   p.slope = a->negative_slope; p.apply_gelu = a->apply_gelu; p.rows_per_wave_iter = 1;
   set_dropout(p, a->dropout_p, a->seed, a->seed_dev);
@@ -219,10 +215,6 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
   p.gxl = a->grad_xl; p.ld_gxl = a->ld_gxl; p.gxr = a->grad_xr; p.ld_gxr = a->ld_gxr;
   p.slab = static_cast<float*>(a->workspace);
   p.slope = a->negative_slope; p.apply_gelu = a->apply_gelu;
-  if (a->gelu_grad && a->apply_gelu && specialised && n_dst > 0) {
-    CHECK_RC(check_rows("gelu_grad", a->gelu_grad, a->ld_gelu_grad, a->dtype, hc));
-    p.gact = const_cast<void*>(a->gelu_grad); p.ld_gact = a->ld_gelu_grad;
-  }
   set_dropout(p, a->dropout_p, a->seed, a->seed_dev);
 
   // ---- destination side ------------------------------------------------------

@@ -71,8 +71,6 @@ struct GatParams {
   // forward outputs
   void* out; int64_t ld_out;
   void* pre; int64_t ld_pre;     // fwd: output (nullable); bwd: input
-  void* gact; int64_t ld_gact;   // gelu'(pre), same shape as pre.  fwd: output (nullable); dst pass: input (nullable:
-                                 // recomputed from pre, ~21 VALU instructions per channel incl. two v_exp_f32)
   float* lse;                    // fwd: output (nullable); bwd: input
   float* alpha;
   // backward
@@ -252,9 +250,7 @@ __device__ __forceinline__ float logit_partial(const f32x2 (&t)[4], const f32x2 
 //   s = bits(-de) ^ (bits(nt) & 0x80000000)                     (v_bitop3_b32),
 // which also yields de * |t| = s * t without a compare / select per channel.
 __device__ __forceinline__ f32x2 neg_canon_zero(f32x2 a) {          // -a, with +-0 -> +0
-  // IEEE round-to-nearest: (+0) - (+0) = +0 and (+0) - (-0) = +0, and 0 - a = -a otherwise: one subtraction instead
-  // of a compare + select per channel (the compiler may not fold 0 - a into -a: it is not compiled with nsz)
-  return f32x2{0.f, 0.f} - a;
+  return f32x2{a.x == 0.f ? 0.f : -a.x, a.y == 0.f ? 0.f : -a.y};
 }
 __device__ __forceinline__ float sign_mul(float nde, float nt) {     // de * sgn(t) given -de and nt
   // a ^ (b & c) as one v_bitop3_b32 (truth table 0xF0 ^ (0xCC & 0xAA) = 0x78); the compiler does not fold the
@@ -413,22 +409,8 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
     if (p.pre && (p.pre != p.out || p.apply_gelu))
       store_pairs(static_cast<T*>(p.pre) + row * p.ld_pre + ch0, o);
     if (p.apply_gelu) {
-      if (p.gact) {
-        // the backward's gelu'(pre) = Phi(pre) + pre * phi(pre), while Phi is at hand: one more exp per channel here
-        // instead of a second evaluation of Phi AND phi per channel in the destination pass (these kernels are bound
-        // by VALU issue, not by the 16 bytes per lane this stores and the backward reads back)
-        f32x2 gp[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float cx = normal_cdf(o[i].x), cy = normal_cdf(o[i].y);
-          gp[i] = f32x2{cx + o[i].x * normal_pdf(o[i].x), cy + o[i].y * normal_pdf(o[i].y)};
-          o[i] = f32x2{o[i].x * cx, o[i].y * cy};
-        }
-        store_pairs(static_cast<T*>(p.gact) + row * p.ld_gact + ch0, gp);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = f32x2{gelu_erf(o[i].x), gelu_erf(o[i].y)};
-      }
+      for (int i = 0; i < 4; ++i) o[i] = f32x2{gelu_erf(o[i].x), gelu_erf(o[i].y)};
     }
     store_pairs(static_cast<T*>(p.out) + row * p.ld_out + ch0, o);
     if (p.lse && head_leader) p.lse[row * H + h] = lse;
@@ -511,13 +493,9 @@ __global__ __launch_bounds__(256, DIRECT ? 2 : SEGGER_BWD_DST_WAVES) void gatv2_
       load_pairs(static_cast<const T*>(p.gout) + row * p.ld_go + ch0, gy);
       load_pairs(static_cast<const T*>(p.pre) + row * p.ld_pre + ch0, pr);
       f32x2 d2 = splat(0.f);
-      f32x2 gp[4];
-      const bool have_gact = p.apply_gelu && p.gact != nullptr;        // (uniform over the launch)
-      if (have_gact) load_pairs(static_cast<const T*>(p.gact) + row * p.ld_gact + ch0, gp);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (have_gact) g[i] = gy[i] * gp[i];
-        else g[i] = p.apply_gelu ? f32x2{gy[i].x * gelu_erf_grad(pr[i].x), gy[i].y * gelu_erf_grad(pr[i].y)} : gy[i];
+        g[i] = p.apply_gelu ? f32x2{gy[i].x * gelu_erf_grad(pr[i].x), gy[i].y * gelu_erf_grad(pr[i].y)} : gy[i];
         f32x2 b = splat(0.f);
         if (p.bias) b = f32x2{p.bias[ch0 + 2 * i], p.bias[ch0 + 2 * i + 1]};
         d2 = pk_fma(g[i], pr[i] - b, d2);

@@ -116,9 +116,7 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
                      heads: int, channels: int, out: Tensor, *, pre: Optional[Tensor] = None,
                      lse: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
                      apply_gelu: bool = False, negative_slope: float = 0.2,
-                     dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tensor] = None,
-                     gelu_grad: Optional[Tensor] = None) -> None:
-    """``gelu_grad`` (with ``apply_gelu``): [n_dst, H*C] output, gelu'(pre) for :func:`gatv2_bwd_launch`."""
+                     dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tensor] = None) -> None:
     _lib.require_cuda(xl, xr, att, out)
     lib = _lib.load()
     hc = heads * channels
@@ -141,8 +139,6 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
     a.lse, a.alpha = _lib.ptr(lse), _lib.ptr(alpha)
     if keep_bits is not None and dropout_p > 0.0:
         a.keep_bits = _bits_ptr(keep_bits, by_dst.n_edges)
-    if gelu_grad is not None and apply_gelu:
-        a.gelu_grad, a.ld_gelu_grad = _rows(gelu_grad, hc, "gelu_grad")
     with _lib.on_device(xl.device):
         rc = lib.segger_gatv2_fwd(C.byref(a), _lib.stream_ptr(xl.device))
     _lib.check(rc, "segger_gatv2_fwd")
@@ -152,12 +148,11 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
                      heads: int, channels: int, grad_out: Tensor, pre: Tensor, lse: Tensor,
                      grad_xl: Tensor, grad_xr: Tensor, *, apply_gelu: bool, negative_slope: float = 0.2,
                      dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tuple] = None,
-                     zero_rows_out: Optional[Tensor] = None, grad_xl_zeroed: bool = False,
-                     gelu_grad: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+                     zero_rows_out: Optional[Tensor] = None, grad_xl_zeroed: bool = False) -> Tuple[Tensor, Tensor]:
     """Writes grad_xl / grad_xr (views allowed); returns (grad_att[HC], grad_bias[HC]) fp32.  ``zero_rows_out``: a
     second [n_src, HC] matrix the source pass zero-fills on its way (ignored -> ``False`` comes back in
     ``gatv2_bwd_launch.zero_filled`` when this edge type runs the one-pass form or the generic kernels);
-    ``grad_xl_zeroed``: the one-pass form may skip its own zero fill; ``gelu_grad``: the forward's gelu'(pre)."""
+    ``grad_xl_zeroed``: the one-pass form may skip its own zero fill."""
     _lib.require_cuda(xl, xr, grad_out)
     lib = _lib.load()
     hc = heads * channels
@@ -192,8 +187,6 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
         grad_out = grad_out.contiguous()
     a.grad_out, a.ld_go = _rows(grad_out, hc, "grad_out")
     a.pre, a.ld_pre = _rows(pre, hc, "pre")
-    if gelu_grad is not None and apply_gelu:
-        a.gelu_grad, a.ld_gelu_grad = _rows(gelu_grad, hc, "gelu_grad")
     a.lse = lse.data_ptr()
     grad_pre = torch.empty((n_dst, hc), dtype=dt, device=dev)
     dsum = torch.empty((n_dst, heads, 2), dtype=torch.float32, device=dev)     # (lse, D) pairs for the source pass
@@ -213,11 +206,6 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
     return gparams[0], gparams[1]
 
 
-# training forwards also store gelu'(pre) (one more [n, H*C] matrix per conv) so that the backward does not evaluate Phi
-# and phi a second time: the kernels are bound by VALU issue, not by HBM traffic; tools flip it for A/B
-STORE_GELU_GRAD = True
-
-
 class _GatV2Aggregate(torch.autograd.Function):
     """One edge type: (x_l, x_r, att, bias) -> out [n_dst, H*C] (GELU optionally fused)."""
 
@@ -230,14 +218,12 @@ class _GatV2Aggregate(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad[:4])
         out = torch.empty((n_dst, hc), dtype=dt, device=dev)
         pre = torch.empty((n_dst, hc), dtype=dt, device=dev) if (need_grad and apply_gelu) else None
-        gact = torch.empty((n_dst, hc), dtype=dt, device=dev) if (need_grad and apply_gelu and STORE_GELU_GRAD) else None
         lse = torch.empty((n_dst, heads), dtype=torch.float32, device=dev) if need_grad else None
         alpha = torch.empty((graph.n_edges, heads), dtype=torch.float32, device=dev) if want_alpha else None
         gatv2_fwd_launch(graph.by_dst, xl, xr, att, bias, heads, channels, out, pre=pre, lse=lse, alpha=alpha,
                          apply_gelu=apply_gelu, negative_slope=negative_slope, dropout_p=dropout_p, seed=seed,
-                         keep_bits=None if keep_bits is None else keep_bits[0], gelu_grad=gact)
+                         keep_bits=None if keep_bits is None else keep_bits[0])
         if need_grad:
-            ctx.gact = gact
             ctx.save_for_backward(xl, xr, att, bias, pre if apply_gelu else out, lse)
             ctx.graph, ctx.cfg = graph, (heads, channels, apply_gelu, negative_slope, dropout_p, seed)
             ctx.keep_bits = keep_bits
@@ -256,7 +242,7 @@ class _GatV2Aggregate(torch.autograd.Function):
         gxr = torch.empty((g.n_dst, hc), dtype=xl.dtype, device=xl.device)
         gatt, gbias = gatv2_bwd_launch(g, xl, xr, att, bias, heads, channels, grad_out, pre, lse, gxl, gxr,
                                        apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed,
-                                       keep_bits=ctx.keep_bits, gelu_grad=ctx.gact)
+                                       keep_bits=ctx.keep_bits)
         gatt = gatt.reshape(att.shape).to(att.dtype)
         gbias = gbias.reshape(bias.shape).to(bias.dtype) if bias is not None else None
         return gxl, gxr, gatt, gbias, None, None, None, None, None, None, None, None, None
@@ -292,21 +278,19 @@ class _HeteroGatLayer(torch.autograd.Function):
         y_bd = torch.empty((nb, hc), dtype=dt, device=dev)
         mk = lambda n: torch.empty((n, hc), dtype=dt, device=dev) if (need_grad and apply_gelu) else None
         pre_tx, pre_bd = mk(nt), mk(nb)
-        gact_tx, gact_bd = (mk(nt), mk(nb)) if STORE_GELU_GRAD else (None, None)
         lse_tx = torch.empty((nt, heads), dtype=torch.float32, device=dev) if need_grad else None
         lse_bd = torch.empty((nb, heads), dtype=torch.float32, device=dev) if need_grad else None
         alpha = torch.empty((g_tt.n_edges, heads), dtype=torch.float32, device=dev) if want_alpha else None
         gatv2_fwd_launch(g_tt.by_dst, xl_tt, xr_tt, att_tt, bias_tt, heads, channels, y_tx, pre=pre_tx, lse=lse_tx,
                          alpha=alpha, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tt,
-                         keep_bits=None if bits_tt is None else bits_tt[0], gelu_grad=gact_tx)
+                         keep_bits=None if bits_tt is None else bits_tt[0])
         gatv2_fwd_launch(g_tb.by_dst, xl_tb, xp_bd, att_tb, bias_tb, heads, channels, y_bd, pre=pre_bd, lse=lse_bd,
                          apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tb,
-                         keep_bits=None if bits_tb is None else bits_tb[0], gelu_grad=gact_bd)
+                         keep_bits=None if bits_tb is None else bits_tb[0])
         if need_grad:
             ctx.save_for_backward(xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb,
                                   pre_tx if apply_gelu else y_tx, pre_bd if apply_gelu else y_bd, lse_tx, lse_bd)
             ctx.graphs = (g_tt, g_tb)
-            ctx.gact = (gact_tx, gact_bd)
             ctx.cfg = (heads, channels, apply_gelu, slope, dropout_p, seed_tt, seed_tb)
             ctx.bits = (bits_tt, bits_tb)
         if want_alpha:
@@ -332,12 +316,12 @@ class _HeteroGatLayer(torch.autograd.Function):
         gatt_tt, gbias_tt = gatv2_bwd_launch(
             g_tt, xp_tx[:, :hc], xp_tx[:, hc:2 * hc], att_tt, bias_tt, heads, channels, gy_tx, pre_tx, lse_tx,
             gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc], apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tt,
-            keep_bits=ctx.bits[0], zero_rows_out=gxp_tx[:, 2 * hc:], gelu_grad=ctx.gact[0])
+            keep_bits=ctx.bits[0], zero_rows_out=gxp_tx[:, 2 * hc:])
         zeroed = gatv2_bwd_launch.zero_filled
         gatt_tb, gbias_tb = gatv2_bwd_launch(
             g_tb, xp_tx[:, 2 * hc:], xp_bd, att_tb, bias_tb, heads, channels, gy_bd, pre_bd, lse_bd,
             gxp_tx[:, 2 * hc:], gxp_bd, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb,
-            keep_bits=ctx.bits[1], grad_xl_zeroed=zeroed, gelu_grad=ctx.gact[1])
+            keep_bits=ctx.bits[1], grad_xl_zeroed=zeroed)
         r = lambda gt, ref: gt.reshape(ref.shape).to(ref.dtype) if ref is not None else None
         return (gxp_tx, gxp_bd, r(gatt_tt, att_tt), r(gbias_tt, bias_tt), r(gatt_tb, att_tb), r(gbias_tb, bias_tb),
                 None, None, None, None, None, None, None, None, None, None, None, None)
