@@ -250,7 +250,9 @@ __device__ __forceinline__ float logit_partial(const f32x2 (&t)[4], const f32x2 
 //   s = bits(-de) ^ (bits(nt) & 0x80000000)                     (v_bitop3_b32),
 // which also yields de * |t| = s * t without a compare / select per channel.
 __device__ __forceinline__ f32x2 neg_canon_zero(f32x2 a) {          // -a, with +-0 -> +0
-  return f32x2{a.x == 0.f ? 0.f : -a.x, a.y == 0.f ? 0.f : -a.y};
+  // IEEE round-to-nearest: (+0) - (+0) = +0 and (+0) - (-0) = +0, and 0 - a = -a otherwise: one subtraction instead
+  // of a compare + select per channel (the compiler may not fold 0 - a into -a: it is not compiled with nsz)
+  return f32x2{0.f, 0.f} - a;
 }
 __device__ __forceinline__ float sign_mul(float nde, float nt) {     // de * sgn(t) given -de and nt
   // a ^ (b & c) as one v_bitop3_b32 (truth table 0xF0 ^ (0xCC & 0xAA) = 0x78); the compiler does not fold the

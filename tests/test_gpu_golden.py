@@ -112,9 +112,9 @@ def test_16bit_gradients_follow_the_fp32_hip_gradients_per_layer(cuda, dtype, u)
     for k, g in g32.items():
         err, own, flow = float((g16[k] - g).norm()), float(g.norm()), layer_max[_layer_of(k)]
         assert err <= 16 * u * own + 2 * u * flow, f"{k}: |dg| {err:.3e} vs |g| {own:.3e} (layer {flow:.3e})"
-        if own > 0.1 * flow:
+        if own > 0.5 * flow:
             worst = max(worst, err / own)
-    assert worst < 12 * u                              # the tensors that carry a layer's gradient: well inside the bound
+    assert worst < 8 * u                               # the tensors that carry a layer's gradient: well inside the bound
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
