@@ -389,7 +389,7 @@ def _triplet_args(src, pos, neg, za, zb, margin, eps):
     return a
 
 
-_CONTRIB_MIN_EDGES = 131072
+_CONTRIB_MIN_EDGES = 16384      # (packed 16-bit atomics into a gradient of the embeddings' dtype from this many triplets on: no fp32 staging + cast)
 
 
 class _TripletEdgeLoss(torch.autograd.Function):
