@@ -88,8 +88,8 @@ def _golden_grads(cuda, dtype):
     return float(loss), {k: p.grad.double().cpu() for k, p in m.named_parameters() if p.grad is not None}
 
 
-@pytest.mark.parametrize("dtype,u", [(torch.bfloat16, 2.0 ** -8), (torch.float16, 2.0 ** -11)])
-def test_16bit_gradients_follow_the_fp32_hip_gradients_per_layer(cuda, dtype, u):
+@pytest.mark.parametrize("dtype,u,flow_coef", [(torch.bfloat16, 2.0 ** -8, 2.0), (torch.float16, 2.0 ** -11, 8.0)])
+def test_16bit_gradients_follow_the_fp32_hip_gradients_per_layer(cuda, dtype, u, flow_coef):
     """Every parameter gradient of the 16-bit step against the SAME kernels at fp32 storage (the exact-fp32 MFMA
     projections, fp32 aggregation), per tensor, in the Euclidean norm:
         || g16 - g32 ||  <=  16 u || g32 ||  +  2 u G_layer ,     G_layer = max over the tensors of the same layer of || g32 ||
@@ -98,7 +98,9 @@ def test_16bit_gradients_follow_the_fp32_hip_gradients_per_layer(cuda, dtype, u)
     many stored gradient matrices, ~ 30 roundings of u / 2 on the longest path: 16 u.  The additive term is what a tensor
     whose own gradient nearly cancels (lin_r / att of the late layers, the tx-belongs-bd convs of the early ones: 10^2-10^6
     times smaller than their layer's largest tensor) inherits from the rounding of the activations it is summed over:
-    proportional to the layer's gradient flow, not to its own size.  Measured (tools output in DESIGN.md 1): the large
+    proportional to the layer's gradient flow, not to its own size (coefficient 2; 8 for f16, whose stored gradient
+    matrices -- entries of 1e-6 .. 1e-8 on this batch -- sit in the format's subnormal range, spacing 2^-24, and lose
+    absolute rather than relative precision).  Measured (tools output in DESIGN.md 1): the large
     tensors differ by 1.2-2.5 % (bf16) / 0.2-0.6 % (f16), the loss by < 1e-3.  This replaces the 12 %-of-max bound the
     bf16 run was held to against the stored oracle gradients."""
     loss32, g32 = _golden_grads(cuda, torch.float32)
@@ -111,7 +113,7 @@ def test_16bit_gradients_follow_the_fp32_hip_gradients_per_layer(cuda, dtype, u)
     worst = 0.0
     for k, g in g32.items():
         err, own, flow = float((g16[k] - g).norm()), float(g.norm()), layer_max[_layer_of(k)]
-        assert err <= 16 * u * own + 2 * u * flow, f"{k}: |dg| {err:.3e} vs |g| {own:.3e} (layer {flow:.3e})"
+        assert err <= 16 * u * own + flow_coef * u * flow, f"{k}: |dg| {err:.3e} vs |g| {own:.3e} (layer {flow:.3e})"
         if own > 0.5 * flow:
             worst = max(worst, err / own)
     assert worst < 8 * u                               # the tensors that carry a layer's gradient: well inside the bound
