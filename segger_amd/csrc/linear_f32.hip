@@ -208,9 +208,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_f32_kernel(WgF32Params p) {
   static_assert(TM % WM == 0 && TK % WK == 0, "tile grid does not split over the waves");
   constexpr int MT = TM / WM, KT = TK / WK;
   static_assert(MT * KT <= 12, "accumulator does not fit the register file");
-  // row pairs per software-pipeline stage (the next stage's operands are in flight under this stage's MFMAs): few tiles
-  // per wave = few MFMAs per loaded operand = a memory-bound shape that needs more bytes in flight
-  constexpr int U = MT * KT > 6 ? 2 : (MT * KT == 6 ? 4 : (MT + KT <= 2 ? 16 : 8));
+  // ring slots (steps of look-ahead + 1): few tiles per wave = few MFMAs per loaded operand = a memory-bound shape that
+  // needs more loads in flight
+  constexpr int R = MT * KT >= 6 ? 8 : (MT + KT <= 2 ? 24 : 12);
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave % WM, wk = wave / WM;
@@ -233,50 +233,58 @@ __global__ __launch_bounds__(NW * 64) void wgrad_f32_kernel(WgF32Params p) {
 
   const float* __restrict__ dyb = p.dy + 32 * wm * MT + r;
   const float* __restrict__ xb = p.x + 32 * wk * KT + r;
-  // rows past the slab / the matrix: the loads are clamped to the last row (never out of bounds, no branch around a
-  // load) and the A operand is zeroed when it is used
-  const int64_t row_last = (2 * s_end < p.n_rows ? 2 * s_end : p.n_rows) - 1;     // last row of this slab
-  float fa[2][U][MT], fb[2][U][KT];
-  auto fetch = [&](int buf, int64_t s0) {
+  // A ring of R steps (row pairs) in registers: a step's operands are requested R - 1 steps before its MFMAs and its
+  // slot is refilled right after them, so R - 1 steps of loads are always in flight.  (With every CU streaming, a
+  // 4-byte-per-lane load takes longer to come back than a few MFMAs last: with 4 steps of look-ahead the waves sat in
+  // s_waitcnt 47 % of the time and the matrix pipe was 44 % busy -- PMC, round 3.)  Full steps -- both rows inside
+  // the slab and the matrix -- run without any bounds arithmetic; the running read position stops at the last full
+  // step (re-read, never out of bounds, values unused).
+  const int64_t rows_end = 2 * s_end < p.n_rows ? 2 * s_end : p.n_rows;          // rows of this slab: [2 s_beg, rows_end)
+  const int64_t full_steps = rows_end / 2 > s_beg ? rows_end / 2 - s_beg : 0;    // steps whose two rows both exist
+  const int64_t ld_a = p.ld_dy, ld_b = p.ld_x;
+  float fa[R][MT], fb[R][KT];
+  const float* pa = dyb + (2 * s_beg + h) * ld_a;
+  const float* pb = xb + (2 * s_beg + h) * ld_b;
+  int64_t nxt = 0;                                     // step the next fetch reads (uniform)
+  auto fetch = [&](int slot) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int64_t row = 2 * (s0 + u) + h;
-      row = row < row_last ? row : row_last;
-      const float* pa = dyb + row * p.ld_dy;
-      const float* pb = xb + row * p.ld_x;
+    for (int a = 0; a < MT; ++a) fa[slot][a] = pa[32 * a];
 #pragma unroll
-      for (int a = 0; a < MT; ++a) fa[buf][u][a] = pa[32 * a];
+    for (int b = 0; b < KT; ++b) fb[slot][b] = pb[32 * b];
+    if (nxt + 1 < full_steps) { pa += 2 * ld_a; pb += 2 * ld_b; ++nxt; }
+  };
+  auto compute = [&](int slot) {
 #pragma unroll
-      for (int b = 0; b < KT; ++b) fb[buf][u][b] = pb[32 * b];
+    for (int a = 0; a < MT; ++a) {
+      if (wk == 0) dbias[a] += fa[slot][a];
+#pragma unroll
+      for (int b = 0; b < KT; ++b) acc[a][b] = mfma_f32(fa[slot][a], fb[slot][b], acc[a][b]);
     }
   };
-  auto compute = [&](int buf, int64_t s0) {
+  if (full_steps > 0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const bool ok = 2 * (s0 + u) + h <= row_last;
+    for (int j = 0; j < R; ++j) fetch(j);
+    int64_t i = 0;
+    for (; i + R <= full_steps; i += R) {
 #pragma unroll
-      for (int a = 0; a < MT; ++a) {
-        const float av = ok ? fa[buf][u][a] : 0.f;
-        if (wk == 0) dbias[a] += av;
-#pragma unroll
-        for (int b = 0; b < KT; ++b) acc[a][b] = mfma_f32(av, fb[buf][u][b], acc[a][b]);
-      }
+      for (int j = 0; j < R; ++j) { compute(j); fetch(j); }
     }
-  };
-  if (s_beg < s_end) {
-    // two register stages: the operands of rows s + 8 .. s + 15 are requested before the MFMAs of rows s .. s + 7
-    // (a stage past the slab reads nothing and holds zeros)
-    int64_t s = s_beg;
-    fetch(0, s);
-    while (true) {
-      fetch(1, s + U);
-      compute(0, s);
-      s += U;
-      if (s >= s_end) break;
-      fetch(0, s + U);
-      compute(1, s);
-      s += U;
-      if (s >= s_end) break;
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+      if (i + j < full_steps) compute(j);
+  }
+  // the rest of the slab: at the end of the matrix, one step with a single row
+  for (int64_t s = s_beg + full_steps; s < s_end; ++s) {
+    const int64_t row = 2 * s + h;
+    const bool ok = row < rows_end;
+    const int64_t rc = ok ? row : rows_end - 1;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+      const float v = dyb[rc * ld_a + 32 * a];
+      const float av = ok ? v : 0.f;
+      if (wk == 0) dbias[a] += av;
+#pragma unroll
+      for (int b = 0; b < KT; ++b) acc[a][b] = mfma_f32(av, xb[rc * ld_b + 32 * b], acc[a][b]);
     }
   }
 
