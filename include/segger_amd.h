@@ -216,12 +216,15 @@ size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads, int32_t ch
 int segger_gatv2_bwd(const segger_gatv2_bwd_args* args, segger_stream_t stream);
 /*
  * segger_dropout_bits: the attention-dropout mask of n_seeds layers as bit planes over the slots of one CSR view:
- *   bits[l * n_edges + slot] = sum_h keep(eid[slot], h; seeds[l] + *seed_dev) << h        (heads <= 8)
+ *   bits[l * plane_stride + slot] = sum_h keep(eid[slot], h; seeds[l] + *seed_dev) << h        (heads <= 8)
  * with keep() exactly the counter-based mask of segger_gatv2_fwd.  One launch per view per training step replaces
  * 3 passes x n_seeds layers of per-(edge, head) hashing inside the aggregation kernels.  seeds is a HOST array.
+ * plane_stride: bytes between the planes of consecutive layers, a multiple of 4 and >= n_edges (a thread writes four
+ * slots of a plane as one word); bits 4-byte aligned.
  */
 int segger_dropout_bits(const int32_t* eid, int64_t n_edges, int32_t heads, float dropout_p, const uint64_t* seeds,
-                        int32_t n_seeds, const uint64_t* seed_dev, uint8_t* bits, segger_stream_t stream);
+                        int32_t n_seeds, const uint64_t* seed_dev, uint8_t* bits, int64_t plane_stride,
+                        segger_stream_t stream);
 
 /* 1 when (heads, channels) runs on the specialised kernels (channels in {32,64}, heads in 1..4), 0 = generic kernels */
 int segger_gatv2_has_specialised(int32_t heads, int32_t channels);
@@ -438,7 +441,7 @@ int segger_linear_fwd_silu_grad(const void* x, int64_t ldx, const void* w, const
                                 int64_t ldy, int64_t n_rows, int32_t k_in, int32_t m_out, int32_t dtype,
                                 segger_stream_t stream);
 /* segger_linear_fwd_rowbias: the same with  y[row, :] += rowbias[rowidx[row], :]  added in the epilogue (table
- * [n_ids, ld_rb >= m_out] in `dtype`, added in fp32; int32 ids in range -- not checked): the gene-embedding half of the first layer's projections
+ * [n_ids, ld_rb >= m_out] in `dtype`, 16-byte aligned rows, added in fp32; int32 ids in range -- not checked): the gene-embedding half of the first layer's projections
  * collapses to a per-gene table T = gelu(E) Wa^T + b ([n_genes, 384]), so the GEMM runs over the positional half only
  * (K 256 -> 128) and gelu(cat(E[g], pe)) is never materialised (ist_encoder.py:312-325 + GATv2Conv.lin_l / lin_r). */
 int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void* w, const float* bias, const void* rowbias,

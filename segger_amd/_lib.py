@@ -126,7 +126,7 @@ EXPORTS = {
     "segger_gatv2_fwd": (C.c_int, [C.POINTER(GatFwdArgs), vp]),
     "segger_gatv2_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "segger_gatv2_bwd": (C.c_int, [C.POINTER(GatBwdArgs), vp]),
-    "segger_dropout_bits": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_float, vp, C.c_int32, vp, vp, vp]),
+    "segger_dropout_bits": (C.c_int, [vp, C.c_int64, C.c_int32, C.c_float, vp, C.c_int32, vp, vp, C.c_int64, vp]),
     "segger_gatv2_has_specialised": (C.c_int, [C.c_int32, C.c_int32]),
     "segger_coo_unique": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
     "segger_stage": (C.c_int, [C.POINTER(StageSeg), C.c_int32, vp]),

@@ -40,20 +40,35 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(char* __restrict__ base,
   *reinterpret_cast<u32x4*>(base + (i / pieces) * pitch + (i % pieces) * 16) = u32x4{0u, 0u, 0u, 0u};
 }
 
-// bits[l][slot] = OR_h keep(eid[slot], h; seed_l) << h   (one thread per slot, all layers)
-struct BitsParams { const int32_t* eid; int64_t n_edges; int heads; uint32_t thr; int n_seeds; uint64_t seeds[16];
-                    const uint64_t* seed_dev; uint8_t* bits; };
+// bits[l][slot] = OR_h keep(eid[slot], h; seed_l) << h for all layers; a thread owns FOUR consecutive slots: one 16-byte
+// load of their edge ids and one 4-byte store per plane (byte stores, one slot per thread, ran at 2.3 TB/s)
+struct BitsParams { const int32_t* eid; int64_t n_edges; int64_t plane_stride; int heads; uint32_t thr; int n_seeds;
+                    int eid_aligned; uint64_t seeds[16]; const uint64_t* seed_dev; uint8_t* bits; };
 __global__ __launch_bounds__(256) void dropout_bits_kernel(BitsParams p) {
-  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (s >= p.n_edges) return;
-  const uint32_t e = (uint32_t)p.eid[s];
+  const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (s0 >= p.n_edges) return;
+  const bool full = s0 + 3 < p.n_edges;
+  uint32_t e[4] = {0u, 0u, 0u, 0u};
+  if (full && p.eid_aligned) {                          // (a view sliced out of a slide-level sort may start anywhere)
+    const u32x4 v = *reinterpret_cast<const u32x4*>(p.eid + s0);
+    e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
+  } else {
+    for (int k = 0; k < 4 && s0 + k < p.n_edges; ++k) e[k] = (uint32_t)p.eid[s0 + k];
+  }
   const uint64_t dev = p.seed_dev ? *p.seed_dev : 0ull;
   for (int l = 0; l < p.n_seeds; ++l) {
     const uint64_t mixed = splitmix64(p.seeds[l] + dev);
     const uint32_t lo = (uint32_t)mixed, hi = (uint32_t)(mixed >> 32);
-    uint32_t b = 0;
-    for (int h = 0; h < p.heads; ++h) b |= (uint32_t)dropout_keep(e, p.heads, h, lo, hi, p.thr) << h;
-    p.bits[(int64_t)l * p.n_edges + s] = (uint8_t)b;
+    uint32_t word = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t b = 0;
+      for (int h = 0; h < p.heads; ++h) b |= (uint32_t)dropout_keep(e[k], p.heads, h, lo, hi, p.thr) << h;
+      word |= b << (8 * k);
+    }
+    uint8_t* plane = p.bits + (int64_t)l * p.plane_stride + s0;
+    if (full) *reinterpret_cast<uint32_t*>(plane) = word;          // (plane_stride % 4 == 0: checked by the host)
+    else for (int k = 0; k < 4 && s0 + k < p.n_edges; ++k) plane[k] = (uint8_t)(word >> (8 * k));
   }
 }
 
@@ -270,17 +285,20 @@ extern "C" int segger_gatv2_has_specialised(int32_t heads, int32_t channels) {
 
 extern "C" int segger_dropout_bits(const int32_t* eid, int64_t n_edges, int32_t heads, float dropout_p,
                                    const uint64_t* seeds, int32_t n_seeds, const uint64_t* seed_dev, uint8_t* bits,
-                                   segger_stream_t stream) {
+                                   int64_t plane_stride, segger_stream_t stream) {
   SEGGER_REQUIRE(n_edges >= 0 && heads > 0 && heads <= 8, "segger_dropout_bits: heads must be in 1..8");
   SEGGER_REQUIRE(n_seeds > 0 && n_seeds <= 16 && seeds, "segger_dropout_bits: 1..16 seeds");
   SEGGER_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "segger_dropout_bits: dropout_p must be in [0,1)");
   if (n_edges == 0) return SEGGER_OK;
   SEGGER_REQUIRE(eid && bits, "segger_dropout_bits: NULL pointer");
+  SEGGER_REQUIRE(plane_stride >= n_edges && plane_stride % 4 == 0 && ((uintptr_t)bits & 3u) == 0,
+                 "segger_dropout_bits: plane_stride must be a multiple of 4 >= n_edges and bits 4-byte aligned");
   BitsParams p{};
-  p.eid = eid; p.n_edges = n_edges; p.heads = heads; p.n_seeds = n_seeds; p.seed_dev = seed_dev; p.bits = bits;
+  p.eid = eid; p.n_edges = n_edges; p.plane_stride = plane_stride; p.heads = heads; p.n_seeds = n_seeds;
+  p.seed_dev = seed_dev; p.bits = bits; p.eid_aligned = aligned16(eid) ? 1 : 0;
   p.thr = (uint32_t)((double)dropout_p * 16777216.0);
   for (int l = 0; l < n_seeds; ++l) p.seeds[l] = seeds[l];
-  hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)((n_edges + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)((n_edges + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, p);
   SEGGER_LAUNCH_CHECK("dropout_bits_kernel");
   return SEGGER_OK;
 }

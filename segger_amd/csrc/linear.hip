@@ -103,12 +103,20 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
 
   const int n_chunks = p.m_out / kChunk;
   // per-row additive table row of this lane's data row (its columns are fetched per chunk, ahead of the MFMAs)
-  const T* rb_row = nullptr;
   const T* gate_row = nullptr;
+  // RB: the table rows of this wave's 32 data rows are fetched as whole 128-byte chunk segments -- lane (8 i + lane / 8,
+  // piece lane % 8) loads 16 bytes, 8 rows x 128 B per instruction -- and handed to the lanes that own the output
+  // columns through the wave's epilogue tile.  (Round 2 let every lane fetch its own 8-byte column groups: 32 table
+  // rows x 16 B per instruction, twice the instructions and four times the cache lines per instruction: 0.31 ms for
+  // the first layer against 0.22 ms for the plain projection.)
+  const T* rb_rows[4] = {nullptr, nullptr, nullptr, nullptr};
   if (RB) {
-    int64_t row = row0 + r;
-    if (row >= p.n_rows) row = p.n_rows - 1;
-    rb_row = static_cast<const T*>(p.rowbias) + (int64_t)p.rowidx[row] * p.ld_rb + 4 * h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int64_t row = row0 + 8 * i + (lane >> 3);
+      if (row >= p.n_rows) row = p.n_rows - 1;
+      rb_rows[i] = static_cast<const T*>(p.rowbias) + (int64_t)p.rowidx[row] * p.ld_rb + 8 * (lane & 7);
+    }
   }
   if (SG) {
     int64_t row = row0 + r;
@@ -122,13 +130,17 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
     __syncthreads();
     if (c + 1 < n_chunks) w_fetch(c0 + kChunk);    // prefetch under the MFMAs
     // this lane's 4-column groups of the table row / the gate row, requested ahead of the MFMAs
-    uint2 rbv[(RB || SG) ? 2 : 1][(RB || SG) ? 4 : 1];
-    if (RB || SG) {
-      const T* src = RB ? rb_row : gate_row;
+    uint2 rbv[SG ? 2 : 1][SG ? 4 : 1];
+    u32x4 rbq[RB ? 4 : 1];
+    if (SG) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) rbv[ct][g] = *reinterpret_cast<const uint2*>(src + c0 + ct * 32 + 8 * g);
+        for (int g = 0; g < 4; ++g) rbv[ct][g] = *reinterpret_cast<const uint2*>(gate_row + c0 + ct * 32 + 8 * g);
+    }
+    if (RB) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rbq[i] = *reinterpret_cast<const u32x4*>(rb_rows[i] + c0);
     }
 
     f32x16 acc[2];
@@ -148,6 +160,13 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
 
     // ---- epilogue: lane owns data row r and output columns ct*32 + 8g + 4h + {0..3} -------------
     unsigned char* et = lds_e + wave * 32 * ESTRIDE;
+    if (RB) {
+      // table segments -> the wave's tile (same layout as the output tile); every lane then reads its own column
+      // groups back and overwrites exactly those bytes with the result: LDS operations of one wave execute in order
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<u32x4*>(et + (8 * i + (lane >> 3)) * ESTRIDE + (lane & 7) * 16) = rbq[i];
+    }
 
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
@@ -158,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = acc[ct][4 * g + j] + (p.bias ? p.bias[c0 + col + j] : 0.f);
         if (RB) {
-          const uint2 tt = rbv[RB ? ct : 0][RB ? g : 0];
+          const uint2 tt = *reinterpret_cast<const uint2*>(et + r * ESTRIDE + col * 2);
           float t4[4];
           Vec8<T>::unpack2(tt.x, t4[0], t4[1]);
           Vec8<T>::unpack2(tt.y, t4[2], t4[3]);
@@ -284,8 +303,8 @@ extern "C" int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void*
   SEGGER_REQUIRE(ldx >= k_in && ldy >= m_out && (ldx * 2) % 16 == 0 && (ldy * 2) % 16 == 0,
                  "segger_linear_fwd: bad leading dimension");
   SEGGER_REQUIRE(!rowbias == !rowidx, "segger_linear_fwd_rowbias: rowbias and rowidx go together");
-  SEGGER_REQUIRE(!rowbias || (aligned16(rowbias) && ld_rb >= m_out && ld_rb % 4 == 0),
-                 "segger_linear_fwd_rowbias: the table needs 8-byte aligned rows of at least m_out elements");
+  SEGGER_REQUIRE(!rowbias || (aligned16(rowbias) && ld_rb >= m_out && ld_rb % 8 == 0),
+                 "segger_linear_fwd_rowbias: the table needs 16-byte aligned rows of at least m_out elements");
   LinearParams p{x, ldx, w, bias, y, ldy, n_rows, m_out, rowbias, rowidx, ld_rb, nullptr, 0};
   return dtype == SEGGER_BF16 ? launch_linear<bf16_t>(p, k_in, (hipStream_t)stream)
                               : launch_linear<f16_t>(p, k_in, (hipStream_t)stream);

@@ -53,13 +53,14 @@ def dropout_bits(csr: EdgeCSR, heads: int, dropout_p: float, seeds, seed_dev: Op
     _lib.require_cuda(csr.col)
     lib = _lib.load()
     seeds = [int(v) & 0xFFFFFFFFFFFFFFFF for v in seeds]
-    out = torch.empty((len(seeds), csr.n_edges), dtype=torch.uint8, device=csr.col.device)
+    stride = (csr.n_edges + 15) // 16 * 16                 # planes start 16-byte aligned: four slots are stored as one word
+    out = torch.empty((len(seeds), stride), dtype=torch.uint8, device=csr.col.device)
     arr = (C.c_uint64 * len(seeds))(*seeds)
     with _lib.on_device(out.device):
         rc = lib.segger_dropout_bits(csr.eid.data_ptr() if csr.n_edges else None, csr.n_edges, heads, dropout_p, arr,
-                                     len(seeds), _lib.ptr(seed_dev), out.data_ptr(), _lib.stream_ptr(out.device))
+                                     len(seeds), _lib.ptr(seed_dev), out.data_ptr(), stride, _lib.stream_ptr(out.device))
     _lib.check(rc, "segger_dropout_bits")
-    return out
+    return out[:, :csr.n_edges]
 
 
 # ---- deferred partial sums (csrc/reduce.hip) ----------------------------------------------------------------
