@@ -470,11 +470,17 @@ int segger_linear_wgrad(const void* dy, int64_t ld_dy, const void* x, int64_t ld
  * lin_l | lin_r | lin_l projections is the widest matrix of a layer's backward; the separate data-gradient GEMM
  * (segger_linear_fwd on W^T) read it a second time.  w_t = W^T, [k_in, m_out] contiguous in `dtype`; dx row stride
  * ld_dx (elements, 16-byte aligned rows); covered: k_in == 128, m_out in {64,128,192,384}, bf16 / f16
- * (segger_linear_wgrad_dx_supported); workspace as for segger_linear_wgrad. */
+ * (segger_linear_wgrad_dx_supported); workspace as for segger_linear_wgrad.
+ * gelu_gate (optional, [n, k_in] in `dtype`, row stride ld_gate): dx[row, c] *= gelu'(gelu_gate[row, c]) in the epilogue
+ * -- the projection's input was gelu(gate) (ISTEncoder's GELU on the concatenated first-layer input,
+ * ist_encoder.py:320): the gradient leaves as d / d gate without an elementwise pass of its own; covered for m_out in
+ * {128, 384} (segger_linear_wgrad_dx_gate_supported); NULL = plain dX. */
 int segger_linear_wgrad_dx_supported(int32_t m_out, int32_t k_in, int32_t dtype);
+int segger_linear_wgrad_dx_gate_supported(int32_t m_out, int32_t k_in, int32_t dtype);
 int segger_linear_wgrad_dx(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, const void* w_t, int64_t n_rows,
                            int32_t m_out, int32_t k_in, int32_t dtype, float* grad_w, float* grad_b, void* dx,
-                           int64_t ld_dx, void* workspace, size_t workspace_bytes, segger_stream_t stream);
+                           int64_t ld_dx, const void* gelu_gate, int64_t ld_gate, void* workspace, size_t workspace_bytes,
+                           segger_stream_t stream);
 
 /*
  * Deferred partial sums.  segger_linear_wgrad / _wgrad_dx / segger_posmlp_wgrad and segger_gatv2_bwd finish with a small

@@ -161,8 +161,9 @@ EXPORTS = {
     "segger_reductions_pending": (C.c_int, []),
     "segger_reductions_flush": (C.c_int, [vp]),
     "segger_linear_wgrad_dx_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "segger_linear_wgrad_dx_gate_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "segger_linear_wgrad_dx": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp, vp,
-                                         vp, C.c_int64, vp, C.c_size_t, vp]),
+                                         vp, C.c_int64, vp, C.c_int64, vp, C.c_size_t, vp]),
     "segger_posfreq": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_float, C.c_float, vp, C.c_int32, vp]),
     "segger_embed_gelu_fwd": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, C.c_int32, vp]),
     "segger_embed_gelu_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),

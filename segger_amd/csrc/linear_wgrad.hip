@@ -83,6 +83,7 @@ struct WgradParams {
   float log_max_period;
   const void* wt;            // DX: W^T [K, M] row-major in the activation dtype
   void* dx; int64_t ld_dx;   // DX: dX [n_rows, K]
+  const void* gate; int64_t ld_gate;   // DX, optional: dX[row, c] *= gelu'(gate[row, c]) (the GELU the projection's input went through)
 };
 
 // One LDS-DMA wave-instruction: every lane fetches 16 bytes at rsrc + voffset + soffset (zeros when that is past
@@ -116,6 +117,10 @@ template <int M, int K, int NW, bool GEN = false> struct WgGeo {
   static constexpr int LDS = kNBuf * BUF;
   static constexpr int SO = K * 2 + 16;                           // DX: row stride of the dX stage tile
   static constexpr int OUT = kStageRows * SO;                     // DX: one dX stage tile (two of them behind the ring)
+  // DX with a gate (dX *= gelu'(gate)): 16 rows of the gate matrix [n, K] ride behind the X rows of the stage image when
+  // the ring slot has the room anyway (chunks past IMG are fetched -- as zeros -- regardless: no extra DMA instruction)
+  static constexpr int IMG_G = IMG + kStageRows * SX;
+  static constexpr bool GATE_OK = !GEN && IMG % 1024 == 0 && IMG_G <= BUF;
 };
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {   // lgkmcnt / expcnt untouched
@@ -156,6 +161,9 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
   const i32x4 rx = GEN ? make_rsrc(p.pn + row_beg, span_rows * 4) : make_rsrc(x + row_beg * p.ld_x, span_rows * p.ld_x * 2);
   const int stage_bytes_y = kStageRows * (int)p.ld_dy * 2;
   const int stage_bytes_x = GEN ? kStageRows * 4 : kStageRows * (int)p.ld_x * 2;
+  const bool gated = DX && G::GATE_OK && p.gate != nullptr;                     // (uniform over the launch)
+  const i32x4 rg = gated ? make_rsrc(static_cast<const T*>(p.gate) + row_beg * p.ld_gate, span_rows * p.ld_gate * 2) : rx;
+  const int stage_bytes_g = gated ? kStageRows * (int)p.ld_gate * 2 : 0;
   int voff[P];
 #pragma unroll
   for (int j = 0; j < P; ++j) {
@@ -171,6 +179,10 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
         const int row = oo / SX, w = oo % SX;
         voff[j] = row * (int)p.ld_x * 2 + (w < K * 2 ? w : 0);
       }
+    } else if (gated && o < G::IMG_G) {
+      const int oo = o - G::IMG;
+      const int row = oo / SX, w = oo % SX;
+      voff[j] = row * (int)p.ld_gate * 2 + (w < K * 2 ? w : 0);
     } else {
       voff[j] = kOutOfRange;
     }
@@ -180,8 +192,13 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
     const uint32_t dst = lds_base + (uint32_t)((local_stage % kNBuf) * BUF + wave * 1024);
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-      const bool is_y = (wave + j * NW) * 1024 < kStageRows * SY;      // wave-uniform
-      lds_dma16(is_y ? ry : rx, dst + j * NW * 1024, voff[j], local_stage * (is_y ? stage_bytes_y : stage_bytes_x));
+      const int co = (wave + j * NW) * 1024;                           // wave-uniform: which matrix this chunk belongs to
+      const bool is_y = co < kStageRows * SY, is_g = DX && G::GATE_OK && co >= G::IMG;
+      if (is_g) {                                                      // (compile-time false without a gate region)
+        lds_dma16(rg, dst + j * NW * 1024, voff[j], local_stage * stage_bytes_g);
+      } else {
+        lds_dma16(is_y ? ry : rx, dst + j * NW * 1024, voff[j], local_stage * (is_y ? stage_bytes_y : stage_bytes_x));
+      }
     }
   };
 
@@ -333,6 +350,17 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
         for (int ct = 0; ct < CT; ++ct) dacc[ct] = WgMfma<T>::run16(wf[ct][ks], fy, dacc[ct]);
       }
       unsigned char* ot = lds_out + (s & 1) * G::OUT + dj * SO;
+      if (gated) {                                       // this lane's 4 columns of row dj of the staged gate rows
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          const u32x2 gv = *reinterpret_cast<const u32x2*>(base + G::IMG + dj * SX + (16 * (wave * CT + ct) + 4 * dq) * 2);
+          float z0, z1, z2, z3;
+          Vec8<T>::unpack2(gv.x, z0, z1);
+          Vec8<T>::unpack2(gv.y, z2, z3);
+          dacc[ct] = f32x4{dacc[ct].x * gelu_erf_grad(z0), dacc[ct].y * gelu_erf_grad(z1),
+                           dacc[ct].z * gelu_erf_grad(z2), dacc[ct].w * gelu_erf_grad(z3)};
+        }
+      }
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         const u32x2 pk = u32x2{Vec8<T>::pack(dacc[ct].x, dacc[ct].y), Vec8<T>::pack(dacc[ct].z, dacc[ct].w)};
@@ -468,6 +496,9 @@ void launch_wgrad_dx(const WgradParams& p, int64_t grid, hipStream_t stream) {
 }
 
 bool dx_shape_ok(int m, int k) { return k == 128 && (m == 384 || m == 192 || m == 128 || m == 64); }
+bool dx_gate_ok(int m, int k) {          // WgGeo::GATE_OK of the instantiated shapes
+  return k == 128 && ((m == 384 && WgGeo<384, 128, 8>::GATE_OK) || (m == 128 && WgGeo<128, 128, 8>::GATE_OK));
+}
 
 template <typename T>
 int dispatch_wgrad_dx(const WgradParams& p, int m, int64_t grid, hipStream_t stream) {
@@ -513,10 +544,14 @@ extern "C" int segger_linear_wgrad_dx_supported(int32_t m_out, int32_t k_in, int
   return dx_shape_ok(m_out, k_in) && (dtype == SEGGER_BF16 || dtype == SEGGER_F16);
 }
 
+extern "C" int segger_linear_wgrad_dx_gate_supported(int32_t m_out, int32_t k_in, int32_t dtype) {
+  return segger_linear_wgrad_dx_supported(m_out, k_in, dtype) && dx_gate_ok(m_out, k_in);
+}
+
 extern "C" int segger_linear_wgrad_dx(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, const void* w_t,
                                       int64_t n_rows, int32_t m_out, int32_t k_in, int32_t dtype, float* grad_w,
-                                      float* grad_b, void* dx, int64_t ld_dx, void* workspace, size_t workspace_bytes,
-                                      segger_stream_t stream_) {
+                                      float* grad_b, void* dx, int64_t ld_dx, const void* gelu_gate, int64_t ld_gate,
+                                      void* workspace, size_t workspace_bytes, segger_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SEGGER_REQUIRE(n_rows >= 0 && m_out > 0 && k_in > 0, "segger_linear_wgrad_dx: bad sizes");
   SEGGER_REQUIRE(grad_w != nullptr, "segger_linear_wgrad_dx: grad_w is NULL");
@@ -535,6 +570,11 @@ extern "C" int segger_linear_wgrad_dx(const void* dy, int64_t ld_dy, const void*
                  "segger_linear_wgrad_dx: pointers must be 16-byte aligned");
   SEGGER_REQUIRE(ld_dy >= m_out && ld_x >= k_in && ld_dx >= k_in && (ld_dy * 2) % 16 == 0 && (ld_x * 2) % 16 == 0 &&
                      (ld_dx * 2) % 16 == 0, "segger_linear_wgrad_dx: bad leading dimension");
+  if (gelu_gate) {
+    SEGGER_REQUIRE(dx_gate_ok(m_out, k_in), "segger_linear_wgrad_dx: the gate form covers m_out in {128, 384} (k_in 128)");
+    SEGGER_REQUIRE(aligned16(gelu_gate) && ld_gate >= k_in && (ld_gate * 2) % 16 == 0,
+                   "segger_linear_wgrad_dx: gate rows must be 16-byte aligned");
+  }
   const size_t need = segger_linear_wgrad_workspace_bytes(n_rows, m_out, k_in);     // (the dX form never uses more slabs)
   if (workspace == nullptr || workspace_bytes < need) {
     set_error("segger_linear_wgrad_dx: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -546,8 +586,12 @@ extern "C" int segger_linear_wgrad_dx(const void* dy, int64_t ld_dy, const void*
     const int64_t span = ((stages + grid - 1) / grid) * kStageRows * (ld_dy > ld_x ? ld_dy : ld_x) * 2;
     SEGGER_REQUIRE(span < (int64_t)kOutOfRange, "segger_linear_wgrad_dx: a workgroup's row slab exceeds 1 GiB");
   }
+  {
+    const int64_t span_g = ((stages + grid - 1) / grid) * kStageRows * ld_gate * 2;
+    SEGGER_REQUIRE(!gelu_gate || span_g < (int64_t)kOutOfRange, "segger_linear_wgrad_dx: a workgroup's row slab exceeds 1 GiB");
+  }
   WgradParams p{dy, ld_dy, x, ld_x, n_rows, stages, (stages + grid - 1) / grid, static_cast<float*>(workspace), nullptr, 0.f,
-                w_t, dx, ld_dx};
+                w_t, dx, ld_dx, gelu_gate, ld_gate};
   const int rc = dtype == SEGGER_BF16 ? dispatch_wgrad_dx<bf16_t>(p, m_out, grid, stream)
                                       : dispatch_wgrad_dx<f16_t>(p, m_out, grid, stream);
   if (rc != SEGGER_OK) return rc;

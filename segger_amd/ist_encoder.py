@@ -87,8 +87,10 @@ class Positional2dEmbedder(Module):
         return (pos - lo) / (hi - lo + 1e-8)                # ist_encoder.py:74
 
     def forward(self, pos: Tensor, batch: Optional[Tensor] = None, *, num_graphs: Optional[int] = None,
-                dtype: torch.dtype = torch.float32, gelu: bool = False) -> Tensor:
-        """``gelu`` (not in the reference): also apply the GELU that ISTEncoder puts on its concatenated input."""
+                dtype: torch.dtype = torch.float32, gelu: bool = False, return_pre: bool = False):
+        """``gelu`` (not in the reference): also apply the GELU that ISTEncoder puts on its concatenated input;
+        ``return_pre`` (with ``gelu``): ``(gelu(h), h)`` as ``ops.posmlp`` documents it, or ``(gelu(h), None)`` on the
+        routes that keep the GELU in autograd."""
         n = pos.shape[0]
         fd = self.frequency_embedding_size
         if batch is not None and fd % 16 == 0:
@@ -102,7 +104,7 @@ class Positional2dEmbedder(Module):
                 # sinusoid + Linear + SiLU + Linear in one kernel: the [2n, 256] feature matrix is generated in
                 # registers (and stored once for the weight gradient when training) instead of written and re-read
                 return ops.posmlp(pos, batch, mins, maxs, l0.weight, l0.bias, l2.weight, l2.bias, dtype,
-                                  eps=1e-8, max_period=10000.0, gelu=gelu)
+                                  eps=1e-8, max_period=10000.0, gelu=gelu, return_pre=return_pre and gelu)
             freq = ops.posfreq(pos, batch, mins, maxs, fd, dtype, eps=1e-8, max_period=10000.0)
         else:
             pos = self.normalize(pos, batch, num_graphs)
@@ -110,6 +112,8 @@ class Positional2dEmbedder(Module):
         l0, l2 = self.mlp[0], self.mlp[2]
         h = F.silu(ops.linear(freq, l0.weight, l0.bias))
         h = ops.linear(h, l2.weight, l2.bias).flatten(-2)
+        if gelu and return_pre:
+            return F.gelu(h), None
         return F.gelu(h) if gelu else h
 
 
@@ -333,21 +337,24 @@ class ISTEncoder(Module):
         return out
 
     def _pos_embed_pair(self, pos_dict, batch_dict, num_graphs, dt, gelu: bool, graphs):
-        """(pe_tx, pe_bd): ``pos_emb`` of both node types, in one call where the batch vectors allow it."""
+        """(pe_tx, pe_bd): ``pos_emb`` of both node types, in one call where the batch vectors allow it.  With ``gelu``
+        pe_tx is the pair ``(gelu(h), h or None)`` of ``Positional2dEmbedder.forward(return_pre=True)``."""
         b_tx, b_bd = batch_dict.get("tx"), batch_dict.get("bd")
         staged = graphs.get("pos_all") if graphs is not None else None
         # (large batches -- the `split` route -- keep one call per type: there the launches do not matter, and joining
         # the two gradients of the embedder's output would copy a [n_tx, D] matrix)
         if staged is None and (not MERGED_POS_EMBED or gelu or b_tx is None or b_bd is None or num_graphs is None):
-            one = lambda k: self.pos_emb(pos_dict[k], batch_dict.get(k), num_graphs=num_graphs, dtype=dt, gelu=gelu)
-            return one("tx"), one("bd")
+            one = lambda k, **kw: self.pos_emb(pos_dict[k], batch_dict.get(k), num_graphs=num_graphs, dtype=dt, gelu=gelu,
+                                               **kw)
+            return (one("tx", return_pre=True) if gelu else one("tx")), one("bd")
         if staged is not None:                               # a captured step stages the concatenation itself
             pos_all, batch_all = staged
         else:
             pos_all = torch.cat((pos_dict["tx"].float(), pos_dict["bd"].float()), 0)
             batch_all = torch.cat((b_tx.long(), b_bd.long() + int(num_graphs)), 0)
         pe = self.pos_emb(pos_all, batch_all, num_graphs=2 * int(num_graphs), dtype=dt, gelu=gelu)
-        return _SplitRows.apply(pe, int(pos_dict["tx"].shape[0]))
+        pe_tx, pe_bd = _SplitRows.apply(pe, int(pos_dict["tx"].shape[0]))
+        return ((pe_tx, None) if gelu else pe_tx), pe_bd
 
     def _materialize_bd(self, d_in: int, device) -> None:
         if "bd" not in self.lin_first:
@@ -379,6 +386,9 @@ class ISTEncoder(Module):
             # postpone its partial sums, ops.deferred_reductions).  `split`: the GELU of ist_encoder.py:320 comes
             # applied (gelu(cat(a, b)) = cat(gelu(a), gelu(b))).
             pe_tx, pe_bd = self._pos_embed_pair(pos_dict, batch_dict, num_graphs, dt, split, graphs)
+            pre_tx = None
+            if split:
+                pe_tx, pre_tx = pe_tx
             x_bd = torch.cat((F.gelu(x_bd), pe_bd), -1) if split else F.gelu(torch.cat((x_bd, pe_bd), -1))
             if fused_tx:
                 # gather + concat + GELU in one kernel; its table gradient sums over rows grouped by gene id: one
@@ -394,7 +404,7 @@ class ISTEncoder(Module):
                             cache[key] = by_gene
                 if split:
                     # keep gelu(cat(E[g], pe)) as its parts: the first layer projects it as T[g] + W_pe gelu(pe)
-                    x_tx = ops.EmbedInput(emb.weight, ids.to(torch.int32).contiguous(), pe_tx, by_gene)
+                    x_tx = ops.EmbedInput(emb.weight, ids.to(torch.int32).contiguous(), pe_tx, by_gene, pre_tx)
                 else:
                     x_tx = ops.embed_gelu(emb.weight, ids, pe_tx, by_gene)
             else:

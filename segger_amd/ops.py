@@ -851,13 +851,20 @@ def linear_wgrad_dx_supported(m_out: int, k_in: int, dtype: torch.dtype) -> bool
         _lib.load().segger_linear_wgrad_dx_supported(int(m_out), int(k_in), DTYPE_CODE[dtype]))
 
 
+def linear_wgrad_dx_gate_supported(m_out: int, k_in: int, dtype: torch.dtype) -> bool:
+    return dtype in (torch.bfloat16, torch.float16) and bool(
+        _lib.load().segger_linear_wgrad_dx_gate_supported(int(m_out), int(k_in), DTYPE_CODE[dtype]))
+
+
 FUSED_WGRAD_DX = True        # tools flip it for A/B runs: False = separate data-gradient GEMM + weight-gradient kernel
+FUSED_GELU_GATE = True       # tools flip it: False = the first layer's GELU derivative as an elementwise pass of its own
 
 
-def linear_wgrad_dx_launch(gy: Tensor, x: Tensor, wt: Tensor, want_bias: bool = True
+def linear_wgrad_dx_launch(gy: Tensor, x: Tensor, wt: Tensor, want_bias: bool = True, gate: Optional[Tensor] = None
                            ) -> Tuple[Tensor, Tensor, Optional[Tensor]]:
     """(dX[n, K], dW[M, K], db[M]) of ``y = x @ W.T + b`` in ONE pass over ``gy`` [n, M] (``segger_linear_wgrad_dx``):
-    ``wt`` = W^T [K, M] contiguous in the activation dtype; dX in the activation dtype, dW / db fp32."""
+    ``wt`` = W^T [K, M] contiguous in the activation dtype; dX in the activation dtype, dW / db fp32.  ``gate`` [n, K]:
+    dX comes multiplied by gelu'(gate) (x was gelu(gate); ``linear_wgrad_dx_gate_supported``)."""
     _lib.require_cuda(gy, x, wt)
     lib = _lib.load()
     n, m = gy.shape
@@ -866,6 +873,12 @@ def linear_wgrad_dx_launch(gy: Tensor, x: Tensor, wt: Tensor, want_bias: bool = 
         raise ValueError("linear_wgrad_dx: gy [n, M], x [n, K] and a contiguous W^T [K, M] of one dtype")
     gp, ldg = _rows(gy, m, "gy")
     xp, ldx = _rows(x, k, "x")
+    qp, ldq = None, 0
+    if gate is not None:
+        if tuple(gate.shape) != (n, k) or gate.dtype != x.dtype:
+            raise ValueError("linear_wgrad_dx: gate must be [n, K] in the activation dtype")
+        _lib.require_cuda(gate)
+        qp, ldq = _rows(gate, k, "gate")
     gx = torch.empty((n, k), dtype=x.dtype, device=x.device)
     gw = torch.empty((m, k), dtype=torch.float32, device=x.device)
     gb = torch.empty(m, dtype=torch.float32, device=x.device) if want_bias else None
@@ -873,7 +886,8 @@ def linear_wgrad_dx_launch(gy: Tensor, x: Tensor, wt: Tensor, want_bias: bool = 
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     with _lib.on_device(x.device):
         rc = lib.segger_linear_wgrad_dx(gp, ldg, xp, ldx, wt.data_ptr(), n, m, k, DTYPE_CODE[x.dtype], gw.data_ptr(),
-                                        _lib.ptr(gb), gx.data_ptr(), k, ws.data_ptr(), ws_bytes, _lib.stream_ptr(x.device))
+                                        _lib.ptr(gb), gx.data_ptr(), k, qp, ldq, ws.data_ptr(), ws_bytes,
+                                        _lib.stream_ptr(x.device))
     _lib.check(rc, "segger_linear_wgrad_dx")
     _defer_keep(ws, gw, gb)
     return gx, gw, gb
@@ -1235,17 +1249,27 @@ class _PosMlp(torch.autograd.Function):
                                        DTYPE_CODE[dtype],
                                        _lib.stream_ptr(dev))
         _lib.check(rc, "segger_posmlp_fwd")
+        ctx.by_pre = bool(train and int(gelu) == 2)
         if train:
             ctx.save_for_backward(z1, pn, pre, h1)
             ctx.pk2, ctx.key2, ctx.max_period = pk2, pk2.key, float(max_period)
+        if ctx.by_pre:
+            # the consumer applies gelu' itself (in the epilogue of its data-gradient kernel) and returns d loss / d pre:
+            # `pe` = gelu(pre) leaves as a constant, `pre` as the differentiable output
+            ctx.mark_non_differentiable(pe)
+            return pe, pre
         return pe
 
     @staticmethod
-    def backward(ctx, gpe):
+    def backward(ctx, gpe, gpre=None):
         z1, pn, pre, h1 = ctx.saved_tensors
         dt = z1.dtype
         d = z1.shape[1]
-        if pre is not None:                                  # the output was gelu(embedder output)
+        if ctx.by_pre:
+            if gpre is None:
+                gpre = torch.zeros_like(pre)
+            gpe = gpre
+        elif pre is not None:                                # the output was gelu(embedder output)
             gpe = torch.ops.aten.gelu_backward(gpe.to(dt), pre)
         g = gpe.to(dt).reshape(-1, d)
         if g.shape[0] > 1 and g.stride(1) != 1:
@@ -1281,35 +1305,46 @@ class _PosMlp(torch.autograd.Function):
 
 
 def posmlp(pos: Tensor, batch: Optional[Tensor], mins: Tensor, maxs: Tensor, w0: Tensor, b0: Tensor, w2: Tensor,
-           b2: Tensor, dtype: torch.dtype, eps: float = 1e-8, max_period: float = 10000.0, gelu: bool = False) -> Tensor:
+           b2: Tensor, dtype: torch.dtype, eps: float = 1e-8, max_period: float = 10000.0, gelu: bool = False,
+           return_pre: bool = False):
     """``Positional2dEmbedder.forward`` (reference ist_encoder.py:33-79) for bf16 / f16 activations; ``gelu``: the GELU
-    that ISTEncoder applies to the concatenated input (ist_encoder.py:324-325) on top, in the same kernel."""
+    that ISTEncoder applies to the concatenated input (ist_encoder.py:324-325) on top, in the same kernel.
+    ``return_pre`` (with ``gelu``): ``(gelu(pre), pre)`` where the first is a constant for autograd and ``pre`` (the
+    embedder's output, None when nothing needs a gradient) carries the gradient -- for a consumer that multiplies by
+    gelu'(pre) itself (``embed_linear``)."""
     if not posmlp_supported(w0.shape[1], w0.shape[0], dtype) or tuple(w2.shape) != (w0.shape[0], w0.shape[0]):
         raise ValueError("posmlp: unsupported shapes (see segger_posmlp_supported)")
     if b0 is None or b2 is None:
         raise ValueError("posmlp: the embedder's Linear layers carry biases")
     train = torch.is_grad_enabled() and any(t.requires_grad for t in (w0, b0, w2, b2))   # else nothing is stored
-    return _PosMlp.apply(pos, batch, mins, maxs, eps, max_period, dtype, train, bool(gelu), w0, b0, w2, b2)
+    if return_pre and gelu:
+        if train:
+            return _PosMlp.apply(pos, batch, mins, maxs, eps, max_period, dtype, train, 2, w0, b0, w2, b2)
+        return _PosMlp.apply(pos, batch, mins, maxs, eps, max_period, dtype, train, 1, w0, b0, w2, b2), None
+    return _PosMlp.apply(pos, batch, mins, maxs, eps, max_period, dtype, train, int(bool(gelu)), w0, b0, w2, b2)
 
 
 class EmbedInput:
     """The transcripts' first-layer input ``gelu(cat(table[ids], pe))`` (ist_encoder.py:312-325) kept as its parts:
     ``table`` fp32 [G, D] (the gene embedding), ``ids`` int32 [n], ``act_pe`` = gelu(positional embedding) [n, D] in the
     compute dtype, ``by_gene`` = rows grouped by id.  :func:`embed_linear` projects it without materialising the
-    concatenation."""
+    concatenation.  ``pre_pe`` (optional): the positional embedding before its GELU when ``act_pe`` is a constant for
+    autograd (``posmlp(return_pre=True)``): the projection's backward then returns d / d pre_pe."""
 
-    def __init__(self, table: Tensor, ids: Tensor, act_pe: Tensor, by_gene: Optional[EdgeCSR]):
-        self.table, self.ids, self.act_pe, self.by_gene = table, ids, act_pe, by_gene
+    def __init__(self, table: Tensor, ids: Tensor, act_pe: Tensor, by_gene: Optional[EdgeCSR],
+                 pre_pe: Optional[Tensor] = None):
+        self.table, self.ids, self.act_pe, self.by_gene, self.pre_pe = table, ids, act_pe, by_gene, pre_pe
         self.shape = (int(act_pe.shape[0]), int(table.shape[1]) + int(act_pe.shape[1]))
         self.dtype, self.device = act_pe.dtype, act_pe.device
 
 
 class _RowBiasLinear(torch.autograd.Function):
     """y = c @ Wc^T + T[ids]  (``segger_linear_fwd_rowbias``).  Backward: dc = dY Wc, dWc = dY^T c (MFMA kernels),
-    dT = rows of dY summed by id (``segger_segment_rowsum`` over the rows-by-gene grouping)."""
+    dT = rows of dY summed by id (``segger_segment_rowsum`` over the rows-by-gene grouping).  ``pre`` (optional):
+    c = gelu(pre) is a constant and the data gradient is returned for ``pre``, gelu'(pre) applied in the kernel."""
 
     @staticmethod
-    def forward(ctx, c, wc, tab, ids, by_gene):
+    def forward(ctx, c, wc, tab, ids, by_gene, pre=None):
         lib = _lib.load()
         dev, dt = c.device, c.dtype
         n, k = c.shape
@@ -1322,31 +1357,39 @@ class _RowBiasLinear(torch.autograd.Function):
             rc = lib.segger_linear_fwd_rowbias(cp, ldc, w16.data_ptr(), None, tab16.data_ptr(), m, ids.data_ptr(),
                                                y.data_ptr(), m, n, k, m, DTYPE_CODE[dt], _lib.stream_ptr(dev))
         _lib.check(rc, "segger_linear_fwd_rowbias")
-        ctx.save_for_backward(c, w16)
+        ctx.save_for_backward(c, w16, pre)
         ctx.by_gene, ctx.ids, ctx.n_ids = by_gene, ids, int(tab.shape[0])
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        c, w16 = ctx.saved_tensors
+        c, w16, pre = ctx.saved_tensors
         dt = c.dtype
         gy = gy.to(dt)
         if gy.shape[0] > 1 and gy.stride(1) != 1:
             gy = gy.contiguous()
         gc = gw = gt = None
         m, k = w16.shape
-        if (FUSED_WGRAD_DX and ctx.needs_input_grad[0] and ctx.needs_input_grad[1] and c.shape[0] > 0
+        want_c = ctx.needs_input_grad[0] or (pre is not None and ctx.needs_input_grad[5])
+        gated = False
+        if (FUSED_WGRAD_DX and want_c and ctx.needs_input_grad[1] and c.shape[0] > 0
                 and linear_wgrad_dx_supported(m, k, dt)):
-            gc, gw, _ = linear_wgrad_dx_launch(gy, c, w16.t().contiguous(), want_bias=False)   # dY read once for both
+            gated = pre is not None and FUSED_GELU_GATE and linear_wgrad_dx_gate_supported(m, k, dt)
+            gc, gw, _ = linear_wgrad_dx_launch(gy, c, w16.t().contiguous(), want_bias=False,     # dY read once for both
+                                               gate=pre if gated else None)
         else:
-            if ctx.needs_input_grad[0]:
+            if want_c:
                 gc = linear_fwd_launch(gy, w16.t().contiguous(), None)          # [n, M] @ Wc -> [n, K]
             if ctx.needs_input_grad[1]:
                 gw, _ = linear_wgrad_launch(gy, c, want_bias=False)
         if ctx.needs_input_grad[2]:
             by_gene = ctx.by_gene if ctx.by_gene is not None else rows_by_id(ctx.ids, ctx.n_ids)
             gt = segment_rowsum(gy, by_gene)
-        return gc, gw, gt, None, None
+        if pre is not None:
+            if gc is not None and not gated:
+                gc = torch.ops.aten.gelu_backward(gc, pre)
+            return None, gw, gt, None, None, gc
+        return gc, gw, gt, None, None, None
 
 
 def embed_linear_supported(x: "EmbedInput", m_out: int) -> bool:
@@ -1368,7 +1411,7 @@ def embed_linear(x: "EmbedInput", weight, bias) -> Tensor:
     tab = torch.nn.functional.gelu(x.table) @ w[:, :d].t()                         # [G, M]
     if any(b is not None for b in biases):
         tab = tab + torch.cat([b if b is not None else ww.new_zeros(ww.shape[0]) for ww, b in zip(weights, biases)], 0)
-    return _RowBiasLinear.apply(x.act_pe, w[:, d:], tab, x.ids, x.by_gene)
+    return _RowBiasLinear.apply(x.act_pe, w[:, d:], tab, x.ids, x.by_gene, x.pre_pe)
 
 
 class _EmbedGelu(torch.autograd.Function):

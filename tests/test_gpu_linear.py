@@ -203,6 +203,33 @@ def test_linear_wgrad_dx_operand_maps_exact_and_strided(cuda):
     assert gx0.shape == (0, k) and not gw0.any() and not gb0.any()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("m", [384, 128])
+@pytest.mark.parametrize("n", [1, 17, 1000, 70_001])
+def test_linear_wgrad_dx_gelu_gate(cuda, dtype, m, n):
+    """segger_linear_wgrad_dx with a gate: dX = (dY W) * gelu'(gate) from the fp32 accumulator (one rounding), dW / db
+    bit-identical to the ungated launch; gate given as a column window of a wider matrix."""
+    from segger_amd import ops
+    k = 128
+    assert ops.linear_wgrad_dx_gate_supported(m, k, dtype) and not ops.linear_wgrad_dx_gate_supported(192, k, dtype)
+    g = torch.Generator(device=cuda).manual_seed(3 * n + m)
+    gy = torch.randn(n, m, device=cuda, generator=g).to(dtype)
+    x = torch.randn(n, k, device=cuda, generator=g).to(dtype)
+    w = (torch.randn(m, k, device=cuda, generator=g) / m ** 0.5).to(dtype)
+    wide = (2.0 * torch.randn(n, 2 * k + 8, device=cuda, generator=g)).to(dtype)
+    gate = wide[:, 8:8 + k]
+    gx, gw, gb = ops.linear_wgrad_dx_launch(gy, x, w.t().contiguous(), gate=gate)
+    gx0, gw0, gb0 = ops.linear_wgrad_dx_launch(gy, x, w.t().contiguous())
+    assert torch.equal(gw, gw0) and torch.equal(gb, gb0)
+    z = gate.double()
+    dgelu = 0.5 * (1 + torch.erf(z / 2 ** 0.5)) + z * torch.exp(-0.5 * z * z) / (2 * torch.pi) ** 0.5
+    ref = (gy.double() @ w.double()) * dgelu
+    rel = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert bool(((gx.double() - ref).abs() <= rel * ref.abs() + 1e-3).all())
+    with pytest.raises(RuntimeError):                          # m_out = 192: no room for the gate rows in its stage ring
+        ops.linear_wgrad_dx_launch(gy.new_zeros(n, 192), x, w.new_zeros(k, 192), gate=gate)
+
+
 @pytest.mark.parametrize("m", [384, 64])
 def test_linear_autograd_fused_equals_separate_kernels(cuda, m):
     """ops.linear's backward through the one-pass kernel == through the separate dX GEMM + weight-gradient kernel:

@@ -446,3 +446,18 @@ def test_split_first_layer_projection_matches_concatenated_input(cuda, dtype):
     rel = 0.15 if dtype == torch.bfloat16 else 0.04          # sums of ~1e6 rounded terms that largely cancel
     for k, g in out[False][2].items():
         assert (out[True][2][k] - g).abs().max().item() <= rel * g.abs().max().item() + 2e-3 * rel * gmax, k
+    # the split route hands the GELU derivative of the positional half to the projection's backward kernel
+    # (ops.FUSED_GELU_GATE): same gradients as with the derivative as an elementwise pass of its own
+    from segger_amd import ops
+    m.model.split_first_layer = True
+    ops.FUSED_GELU_GATE = False
+    try:
+        m.zero_grad(set_to_none=True)
+        z = m(bg)
+        (z["tx"].float().square().sum() * 0.3 + z["bd"].float().sum()).backward()
+    finally:
+        ops.FUSED_GELU_GATE = True
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            g = out[True][2][k]
+            assert (p.grad - g).abs().max().item() <= 0.02 * g.abs().max().item() + 1e-4 * gmax, k
