@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEGGER_ABI_VERSION 12
+#define SEGGER_ABI_VERSION 13
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -529,18 +529,28 @@ int segger_posfreq(const float* pos, const int64_t* batch, const float* mins, co
  *   w0 [64, 256], w2 [64, 64] row-major in `dtype` (bf16 / f16), b0 / b2 fp32 [64]
  *   pe   [2n, 64] in `dtype` (= the embedder's [n, 128] output, x half then y half per node)
  *   z1, h1 [2n, 64] in `dtype`, pn [2n] fp32: the pre-activation of the first layer, its SiLU and the normalised
- *        coordinate per row, stored for the backward; all NULL for inference.
+ *        coordinate per row, stored for the backward; all NULL for inference; h1 may be NULL on its own
+ *        (segger_posmlp_bwd recomputes it from z1).
  *   gelu != 0: pe receives gelu(embedder output) -- the positional half of ISTEncoder's gelu(cat(...)),
  *        ist_encoder.py:324-325 -- and, when training, pe_pre [2n, 64] the output itself (for gelu'); else pe_pre NULL.
  * segger_posmlp_wgrad: dW0 [64, 256] = dz1^T F and db0 [64] = sum dz1 with F regenerated from pn inside the weight-
  *   gradient kernel (one float per row read instead of a 512-byte feature row); workspace as
  *   segger_linear_wgrad_workspace_bytes(n_rows, 64, 256); n_rows = 2n.
+ * segger_posmlp_bwd: the embedder's whole backward from ONE read of g = d loss / d pe ([n_rows = 2n, 64], row stride
+ *   ld_g): dW2 = g^T SiLU(z1), db2 = sum g, dz1 = (g W2) * SiLU'(z1) (kept on the chip), dW0 = dz1^T F(pn), db0 =
+ *   sum dz1 -- autograd's two `grad.t() @ x`, two `grad.sum(0)`, the `grad @ W` and the SiLU backward of
+ *   ist_encoder.py:45-49, 76-79.  w2_t = W2^T [64, 64] row-major in `dtype`; outputs fp32; workspace
+ *   segger_posmlp_bwd_workspace_bytes(n_rows); deterministic (per-workgroup partials summed in order).
  * Covered: frequency_embedding_size 256, hidden_size 128 (segger's in_channels default): segger_posmlp_supported.
  */
 int segger_posmlp_supported(int32_t freq_dim, int32_t dim, int32_t dtype);
 int segger_posmlp_fwd(const float* pos, const int64_t* batch, const float* mins, const float* maxs, int64_t n, float eps,
                       float max_period, const void* w0, const float* b0, const void* w2, const float* b2, void* pe,
                       void* z1, float* pn, void* h1, void* pe_pre, int32_t gelu, int32_t dtype, segger_stream_t stream);
+size_t segger_posmlp_bwd_workspace_bytes(int64_t n_rows);
+int segger_posmlp_bwd(const void* g, int64_t ld_g, const void* z1, const float* pn, const void* w2_t, int64_t n_rows,
+                      float max_period, int32_t dtype, float* grad_w0, float* grad_b0, float* grad_w2, float* grad_b2,
+                      void* workspace, size_t workspace_bytes, segger_stream_t stream);
 int segger_posmlp_wgrad(const void* dz1, int64_t ld_dz1, const float* pn, int64_t n_rows, float max_period,
                         int32_t dtype, float* grad_w0, float* grad_b0, void* workspace, size_t workspace_bytes,
                         segger_stream_t stream);

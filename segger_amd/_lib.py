@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
@@ -161,6 +161,9 @@ EXPORTS = {
     "segger_reductions_pending": (C.c_int, []),
     "segger_reductions_flush": (C.c_int, [vp]),
     "segger_linear_wgrad_dx_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "segger_posmlp_bwd_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "segger_posmlp_bwd": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_float, C.c_int32, vp, vp, vp, vp, vp,
+                                    C.c_size_t, vp]),
     "segger_linear_wgrad_dx_gate_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "segger_linear_wgrad_dx": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp, vp,
                                          vp, C.c_int64, vp, C.c_int64, vp, C.c_size_t, vp]),

@@ -403,6 +403,239 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
   }
 }
 
+// ---- the positional embedder's whole backward from ONE read of its incoming gradient (segger_posmlp_bwd) -----------
+// pe = SiLU(F(pn) W0^T + b0) W2^T + b2 per coordinate row (posmlp.hip); with g = d loss / d pe as rows [R = 2n, 64]:
+//     dW2 = g^T h1,  db2 = sum g            h1 = SiLU(z1) recomputed from the stored pre-activation
+//     dz1 = (g W2) * SiLU'(z1)              never leaves the chip
+//     dW0 = dz1^T F(pn),  db0 = sum dz1     F regenerated from one float per row (the GEN form above)
+// Round 2 ran this as three kernels (weight gradient 64x64, data gradient with the SiLU' epilogue, generated-operand
+// weight gradient 64x256): g read twice, dz1 written and read back, h1 stored by the forward and read here.  One ring
+// of 16-row stages {g rows, z1 rows, 16 coordinates} (LDS-DMA, 3 stages ahead, 5 slots so that a stage outlives the
+// iteration after its own).  Iteration s PRODUCES, from stage s: the h1 tile (4 elements per thread) and the dz1 tile
+// (v_mfma_f32_16x16x32 against W2^T fragments held in registers, times SiLU'), both into double-buffered LDS tiles in
+// the staging row stride; it CONSUMES stage s - 1 behind the same barrier: dW2 += g^T h1 (both by transposing reads),
+// dW0 += dz1^T F (A by transposing reads of the dz1 tile, B generated in the fragment layout), the bias sums from the A
+// fragments.  One barrier per stage, no global stores inside the loop (so vmcnt counts the ring's loads only).
+struct PosBwdParams {
+  const void* g; int64_t ld_g;
+  const void* z1;                    // [R, 64] contiguous
+  const float* pn;                   // [R]
+  const void* w2t;                   // W2^T [64 (column of z1), 64 (column of pe)] row-major
+  int64_t n_rows, n_stages, stages_per_block;
+  float* part2;                      // [grid][64*64 + 64]
+  float* part0;                      // [grid][64*256 + 64]
+  float log_max_period;
+};
+constexpr int kPbD = 64, kPbF = 256;
+constexpr int kPbS = kPbD * 2 + 64;                       // LDS row stride of every 64-wide tile (== 192 mod 256)
+constexpr int kPbTile = kStageRows * kPbS;                // 3072 = 3 DMA chunks
+constexpr int kPbOffZ = kPbTile, kPbOffP = 2 * kPbTile;   // stage image: g rows | z1 rows | 16 coordinates
+constexpr int kPbP = 2, kPbBuf = kPbP * 4 * 1024, kPbSlots = 5;
+constexpr int kPbWidth2 = kPbD * kPbD + kPbD, kPbWidth0 = kPbD * kPbF + kPbD;
+
+__device__ __forceinline__ float sigmoid_fast(float z) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void posmlp_bwd_kernel(PosBwdParams p) {
+  constexpr int D = kPbD, F = kPbF, S = kPbS, NW = 4, P = kPbP, BUF = kPbBuf, NB = kPbSlots, TILE = kPbTile;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NB * BUF + 4 * TILE];
+  unsigned char* tile_h = lds + NB * BUF;                   // [2][TILE]: h1 of stages s, s - 1
+  unsigned char* tile_d = tile_h + 2 * TILE;                // [2][TILE]: dz1
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const T* __restrict__ gp = static_cast<const T*>(p.g);
+  const T* __restrict__ zp = static_cast<const T*>(p.z1);
+
+  const int64_t s_beg = (int64_t)blockIdx.x * p.stages_per_block;
+  int64_t s_end = s_beg + p.stages_per_block;
+  if (s_end > p.n_stages) s_end = p.n_stages;
+  const int n_local = (int)(s_end > s_beg ? s_end - s_beg : 0);
+  const int64_t row_beg = s_beg * kStageRows;
+  int64_t span_rows = p.n_rows > row_beg ? p.n_rows - row_beg : 0;
+  if (span_rows > (int64_t)n_local * kStageRows) span_rows = (int64_t)n_local * kStageRows;
+  const i32x4 rg = make_rsrc(gp + row_beg * p.ld_g, span_rows * p.ld_g * 2);
+  const i32x4 rz = make_rsrc(zp + row_beg * D, span_rows * D * 2);
+  const i32x4 rp = make_rsrc(p.pn + row_beg, span_rows * 4);
+  const int stage_bytes_g = kStageRows * (int)p.ld_g * 2;
+  int voff[P];
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    const int o = (wave + j * NW) * 1024 + lane * 16;
+    if (o < kPbOffZ) {
+      const int row = o / S, w = o % S;
+      voff[j] = row * (int)p.ld_g * 2 + (w < D * 2 ? w : 0);
+    } else if (o < kPbOffP) {
+      const int oo = o - kPbOffZ;
+      const int row = oo / S, w = oo % S;
+      voff[j] = row * D * 2 + (w < D * 2 ? w : 0);
+    } else if (o < kPbOffP + kStageRows * 4) {
+      voff[j] = o - kPbOffP;
+    } else {
+      voff[j] = kOutOfRange;
+    }
+  }
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  auto issue = [&](int local_stage) {                  // always P loads per wave
+    const uint32_t dst = lds_base + (uint32_t)((local_stage % NB) * BUF + wave * 1024);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int co = (wave + j * NW) * 1024;                           // wave-uniform
+      if (co < kPbOffZ) lds_dma16(rg, dst + j * NW * 1024, voff[j], local_stage * stage_bytes_g);
+      else if (co < kPbOffP) lds_dma16(rz, dst + j * NW * 1024, voff[j], local_stage * (kStageRows * D * 2));
+      else lds_dma16(rp, dst + j * NW * 1024, voff[j], local_stage * (kStageRows * 4));
+    }
+  };
+
+  // transposing-read address of this lane inside a 16-row tile of stride S (+ 64 bytes per 32-column tile)
+  const int g4 = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+  const int off_a = (8 * (g4 >> 1) + tq) * S + (16 * (g4 & 1) + 4 * tp) * 2;
+  const int wm2 = wave & 1, wk2 = wave >> 1;           // this wave's 32x32 tile of dW2: rows (pe columns), columns (h1)
+  const int dq = lane >> 4, dj = lane & 15;            // dz1: lane (row dj, columns 16 wave + 4 dq ..+4)
+  const int r = lane & 31, h = lane >> 5;
+
+  f32x16 acc2, acc0[2][2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    acc2[e] = 0.f;
+    acc0[0][0][e] = 0.f; acc0[0][1][e] = 0.f; acc0[1][0][e] = 0.f; acc0[1][1][e] = 0.f;
+  }
+  float db2 = 0.f, db0[2] = {0.f, 0.f};
+  // this wave's feature columns f = 64 wave + 32 b + r: revolutions per unit coordinate; cos for f < 128, sin above
+  float omega[2];
+  const bool gen_sin = wave >= 2;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int f = (64 * wave + 32 * b + r) % (F / 2);
+    omega[b] = expf(-p.log_max_period * (float)f / (float)(F / 2)) * 0.15915494309189535f;
+  }
+  u32x4 wf[2];                                          // W2^T rows 16 wave + dj, k-steps of 32 pe columns
+  {
+    const T* wt = static_cast<const T*>(p.w2t);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      wf[ks] = *reinterpret_cast<const u32x4*>(wt + (16 * wave + dj) * D + 32 * ks + 8 * dq);
+  }
+
+  auto consume = [&](int t) {
+    const unsigned char* pb = lds + (t % NB) * BUF;
+    const unsigned char* th = tile_h + (t & 1) * TILE;
+    const unsigned char* td = tile_d + (t & 1) * TILE;
+    {
+      const u32x2 lo = lds_read_tr(pb + off_a + wm2 * 64), hi = lds_read_tr(pb + off_a + wm2 * 64 + 4 * S);
+      const u32x4 fa = u32x4{lo.x, lo.y, hi.x, hi.y};
+      if (wk2 == 0) {
+        db2 = WgMfma<T>::sum2(fa.x, db2); db2 = WgMfma<T>::sum2(fa.y, db2);
+        db2 = WgMfma<T>::sum2(fa.z, db2); db2 = WgMfma<T>::sum2(fa.w, db2);
+      }
+      const u32x2 lo2 = lds_read_tr(th + off_a + wk2 * 64), hi2 = lds_read_tr(th + off_a + wk2 * 64 + 4 * S);
+      acc2 = WgMfma<T>::run(fa, u32x4{lo2.x, lo2.y, hi2.x, hi2.y}, acc2);
+    }
+    u32x4 fd[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const u32x2 lo = lds_read_tr(td + off_a + a * 64), hi = lds_read_tr(td + off_a + a * 64 + 4 * S);
+      fd[a] = u32x4{lo.x, lo.y, hi.x, hi.y};
+    }
+    if (wave == 0) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        float d = db0[a];
+        d = WgMfma<T>::sum2(fd[a].x, d); d = WgMfma<T>::sum2(fd[a].y, d);
+        d = WgMfma<T>::sum2(fd[a].z, d); d = WgMfma<T>::sum2(fd[a].w, d);
+        db0[a] = d;
+      }
+    }
+    // B fragment of feature tile b: lane (column r, half h) supplies F[row 8 h + i][f], i = 0..7
+    const float* pr = reinterpret_cast<const float*>(pb + kPbOffP) + 8 * h;
+    const f32x4 pa = *reinterpret_cast<const f32x4*>(pr), pc = *reinterpret_cast<const f32x4*>(pr + 4);
+    const float pv[8] = {pa.x, pa.y, pa.z, pa.w, pc.x, pc.y, pc.z, pc.w};
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float rev = pv[i] * omega[b];
+        v[i] = gen_sin ? __builtin_amdgcn_sinf(rev) : __builtin_amdgcn_cosf(rev);
+      }
+      const u32x4 fb = u32x4{Vec8<T>::pack(v[0], v[1]), Vec8<T>::pack(v[2], v[3]), Vec8<T>::pack(v[4], v[5]),
+                             Vec8<T>::pack(v[6], v[7])};
+#pragma unroll
+      for (int a = 0; a < 2; ++a) acc0[a][b] = WgMfma<T>::run(fd[a], fb, acc0[a][b]);
+    }
+  };
+
+  for (int d = 0; d < kAhead; ++d) issue(d);
+  for (int s = 0; s < n_local; ++s) {
+    wait_vmcnt<(kAhead - 1) * P>();
+    __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): last iteration's tile writes and reads
+    __builtin_amdgcn_s_barrier();
+    issue(s + kAhead);                                     // slot (s + 3) % 5: last read by consume(s - 2)
+    const unsigned char* base = lds + (s % NB) * BUF;
+    {                                                      // h1 tile: 4 elements per thread
+      const int row = tid >> 4, c4 = (tid & 15) * 4;
+      const u32x2 zv = *reinterpret_cast<const u32x2*>(base + kPbOffZ + row * S + c4 * 2);
+      float z0, z1, z2, z3;
+      Vec8<T>::unpack2(zv.x, z0, z1);
+      Vec8<T>::unpack2(zv.y, z2, z3);
+      const u32x2 hv = u32x2{Vec8<T>::pack(z0 * sigmoid_fast(z0), z1 * sigmoid_fast(z1)),
+                             Vec8<T>::pack(z2 * sigmoid_fast(z2), z3 * sigmoid_fast(z3))};
+      *reinterpret_cast<u32x2*>(tile_h + (s & 1) * TILE + row * S + c4 * 2) = hv;
+    }
+    {                                                      // dz1 tile
+      f32x4 dacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const u32x4 fy = *reinterpret_cast<const u32x4*>(base + dj * S + (32 * ks + 8 * dq) * 2);
+        dacc = WgMfma<T>::run16(wf[ks], fy, dacc);
+      }
+      const u32x2 zv = *reinterpret_cast<const u32x2*>(base + kPbOffZ + dj * S + (16 * wave + 4 * dq) * 2);
+      float z[4];
+      Vec8<T>::unpack2(zv.x, z[0], z[1]);
+      Vec8<T>::unpack2(zv.y, z[2], z[3]);
+      float o[4] = {dacc.x, dacc.y, dacc.z, dacc.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float sg = sigmoid_fast(z[e]);
+        o[e] *= sg * (1.0f + z[e] * (1.0f - sg));          // SiLU'(z)
+      }
+      *reinterpret_cast<u32x2*>(tile_d + (s & 1) * TILE + dj * S + (16 * wave + 4 * dq) * 2) =
+          u32x2{Vec8<T>::pack(o[0], o[1]), Vec8<T>::pack(o[2], o[3])};
+    }
+    if (s > 0) consume(s - 1);
+  }
+  if (n_local > 0) {
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    consume(n_local - 1);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);                      // the ring ran kAhead stages past the slab
+
+  float* out2 = p.part2 + (int64_t)blockIdx.x * kPbWidth2;
+  float* out0 = p.part0 + (int64_t)blockIdx.x * kPbWidth0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
+    out2[(32 * wm2 + m) * D + 32 * wk2 + r] = acc2[e];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) out0[(32 * a + m) * F + 64 * wave + 32 * b + r] = acc0[a][b][e];
+  }
+  if (wk2 == 0) {
+    const float d = db2 + __shfl_xor(db2, 32, 64);
+    if (h == 0) out2[D * D + 32 * wm2 + r] = d;
+  }
+  if (wave == 0) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float d = db0[a] + __shfl_xor(db0[a], 32, 64);
+      if (h == 0) out0[D * F + 32 * a + r] = d;
+    }
+  }
+}
+
 // out[e] = sum_s partial[s][e] in two deterministic stages (a single pass would leave each of the few thousand
 // threads a serial chain of up to 1024 dependent-latency loads): stage 1 sums every kRedGroups-th slab into
 // part2[g][e] (grid = columns x groups), stage 2 adds the groups in order; grad_w = first M*K entries, grad_b the rest
@@ -704,4 +937,58 @@ extern "C" int segger_posmlp_wgrad(const void* dz1, int64_t ld_dz1, const float*
   SEGGER_LAUNCH_CHECK("wgrad_kernel (generated operand)");
   return reduce_partials(p.partial, grid, M, K, grad_w0, grad_b0, stream);
 
+}
+
+// grid of the fused positional backward: 2 workgroups per CU (VALU-bound on the regenerated features; every workgroup
+// leaves an 82 KB partial), at least kMinStagesPerBlock stages each
+static int64_t posmlp_bwd_grid(int64_t n_rows) {
+  const int64_t stages = (n_rows + kStageRows - 1) / kStageRows;
+  const int64_t want = (stages + kMinStagesPerBlock - 1) / kMinStagesPerBlock;
+  const int64_t cap = 2 * kNumCu;
+  return want < cap ? (want < 1 ? 1 : want) : cap;
+}
+
+extern "C" size_t segger_posmlp_bwd_workspace_bytes(int64_t n_rows) {
+  if (n_rows <= 0) return 16;
+  return (size_t)(posmlp_bwd_grid(n_rows) + kRedGroups) * (size_t)(kPbWidth2 + kPbWidth0) * sizeof(float);
+}
+
+extern "C" int segger_posmlp_bwd(const void* g, int64_t ld_g, const void* z1, const float* pn, const void* w2_t,
+                                 int64_t n_rows, float max_period, int32_t dtype, float* grad_w0, float* grad_b0,
+                                 float* grad_w2, float* grad_b2, void* workspace, size_t workspace_bytes,
+                                 segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGGER_REQUIRE(n_rows >= 0, "segger_posmlp_bwd: negative size");
+  SEGGER_REQUIRE(dtype == SEGGER_BF16 || dtype == SEGGER_F16, "segger_posmlp_bwd: bf16 / f16 only");
+  SEGGER_REQUIRE(grad_w0 && grad_b0 && grad_w2 && grad_b2, "segger_posmlp_bwd: NULL output");
+  if (n_rows == 0) {
+    SEGGER_HIP(hipMemsetAsync(grad_w0, 0, (size_t)kPbD * kPbF * sizeof(float), stream));
+    SEGGER_HIP(hipMemsetAsync(grad_b0, 0, (size_t)kPbD * sizeof(float), stream));
+    SEGGER_HIP(hipMemsetAsync(grad_w2, 0, (size_t)kPbD * kPbD * sizeof(float), stream));
+    SEGGER_HIP(hipMemsetAsync(grad_b2, 0, (size_t)kPbD * sizeof(float), stream));
+    return SEGGER_OK;
+  }
+  SEGGER_REQUIRE(g && z1 && pn && w2_t, "segger_posmlp_bwd: NULL input");
+  SEGGER_REQUIRE(aligned16(g) && aligned16(z1) && aligned16(pn) && aligned16(w2_t) && ld_g >= kPbD && (ld_g * 2) % 16 == 0,
+                 "segger_posmlp_bwd: rows must be 16-byte aligned");
+  const size_t need = segger_posmlp_bwd_workspace_bytes(n_rows);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("segger_posmlp_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
+    return SEGGER_EWORKSPACE;
+  }
+  const int64_t grid = posmlp_bwd_grid(n_rows);
+  const int64_t stages = (n_rows + kStageRows - 1) / kStageRows;
+  SEGGER_REQUIRE(((stages + grid - 1) / grid + kAhead) * kStageRows * ld_g * 2 < (int64_t)kOutOfRange,
+                 "segger_posmlp_bwd: a workgroup's row slab exceeds 1 GiB");
+  float* part2 = static_cast<float*>(workspace);
+  float* part0 = part2 + (size_t)(grid + kRedGroups) * kPbWidth2;
+  PosBwdParams p{g, ld_g, z1, pn, w2_t, n_rows, stages, (stages + grid - 1) / grid, part2, part0, logf(max_period)};
+  if (dtype == SEGGER_BF16)
+    hipLaunchKernelGGL((posmlp_bwd_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((posmlp_bwd_kernel<f16_t>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+  SEGGER_LAUNCH_CHECK("posmlp_bwd_kernel");
+  const int rc = reduce_partials(part2, grid, kPbD, kPbD, grad_w2, grad_b2, stream);
+  if (rc != SEGGER_OK) return rc;
+  return reduce_partials(part0, grid, kPbD, kPbF, grad_w0, grad_b0, stream);
 }

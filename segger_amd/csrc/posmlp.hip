@@ -41,7 +41,7 @@ struct PosMlpParams {
   const void* w0; const float* b0; const void* w2; const float* b2;
   void* pe; void* z1; float* pn;
   void* pe_pre;            // GELU && TRAIN: the embedder's own output; `pe` then receives gelu(pe_pre)
-  void* h1;                // TRAIN: SiLU(z1), the second layer's input (its weight gradient reads it)
+  void* h1;                // TRAIN, optional: SiLU(z1), the second layer's input (for the unfused weight gradient)
 };
 
 // sin / cos on the hardware units (v_sin_f32 / v_cos_f32 take revolutions and reduce the range themselves; absolute
@@ -185,19 +185,21 @@ __global__ __launch_bounds__(256, 2) void posmlp_fwd_kernel(PosMlpParams p) {
       __builtin_amdgcn_wave_barrier();                    // the tile is wave-private: one wave's LDS ops stay in order
       store_tile<T>(et, static_cast<T*>(p.z1), row0, n_rows, lane);
       __builtin_amdgcn_wave_barrier();
+      if (p.h1) {                                         // (segger_posmlp_bwd recomputes it from z1 instead)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) {
+        for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-          uint2 pk;
-          pk.x = Vec8<T>::pack(h1[ct][4 * gq + 0], h1[ct][4 * gq + 1]);
-          pk.y = Vec8<T>::pack(h1[ct][4 * gq + 2], h1[ct][4 * gq + 3]);
-          *reinterpret_cast<uint2*>(et + r * kEStride + (ct * 32 + 8 * gq + 4 * h) * 2) = pk;
+          for (int gq = 0; gq < 4; ++gq) {
+            uint2 pk;
+            pk.x = Vec8<T>::pack(h1[ct][4 * gq + 0], h1[ct][4 * gq + 1]);
+            pk.y = Vec8<T>::pack(h1[ct][4 * gq + 2], h1[ct][4 * gq + 3]);
+            *reinterpret_cast<uint2*>(et + r * kEStride + (ct * 32 + 8 * gq + 4 * h) * 2) = pk;
+          }
         }
+        __builtin_amdgcn_wave_barrier();
+        store_tile<T>(et, static_cast<T*>(p.h1), row0, n_rows, lane);
+        __builtin_amdgcn_wave_barrier();
       }
-      __builtin_amdgcn_wave_barrier();
-      store_tile<T>(et, static_cast<T*>(p.h1), row0, n_rows, lane);
-      __builtin_amdgcn_wave_barrier();
     }
 
     // ---- GEMM 2: pe[m2][row] = sum_m W2[m2][m] h1[m][row]; k-step (ct, gp) covers m = ct*32 + 16gp + {0..15} in the
@@ -275,8 +277,8 @@ extern "C" int segger_posmlp_fwd(const float* pos, const int64_t* batch, const f
   SEGGER_REQUIRE(dtype == SEGGER_BF16 || dtype == SEGGER_F16, "segger_posmlp_fwd: bf16 / f16 only");
   if (n == 0) return SEGGER_OK;
   SEGGER_REQUIRE(pos && mins && maxs && w0 && b0 && w2 && b2 && pe, "segger_posmlp_fwd: NULL pointer");
-  SEGGER_REQUIRE(!z1 == !pn && !z1 == !h1,
-                 "segger_posmlp_fwd: z1, pn and h1 go together (all for training, none for inference)");
+  SEGGER_REQUIRE(!z1 == !pn && (z1 || !h1),
+                 "segger_posmlp_fwd: z1 and pn go together (both for training, none for inference); h1 only with them");
   SEGGER_REQUIRE(aligned16(h1), "segger_posmlp_fwd: h1 must be 16-byte aligned");
   SEGGER_REQUIRE(aligned16(w0) && aligned16(w2) && aligned16(pe) && aligned16(z1) && aligned16(pn),
                  "segger_posmlp_fwd: matrices must be 16-byte aligned");

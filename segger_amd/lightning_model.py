@@ -191,7 +191,14 @@ class LitISTEncoder(_Base):
         if embeddings is None:
             embeddings = self.forward(batch)
         tx_mask = batch['tx']['mask']
-        bd_mask = batch['bd']['mask'] & (batch['bd']['cluster'] >= 0)
+        # (kept with the batch: the samplers' per-batch indices are keyed by the mask tensor they were built from, and a
+        # mask recomputed every step would rebuild the boundary index -- ~50 small launches -- every step)
+        bm, bc = batch['bd']['mask'], batch['bd']['cluster']
+        cache = batch_cache(batch)
+        mkey = ("bd_loss_mask", bm.data_ptr(), bc.data_ptr(), int(bm.numel()))
+        bd_mask = cache.get(mkey)
+        if bd_mask is None:
+            bd_mask = cache[mkey] = bm & (bc >= 0)
         u_tx, u_bd = uniforms if uniforms is not None else (None, None)
         if (self.fused_loss_head and self._sg_loss_type == 'triplet' and embeddings['tx'].is_cuda
                 and embeddings['tx'].shape[0] > 0 and embeddings['bd'].shape[0] > 0):

@@ -1219,6 +1219,9 @@ def posmlp_supported(freq_dim: int, dim: int, dtype: torch.dtype) -> bool:
         _lib.load().segger_posmlp_supported(int(freq_dim), int(dim), DTYPE_CODE[dtype]))
 
 
+FUSED_POSMLP_BWD = True      # tools flip it: False = the embedder's backward as three kernels (round 2)
+
+
 class _PosMlp(torch.autograd.Function):
     """Positional2dEmbedder in one kernel (``segger_posmlp_fwd``): [n, 2] positions -> [n, 128].  With gradients the
     kernel also stores the first layer's pre-activation and the normalised coordinates (4 bytes per row), and the
@@ -1240,7 +1243,8 @@ class _PosMlp(torch.autograd.Function):
         z1 = torch.empty((2 * n, w0.shape[0]), dtype=dtype, device=dev) if train else None
         pn = torch.empty(2 * n, dtype=torch.float32, device=dev) if train else None
         pre = torch.empty_like(pe) if (train and gelu) else None
-        h1 = torch.empty_like(z1) if train else None
+        h1 = torch.empty_like(z1) if (train and not FUSED_POSMLP_BWD) else None    # (the one-pass backward recomputes it)
+        ctx.set_materialize_grads(False)
         with _lib.on_device(dev):
             rc = lib.segger_posmlp_fwd(pos.data_ptr(), _lib.ptr(batch), mins.data_ptr(), maxs.data_ptr(), n, float(eps),
                                        float(max_period), pk0.w.data_ptr(), pk0.b.data_ptr(), pk2.w.data_ptr(),
@@ -1266,16 +1270,36 @@ class _PosMlp(torch.autograd.Function):
         dt = z1.dtype
         d = z1.shape[1]
         if ctx.by_pre:
-            if gpre is None:
-                gpre = torch.zeros_like(pre)
             gpe = gpre
-        elif pre is not None:                                # the output was gelu(embedder output)
+        if gpe is None:                                      # (nothing downstream used the output)
+            return (None,) * 13
+        if pre is not None and not ctx.by_pre:               # the output was gelu(embedder output)
             gpe = torch.ops.aten.gelu_backward(gpe.to(dt), pre)
         g = gpe.to(dt).reshape(-1, d)
         if g.shape[0] > 1 and g.stride(1) != 1:
             g = g.contiguous()
         if ctx.pk2.key != ctx.key2:
             raise RuntimeError("the positional MLP's weights changed between this forward and its backward")
+        need = ctx.needs_input_grad
+        if h1 is None:                                       # one pass over g: all four parameter gradients
+            lib = _lib.load()
+            dev = z1.device
+            gw0 = torch.empty((d, 4 * d), dtype=torch.float32, device=dev)
+            gb0 = torch.empty(d, dtype=torch.float32, device=dev)
+            gw2 = torch.empty((d, d), dtype=torch.float32, device=dev)
+            gb2 = torch.empty(d, dtype=torch.float32, device=dev)
+            n_rows = int(g.shape[0])
+            ws_bytes = lib.segger_posmlp_bwd_workspace_bytes(n_rows)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            gp, ldg = _rows(g, d, "g")
+            with _lib.on_device(dev):
+                rc = lib.segger_posmlp_bwd(gp, ldg, z1.data_ptr(), pn.data_ptr(), ctx.pk2.wt.data_ptr(), n_rows,
+                                           ctx.max_period, DTYPE_CODE[dt], gw0.data_ptr(), gb0.data_ptr(), gw2.data_ptr(),
+                                           gb2.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
+            _lib.check(rc, "segger_posmlp_bwd")
+            _defer_keep(ws, gw0, gb0, gw2, gb2)
+            return (None, None, None, None, None, None, None, None, None, gw0 if need[9] else None,
+                    gb0 if need[10] else None, gw2 if need[11] else None, gb2 if need[12] else None)
         gw2, gb2 = linear_wgrad_launch(g, h1)
         # dz1 = (g @ W2) * silu'(z1): the SiLU derivative is applied in the GEMM's epilogue
         lib0 = _lib.load()
@@ -1299,7 +1323,6 @@ class _PosMlp(torch.autograd.Function):
                                          gw0.data_ptr(), gb0.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
         _lib.check(rc, "segger_posmlp_wgrad")
         _defer_keep(ws, gw0, gb0)
-        need = ctx.needs_input_grad
         return (None, None, None, None, None, None, None, None, None, gw0 if need[9] else None,
                 gb0 if need[10] else None, gw2 if need[11] else None, gb2 if need[12] else None)
 

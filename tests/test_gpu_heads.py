@@ -361,5 +361,21 @@ def test_fused_positional_embedder_matches_unfused_route(cuda, dtype, n):
     for a, p_ in zip(got, emb.parameters()):
         scale = p_.grad.abs().max().item() + 1e-6
         assert (a - p_.grad).abs().max().item() <= 3e-2 * scale
+    # the one-pass backward (segger_posmlp_bwd) against round 2's three kernels and against fp64 on the stored z1
+    ops.FUSED_POSMLP_BWD = False
+    try:
+        emb.zero_grad()
+        emb(pos, batch, num_graphs=3, dtype=dtype).backward(gy)
+    finally:
+        ops.FUSED_POSMLP_BWD = True
+    g64 = gy.double().reshape(-1, 64)
+    z1r = z1.to(dtype).double()
+    sg = torch.sigmoid(z1r)
+    dz1 = ((g64 @ l2.weight.detach().to(dtype).double()) * (sg * (1 + z1r * (1 - sg)))).to(dtype).double()
+    ref64 = [dz1.t() @ feat, dz1.sum(0), g64.t() @ (z1r * sg).to(dtype).double(), g64.sum(0)]
+    for a, p_, r64 in zip(got, emb.parameters(), ref64):
+        scale = r64.abs().max().item() + 1e-6
+        assert (a - p_.grad).abs().max().item() <= 1e-2 * scale
+        assert (a.double() - r64).abs().max().item() <= 1e-2 * scale
     with torch.no_grad():                                    # inference: same values, nothing stored
         assert torch.equal(emb(pos, batch, num_graphs=3, dtype=dtype), pe)
