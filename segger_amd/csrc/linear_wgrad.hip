@@ -410,7 +410,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
 //     dW0 = dz1^T F(pn),  db0 = sum dz1     F regenerated from one float per row (the GEN form above)
 // Round 2 ran this as three kernels (weight gradient 64x64, data gradient with the SiLU' epilogue, generated-operand
 // weight gradient 64x256): g read twice, dz1 written and read back, h1 stored by the forward and read here.  One ring
-// of 16-row stages {g rows, z1 rows, 16 coordinates} (LDS-DMA, 3 stages ahead, 5 slots so that a stage outlives the
+// of 16-row stages {g rows, z1 rows, 16 coordinates} (LDS-DMA, 6 stages ahead, 8 slots so that a stage outlives the
 // iteration after its own).  Iteration s PRODUCES, from stage s: the h1 tile (4 elements per thread) and the dz1 tile
 // (v_mfma_f32_16x16x32 against W2^T fragments held in registers, times SiLU'), both into double-buffered LDS tiles in
 // the staging row stride; it CONSUMES stage s - 1 behind the same barrier: dW2 += g^T h1 (both by transposing reads),
@@ -430,7 +430,10 @@ constexpr int kPbD = 64, kPbF = 256;
 constexpr int kPbS = kPbD * 2 + 64;                       // LDS row stride of every 64-wide tile (== 192 mod 256)
 constexpr int kPbTile = kStageRows * kPbS;                // 3072 = 3 DMA chunks
 constexpr int kPbOffZ = kPbTile, kPbOffP = 2 * kPbTile;   // stage image: g rows | z1 rows | 16 coordinates
-constexpr int kPbP = 2, kPbBuf = kPbP * 4 * 1024, kPbSlots = 5;
+constexpr int kPbBuf = 8 * 1024;                       // one 1 KiB DMA chunk per wave (8 waves) per stage
+// a stage is only 6 KB of payload: 3 stages ahead (as in wgrad_kernel) leave 2 x 18 KB in flight per CU, too little to
+// cover the memory latency at this stage rate (measured 1.9 TB/s); 6 ahead, + the current stage + the one consume() reads
+constexpr int kPbAhead = 6, kPbSlots = kPbAhead + 2;
 constexpr int kPbWidth2 = kPbD * kPbD + kPbD, kPbWidth0 = kPbD * kPbF + kPbD;
 
 __device__ __forceinline__ float sigmoid_fast(float z) {
@@ -438,8 +441,12 @@ __device__ __forceinline__ float sigmoid_fast(float z) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void posmlp_bwd_kernel(PosBwdParams p) {
-  constexpr int D = kPbD, F = kPbF, S = kPbS, NW = 4, P = kPbP, BUF = kPbBuf, NB = kPbSlots, TILE = kPbTile;
+__global__ __launch_bounds__(512, 2) void posmlp_bwd_kernel(PosBwdParams p) {
+  // 8 waves: wave w stages DMA chunk w of every stage and owns feature tile w of dW0 (both 32-row tiles of dz1
+  // columns); waves 0..3 also produce the dz1 tile (16 columns each) and own one tile of dW2, waves 4..7 produce the
+  // h1 tile.  ~110 registers per lane -> 4 waves per SIMD: the loop is a dependent VALU / transcendental stream
+  // (sin / cos, exp, rcp per element) that needs the other waves to fill its issue slots
+  constexpr int D = kPbD, F = kPbF, S = kPbS, NW = 8, BUF = kPbBuf, NB = kPbSlots, TILE = kPbTile;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[NB * BUF + 4 * TILE];
   unsigned char* tile_h = lds + NB * BUF;                   // [2][TILE]: h1 of stages s, s - 1
   unsigned char* tile_d = tile_h + 2 * TILE;                // [2][TILE]: dz1
@@ -455,74 +462,64 @@ __global__ __launch_bounds__(256) void posmlp_bwd_kernel(PosBwdParams p) {
   const int64_t row_beg = s_beg * kStageRows;
   int64_t span_rows = p.n_rows > row_beg ? p.n_rows - row_beg : 0;
   if (span_rows > (int64_t)n_local * kStageRows) span_rows = (int64_t)n_local * kStageRows;
-  const i32x4 rg = make_rsrc(gp + row_beg * p.ld_g, span_rows * p.ld_g * 2);
-  const i32x4 rz = make_rsrc(zp + row_beg * D, span_rows * D * 2);
-  const i32x4 rp = make_rsrc(p.pn + row_beg, span_rows * 4);
-  const int stage_bytes_g = kStageRows * (int)p.ld_g * 2;
-  int voff[P];
-#pragma unroll
-  for (int j = 0; j < P; ++j) {
-    const int o = (wave + j * NW) * 1024 + lane * 16;
-    if (o < kPbOffZ) {
+  // this wave's chunk: 0..2 g rows, 3..5 z1 rows, 6 the coordinates, 7 padding (reads zeros)
+  i32x4 rs; int stage_bytes, voff;
+  {
+    const int o = wave * 1024 + lane * 16;
+    if (wave < 3) {
+      rs = make_rsrc(gp + row_beg * p.ld_g, span_rows * p.ld_g * 2);
+      stage_bytes = kStageRows * (int)p.ld_g * 2;
       const int row = o / S, w = o % S;
-      voff[j] = row * (int)p.ld_g * 2 + (w < D * 2 ? w : 0);
-    } else if (o < kPbOffP) {
+      voff = row * (int)p.ld_g * 2 + (w < D * 2 ? w : 0);
+    } else if (wave < 6) {
+      rs = make_rsrc(zp + row_beg * D, span_rows * D * 2);
+      stage_bytes = kStageRows * D * 2;
       const int oo = o - kPbOffZ;
       const int row = oo / S, w = oo % S;
-      voff[j] = row * D * 2 + (w < D * 2 ? w : 0);
-    } else if (o < kPbOffP + kStageRows * 4) {
-      voff[j] = o - kPbOffP;
+      voff = row * D * 2 + (w < D * 2 ? w : 0);
     } else {
-      voff[j] = kOutOfRange;
+      rs = make_rsrc(p.pn + row_beg, span_rows * 4);
+      stage_bytes = kStageRows * 4;
+      voff = (wave == 6 && lane < kStageRows / 4) ? lane * 16 : kOutOfRange;
     }
   }
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-  auto issue = [&](int local_stage) {                  // always P loads per wave
-    const uint32_t dst = lds_base + (uint32_t)((local_stage % NB) * BUF + wave * 1024);
-#pragma unroll
-    for (int j = 0; j < P; ++j) {
-      const int co = (wave + j * NW) * 1024;                           // wave-uniform
-      if (co < kPbOffZ) lds_dma16(rg, dst + j * NW * 1024, voff[j], local_stage * stage_bytes_g);
-      else if (co < kPbOffP) lds_dma16(rz, dst + j * NW * 1024, voff[j], local_stage * (kStageRows * D * 2));
-      else lds_dma16(rp, dst + j * NW * 1024, voff[j], local_stage * (kStageRows * 4));
-    }
+  auto issue = [&](int local_stage) {                  // always one load per wave
+    lds_dma16(rs, lds_base + (uint32_t)((local_stage % NB) * BUF + wave * 1024), voff, local_stage * stage_bytes);
   };
 
   // transposing-read address of this lane inside a 16-row tile of stride S (+ 64 bytes per 32-column tile)
   const int g4 = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
   const int off_a = (8 * (g4 >> 1) + tq) * S + (16 * (g4 & 1) + 4 * tp) * 2;
-  const int wm2 = wave & 1, wk2 = wave >> 1;           // this wave's 32x32 tile of dW2: rows (pe columns), columns (h1)
-  const int dq = lane >> 4, dj = lane & 15;            // dz1: lane (row dj, columns 16 wave + 4 dq ..+4)
+  const int wm2 = wave & 1, wk2 = (wave >> 1) & 1;     // waves 0..3: their 32x32 tile of dW2 (pe columns x h1 columns)
+  const int dq = lane >> 4, dj = lane & 15;            // waves 0..3: dz1 lane (row dj, columns 16 wave + 4 dq ..+4)
   const int r = lane & 31, h = lane >> 5;
+  const bool lo_half = wave < 4;                        // (wave-uniform)
 
-  f32x16 acc2, acc0[2][2];
+  f32x16 acc2, acc0[2];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    acc2[e] = 0.f;
-    acc0[0][0][e] = 0.f; acc0[0][1][e] = 0.f; acc0[1][0][e] = 0.f; acc0[1][1][e] = 0.f;
-  }
+  for (int e = 0; e < 16; ++e) { acc2[e] = 0.f; acc0[0][e] = 0.f; acc0[1][e] = 0.f; }
   float db2 = 0.f, db0[2] = {0.f, 0.f};
-  // this wave's feature columns f = 64 wave + 32 b + r: revolutions per unit coordinate; cos for f < 128, sin above
-  float omega[2];
-  const bool gen_sin = wave >= 2;
-#pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int f = (64 * wave + 32 * b + r) % (F / 2);
-    omega[b] = expf(-p.log_max_period * (float)f / (float)(F / 2)) * 0.15915494309189535f;
-  }
-  u32x4 wf[2];                                          // W2^T rows 16 wave + dj, k-steps of 32 pe columns
-  {
+  // this wave's feature columns f = 32 wave + r: revolutions per unit coordinate; cos for f < 128, sin above
+  const float omega = expf(-p.log_max_period * (float)((32 * wave + r) % (F / 2)) / (float)(F / 2)) * 0.15915494309189535f;
+  u32x4 wf[2] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};  // W2^T rows 16 wave + dj, k-steps of 32 pe columns
+  if (lo_half) {
     const T* wt = static_cast<const T*>(p.w2t);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
       wf[ks] = *reinterpret_cast<const u32x4*>(wt + (16 * wave + dj) * D + 32 * ks + 8 * dq);
   }
+  // these are the kernel's only compiler-visible global loads: retire them here, or hipcc -- which cannot see the
+  // asm DMA loads sharing the counter -- waits for them with vmcnt(0) at their first use INSIDE the loop, draining the
+  // ring every iteration (seen in the ISA of the first version: 1.9 TB/s)
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  asm volatile("" : "+v"(wf[0]), "+v"(wf[1]));
 
   auto consume = [&](int t) {
     const unsigned char* pb = lds + (t % NB) * BUF;
     const unsigned char* th = tile_h + (t & 1) * TILE;
     const unsigned char* td = tile_d + (t & 1) * TILE;
-    {
+    if (lo_half) {
       const u32x2 lo = lds_read_tr(pb + off_a + wm2 * 64), hi = lds_read_tr(pb + off_a + wm2 * 64 + 4 * S);
       const u32x4 fa = u32x4{lo.x, lo.y, hi.x, hi.y};
       if (wk2 == 0) {
@@ -538,7 +535,7 @@ __global__ __launch_bounds__(256) void posmlp_bwd_kernel(PosBwdParams p) {
       const u32x2 lo = lds_read_tr(td + off_a + a * 64), hi = lds_read_tr(td + off_a + a * 64 + 4 * S);
       fd[a] = u32x4{lo.x, lo.y, hi.x, hi.y};
     }
-    if (wave == 0) {
+    if (wave == 7) {
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         float d = db0[a];
@@ -547,34 +544,33 @@ __global__ __launch_bounds__(256) void posmlp_bwd_kernel(PosBwdParams p) {
         db0[a] = d;
       }
     }
-    // B fragment of feature tile b: lane (column r, half h) supplies F[row 8 h + i][f], i = 0..7
+    // B fragment of this wave's feature tile: lane (column r, half h) supplies F[row 8 h + i][f], i = 0..7
     const float* pr = reinterpret_cast<const float*>(pb + kPbOffP) + 8 * h;
     const f32x4 pa = *reinterpret_cast<const f32x4*>(pr), pc = *reinterpret_cast<const f32x4*>(pr + 4);
     const float pv[8] = {pa.x, pa.y, pa.z, pa.w, pc.x, pc.y, pc.z, pc.w};
+    float v[8];
+    if (lo_half) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      float v[8];
+      for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_cosf(pv[i] * omega);
+    } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float rev = pv[i] * omega[b];
-        v[i] = gen_sin ? __builtin_amdgcn_sinf(rev) : __builtin_amdgcn_cosf(rev);
-      }
-      const u32x4 fb = u32x4{Vec8<T>::pack(v[0], v[1]), Vec8<T>::pack(v[2], v[3]), Vec8<T>::pack(v[4], v[5]),
-                             Vec8<T>::pack(v[6], v[7])};
-#pragma unroll
-      for (int a = 0; a < 2; ++a) acc0[a][b] = WgMfma<T>::run(fd[a], fb, acc0[a][b]);
+      for (int i = 0; i < 8; ++i) v[i] = __builtin_amdgcn_sinf(pv[i] * omega);
     }
+    const u32x4 fb = u32x4{Vec8<T>::pack(v[0], v[1]), Vec8<T>::pack(v[2], v[3]), Vec8<T>::pack(v[4], v[5]),
+                           Vec8<T>::pack(v[6], v[7])};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) acc0[a] = WgMfma<T>::run(fd[a], fb, acc0[a]);
   };
 
-  for (int d = 0; d < kAhead; ++d) issue(d);
+  for (int d = 0; d < kPbAhead; ++d) issue(d);
   for (int s = 0; s < n_local; ++s) {
-    wait_vmcnt<(kAhead - 1) * P>();
+    wait_vmcnt<kPbAhead - 1>();
     __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0): last iteration's tile writes and reads
     __builtin_amdgcn_s_barrier();
-    issue(s + kAhead);                                     // slot (s + 3) % 5: last read by consume(s - 2)
+    issue(s + kPbAhead);                                   // the slot consume(s - 2) read last
     const unsigned char* base = lds + (s % NB) * BUF;
-    {                                                      // h1 tile: 4 elements per thread
-      const int row = tid >> 4, c4 = (tid & 15) * 4;
+    if (!lo_half) {                                        // h1 tile: 4 elements per thread of waves 4..7
+      const int t4 = tid - 256, row = t4 >> 4, c4 = (t4 & 15) * 4;
       const u32x2 zv = *reinterpret_cast<const u32x2*>(base + kPbOffZ + row * S + c4 * 2);
       float z0, z1, z2, z3;
       Vec8<T>::unpack2(zv.x, z0, z1);
@@ -582,8 +578,7 @@ __global__ __launch_bounds__(256) void posmlp_bwd_kernel(PosBwdParams p) {
       const u32x2 hv = u32x2{Vec8<T>::pack(z0 * sigmoid_fast(z0), z1 * sigmoid_fast(z1)),
                              Vec8<T>::pack(z2 * sigmoid_fast(z2), z3 * sigmoid_fast(z3))};
       *reinterpret_cast<u32x2*>(tile_h + (s & 1) * TILE + row * S + c4 * 2) = hv;
-    }
-    {                                                      // dz1 tile
+    } else {                                               // dz1 tile: 16 columns per wave of waves 0..3
       f32x4 dacc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -610,24 +605,22 @@ __global__ __launch_bounds__(256) void posmlp_bwd_kernel(PosBwdParams p) {
     __builtin_amdgcn_s_barrier();
     consume(n_local - 1);
   }
-  __builtin_amdgcn_s_waitcnt(0x0F70);                      // the ring ran kAhead stages past the slab
+  __builtin_amdgcn_s_waitcnt(0x0F70);                      // the ring ran kPbAhead stages past the slab
 
   float* out2 = p.part2 + (int64_t)blockIdx.x * kPbWidth2;
   float* out0 = p.part0 + (int64_t)blockIdx.x * kPbWidth0;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
-    out2[(32 * wm2 + m) * D + 32 * wk2 + r] = acc2[e];
+    if (lo_half) out2[(32 * wm2 + m) * D + 32 * wk2 + r] = acc2[e];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < 2; ++b) out0[(32 * a + m) * F + 64 * wave + 32 * b + r] = acc0[a][b][e];
+    for (int a = 0; a < 2; ++a) out0[(32 * a + m) * F + 32 * wave + r] = acc0[a][e];
   }
-  if (wk2 == 0) {
+  if (lo_half && wk2 == 0) {
     const float d = db2 + __shfl_xor(db2, 32, 64);
     if (h == 0) out2[D * D + 32 * wm2 + r] = d;
   }
-  if (wave == 0) {
+  if (wave == 7) {
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
       const float d = db0[a] + __shfl_xor(db0[a], 32, 64);
@@ -978,15 +971,15 @@ extern "C" int segger_posmlp_bwd(const void* g, int64_t ld_g, const void* z1, co
   }
   const int64_t grid = posmlp_bwd_grid(n_rows);
   const int64_t stages = (n_rows + kStageRows - 1) / kStageRows;
-  SEGGER_REQUIRE(((stages + grid - 1) / grid + kAhead) * kStageRows * ld_g * 2 < (int64_t)kOutOfRange,
+  SEGGER_REQUIRE(((stages + grid - 1) / grid + kPbAhead) * kStageRows * ld_g * 2 < (int64_t)kOutOfRange,
                  "segger_posmlp_bwd: a workgroup's row slab exceeds 1 GiB");
   float* part2 = static_cast<float*>(workspace);
   float* part0 = part2 + (size_t)(grid + kRedGroups) * kPbWidth2;
   PosBwdParams p{g, ld_g, z1, pn, w2_t, n_rows, stages, (stages + grid - 1) / grid, part2, part0, logf(max_period)};
   if (dtype == SEGGER_BF16)
-    hipLaunchKernelGGL((posmlp_bwd_kernel<bf16_t>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((posmlp_bwd_kernel<bf16_t>), dim3((unsigned)grid), dim3(512), 0, stream, p);
   else
-    hipLaunchKernelGGL((posmlp_bwd_kernel<f16_t>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((posmlp_bwd_kernel<f16_t>), dim3((unsigned)grid), dim3(512), 0, stream, p);
   SEGGER_LAUNCH_CHECK("posmlp_bwd_kernel");
   const int rc = reduce_partials(part2, grid, kPbD, kPbD, grad_w2, grad_b2, stream);
   if (rc != SEGGER_OK) return rc;
