@@ -346,6 +346,13 @@ typedef struct segger_triplet_args {
                                 not accumulated, so grad_b needs no zero-fill -- and only the negatives, which are
                                 sampled uniformly and therefore uncontended, use fp32 atomics.  (Positives are the hot
                                 rows: a boundary's ~40 edges sit next to each other and hammer one row.) */
+  int32_t anchor_unique;     /* bwd, with pos_indptr: 1 = no row of z_a is the anchor of two triplets (tx-belongs-bd: a
+                                transcript lies in at most one boundary, heterodata.py:147).  The whole backward is then
+                                ONE walk over the groups: the anchor's row of grad_a is STORED (non-anchor rows keep the
+                                caller's zeros; later kernels may add to it), the group's positive row is summed in
+                                registers and added once, negatives add by fp32 atomics -- grad_b is ACCUMULATED INTO
+                                (caller zero-fills it), every embedding row is read once.  C in {32, 64, 96, 128}. */
+  int32_t reserved_;
 } segger_triplet_args;
 
 /*

@@ -332,6 +332,100 @@ __global__ __launch_bounds__(256) void triplet_pos_kernel(TripletParams p) {
   }
 }
 
+// The whole backward of the tx-belongs-bd triplets in ONE walk over the groups (triplets grouped by positive row j, as
+// triplet_pos_kernel), for triplets whose anchors are all different (a transcript lies in at most one boundary):
+//   * anchor row: STORED (one 4-byte pair or 8 bytes per lane; rows that are no anchor keep the caller's zeros) instead
+//     of 32 packed atomics per triplet;
+//   * positive row j: accumulated in registers over the group, added to grad_b ONCE per boundary;
+//   * negative row: fp32 atomics (uniformly sampled: uncontended).
+// Every row of z_a / z_b is read once per triplet (the two-kernel route reads them twice).  Lane gl of a 16-lane group
+// owns the channel pairs 2 gl + 32 k, k < C / 32 (C % 32 == 0, C <= 128): 4-byte loads for 16-bit embeddings.
+template <typename T> __device__ __forceinline__ void load2(const T* p, float& a, float& b);
+template <> __device__ __forceinline__ void load2<float>(const float* p, float& a, float& b) {
+  const float2 v = *reinterpret_cast<const float2*>(p);
+  a = v.x; b = v.y;
+}
+template <> __device__ __forceinline__ void load2<bf16_t>(const bf16_t* p, float& a, float& b) {
+  Vec8<bf16_t>::unpack2(*reinterpret_cast<const uint32_t*>(p), a, b);
+}
+template <> __device__ __forceinline__ void load2<f16_t>(const f16_t* p, float& a, float& b) {
+  Vec8<f16_t>::unpack2(*reinterpret_cast<const uint32_t*>(p), a, b);
+}
+
+template <typename T, int KP>
+__global__ __launch_bounds__(256) void triplet_grouped_kernel(TripletParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane >> 4, gl = lane & 15;
+  constexpr int C = 32 * KP;
+  const int64_t j = (int64_t)blockIdx.x * 4 + wave;
+  if (j >= p.n_b) return;                               // wave-uniform
+  const T* za = static_cast<const T*>(p.za);
+  const T* zb = static_cast<const T*>(p.zb);
+  float* gb = static_cast<float*>(p.gb);
+  const int64_t beg = p.pos_indptr[j], end = p.pos_indptr[j + 1];
+  if (beg == end) return;
+  const float sc = p.scale_dev ? p.scale * p.scale_dev[0] : p.scale;
+  float pj[KP][2], acc[KP][2];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    load2(zb + j * p.ld_zb + 2 * gl + 32 * k, pj[k][0], pj[k][1]);
+    acc[k][0] = 0.f; acc[k][1] = 0.f;
+  }
+  for (int64_t s0 = beg; s0 < end; s0 += 4) {
+    const int64_t s = s0 + grp;
+    bool ok = s < end;
+    const int64_t e = ok ? (int64_t)p.pos_eid[s] : 0;
+    int64_t ia = ok ? p.src[e] : 0, in = ok ? p.neg[e] : 0;
+    // a triplet whose own positive is not this group's row (padding: pos = -1) or with ids outside the matrices is skipped
+    if ((ok && p.pos[e] != j) || (uint64_t)ia >= (uint64_t)p.n_a || (uint64_t)in >= (uint64_t)p.n_b) { ok = false; ia = in = 0; }
+    float dp[KP][2], dn[KP][2];
+    float sp = 0.f, sn = 0.f;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      float a0, a1, n0, n1;
+      load2(za + ia * p.ld_za + 2 * gl + 32 * k, a0, a1);
+      load2(zb + in * p.ld_zb + 2 * gl + 32 * k, n0, n1);
+      dp[k][0] = a0 - pj[k][0] + p.eps; dp[k][1] = a1 - pj[k][1] + p.eps;
+      dn[k][0] = a0 - n0 + p.eps;       dn[k][1] = a1 - n1 + p.eps;
+      sp = fmaf(dp[k][0], dp[k][0], sp); sp = fmaf(dp[k][1], dp[k][1], sp);
+      sn = fmaf(dn[k][0], dn[k][0], sn); sn = fmaf(dn[k][1], dn[k][1], sn);
+    }
+    sp = lane_block_sum<16>(sp);
+    sn = lane_block_sum<16>(sn);
+    const float dap = sqrtf(sp), dan = sqrtf(sn);
+    if (ok && dap - dan + p.margin > 0.f) {              // group-uniform
+      const float ip_ = dap > 0.f ? sc / dap : 0.f;
+      const float in_ = dan > 0.f ? sc / dan : 0.f;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        const float p0 = dp[k][0] * ip_, p1 = dp[k][1] * ip_, n0 = dn[k][0] * in_, n1 = dn[k][1] * in_;
+        acc[k][0] -= p0; acc[k][1] -= p1;
+        const int64_t ea = ia * C + 2 * gl + 32 * k;
+        bool stored = false;
+        if constexpr (sizeof(T) == 2) {
+          if (p.ga_packed) {
+            *reinterpret_cast<uint32_t*>(static_cast<T*>(p.ga) + ea) = Vec8<T>::pack(p0 - n0, p1 - n1);
+            stored = true;
+          }
+        }
+        if (!stored) *reinterpret_cast<float2*>(static_cast<float*>(p.ga) + ea) = float2{p0 - n0, p1 - n1};
+        atomicAdd(gb + in * C + 2 * gl + 32 * k, n0);
+        atomicAdd(gb + in * C + 2 * gl + 32 * k + 1, n1);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float v = acc[k][q];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (grp == 0) atomicAdd(gb + j * C + 2 * gl + 32 * k + q, v);     // (negatives of other groups land here too)
+    }
+  }
+}
+
 // C == 64 fast path: a lane owns 4 consecutive channels (one 8-byte load per row for 16-bit embeddings, 16 bytes
 // for fp32), 16 lanes per triplet, 4 triplets per wave-iteration; the backward issues two packed (or four fp32)
 // atomics per row and lane.
@@ -608,6 +702,30 @@ static int triplet_common(const segger_triplet_args* a, bool bwd, hipStream_t st
     }
   }
   dim3 grid((unsigned)nb), block(256);
+  if (bwd && a->anchor_unique && p.pos_indptr) {
+    // one walk over the groups does everything (see triplet_grouped_kernel); grad_b is accumulated into
+    const size_t es0 = a->dtype == SEGGER_F32 ? 4 : 2;
+    SEGGER_REQUIRE(a->channels % 32 == 0 && a->channels <= 128 && (a->ld_za * es0) % 4 == 0 && (a->ld_zb * es0) % 4 == 0 &&
+                       ((uintptr_t)a->z_a % 8) == 0 && ((uintptr_t)a->z_b % 8) == 0 && ((uintptr_t)a->grad_a % 8) == 0,
+                   "segger_triplet_bwd: anchor_unique needs C in {32, 64, 96, 128} and 8-byte aligned rows");
+    const dim3 ggrid((unsigned)((a->n_b + 3) / 4));
+#define GROUPED(T)                                                                                         \
+    switch (a->channels / 32) {                                                                            \
+      case 1: hipLaunchKernelGGL((triplet_grouped_kernel<T, 1>), ggrid, block, 0, stream, p); break;       \
+      case 2: hipLaunchKernelGGL((triplet_grouped_kernel<T, 2>), ggrid, block, 0, stream, p); break;       \
+      case 3: hipLaunchKernelGGL((triplet_grouped_kernel<T, 3>), ggrid, block, 0, stream, p); break;       \
+      default: hipLaunchKernelGGL((triplet_grouped_kernel<T, 4>), ggrid, block, 0, stream, p); break;      \
+    }
+    switch (a->dtype) {
+      case SEGGER_F32:  GROUPED(float); break;
+      case SEGGER_BF16: GROUPED(bf16_t); break;
+      case SEGGER_F16:  GROUPED(f16_t); break;
+      default: set_error("segger_triplet: unknown dtype %d", a->dtype); return SEGGER_EINVAL;
+    }
+#undef GROUPED
+    SEGGER_LAUNCH_CHECK("triplet_grouped_kernel");
+    return SEGGER_OK;
+  }
   // C == 64 with rows that admit 4-channel vector loads -> the vectorised kernel
   const size_t es = a->dtype == SEGGER_F32 ? 4 : 2;
   const bool c64 = a->channels == 64 && (a->ld_za * es) % (4 * es) == 0 && (a->ld_zb * es) % (4 * es) == 0 &&

@@ -172,7 +172,7 @@ class LitISTEncoder(_Base):
             g = edge_graph(batch_cache(batch), TX_BD, batch[TX_BD].edge_index, z_tx.size(0), num_bd,
                            need_by_src="lazy" if torch.is_grad_enabled() else False, validate="deferred")
             return ops.triplet_edge_loss(z_tx, z_bd, src_pos, dst_pos, dst_neg, self._sg_margin, eps=1e-6,
-                                         pos_groups=g.by_dst)
+                                         pos_groups=g.by_dst, anchors_unique=g.src_unique)
         # BCE on dot-product logits (:190-207); unique/inverse in the reference only dedups gathers
         src = torch.cat([src_pos, src_pos]).long()
         dst = torch.cat([dst_pos, dst_neg]).long()
@@ -241,7 +241,7 @@ class LitISTEncoder(_Base):
                 dst_neg = ops.sample_negatives(dst_pos, n_bd)                # :178-180, one launch
             g = edge_graph(cache, TX_BD, batch[TX_BD].edge_index, n_tx, n_bd,
                            need_by_src="lazy" if torch.is_grad_enabled() else False, validate="deferred")
-            sg = (src_pos, dst_pos, dst_neg, self._sg_margin, 1e-6, g.by_dst)
+            sg = (src_pos, dst_pos, dst_neg, self._sg_margin, 1e-6, g.by_dst, g.src_unique)
         w = self._scheduled_weights(self._w_start, self._w_end)
         key = tuple(float(v) for v in w)
         wdev = self.__dict__.setdefault("_head_weights", {})

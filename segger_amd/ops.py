@@ -398,7 +398,7 @@ class _TripletEdgeLoss(torch.autograd.Function):
     (loss_tx); one gradient buffer receives all three contributions."""
 
     @staticmethod
-    def forward(ctx, za, zb, src, pos, neg, margin, eps, pos_groups):
+    def forward(ctx, za, zb, src, pos, neg, margin, eps, pos_groups, anchors_unique=False):
         same = zb is None
         zb_ = za if same else zb
         _lib.require_cuda(za, zb_, src)
@@ -417,7 +417,7 @@ class _TripletEdgeLoss(torch.autograd.Function):
         _lib.check(rc, "segger_triplet_fwd")
         ctx.save_for_backward(za, zb_, src, pos, neg)
         ctx.cfg = (margin, eps, same)
-        ctx.pos_groups = pos_groups
+        ctx.pos_groups, ctx.anchors_unique = pos_groups, anchors_unique
         return loss[0]
 
     @staticmethod
@@ -443,9 +443,12 @@ class _TripletEdgeLoss(torch.autograd.Function):
             # (0.58 ms of contended fp32 atomics at C2) -- are a segmented sum over the triplets grouped by positive
             # row (for tx-belongs-bd edges: the by-destination view the encoder already built), which also WRITES
             # every row of grad_b; the uniformly sampled negatives add themselves with (uncontended) fp32 atomics
-            gb = torch.empty(zb.shape, dtype=torch.float32, device=dev)
+            uniq = ctx.anchors_unique
+            uniq = bool(uniq() if callable(uniq) else uniq) and za.shape[1] % 32 == 0 and za.shape[1] <= 128
+            gb = (torch.zeros if uniq else torch.empty)(zb.shape, dtype=torch.float32, device=dev)
             a.grad_b = gb.data_ptr()
             a.pos_indptr, a.pos_eid = pg.indptr.data_ptr(), (pg.eid.data_ptr() if pg.n_edges else None)
+            a.anchor_unique = int(uniq)
         else:
             gb = torch.zeros(zb.shape, dtype=torch.float32, device=dev)
             a.grad_b = gb.data_ptr()
@@ -454,20 +457,23 @@ class _TripletEdgeLoss(torch.autograd.Function):
         with _lib.on_device(dev):
             rc = lib.segger_triplet_bwd(C.byref(a), _lib.stream_ptr(dev))
         _lib.check(rc, "segger_triplet_bwd")
-        return ga.to(za.dtype), (None if same else gb.to(zb.dtype)), None, None, None, None, None, None
+        return ga.to(za.dtype), (None if same else gb.to(zb.dtype)), None, None, None, None, None, None, None
 
 
 def triplet_edge_loss(za: Tensor, zb: Optional[Tensor], src: Tensor, pos: Tensor, neg: Tensor,
-                      margin: float, eps: float = 1e-6, pos_groups: Optional[EdgeCSR] = None) -> Tensor:
+                      margin: float, eps: float = 1e-6, pos_groups: Optional[EdgeCSR] = None,
+                      anchors_unique=False) -> Tensor:
     """mean_e max(||za[src]-zb[pos]+eps|| - ||za[src]-zb[neg]+eps|| + margin, 0).
     Pass ``zb=None`` (or ``zb is za``) when positives / negatives index the anchor matrix itself.
     ``pos_groups``: the triplets grouped by positive row (``indptr`` over rows of ``zb``, ``eid`` = triplet ids), e.g.
-    the by-destination view of the edge store the triplets come from: the backward then needs no atomics for them."""
+    the by-destination view of the edge store the triplets come from: the backward then needs no atomics for them.
+    ``anchors_unique`` (bool, or a callable asked in the backward, e.g. ``EdgeGraph.src_unique``; with ``pos_groups``):
+    no row of ``za`` anchors two triplets -- the backward is then one walk over the groups storing the anchors' rows."""
     if zb is za:
         zb = None
     if pos_groups is not None and (zb is None or pos_groups.n_rows != zb.shape[0] or pos_groups.n_edges != src.numel()):
         raise ValueError("triplet_edge_loss: pos_groups does not describe these triplets")
-    return _TripletEdgeLoss.apply(za, zb, src, pos, neg, float(margin), float(eps), pos_groups)
+    return _TripletEdgeLoss.apply(za, zb, src, pos, neg, float(margin), float(eps), pos_groups, anchors_unique)
 
 
 class _MetricLoss(torch.autograd.Function):
@@ -520,8 +526,10 @@ def metric_loss(z: Tensor, pos: Tensor, neg: Tensor, d_pos: Tensor, d_neg: Tenso
 class LossHeadSpec:
     """What :func:`loss_head` needs besides the embeddings.  ``tx`` = (anchors, positives, negatives, margin, eps) of
     loss_tx (rows of z_tx; ``-1`` = skip); ``bd`` = (positives, negatives, d_pos, d_neg, weights, eps) of loss_bd (rows
-    of z_bd); ``sg`` = (src, pos, neg, margin, eps, pos_groups | None) of the segmentation triplets, or None when the
-    batch has at most one boundary (lightning_model.py:173-175: that loss is then 0)."""
+    of z_bd); ``sg`` = (src, pos, neg, margin, eps, pos_groups | None[, anchors_unique]) of the segmentation triplets, or
+    None when the batch has at most one boundary (lightning_model.py:173-175: that loss is then 0).  ``anchors_unique``
+    (bool, or a callable asked in the backward, e.g. ``EdgeGraph.src_unique``): no transcript is the anchor of two
+    triplets -- the backward then walks the groups once and stores the anchors' gradient rows."""
 
     def __init__(self, tx, bd, sg):
         self.tx, self.bd, self.sg = tx, bd, sg
@@ -569,7 +577,7 @@ class _LossHead(torch.autograd.Function):
             keep.append(ws)
             sg = None
             if spec.sg is not None:
-                src, spos, sneg, smargin, seps, pg = spec.sg
+                src, spos, sneg, smargin, seps, pg = spec.sg[:6]
                 sg = tuple(i64(t) for t in (src, spos, sneg))
                 if pg is not None and (pg.n_rows != nb or pg.n_edges != sg[0].numel()):
                     raise ValueError("loss_head: pos_groups does not describe the segmentation triplets")
@@ -604,7 +612,11 @@ class _LossHead(torch.autograd.Function):
         packed = dt in (torch.bfloat16, torch.float16) and c % 2 == 0 and tx[0].numel() >= _CONTRIB_MIN_EDGES
         ga = torch.zeros(z_tx.shape, dtype=dt if packed else torch.float32, device=dev)
         pg = spec.sg[5] if spec.sg is not None else None
-        gb = (torch.empty if pg is not None else torch.zeros)(z_bd.shape, dtype=torch.float32, device=dev)
+        uniq = False
+        if pg is not None and len(spec.sg) > 6 and c % 32 == 0 and c <= 128:
+            uniq = spec.sg[6]
+            uniq = bool(uniq() if callable(uniq) else uniq)
+        gb = (torch.empty if (pg is not None and not uniq) else torch.zeros)(z_bd.shape, dtype=torch.float32, device=dev)
         stream = _lib.stream_ptr(dev)
         with _lib.on_device(dev):
             _lib.check(lib.segger_loss_combine_bwd(g_out.data_ptr(), a.data_ptr(), b.data_ptr(), 3, graw.data_ptr(), stream),
@@ -614,6 +626,7 @@ class _LossHead(torch.autograd.Function):
                 sa.grad_a, sa.grad_a_packed, sa.grad_b, sa.grad_b_packed = ga.data_ptr(), int(packed), gb.data_ptr(), 0
                 if pg is not None:
                     sa.pos_indptr, sa.pos_eid = pg.indptr.data_ptr(), (pg.eid.data_ptr() if pg.n_edges else None)
+                    sa.anchor_unique = int(uniq)      # one walk over the groups: anchor rows stored, not added
                 sa.grad_scale, sa.grad_scale_dev = 1.0, graw[2:3].data_ptr()
                 _lib.check(lib.segger_triplet_bwd(C.byref(sa), stream), "segger_triplet_bwd")
             zp, ld = _rows(z_bd, c, "z_bd")

@@ -254,7 +254,7 @@ class GraphedTrainStep:
             (pos, neg), (bpos, bneg, dp, dn), dst_neg = fixed["tx"], fixed["bd"], fixed["dst_neg"]
         spec = ops.LossHeadSpec((self._iota, pos, neg, lit.loss_tx.margin, lit.loss_tx.eps),
                                 (bpos, bneg, dp, dn, self.bd_weight, 1e-8),
-                                (self.sg_src, self.sg_pos, dst_neg, lit._sg_margin, 1e-6, self.g_tb.by_dst))
+                                (self.sg_src, self.sg_pos, dst_neg, lit._sg_margin, 1e-6, self.g_tb.by_dst, True))
         out = ops.loss_head(z["tx"], z["bd"], self.head_a, self.scal[3:6], spec)
         if self.defer_sums:                                   # ~30 partial sums of the backward as one launch
             with ops.deferred_reductions(self.dev):

@@ -86,6 +86,48 @@ def test_triplet_edge_loss(oracle, cuda, dtype, C, boundary_side, monkeypatch):
     assert torch.allclose(db.grad.cpu().double(), b.grad, rtol=rtol, atol=atol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C", [64, 32, 128])
+@pytest.mark.parametrize("packed", [False, True])
+def test_triplet_backward_in_one_walk_over_the_groups(oracle, cuda, dtype, C, packed, monkeypatch):
+    """``anchors_unique`` (tx-belongs-bd: a transcript lies in at most one boundary): segger_triplet_bwd walks the
+    triplets grouped by positive row once -- anchor rows stored (fp32, or packed pairs in the embeddings' dtype),
+    positives summed in registers, negatives by fp32 atomics -- against the float64 oracle; a transcript without an
+    edge keeps a zero gradient; a boundary that is nobody's positive still collects its negatives."""
+    from segger_amd import ops
+    from segger_amd.graph import csr_from_coo
+    monkeypatch.setattr(ops, "_CONTRIB_MIN_EDGES", 0 if packed else 1 << 60)
+    g = torch.Generator().manual_seed(11 + C)
+    n_tx, n_bd = 3000, 40
+    z_tx = torch.nn.functional.normalize(torch.randn(n_tx, C, generator=g), dim=-1).to(dtype)
+    z_bd = torch.nn.functional.normalize(torch.randn(n_bd, C, generator=g), dim=-1).to(dtype)
+    src = torch.randperm(n_tx, generator=g)[:2500]                  # unique anchors; 500 transcripts without an edge
+    dst = torch.randint(0, n_bd, (2500,), generator=g)
+    dst[dst == 7] = 8
+    neg = (dst + torch.randint(1, n_bd, (2500,), generator=g)) % n_bd
+    a, b = z_tx.double().requires_grad_(True), z_bd.double().requires_grad_(True)
+    ref = oracle.segmentation_loss(a, b, torch.stack([src, dst]), neg, "triplet", 0.4)
+    (ref * 0.37).backward()
+    da, db = z_tx.to(cuda).requires_grad_(True), z_bd.to(cuda).requires_grad_(True)
+    groups = csr_from_coo(dst.to(cuda), src.to(cuda), n_bd, n_tx, validate=False)
+    asked = []
+    loss = ops.triplet_edge_loss(da, db, src.to(cuda), dst.to(cuda), neg.to(cuda), 0.4, pos_groups=groups,
+                                 anchors_unique=lambda: asked.append(1) or True)
+    (loss * 0.37).backward()
+    assert asked == [1]                                             # asked in the backward, once
+    assert abs(loss.item() - ref.item()) < 1e-5
+    rtol, atol = (1e-5, 1e-7) if dtype == torch.float32 else (1e-2, 2e-6)
+    assert torch.allclose(da.grad.cpu().double(), a.grad, rtol=rtol, atol=atol)
+    assert torch.allclose(db.grad.cpu().double(), b.grad, rtol=rtol, atol=atol)
+    free = torch.ones(n_tx, dtype=torch.bool); free[src] = False
+    assert not da.grad.cpu()[free].any()
+    # the two-kernel route (anchors not known to be unique) gives the same gradients
+    d2, b2 = z_tx.to(cuda).requires_grad_(True), z_bd.to(cuda).requires_grad_(True)
+    (ops.triplet_edge_loss(d2, b2, src.to(cuda), dst.to(cuda), neg.to(cuda), 0.4, pos_groups=groups) * 0.37).backward()
+    assert torch.allclose(d2.grad.float(), da.grad.float(), rtol=rtol, atol=atol)
+    assert torch.allclose(b2.grad.float(), db.grad.float(), rtol=rtol, atol=1e-6)
+
+
 def test_masked_losses_equal_the_gathered_form(cuda):
     """loss_tx / loss_bd under a mask (no compaction, no host sync: the selector works under the mask, the fused
     triplet kernel skips the unmasked anchors) equal TripletLoss / MetricLoss on ``embeddings[mask], labels[mask]`` --
