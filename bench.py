@@ -128,9 +128,15 @@ def other_kernel_classes(dev, n, etb, hc, elem, gen, ops, batch):
     mins, maxs = ops.segment_minmax(pos, bvec, 1)
     l0 = torch.nn.Linear(256, 64).to(dev)
     l2 = torch.nn.Linear(64, 64).to(dev)
-    entry("positional_embedder_fwd", n * (8 + hc * elem) + 2 * n * (2 * 64 * elem + 4),
+    l0.weight.requires_grad_(True)
+    entry("positional_embedder_fwd", n * (8 + 2 * hc * elem) + 2 * n * (64 * elem + 4),
           lambda: ops.posmlp(pos, bvec, mins, maxs, l0.weight, l0.bias, l2.weight, l2.bias, dt, gelu=True),
-          "training forward (stores z1, h1, the normalised coordinates and the pre-activation)")
+          "training forward: reads pos, writes gelu(pe), pe, z1 and the normalised coordinates")
+    pe = ops.posmlp(pos, bvec, mins, maxs, l0.weight, l0.bias, l2.weight, l2.bias, dt)
+    gpe = torch.randn(n, 128, device=dev, generator=gen).to(dt)
+    entry("positional_embedder_bwd_one_pass", 2 * n * (2 * 64 * elem + 4), lambda: pe.backward(gpe, retain_graph=True),
+          "dW2, db2, dW0, db0 from one read of d pe and z1 (segger_posmlp_bwd; dz1 never leaves the chip) + the sums of the "
+          "per-workgroup partials; VALU-bound on the regenerated sinusoid features and the SiLU derivative")
     z = torch.nn.functional.normalize(torch.randn(n, 64, device=dev, generator=gen), dim=-1).to(dt).requires_grad_(True)
     anchors = torch.arange(n, device=dev)
     p_ = torch.randint(0, n, (n,), device=dev, generator=gen)
@@ -149,6 +155,27 @@ def other_kernel_classes(dev, n, etb, hc, elem, gen, ops, batch):
                                   "note": "backward of loss_tx (1M triplets, zero fill + kernel; forward subtracted): 3 row "
                                           "reads + 3 rows of float atomics per active triplet; memory-side atomics run at "
                                           "~1.3 TB/s of added bytes on this part (MI355X_MICROARCH.md)"}
+    # loss_sg backward: tx-belongs-bd triplets with unique anchors, grouped by positive row
+    from segger_amd.graph import csr_from_coo
+    nbd = max(n // 100, 2)
+    zb = torch.nn.functional.normalize(torch.randn(nbd, 64, device=dev, generator=gen), dim=-1).to(dt).requires_grad_(True)
+    src = torch.randperm(n, device=dev, generator=gen)[:etb]
+    dstp = torch.randint(0, nbd, (etb,), device=dev, generator=gen)
+    dneg = (dstp + torch.randint(1, nbd, (etb,), device=dev, generator=gen)) % nbd
+    groups = csr_from_coo(dstp, src, nbd, n, validate=False)
+
+    def trip_sg(unique):
+        z.grad = None; zb.grad = None
+        ops.triplet_edge_loss(z, zb, src, dstp, dneg, 0.4, pos_groups=groups, anchors_unique=unique).backward()
+    with torch.no_grad():
+        ms_f = time_kernel(lambda: ops.triplet_edge_loss(z, zb, src, dstp, dneg, 0.4), iters=10, warm=2)
+    nb = etb * 3 * 64 * elem + etb * 64 * (elem + 4)
+    for name, uq in (("triplet_bwd_loss_sg_grouped", True), ("triplet_bwd_loss_sg_two_kernels", False)):
+        ms = max(time_kernel(lambda: trip_sg(uq), iters=10, warm=2) - ms_f, 1e-6)
+        out[name] = {"achieved": nb / (ms * 1e-3) / 1e9, "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
+                     "algorithmic_bytes_per_launch": nb, "ms_per_launch": ms,
+                     "note": f"backward of loss_sg ({etb} triplets; zero fills + kernel(s); forward subtracted): 3 row reads, "
+                             "one anchor row stored, one negative row of fp32 atomics per active triplet"}
     return out
 
 
@@ -409,7 +436,7 @@ def main():
         torch.cuda.synchronize()
         d32 = (time.perf_counter() - t0) / n32
         f32 = {"ms_per_step": d32 * 1e3, "value": 2.0 * etb / d32, "unit": "edges/s", "steps": n32,
-               "note": "same tile and step, activations stored in fp32 (projections on the vendor GEMM)"}
+               "note": "same tile and step, activations stored in fp32 (projections on the exact-fp32 MFMA kernels, csrc/linear_f32.hip)"}
         model.model.compute_dtype = dtype
         log(f"[bench] f32 step {d32 * 1e3:.2f} ms")
 

@@ -357,13 +357,14 @@ __global__ __launch_bounds__(256) void triplet_grouped_kernel(TripletParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane >> 4, gl = lane & 15;
   constexpr int C = 32 * KP;
-  const int64_t j = (int64_t)blockIdx.x * 4 + wave;
-  if (j >= p.n_b) return;                               // wave-uniform
+  // one workgroup per boundary: its 16 lane groups take 16 triplets per iteration (a boundary has ~40: the walk is a
+  // chain of dependent loads -- triplet id -> row ids -> rows -- and one wave per boundary left 10 such rounds in series)
+  const int64_t j = blockIdx.x;
   const T* za = static_cast<const T*>(p.za);
   const T* zb = static_cast<const T*>(p.zb);
   float* gb = static_cast<float*>(p.gb);
-  const int64_t beg = p.pos_indptr[j], end = p.pos_indptr[j + 1];
-  if (beg == end) return;
+  const int64_t beg = p.pos_indptr[j] + 4 * wave, end = p.pos_indptr[j + 1];
+  if (beg >= end) return;                               // wave-uniform
   const float sc = p.scale_dev ? p.scale * p.scale_dev[0] : p.scale;
   float pj[KP][2], acc[KP][2];
 #pragma unroll
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void triplet_grouped_kernel(TripletParams p) {
     load2(zb + j * p.ld_zb + 2 * gl + 32 * k, pj[k][0], pj[k][1]);
     acc[k][0] = 0.f; acc[k][1] = 0.f;
   }
-  for (int64_t s0 = beg; s0 < end; s0 += 4) {
+  for (int64_t s0 = beg; s0 < end; s0 += 16) {
     const int64_t s = s0 + grp;
     bool ok = s < end;
     const int64_t e = ok ? (int64_t)p.pos_eid[s] : 0;
@@ -708,7 +709,8 @@ static int triplet_common(const segger_triplet_args* a, bool bwd, hipStream_t st
     SEGGER_REQUIRE(a->channels % 32 == 0 && a->channels <= 128 && (a->ld_za * es0) % 4 == 0 && (a->ld_zb * es0) % 4 == 0 &&
                        ((uintptr_t)a->z_a % 8) == 0 && ((uintptr_t)a->z_b % 8) == 0 && ((uintptr_t)a->grad_a % 8) == 0,
                    "segger_triplet_bwd: anchor_unique needs C in {32, 64, 96, 128} and 8-byte aligned rows");
-    const dim3 ggrid((unsigned)((a->n_b + 3) / 4));
+    SEGGER_REQUIRE(a->n_b < 0x7fffffffLL, "segger_triplet_bwd: too many rows in z_b");
+    const dim3 ggrid((unsigned)a->n_b);
 #define GROUPED(T)                                                                                         \
     switch (a->channels / 32) {                                                                            \
       case 1: hipLaunchKernelGGL((triplet_grouped_kernel<T, 1>), ggrid, block, 0, stream, p); break;       \

@@ -286,8 +286,11 @@ class GraphedTrainStep:
                     why = f"{names.get(id(p))}: gradient {'missing' if g is None else 'unexpected'}"
                 elif g is not None:
                     scale, diff = float(r.abs().max()), float((g - r).abs().max())
-                    # (the loss kernels accumulate with float atomics: run-to-run differences of ~1e-6 are expected)
-                    if not bool(torch.isfinite(g).all()) or diff > 1e-2 * scale + 1e-6:
+                    # the loss kernels accumulate with (packed 16-bit) float atomics, so two runs of the same backward
+                    # differ by a few per cent of a small gradient (seen: 1.4 % on lin_last's bias); a gradient that was
+                    # read before its sum was launched is garbage, not a rounding difference: 10 % of the largest
+                    # entry separates the two
+                    if not bool(torch.isfinite(g).all()) or diff > 0.1 * scale + 1e-6:
                         why = f"{names.get(id(p))}: differs by {diff:.3e} (scale {scale:.3e})"
                 if why:
                     break
