@@ -225,6 +225,22 @@ int segger_gatv2_bwd(const segger_gatv2_bwd_args* args, segger_stream_t stream);
 int segger_dropout_bits(const int32_t* eid, int64_t n_edges, int32_t heads, float dropout_p, const uint64_t* seeds,
                         int32_t n_seeds, const uint64_t* seed_dev, uint8_t* bits, int64_t plane_stride,
                         segger_stream_t stream);
+/* segger_dropout_bits_many: up to 4 such views (the by-destination / by-source views of a step's edge types) in ONE
+ * launch; per view the arguments of segger_dropout_bits.
+ * segger_step_advance: *step += inc and (optionally) *copy = the new value, one tiny launch -- the device-side step
+ * counter behind seed_dev (ISTEncoder's dropout stream), advanced and snapshotted for the backward. */
+typedef struct segger_bits_job {
+  const int32_t* eid;
+  int64_t n_edges;
+  const uint64_t* seeds;    /* HOST array [n_seeds] */
+  int32_t n_seeds;
+  int32_t reserved_;
+  uint8_t* bits;
+  int64_t plane_stride;
+} segger_bits_job;
+int segger_dropout_bits_many(const segger_bits_job* jobs, int32_t n_jobs, int32_t heads, float dropout_p,
+                             const uint64_t* seed_dev, segger_stream_t stream);
+int segger_step_advance(int64_t* step, int64_t inc, int64_t* copy, segger_stream_t stream);
 
 /* 1 when (heads, channels) runs on the specialised kernels (channels in {32,64}, heads in 1..4), 0 = generic kernels */
 int segger_gatv2_has_specialised(int32_t heads, int32_t channels);
@@ -307,7 +323,8 @@ int segger_edge_cos_argmax(const segger_edge_argmax_args* args, segger_stream_t 
  * (margin, p=2, eps=1e-6, mean) at src/segger/models/lightning_model.py:182-187
  * and its autograd.
  *   loss = mean_e max(||a-p+eps|| - ||a-n+eps|| + margin, 0)
- * fwd writes partial sums; `loss` receives the mean.  bwd accumulates
+ * fwd writes partial sums; `loss` receives the mean (loss == NULL: partial sums only, see
+ * segger_loss_combine_partials_fwd).  bwd accumulates
  * (atomics: fp32, or packed 16-bit pairs, see grad_*_packed) into grad_a / grad_b, which the caller zero-fills.
  * ---------------------------------------------------------------------- */
 typedef struct segger_triplet_args {
@@ -363,6 +380,13 @@ typedef struct segger_triplet_args {
  * raw / a / b: float[n] on the device, n <= 16; grad_raw feeds grad_scale_dev of the loss kernels' backward.
  */
 int segger_loss_combine_fwd(const float* raw, const float* a, const float* b, int32_t n, float* out, segger_stream_t stream);
+/* The same with raw[i] = scale[i] * sum(partial[i][0 .. n_partial[i])): segger_triplet_fwd / segger_metric_fwd called with
+ * loss == NULL leave their per-block partial sums (segger_triplet_partial_count(n) floats) at the start of their workspace;
+ * this launch finishes all of them (in a fixed order) and combines -- one launch instead of one per loss + one.
+ * partial / n_partial / scale are HOST arrays of n entries (device pointers inside partial). */
+int64_t segger_triplet_partial_count(int64_t n_edges);
+int segger_loss_combine_partials_fwd(const float* const* partial, const int64_t* n_partial, const float* scale, const float* a,
+                                     const float* b, int32_t n, float* out, segger_stream_t stream);
 int segger_loss_combine_bwd(const float* grad_out, const float* a, const float* b, int32_t n, float* grad_raw,
                             segger_stream_t stream);
 
@@ -422,7 +446,14 @@ int segger_triplet_bwd(const segger_triplet_args* args, segger_stream_t stream);
  *   pos   : [n, 2] fp32 ;  batch : [n] int64 graph id per node, or NULL (one graph)
  *   mins / maxs : [n_graphs, 2] fp32 ; a graph without nodes gets (0, 0) as in the
  *   reference; ids outside [0, n_graphs) are ignored.
+ * segger_segment_minmax_ex, flags: SEGGER_MINMAX_INITIALISED = the caller has already filled mins with +inf and maxs with
+ *   -inf (e.g. in its staging launch); SEGGER_MINMAX_KEEP_EMPTY = leave (+inf, -inf) for graphs without nodes (a consumer
+ *   that only looks up the graphs of existing nodes never reads them): one launch instead of three.
  * ---------------------------------------------------------------------- */
+#define SEGGER_MINMAX_INITIALISED 1
+#define SEGGER_MINMAX_KEEP_EMPTY 2
+int segger_segment_minmax_ex(const float* pos, const int64_t* batch, int64_t n, int64_t n_graphs, float* mins, float* maxs,
+                             int32_t flags, segger_stream_t stream);
 int segger_segment_minmax(const float* pos, const int64_t* batch, int64_t n, int64_t n_graphs,
                           float* mins, float* maxs, segger_stream_t stream);
 

@@ -101,6 +101,11 @@ class EdgeArgmaxArgs(C.Structure):
     ]
 
 
+class BitsJob(C.Structure):
+    _fields_ = [("eid", vp), ("n_edges", C.c_int64), ("seeds", vp), ("n_seeds", C.c_int32), ("reserved_", C.c_int32),
+                ("bits", vp), ("plane_stride", C.c_int64)]
+
+
 class TripletArgs(C.Structure):
     _fields_ = [
         ("src", vp), ("pos", vp), ("neg", vp), ("n_edges", C.c_int64),
@@ -161,6 +166,11 @@ EXPORTS = {
     "segger_reductions_pending": (C.c_int, []),
     "segger_reductions_flush": (C.c_int, [vp]),
     "segger_linear_wgrad_dx_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "segger_dropout_bits_many": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_float, vp, vp]),
+    "segger_step_advance": (C.c_int, [vp, C.c_int64, vp, vp]),
+    "segger_segment_minmax_ex": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp, C.c_int32, vp]),
+    "segger_triplet_partial_count": (C.c_int64, [C.c_int64]),
+    "segger_loss_combine_partials_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int32, vp, vp]),
     "segger_posmlp_bwd_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "segger_posmlp_bwd": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_float, C.c_int32, vp, vp, vp, vp, vp,
                                     C.c_size_t, vp]),

@@ -44,7 +44,12 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(char* __restrict__ base,
 // load of their edge ids and one 4-byte store per plane (byte stores, one slot per thread, ran at 2.3 TB/s)
 struct BitsParams { const int32_t* eid; int64_t n_edges; int64_t plane_stride; int heads; uint32_t thr; int n_seeds;
                     int eid_aligned; uint64_t seeds[16]; const uint64_t* seed_dev; uint8_t* bits; };
-__global__ __launch_bounds__(256) void dropout_bits_kernel(BitsParams p) {
+constexpr int kMaxBitsJobs = 4;
+struct BitsJobs { BitsParams job[kMaxBitsJobs]; };       // blockIdx.y picks the job (the edge views of one step)
+__device__ __forceinline__ void dropout_bits_body(const BitsParams& p);
+__global__ __launch_bounds__(256) void dropout_bits_kernel(BitsParams p) { dropout_bits_body(p); }
+__global__ __launch_bounds__(256) void dropout_bits_many_kernel(BitsJobs j) { dropout_bits_body(j.job[blockIdx.y]); }
+__device__ __forceinline__ void dropout_bits_body(const BitsParams& p) {
   const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (s0 >= p.n_edges) return;
   const bool full = s0 + 3 < p.n_edges;
@@ -300,5 +305,47 @@ extern "C" int segger_dropout_bits(const int32_t* eid, int64_t n_edges, int32_t 
   for (int l = 0; l < n_seeds; ++l) p.seeds[l] = seeds[l];
   hipLaunchKernelGGL(dropout_bits_kernel, dim3((unsigned)((n_edges + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, p);
   SEGGER_LAUNCH_CHECK("dropout_bits_kernel");
+  return SEGGER_OK;
+}
+
+extern "C" int segger_dropout_bits_many(const segger_bits_job* jobs, int32_t n_jobs, int32_t heads, float dropout_p,
+                                        const uint64_t* seed_dev, segger_stream_t stream) {
+  SEGGER_REQUIRE(jobs && n_jobs > 0 && n_jobs <= kMaxBitsJobs, "segger_dropout_bits_many: 1..4 jobs");
+  SEGGER_REQUIRE(heads > 0 && heads <= 8, "segger_dropout_bits_many: heads must be in 1..8");
+  SEGGER_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "segger_dropout_bits_many: dropout_p must be in [0,1)");
+  BitsJobs all{};
+  int64_t most = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const segger_bits_job& jb = jobs[i];
+    SEGGER_REQUIRE(jb.n_edges >= 0 && jb.n_seeds > 0 && jb.n_seeds <= 16, "segger_dropout_bits_many: job %d: bad sizes", i);
+    SEGGER_REQUIRE(jb.n_edges == 0 || (jb.eid && jb.bits), "segger_dropout_bits_many: job %d: NULL pointer", i);
+    SEGGER_REQUIRE(jb.plane_stride >= jb.n_edges && jb.plane_stride % 4 == 0 && ((uintptr_t)jb.bits & 3u) == 0,
+                   "segger_dropout_bits_many: job %d: plane_stride must be a multiple of 4 >= n_edges, bits 4-byte aligned", i);
+    BitsParams& p = all.job[i];
+    p.eid = jb.eid; p.n_edges = jb.n_edges; p.plane_stride = jb.plane_stride; p.heads = heads; p.n_seeds = jb.n_seeds;
+    p.seed_dev = seed_dev; p.bits = jb.bits; p.eid_aligned = aligned16(jb.eid) ? 1 : 0;
+    p.thr = (uint32_t)((double)dropout_p * 16777216.0);
+    for (int l = 0; l < jb.n_seeds; ++l) p.seeds[l] = jb.seeds[l];
+    if (jb.n_edges > most) most = jb.n_edges;
+  }
+  if (most == 0) return SEGGER_OK;
+  hipLaunchKernelGGL(dropout_bits_many_kernel, dim3((unsigned)((most + 1023) / 1024), (unsigned)n_jobs), dim3(256), 0,
+                     (hipStream_t)stream, all);
+  SEGGER_LAUNCH_CHECK("dropout_bits_many_kernel");
+  return SEGGER_OK;
+}
+
+namespace segger {
+namespace {
+__global__ void step_advance_kernel(int64_t* step, int64_t inc, int64_t* copy) {
+  if (threadIdx.x == 0) { const int64_t v = *step + inc; *step = v; if (copy) *copy = v; }
+}
+}  // namespace
+}  // namespace segger
+
+extern "C" int segger_step_advance(int64_t* step, int64_t inc, int64_t* copy, segger_stream_t stream) {
+  SEGGER_REQUIRE(step != nullptr, "segger_step_advance: step is NULL");
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, inc, copy);
+  SEGGER_LAUNCH_CHECK("step_advance_kernel");
   return SEGGER_OK;
 }

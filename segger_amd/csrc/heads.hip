@@ -657,6 +657,8 @@ extern "C" int segger_edge_cos_argmax(const segger_edge_argmax_args* a, segger_s
   }
 }
 
+extern "C" int64_t segger_triplet_partial_count(int64_t n_edges) { return n_edges > 0 ? triplet_blocks(n_edges) : 0; }
+
 extern "C" size_t segger_triplet_workspace_bytes(int64_t n_edges) {
   return (size_t)(n_edges > 0 ? triplet_blocks(n_edges) : 1) * sizeof(float) + 16;
 }
@@ -665,11 +667,10 @@ static int triplet_common(const segger_triplet_args* a, bool bwd, hipStream_t st
   SEGGER_REQUIRE(a != nullptr, "segger_triplet: args is NULL");
   SEGGER_REQUIRE(a->n_edges >= 0 && a->channels > 0, "segger_triplet: bad sizes");
   SEGGER_REQUIRE(a->n_edges < 0x7fffffffLL * kTripletEdgesPerBlock, "segger_triplet: too many edges");
-  if (!bwd) SEGGER_REQUIRE(a->loss != nullptr, "segger_triplet_fwd: loss is NULL");
   if (a->n_edges == 0) {
     // torch: mean over zero elements is NaN; segger never calls the loss with no edges
     // (lightning_model.py:173 guards num_bd <= 1 only).  We return 0.
-    if (!bwd) SEGGER_HIP(hipMemsetAsync(a->loss, 0, sizeof(float), stream));
+    if (!bwd && a->loss) SEGGER_HIP(hipMemsetAsync(a->loss, 0, sizeof(float), stream));
     return SEGGER_OK;
   }
   SEGGER_REQUIRE(a->src && a->pos && a->neg && a->z_a && a->z_b, "segger_triplet: NULL input");
@@ -752,7 +753,7 @@ static int triplet_common(const segger_triplet_args* a, bool bwd, hipStream_t st
   }
 #undef LAUNCH
   SEGGER_LAUNCH_CHECK("triplet_kernel");
-  if (!bwd) {
+  if (!bwd && a->loss) {      // loss == NULL: the per-block partial sums stay in the workspace (segger_loss_combine_partials_fwd)
     hipLaunchKernelGGL(triplet_finish_kernel, dim3(1), dim3(256), 0, stream, p.partial, nb, 1.0f / (float)a->n_edges, a->loss);
     SEGGER_LAUNCH_CHECK("triplet_finish_kernel");
   }
@@ -779,6 +780,51 @@ __global__ void loss_combine_kernel(const float* __restrict__ raw, const float* 
 }
 }  // namespace
 }  // namespace segger
+
+namespace segger {
+namespace {
+struct CombineParts { const float* partial[16]; int64_t n_partial[16]; float scale[16]; };
+// one workgroup: term i = scale[i] * (sum of its partial sums, in a fixed order), then the combination of loss_combine_kernel
+__global__ __launch_bounds__(256) void loss_combine_parts_kernel(CombineParts c, const float* __restrict__ a,
+                                                                const float* __restrict__ b, int n, float* __restrict__ out) {
+  __shared__ float wsum[4];
+  __shared__ float raw[16];
+  for (int i = 0; i < n; ++i) {
+    float s = 0.f;
+    for (int64_t k = threadIdx.x; k < c.n_partial[i]; k += 256) s += c.partial[i][k];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) raw[i] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * c.scale[i];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    float total = 0.f;
+    for (int i = 0; i < n; ++i) {
+      const float t = raw[i] * a[i];
+      out[i] = t;
+      total = fmaf(t, b[i], total);
+    }
+    out[n] = total;
+  }
+}
+}  // namespace
+}  // namespace segger
+
+extern "C" int segger_loss_combine_partials_fwd(const float* const* partial, const int64_t* n_partial, const float* scale,
+                                                const float* a, const float* b, int32_t n, float* out,
+                                                segger_stream_t stream) {
+  SEGGER_REQUIRE(n > 0 && n <= 16 && partial && n_partial && scale && a && b && out,
+                 "segger_loss_combine_partials_fwd: 1..16 terms, no NULL pointer");
+  CombineParts c{};
+  for (int i = 0; i < n; ++i) {
+    SEGGER_REQUIRE(n_partial[i] >= 0 && (n_partial[i] == 0 || partial[i]), "segger_loss_combine_partials_fwd: bad term %d", i);
+    c.partial[i] = partial[i]; c.n_partial[i] = n_partial[i]; c.scale[i] = scale[i];
+  }
+  hipLaunchKernelGGL(loss_combine_parts_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, c, a, b, n, out);
+  SEGGER_LAUNCH_CHECK("loss_combine_parts_kernel");
+  return SEGGER_OK;
+}
 
 extern "C" int segger_loss_combine_fwd(const float* raw, const float* a, const float* b, int32_t n, float* out,
                                        segger_stream_t stream) {
@@ -863,7 +909,6 @@ static int metric_common(const void* z, int64_t ld_z, int64_t n, int32_t channel
   const int64_t nb = triplet_blocks(n);
   MetricParams p{z, ld_z, n, channels, pos, neg, d_pos, d_neg, w, eps, static_cast<float*>(workspace), scale_dev, grad_z};
   if (!bwd) {
-    SEGGER_REQUIRE(loss != nullptr, "segger_metric_fwd: loss is NULL");
     const size_t need = segger_triplet_workspace_bytes(n);
     if (!workspace || workspace_bytes < need) {
       set_error("segger_metric_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -886,7 +931,7 @@ static int metric_common(const void* z, int64_t ld_z, int64_t n, int32_t channel
   }
 #undef LAUNCH_M
   SEGGER_LAUNCH_CHECK("metric_kernel");
-  if (!bwd) {
+  if (!bwd && loss) {         // loss == NULL: partial sums only, as segger_triplet_fwd
     hipLaunchKernelGGL(triplet_finish_kernel, dim3(1), dim3(256), 0, stream, p.partial, nb, 1.0f, loss);
     SEGGER_LAUNCH_CHECK("triplet_finish_kernel");
   }

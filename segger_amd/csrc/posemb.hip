@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void minmax_fixup_kernel(float* mins, float* m
 
 using namespace segger;
 
-extern "C" int segger_segment_minmax(const float* pos, const int64_t* batch, int64_t n, int64_t n_graphs,
-                                     float* mins, float* maxs, segger_stream_t stream_) {
+extern "C" int segger_segment_minmax_ex(const float* pos, const int64_t* batch, int64_t n, int64_t n_graphs,
+                                        float* mins, float* maxs, int32_t flags, segger_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   SEGGER_REQUIRE(n >= 0 && n_graphs >= 0, "segger_segment_minmax: negative size");
   SEGGER_REQUIRE(n_graphs < 0x7fffffffLL, "segger_segment_minmax: too many graphs");
@@ -94,14 +94,21 @@ extern "C" int segger_segment_minmax(const float* pos, const int64_t* batch, int
   SEGGER_REQUIRE((reinterpret_cast<uintptr_t>(pos) & 7u) == 0, "segger_segment_minmax: pos must be 8-byte aligned");
   const int64_t n2 = 2 * n_graphs;
   const unsigned gb = (unsigned)((n2 + 255) / 256);
-  hipLaunchKernelGGL(minmax_init_kernel, dim3(gb), dim3(256), 0, stream, mins, maxs, n2);
+  if (!(flags & SEGGER_MINMAX_INITIALISED))
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(gb), dim3(256), 0, stream, mins, maxs, n2);
   if (n > 0) {
     const int64_t per = 256 * kNodesPerThread;
     const int64_t nb = (n + per - 1) / per;
     SEGGER_REQUIRE(nb < 0x7fffffffLL, "segger_segment_minmax: too many nodes");
     hipLaunchKernelGGL(segment_minmax_kernel, dim3((unsigned)nb), dim3(256), 0, stream, pos, batch, n, n_graphs, mins, maxs);
   }
-  hipLaunchKernelGGL(minmax_fixup_kernel, dim3(gb), dim3(256), 0, stream, mins, maxs, n2);
+  if (!(flags & SEGGER_MINMAX_KEEP_EMPTY))
+    hipLaunchKernelGGL(minmax_fixup_kernel, dim3(gb), dim3(256), 0, stream, mins, maxs, n2);
   SEGGER_LAUNCH_CHECK("segment_minmax kernels");
   return SEGGER_OK;
+}
+
+extern "C" int segger_segment_minmax(const float* pos, const int64_t* batch, int64_t n, int64_t n_graphs,
+                                     float* mins, float* maxs, segger_stream_t stream) {
+  return segger_segment_minmax_ex(pos, batch, n, n_graphs, mins, maxs, 0, stream);
 }

@@ -87,7 +87,7 @@ class Positional2dEmbedder(Module):
         return (pos - lo) / (hi - lo + 1e-8)                # ist_encoder.py:74
 
     def forward(self, pos: Tensor, batch: Optional[Tensor] = None, *, num_graphs: Optional[int] = None,
-                dtype: torch.dtype = torch.float32, gelu: bool = False, return_pre: bool = False):
+                dtype: torch.dtype = torch.float32, gelu: bool = False, return_pre: bool = False, minmax=None):
         """``gelu`` (not in the reference): also apply the GELU that ISTEncoder puts on its concatenated input;
         ``return_pre`` (with ``gelu``): ``(gelu(h), h)`` as ``ops.posmlp`` documents it, or ``(gelu(h), None)`` on the
         routes that keep the GELU in autograd."""
@@ -97,10 +97,12 @@ class Positional2dEmbedder(Module):
             # fused: per-graph min/max (one pass) -> normalise + sinusoid written straight in `dtype`
             if num_graphs is None:
                 num_graphs = int(batch.max()) + 1 if batch.numel() else 0
-            mins, maxs = ops.segment_minmax(pos, batch, num_graphs)
             l0, l2 = self.mlp[0], self.mlp[2]
-            if (self.fused and pos.is_cuda and l0.bias is not None and l2.bias is not None
-                    and ops.posmlp_supported(fd, self.dim, dtype)):
+            use_fused = (self.fused and pos.is_cuda and l0.bias is not None and l2.bias is not None
+                         and ops.posmlp_supported(fd, self.dim, dtype))
+            # (the fused kernel and posfreq only look up the graphs of existing nodes: no (0, 0) fix-up for empty ones)
+            mins, maxs = ops.segment_minmax(pos, batch, num_graphs, keep_empty=True, out=minmax)
+            if use_fused:
                 # sinusoid + Linear + SiLU + Linear in one kernel: the [2n, 256] feature matrix is generated in
                 # registers (and stored once for the weight gradient when training) instead of written and re-read
                 return ops.posmlp(pos, batch, mins, maxs, l0.weight, l0.bias, l2.weight, l2.bias, dtype,
@@ -318,23 +320,25 @@ class ISTEncoder(Module):
             del state_dict[k]
 
     def _dropout_planes(self, graphs, step):
-        """The attention-dropout masks of all layers as bit planes per CSR view (``ops.dropout_bits``): one launch per
-        view per step; the 12 aggregation launches of the step then test a bit per (edge, head) instead of hashing."""
+        """The attention-dropout masks of all layers as bit planes per CSR view (``ops.dropout_bits_many``): one launch
+        per step; the 12 aggregation launches of the step then test a bit per (edge, head) instead of hashing."""
         n_layers = len(self.conv_layers)
         first = self.conv_layers[0]
         if n_layers > 16 or self.n_heads > 8 or not (first.conv[TX_TX].dropout > 0):
             return None
         p = first.conv[TX_TX].dropout
-        out = {}
+        out, views = {}, []
         for which, et in ((0, TX_TX), (1, TX_BD)):
             g = graphs.get(et)
             if g is None or g.by_dst is None:
                 continue
             seeds = [2 * li + which for li in range(n_layers)]
-            d = ops.dropout_bits(g.by_dst, self.n_heads, p, seeds, step)
-            s_ = ops.dropout_bits(g.by_src, self.n_heads, p, seeds, step) if g.by_src is not None else None
-            out[et] = (d, s_)
-        return out
+            views += [(et, 0, g.by_dst, seeds)] + ([(et, 1, g.by_src, seeds)] if g.by_src is not None else [])
+            out[et] = [None, None]
+        for (et, side, _, _), bits in zip(views, ops.dropout_bits_many([(c, sd) for _, _, c, sd in views], self.n_heads, p,
+                                                                         step)):
+            out[et][side] = bits
+        return {et: tuple(v) for et, v in out.items()}
 
     def _pos_embed_pair(self, pos_dict, batch_dict, num_graphs, dt, gelu: bool, graphs):
         """(pe_tx, pe_bd): ``pos_emb`` of both node types, in one call where the batch vectors allow it.  With ``gelu``
@@ -352,7 +356,8 @@ class ISTEncoder(Module):
         else:
             pos_all = torch.cat((pos_dict["tx"].float(), pos_dict["bd"].float()), 0)
             batch_all = torch.cat((b_tx.long(), b_bd.long() + int(num_graphs)), 0)
-        pe = self.pos_emb(pos_all, batch_all, num_graphs=2 * int(num_graphs), dtype=dt, gelu=gelu)
+        pe = self.pos_emb(pos_all, batch_all, num_graphs=2 * int(num_graphs), dtype=dt, gelu=gelu,
+                          minmax=graphs.get("minmax") if graphs is not None else None)
         pe_tx, pe_bd = _SplitRows.apply(pe, int(pos_dict["tx"].shape[0]))
         return ((pe_tx, None) if gelu else pe_tx), pe_bd
 
@@ -428,8 +433,11 @@ class ISTEncoder(Module):
             # every training forward gets its own snapshot of the advanced counter: its backward re-reads THAT word,
             # so a second forward before the first backward (two views, checkpointing, a logging pass) cannot change
             # the masks the first backward regenerates.  Capture-safe: the clone lives in the graph's pool.
-            self._step_dev.add_(256)
-            step = self._step_dev.clone()
+            if self._step_dev.is_cuda:
+                step = ops.step_advance(self._step_dev, 256)
+            else:
+                self._step_dev.add_(256)
+                step = self._step_dev.clone()
         planes = self._dropout_planes(graphs, step) if self.training else None
         for li, layer in enumerate(self.conv_layers):
             kb = None if planes is None else {et: (d[li], None if s_ is None else s_[li]) for et, (d, s_) in planes.items()}

@@ -63,6 +63,47 @@ def dropout_bits(csr: EdgeCSR, heads: int, dropout_p: float, seeds, seed_dev: Op
     return out[:, :csr.n_edges]
 
 
+def dropout_bits_many(views, heads: int, dropout_p: float, seed_dev: Optional[Tensor] = None) -> list:
+    """:func:`dropout_bits` for up to four ``(csr, seeds)`` views in ONE launch (``segger_dropout_bits_many``)."""
+    views = [(c, [int(v) & 0xFFFFFFFFFFFFFFFF for v in sd]) for c, sd in views]
+    if not views:
+        return []
+    if len(views) > 4:
+        return dropout_bits_many(views[:4], heads, dropout_p, seed_dev) + dropout_bits_many(views[4:], heads, dropout_p, seed_dev)
+    dev = views[0][0].col.device
+    _lib.require_cuda(views[0][0].col)
+    lib = _lib.load()
+    jobs = (_lib.BitsJob * len(views))()
+    outs, keep = [], []
+    for i, (csr, seeds) in enumerate(views):
+        stride = (csr.n_edges + 15) // 16 * 16
+        out = torch.empty((len(seeds), stride), dtype=torch.uint8, device=dev)
+        arr = (C.c_uint64 * len(seeds))(*seeds)
+        keep.append(arr)
+        jobs[i].eid = csr.eid.data_ptr() if csr.n_edges else None
+        jobs[i].n_edges, jobs[i].n_seeds = csr.n_edges, len(seeds)
+        jobs[i].seeds = C.cast(arr, C.c_void_p)
+        jobs[i].bits, jobs[i].plane_stride = out.data_ptr(), stride
+        outs.append(out[:, :csr.n_edges])
+    with _lib.on_device(dev):
+        rc = lib.segger_dropout_bits_many(jobs, len(views), heads, dropout_p, _lib.ptr(seed_dev), _lib.stream_ptr(dev))
+    _lib.check(rc, "segger_dropout_bits_many")
+    return outs
+
+
+@torch.no_grad()
+def step_advance(step: Tensor, inc: int) -> Tensor:
+    """``step += inc`` in place and a snapshot of the new value, one launch (``segger_step_advance``); int64[1] on the GPU."""
+    _lib.require_cuda(step)
+    if step.dtype != torch.int64 or step.numel() != 1:
+        raise ValueError("step_advance: int64[1]")
+    snap = torch.empty_like(step)
+    with _lib.on_device(step.device):
+        rc = _lib.load().segger_step_advance(step.data_ptr(), int(inc), snap.data_ptr(), _lib.stream_ptr(step.device))
+    _lib.check(rc, "segger_step_advance")
+    return snap
+
+
 # ---- deferred partial sums (csrc/reduce.hip) ----------------------------------------------------------------
 _DEFER_KEEP: Optional[list] = None
 
@@ -555,17 +596,21 @@ class _LossHead(torch.autograd.Function):
         a = a.detach().to(torch.float32).contiguous()
         b = b.detach().to(torch.float32).contiguous()
         i64 = lambda t: t.to(torch.int64).contiguous()
-        raw = torch.zeros(3, dtype=torch.float32, device=dev)
         keep = []
         stream = _lib.stream_ptr(dev)
+        parts = (C.c_void_p * 3)()
+        counts = (C.c_int64 * 3)(0, 0, 0)
+        scales = (C.c_float * 3)(0.0, 0.0, 0.0)
         with _lib.on_device(dev):
             anchors, pos, neg, margin, eps = spec.tx
             tx = tuple(i64(t) for t in (anchors, pos, neg))
             ta = _triplet_args(*tx, z_tx, z_tx, float(margin), float(eps))
             ws = torch.empty(lib.segger_triplet_workspace_bytes(ta.n_edges), dtype=torch.uint8, device=dev)
-            ta.loss, ta.workspace, ta.workspace_bytes = raw[0:1].data_ptr(), ws.data_ptr(), ws.numel()
+            ta.loss, ta.workspace, ta.workspace_bytes = None, ws.data_ptr(), ws.numel()     # partial sums only
             _lib.check(lib.segger_triplet_fwd(C.byref(ta), stream), "segger_triplet_fwd")
             keep.append(ws)
+            if ta.n_edges:
+                parts[0], counts[0], scales[0] = ws.data_ptr(), lib.segger_triplet_partial_count(ta.n_edges), 1.0 / ta.n_edges
             bpos, bneg, dp, dn, w, beps = spec.bd
             bd = (i64(bpos), i64(bneg)) + tuple(t.to(torch.float32).contiguous() for t in (dp, dn, w))
             nb = int(z_bd.shape[0])
@@ -573,8 +618,10 @@ class _LossHead(torch.autograd.Function):
             ws = torch.empty(lib.segger_triplet_workspace_bytes(nb), dtype=torch.uint8, device=dev)
             _lib.check(lib.segger_metric_fwd(zp, ld, nb, c, DTYPE_CODE[dt], bd[0].data_ptr(), bd[1].data_ptr(),
                                              bd[2].data_ptr(), bd[3].data_ptr(), bd[4].data_ptr(), float(beps),
-                                             raw[1:2].data_ptr(), ws.data_ptr(), ws.numel(), stream), "segger_metric_fwd")
+                                             None, ws.data_ptr(), ws.numel(), stream), "segger_metric_fwd")
             keep.append(ws)
+            if nb:
+                parts[1], counts[1], scales[1] = ws.data_ptr(), lib.segger_triplet_partial_count(nb), 1.0
             sg = None
             if spec.sg is not None:
                 src, spos, sneg, smargin, seps, pg = spec.sg[:6]
@@ -583,12 +630,16 @@ class _LossHead(torch.autograd.Function):
                     raise ValueError("loss_head: pos_groups does not describe the segmentation triplets")
                 sa = _triplet_args(*sg, z_tx, z_bd, float(smargin), float(seps))
                 ws = torch.empty(lib.segger_triplet_workspace_bytes(sa.n_edges), dtype=torch.uint8, device=dev)
-                sa.loss, sa.workspace, sa.workspace_bytes = raw[2:3].data_ptr(), ws.data_ptr(), ws.numel()
+                sa.loss, sa.workspace, sa.workspace_bytes = None, ws.data_ptr(), ws.numel()
                 _lib.check(lib.segger_triplet_fwd(C.byref(sa), stream), "segger_triplet_fwd")
                 keep.append(ws)
+                if sa.n_edges:
+                    parts[2], counts[2], scales[2] = ws.data_ptr(), lib.segger_triplet_partial_count(sa.n_edges), 1.0 / sa.n_edges
             out = torch.empty(4, dtype=torch.float32, device=dev)
-            _lib.check(lib.segger_loss_combine_fwd(raw.data_ptr(), a.data_ptr(), b.data_ptr(), 3, out.data_ptr(), stream),
-                       "segger_loss_combine_fwd")
+            # the three means from their per-block partial sums and the weighted total: one launch
+            _lib.check(lib.segger_loss_combine_partials_fwd(parts, counts, scales, a.data_ptr(), b.data_ptr(), 3,
+                                                            out.data_ptr(), stream), "segger_loss_combine_partials_fwd")
+        ctx.keep = keep                                      # (the partial sums are read by the launch above)
         ctx.save_for_backward(z_tx, z_bd, a, b, *tx, *bd, *(sg or ()))
         ctx.spec = spec
         return out
@@ -749,8 +800,12 @@ def stage(segments, device) -> None:
 # Positional embedder: per-graph min / max
 # --------------------------------------------------------------------------
 @torch.no_grad()
-def segment_minmax(pos: Tensor, batch: Optional[Tensor], num_graphs: int) -> Tuple[Tensor, Tensor]:
-    """-> (mins[num_graphs, 2], maxs[num_graphs, 2]) fp32 of ``pos`` grouped by ``batch``."""
+def segment_minmax(pos: Tensor, batch: Optional[Tensor], num_graphs: int, keep_empty: bool = False,
+                   out: Optional[Tuple[Tensor, Tensor]] = None) -> Tuple[Tensor, Tensor]:
+    """-> (mins[num_graphs, 2], maxs[num_graphs, 2]) fp32 of ``pos`` grouped by ``batch``.  ``keep_empty``: graphs
+    without nodes keep (+inf, -inf) instead of the reference's (0, 0) -- for consumers that only look up the graphs of
+    existing nodes (one launch less).  ``out``: buffers the caller has ALREADY filled with +inf / -inf (a captured step
+    does that in its staging launch): no initialising launch either."""
     _lib.require_cuda(pos)
     lib = _lib.load()
     dev = pos.device
@@ -761,12 +816,20 @@ def segment_minmax(pos: Tensor, batch: Optional[Tensor], num_graphs: int) -> Tup
         batch = batch.to(device=dev, dtype=torch.int64).contiguous()
         if batch.numel() != pos.shape[0]:
             raise ValueError("segment_minmax: batch / pos length mismatch")
-    mins = torch.empty((num_graphs, 2), dtype=torch.float32, device=dev)
-    maxs = torch.empty((num_graphs, 2), dtype=torch.float32, device=dev)
+    flags = 2 if keep_empty else 0
+    if out is not None:
+        mins, maxs = out
+        for t in (mins, maxs):
+            if t.dtype != torch.float32 or t.numel() < 2 * num_graphs or not t.is_contiguous() or t.device != dev:
+                raise ValueError("segment_minmax: out must be two contiguous float32 [num_graphs, 2] tensors on pos's device")
+        flags |= 1
+    else:
+        mins = torch.empty((num_graphs, 2), dtype=torch.float32, device=dev)
+        maxs = torch.empty((num_graphs, 2), dtype=torch.float32, device=dev)
     with _lib.on_device(dev):
-        rc = lib.segger_segment_minmax(pos.data_ptr(), _lib.ptr(batch), int(pos.shape[0]), int(num_graphs),
-                                       mins.data_ptr(), maxs.data_ptr(), _lib.stream_ptr(dev))
-    _lib.check(rc, "segger_segment_minmax")
+        rc = lib.segger_segment_minmax_ex(pos.data_ptr(), _lib.ptr(batch), int(pos.shape[0]), int(num_graphs),
+                                          mins.data_ptr(), maxs.data_ptr(), flags, _lib.stream_ptr(dev))
+    _lib.check(rc, "segger_segment_minmax_ex")
     return mins, maxs
 
 

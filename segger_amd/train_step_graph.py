@@ -96,6 +96,9 @@ class GraphedTrainStep:
         # positions / graph ids of both node types back to back: the encoder runs its positional embedder once over
         # the concatenation (boundary graph ids offset by the bucket's graph count), staged here without a launch
         self.pos_all, self.batch_all = z(nt + nb, 2), z(nt + nb, dtype=i64)
+        # per-graph min / max of the positions (both node types: 2 * graphs rows): re-armed with +inf / -inf by the staging
+        # launch of every step, so that the captured forward needs only the accumulating kernel (ops.segment_minmax)
+        self.minmax = (z(2 * sizes["graphs"], 2), z(2 * sizes["graphs"], 2))
         self.nodes = {"tx": {"x": z(nt, dtype=i32), "pos": self.pos_all[:nt], "batch": self.batch_all[:nt]},
                       "bd": {"x": z(nb, *template["bd"]["x"].shape[1:], dtype=template["bd"]["x"].dtype),
                              "pos": self.pos_all[nt:], "batch": z(nb, dtype=i64)}}
@@ -214,6 +217,7 @@ class GraphedTrainStep:
             (self.sg_src, ei[0], *dummies, 0), (self.sg_pos, ei[1], "const", -1, 0, 0),
             (self.bd_weight, ix_bd["weight"], "const", 0, 0, 0),
             (self.n_bd, None, "const", n_bd, 0, 0),
+            (self.minmax[0], None, "const", fb(float("inf")), 0, 0), (self.minmax[1], None, "const", fb(float("-inf")), 0, 0),
             (self.scal[0:1], ix_tx[a0], "const", 0, 0, 0), (self.scal[1:2], None, "const", fb(1.0), 0, 0),
             (self.scal[2:3], None, "const", fb(s["e_tb"] / max(e_tb, 1) if n_bd > 1 else 0.0), 0, 0),   # :173-175
             (self.scal[3:4], None, "const", fb(w[0]), 0, 0), (self.scal[4:5], None, "const", fb(w[1]), 0, 0),
@@ -240,7 +244,7 @@ class GraphedTrainStep:
             ({"tx": tx["x"], "bd": bd["x"]}, {TX_TX: None, TX_BD: None}, {"tx": tx["pos"], "bd": bd["pos"]},
              {"tx": tx["batch"], "bd": bd["batch"]}),
             dict(num_graphs=s["graphs"], graphs={TX_TX: self.g_tt, TX_BD: self.g_tb, "tx_by_gene": self.by_gene,
-                                                 "pos_all": (self.pos_all, self.batch_all)}))
+                                                 "pos_all": (self.pos_all, self.batch_all), "minmax": self.minmax}))
         step = enc._step_dev                                  # advanced by the forward: a fresh stream per replay
         fixed = self.draws
         # the three losses on the staged sampler indices and their weighted sum as one autograd node (ops.loss_head):

@@ -290,6 +290,13 @@ def test_dropout_bit_planes_equal_the_hash(cuda, dtype, H, C, n_src, n_dst, E):
     full_d = torch.empty(E, dtype=torch.uint8, device=cuda); full_d[graph.by_dst.eid.long()] = planes_d[3]
     full_s = torch.empty(E, dtype=torch.uint8, device=cuda); full_s[graph.by_src.eid.long()] = planes_s[3]
     assert torch.equal(full_d, full_s)
+    # all views of a step in one launch (segger_dropout_bits_many) == one launch per view; the step counter advanced and
+    # snapshotted by one launch (segger_step_advance)
+    many = ops.dropout_bits_many([(graph.by_dst, seeds), (graph.by_src, seeds), (graph.by_dst, [seeds[2]])], H, 0.25, step)
+    assert torch.equal(many[0], planes_d) and torch.equal(many[1], planes_s) and torch.equal(many[2][0], keep)
+    ctr = step.clone()
+    snap = ops.step_advance(ctr, 256)
+    assert int(ctr) == 768 and int(snap) == 768 and snap.data_ptr() != ctr.data_ptr()
 
     def run(bits, li):
         leaves = [t.clone().requires_grad_(True) for t in (xl, xr, att, bias)]

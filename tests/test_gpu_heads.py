@@ -186,6 +186,12 @@ def test_posfreq_matches_reference_formula(oracle, cuda, dtype):
         m = batch == b
         assert torch.equal(mins[b].cpu(), pos[m].min(0).values) and torch.equal(maxs[b].cpu(), pos[m].max(0).values)
     assert (mins[5] == 0).all() and (maxs[5] == 0).all()                       # graph without nodes
+    # one-launch form: buffers armed by the caller, empty graphs left at (+inf, -inf)
+    inf = float("inf")
+    armed = (torch.full((6, 2), inf, device=cuda), torch.full((6, 2), -inf, device=cuda))
+    m2, x2 = ops.segment_minmax(pos.to(cuda), batch.to(cuda), 6, keep_empty=True, out=armed)
+    assert m2 is armed[0] and torch.equal(m2[:5], mins[:5]) and torch.equal(x2[:5], maxs[:5])
+    assert (m2[5] == inf).all() and (x2[5] == -inf).all()
     out = ops.posfreq(pos.to(cuda), batch.to(cuda), mins, maxs, 256, dtype)
     p = oracle.normalize_positions(pos.double(), batch)
     ref = oracle.sinusoidal_embedding(p.flatten(), 256, 10000).reshape(n, 2, 256)
