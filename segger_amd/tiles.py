@@ -97,7 +97,8 @@ class SquareTiling:
 # --------------------------------------------------------------------------------------- partition
 class TilePartition:
     """A full-slide graph re-ordered so that tile ``t`` owns nodes ``node_indptr[type][t:t+2]`` and edges
-    ``edge_indptr[etype][t:t+2]``; edges whose endpoints lie in different tiles are dropped (the reference
+    ``edge_indptr[etype][t:t+2]`` (endpoints stored relative to the tile's first node of each type); edges whose
+    endpoints lie in different tiles are dropped (the reference
     does the same, partition/dataset.py:480-494).  ``labels`` maps node type -> tile id per node."""
 
     def __init__(self, data: HeteroBatch, labels: Dict[str, Tensor], num_tiles: int):
@@ -136,7 +137,9 @@ class TilePartition:
             order = torch.argsort(ls[keep], stable=True)
             src, dst, lab = src[keep][order], dst[keep][order], ls[keep][order]
             sizes = torch.bincount(lab, minlength=self.num_tiles)
-            self.data[et]["edge_index"] = torch.stack([src, dst])
+            # TILE-LOCAL endpoints (every kept edge is intra-tile): a single-tile batch is then a plain view of this
+            # store -- no index arithmetic, no launch -- and a batch of tiles adds each tile's offset inside the batch
+            self.data[et]["edge_index"] = torch.stack([src - self.node_indptr[s][lab], dst - self.node_indptr[d][lab]])
             self.edge_sizes[et] = sizes
             self.edge_indptr[et] = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)])
         # host copies of the pointers: batch assembly computes offsets without device syncs
@@ -155,13 +158,6 @@ class TilePartition:
                             dtype=torch.long, device=self.node_perm[nt].device)
             self._zero_vec[nt] = z
         return z[:n]
-
-    def _tile_shift(self, et: EdgeType) -> Tensor:
-        c = self.__dict__.setdefault("_shift_cache", {})
-        if et not in c:
-            s, _, d = et
-            c[et] = torch.stack([self.node_indptr[s][:-1], self.node_indptr[d][:-1]]).to(self.data[et].edge_index.dtype)
-        return c[et]
 
     @staticmethod
     def _h2d(values: List[int], device) -> Tensor:
@@ -202,21 +198,29 @@ class TilePartition:
         self._src_unique: Dict[EdgeType, bool] = {}
         for et in (edge_types or list(self.data._edges.keys())):
             s, _, d = et
-            ei = self.data[et].edge_index
-            # once per slide (one sync here, none per batch): does every source have at most one out-edge?  Then the
-            # backward of this edge type needs no by-source view (graph.EdgeGraph, segger_gatv2_bwd_args.src_unique)
-            self._src_unique[et] = bool(int(sources_unique(ei[0], self.data[s].num_nodes))) if ei.is_cuda else False
+            ei = self.data[et].edge_index                    # tile-local endpoints
             eptr = self._eptr[et]
             tile_ids = torch.arange(self.num_tiles, device=ei.device)
+            # once per slide (one sync here, none per batch): does every source have at most one out-edge?  Then the
+            # backward of this edge type needs no by-source view (graph.EdgeGraph, segger_gatv2_bwd_args.src_unique)
+            if ei.is_cuda:
+                first_src = torch.repeat_interleave(self.node_indptr[s][:-1], self.edge_sizes[et], output_size=int(ei.shape[1]))
+                self._src_unique[et] = bool(int(sources_unique(ei[0] + first_src, self.data[s].num_nodes)))
+                del first_src
+            else:
+                self._src_unique[et] = False
             views = {}
             for side, (row_t, col_t, row, col) in {"by_dst": (d, s, ei[1], ei[0]), "by_src": (s, d, ei[0], ei[1])}.items():
                 rptr, cptr = self._nptr[row_t], self._nptr[col_t]
                 parts = {"ptr": [], "col": [], "eid": []}
                 for t0, t1 in self._sort_chunks(et):
                     e0, e1, r0, r1, c0, c1 = eptr[t0], eptr[t1], rptr[t0], rptr[t1], cptr[t0], cptr[t1]
-                    csr = csr_from_coo(row[e0:e1] - r0, col[e0:e1] - c0, r1 - r0, max(c1 - c0, 1), validate=False)
-                    # tile-local coordinates (edges of a tile stay contiguous under the sort: all of them are intra-tile)
                     tile_of_edge = torch.repeat_interleave(tile_ids[t0:t1], self.edge_sizes[et][t0:t1], output_size=e1 - e0)
+                    # chunk-local coordinates for the sort: tile-local id + the tile's first node inside the chunk
+                    csr = csr_from_coo(row[e0:e1] + (self.node_indptr[row_t][:-1][tile_of_edge] - r0),
+                                       col[e0:e1] + (self.node_indptr[col_t][:-1][tile_of_edge] - c0),
+                                       r1 - r0, max(c1 - c0, 1), validate=False)
+                    # tile-local coordinates (edges of a tile stay contiguous under the sort: all of them are intra-tile)
                     eid_tile = tile_of_edge[csr.eid.long()]
                     parts["col"].append((csr.col.long() + c0 - self.node_indptr[col_t][:-1][eid_tile]).to(torch.int32))
                     parts["eid"].append((csr.eid.long() + e0 - self.edge_indptr[et][:-1][eid_tile]).to(torch.int32))
@@ -301,7 +305,6 @@ class TilePartition:
         new.edge_indptr, new.edge_sizes = {}, {}
         new.data = HeteroBatch(num_graphs=1)
         take = lambda v, ptr: (torch.cat([v[ptr[t]:ptr[t + 1]] for t in ids], 0) if ids else v[:0]).clone()
-        new_base: Dict[str, List[int]] = {}
         for nt, store in self.data._nodes.items():
             ptr = self._nptr[nt]
             sizes = self.node_sizes[nt][ids] if ids else self.node_sizes[nt][:0]
@@ -310,22 +313,15 @@ class TilePartition:
             new.node_perm[nt] = take(self.node_perm[nt], ptr)
             for a, v in store.items():
                 new.data[nt][a] = take(v, ptr) if isinstance(v, Tensor) else v
-            run, base = 0, []
-            for t in ids:
-                base.append(run); run += ptr[t + 1] - ptr[t]
-            new_base[nt] = base
         for et, store in self.data._edges.items():
-            s_, _, d_ = et
             ptr = self._eptr[et]
             sizes = self.edge_sizes[et][ids] if ids else self.edge_sizes[et][:0]
             new.edge_sizes[et] = sizes.clone()
             new.edge_indptr[et] = torch.cat([sizes.new_zeros(1), sizes.cumsum(0)])
             ei = store["edge_index"]
             parts = []
-            for j, t in enumerate(ids):                      # endpoints move with their tile's first node
-                shift = torch.tensor([[new_base[s_][j] - self._nptr[s_][t]], [new_base[d_][j] - self._nptr[d_][t]]],
-                                     dtype=ei.dtype, device=ei.device)
-                parts.append(ei[:, ptr[t]:ptr[t + 1]] + shift)
+            for t in ids:                                    # (tile-local endpoints: nothing to rebase)
+                parts.append(ei[:, ptr[t]:ptr[t + 1]])
             new.data[et]["edge_index"] = torch.cat(parts, 1) if parts else ei[:, :0].clone()
         new._nptr = {k: v.tolist() for k, v in new.node_indptr.items()}
         new._eptr = {k: v.tolist() for k, v in new.edge_indptr.items()}
@@ -411,18 +407,17 @@ class TilePartition:
         for et, store in self.data._edges.items():
             s, _, d = et
             ptr = self._eptr[et]
-            ei = store["edge_index"]
-            shifts = self._tile_shift(et)                    # [2, num_tiles]: first node of every tile, per end
+            ei = store["edge_index"]                         # tile-local endpoints
             if single:
                 t = tile_ids[0]
-                out[et]["edge_index"] = ei[:, ptr[t]:ptr[t + 1]] - shifts[:, t:t + 1]
+                out[et]["edge_index"] = ei[:, ptr[t]:ptr[t + 1]]          # a view: nothing to rebase
             elif tile_ids:
                 e_sizes = [ptr[t + 1] - ptr[t] for t in tile_ids]
                 n_e = sum(e_sizes)
-                meta = self._h2d(list(tile_ids) + e_sizes + base[s] + base[d], ei.device)
+                meta = self._h2d(e_sizes + base[s] + base[d], ei.device)
                 k = len(tile_ids)
-                tid, es = meta[:k], meta[k:2 * k]
-                shift = torch.stack([meta[2 * k:3 * k], meta[3 * k:]]) - shifts[:, tid]      # [2, k]
+                es = meta[:k]
+                shift = torch.stack([meta[k:2 * k], meta[2 * k:]])       # [2, k]: first node of tile j inside the batch
                 per_edge = torch.repeat_interleave(shift, es, dim=1, output_size=n_e)
                 out[et]["edge_index"] = torch.cat([ei[:, ptr[t]:ptr[t + 1]] for t in tile_ids], 1) + per_edge
             else:
