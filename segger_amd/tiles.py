@@ -225,7 +225,15 @@ class TilePartition:
                     parts["col"].append((csr.col.long() + c0 - self.node_indptr[col_t][:-1][eid_tile]).to(torch.int32))
                     parts["eid"].append((csr.eid.long() + e0 - self.edge_indptr[et][:-1][eid_tile]).to(torch.int32))
                     tile_of_row = torch.repeat_interleave(tile_ids[t0:t1], self.node_sizes[row_t][t0:t1], output_size=r1 - r0)
-                    parts["ptr"].append(csr.indptr[:-1] + e0 - self.edge_indptr[et][:-1][tile_of_row])   # row start inside its tile
+                    # row starts inside their tile, with every tile's END appended to its rows: tile t owns entries
+                    # [nptr[t] + t, nptr[t + 1] + t + 1) -- a complete indptr, so a single-tile batch takes a view
+                    starts = csr.indptr[:-1] + e0 - self.edge_indptr[et][:-1][tile_of_row]
+                    k = t1 - t0
+                    ptr_c = torch.empty(r1 - r0 + k, dtype=starts.dtype, device=starts.device)
+                    ptr_c[torch.arange(r1 - r0, device=starts.device) + (tile_of_row - t0)] = starts
+                    ptr_c[(self.node_indptr[row_t][t0 + 1:t1 + 1] - r0) + torch.arange(k, device=starts.device)] = \
+                        self.edge_sizes[et][t0:t1].to(starts.dtype)
+                    parts["ptr"].append(ptr_c)
                 views[side] = {k: (v[0] if len(v) == 1 else torch.cat(v)) for k, v in parts.items()}
             self._csr[et] = views
 
@@ -255,7 +263,7 @@ class TilePartition:
             nptr = self._nptr[row_t]
             if single:                                       # slices are already in batch coordinates
                 t = tile_ids[0]
-                ptr = v["ptr"][nptr[t]:nptr[t + 1]]
+                indptr = v["ptr"][nptr[t] + t:nptr[t + 1] + t + 1]          # the tile's own indptr: a view
                 col, eid = v["col"][eptr[t]:eptr[t + 1]], v["eid"][eptr[t]:eptr[t + 1]]
             else:                                            # one H2D copy of all per-tile offsets
                 r_sizes = [nptr[t + 1] - nptr[t] for t in tile_ids]
@@ -263,14 +271,14 @@ class TilePartition:
                 meta = self._h2d(e_sizes + e_base + r_sizes + list(base[col_t]), dev)
                 es, eb, rs, cb = meta[:k], meta[k:2 * k], meta[2 * k:3 * k], meta[3 * k:]
                 e_off = torch.repeat_interleave(eb, es, output_size=n_edges)
-                ptr = (torch.cat([v["ptr"][nptr[t]:nptr[t + 1]] for t in tile_ids])
+                ptr = (torch.cat([v["ptr"][nptr[t] + t:nptr[t + 1] + t] for t in tile_ids])
                        + torch.repeat_interleave(eb, rs, output_size=n_nodes[row_t]))
                 col = (torch.cat([v["col"][eptr[t]:eptr[t + 1]] for t in tile_ids])
                        + torch.repeat_interleave(cb, es, output_size=n_edges).to(torch.int32))
                 eid = torch.cat([v["eid"][eptr[t]:eptr[t + 1]] for t in tile_ids]) + e_off.to(torch.int32)
-            indptr = torch.empty(ptr.numel() + 1, dtype=torch.long, device=dev)
-            indptr[:-1] = ptr
-            indptr[-1:] = n_edges
+                indptr = torch.empty(ptr.numel() + 1, dtype=torch.long, device=dev)
+                indptr[:-1] = ptr
+                indptr[-1:] = n_edges
             out[side] = EdgeCSR(indptr, col, eid, n_nodes[row_t], n_nodes[col_t]).balanced_order()
         return EdgeGraph(out["by_dst"], out["by_src"], n_nodes[s], n_nodes[d], n_edges, edge_index, unique)
 
@@ -334,7 +342,8 @@ class TilePartition:
                 new._csr[et] = {}
                 for side, row_t in (("by_dst", d_), ("by_src", s_)):
                     v = views[side]
-                    new._csr[et][side] = {"ptr": take(v["ptr"], self._nptr[row_t]),
+                    rp = self._nptr[row_t]
+                    new._csr[et][side] = {"ptr": take(v["ptr"], [rp[t] + t for t in range(self.num_tiles + 1)]),
                                           "col": take(v["col"], self._eptr[et]), "eid": take(v["eid"], self._eptr[et])}
         for k in ("persist_max", "csr_sort_max_edges"):
             if k in self.__dict__:
