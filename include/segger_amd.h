@@ -288,6 +288,21 @@ typedef struct {
   int32_t rows, cols;
 } segger_transpose_seg;
 int segger_transpose_many(const segger_transpose_seg* segs, int32_t n_segs, segger_stream_t stream);
+/* segger_pack_refresh: the compute-dtype copies of fp32 master weights after an optimizer step, all in ONE launch.
+ * Per segment: src fp32 [rows, cols] row-major -> dst (bf16 / f16 per `dtype`, [rows, cols] contiguous: the matrix's row
+ * window of a row-stacked buffer) and, when dst_t != NULL, its transpose into dst_t[c * ld_t + r] (dst_t already points
+ * at the matrix's COLUMN window of the stacked transposed buffer [cols, ld_t]).  dst_f32 != 0: a bias -- `rows` floats
+ * copied fp32 -> fp32 (cols, dst_t ignored).  Replaces torch._foreach_copy_ x 2 + segger_transpose_many. */
+typedef struct {
+  const float* src;
+  void* dst;
+  void* dst_t;
+  int64_t ld_t;
+  int32_t rows, cols;
+  int32_t dst_f32;
+  int32_t reserved_;
+} segger_pack_seg;
+int segger_pack_refresh(const segger_pack_seg* segs, int32_t n_segs, int32_t dtype, segger_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Prediction head: cosine similarity on tx->bd candidate edges + per-transcript

@@ -86,6 +86,11 @@ class TransposeSeg(C.Structure):
     _fields_ = [("dst", vp), ("src", vp), ("rows", C.c_int32), ("cols", C.c_int32)]
 
 
+class PackSeg(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("dst_t", vp), ("ld_t", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32),
+                ("dst_f32", C.c_int32), ("reserved_", C.c_int32)]
+
+
 FILL_CONST, FILL_TILE, FILL_DIV, FILL_MOD, FILL_RAMP = range(5)
 
 
@@ -166,6 +171,7 @@ EXPORTS = {
     "segger_reductions_pending": (C.c_int, []),
     "segger_reductions_flush": (C.c_int, [vp]),
     "segger_linear_wgrad_dx_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "segger_pack_refresh": (C.c_int, [vp, C.c_int32, C.c_int32, vp]),
     "segger_dropout_bits_many": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_float, vp, vp]),
     "segger_step_advance": (C.c_int, [vp, C.c_int64, vp, vp]),
     "segger_segment_minmax_ex": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp, C.c_int32, vp]),

@@ -148,3 +148,85 @@ extern "C" int segger_transpose_many(const segger_transpose_seg* segs, int32_t n
   }
   return SEGGER_OK;
 }
+
+// ---- compute-dtype copies of the fp32 master weights, all of them in one launch (segger_pack_refresh) --------------------
+// After an optimizer step every projection's fp32 weight is cast into its window of a row-stacked 16-bit buffer, copied
+// transposed into the buffer the data gradients stream, and its bias copied into the stacked fp32 bias: torch did this
+// as two multi-tensor copies + segger_transpose_many; here blockIdx.y = segment, 32 x 32 tiles through LDS.
+namespace segger {
+constexpr int kPackMaxSegs = 64;
+struct PackBatch { segger_pack_seg s[kPackMaxSegs]; int dtype; };
+
+template <typename T>
+__device__ __forceinline__ uint16_t cast16(float v);
+template <> __device__ __forceinline__ uint16_t cast16<bf16_t>(float v) { return (uint16_t)(Vec8<bf16_t>::pack(v, 0.f) & 0xffffu); }
+template <> __device__ __forceinline__ uint16_t cast16<f16_t>(float v) { return (uint16_t)(Vec8<f16_t>::pack(v, 0.f) & 0xffffu); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_refresh_kernel(PackBatch b) {
+  __shared__ uint16_t tile[32][33];
+  const segger_pack_seg& g = b.s[blockIdx.y];
+  const float* __restrict__ src = g.src;
+  if (g.dst_f32) {                                      // bias: fp32 -> fp32, rows elements
+    float* __restrict__ d = static_cast<float*>(g.dst);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < g.rows; i += gridDim.x * 256) d[i] = src[i];
+    return;
+  }
+  uint16_t* __restrict__ dst = static_cast<uint16_t*>(g.dst);
+  uint16_t* __restrict__ dst_t = static_cast<uint16_t*>(g.dst_t);
+  const int tr = (g.rows + 31) / 32, tc = (g.cols + 31) / 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8 threads
+  for (int t = blockIdx.x; t < tr * tc; t += gridDim.x) {
+    const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + ty + 8 * i, c = c0 + tx;
+      uint16_t v = 0;
+      if (r < g.rows && c < g.cols) {
+        v = cast16<T>(src[(int64_t)r * g.cols + c]);
+        dst[(int64_t)r * g.cols + c] = v;
+      }
+      tile[ty + 8 * i][tx] = v;
+    }
+    if (dst_t) {                                         // (uniform over the workgroup)
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;                    // dst_t is [cols, ld_t], this matrix at its column window
+        if (c < g.cols && r < g.rows) dst_t[(int64_t)c * g.ld_t + r] = tile[tx][ty + 8 * i];
+      }
+      __syncthreads();
+    }
+  }
+}
+}  // namespace segger
+
+extern "C" int segger_pack_refresh(const segger_pack_seg* segs, int32_t n_segs, int32_t dtype, segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGGER_REQUIRE(n_segs >= 0, "segger_pack_refresh: negative segment count");
+  SEGGER_REQUIRE(n_segs == 0 || segs != nullptr, "segger_pack_refresh: segs is NULL");
+  SEGGER_REQUIRE(dtype == SEGGER_BF16 || dtype == SEGGER_F16, "segger_pack_refresh: bf16 / f16 destinations");
+  for (int32_t s0 = 0; s0 < n_segs; s0 += kPackMaxSegs) {
+    PackBatch b;
+    b.dtype = dtype;
+    const int n = (n_segs - s0 < kPackMaxSegs) ? (n_segs - s0) : kPackMaxSegs;
+    int most = 0;
+    for (int i = 0; i < n; ++i) {
+      const segger_pack_seg& g = segs[s0 + i];
+      SEGGER_REQUIRE(g.rows >= 0 && g.cols >= 0 && (g.rows == 0 || g.cols == 0 || (g.src && g.dst)),
+                     "segger_pack_refresh: segment %d: bad shape or NULL pointer", s0 + i);
+      SEGGER_REQUIRE(!g.dst_t || g.ld_t >= g.rows, "segger_pack_refresh: segment %d: ld_t < rows", s0 + i);
+      b.s[i] = g;
+      const int tiles = g.dst_f32 ? (g.rows + 255) / 256 : ((g.rows + 31) / 32) * ((g.cols + 31) / 32);
+      if (tiles > most) most = tiles;
+    }
+    if (most == 0) continue;
+    if (most > 64) most = 64;
+    if (dtype == SEGGER_BF16)
+      hipLaunchKernelGGL(pack_refresh_kernel<bf16_t>, dim3((unsigned)most, (unsigned)n), dim3(256), 0, stream, b);
+    else
+      hipLaunchKernelGGL(pack_refresh_kernel<f16_t>, dim3((unsigned)most, (unsigned)n), dim3(256), 0, stream, b);
+    SEGGER_LAUNCH_CHECK("pack_refresh_kernel");
+  }
+  return SEGGER_OK;
+}

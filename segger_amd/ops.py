@@ -1127,7 +1127,7 @@ def _refresh_stale_packs(requester: "_Pack") -> None:
     (or, without one, only ``requester``) are touched: see ``_PACK_SCOPE``."""
     scope = _PACK_SCOPE[-1] if _PACK_SCOPE else None
     capturing = requester.w.is_cuda and torch.cuda.is_current_stream_capturing()
-    dsts, srcs, live = [], [], []
+    dsts, srcs, live, one_launch = [], [], [], []
     for pk in _PACKS.values():
         if pk.w is None or pk.w.device != requester.w.device:
             continue
@@ -1139,15 +1139,46 @@ def _refresh_stale_packs(requester: "_Pack") -> None:
         key, ps = pk._current_key()
         if key is None or key == pk.key:
             continue
-        dsts += pk.views
-        srcs += [p.detach() for p in ps]
+        fast = (pk.w.is_cuda and pk.w.element_size() == 2
+                and all(p.dtype == torch.float32 and p.is_contiguous() and p.device == pk.w.device for p in ps))
+        if fast:
+            one_launch.append((pk, ps))
+        else:
+            dsts += pk.views
+            srcs += [p.detach() for p in ps]
         live.append((pk, key))
     if dsts:
         _copy_groups(dsts, srcs)
+    done_t = set()
+    for dt in {pk.w.dtype for pk, _ in one_launch}:
+        # casts into the stacked buffers, transposed copies and bias copies of every stale pack: ONE launch
+        # (segger_pack_refresh) instead of two multi-tensor copies + the transposing launch below
+        group = [(pk, ps) for pk, ps in one_launch if pk.w.dtype == dt]
+        n_seg = sum(len(pk.views) for pk, _ in group)
+        arr = (_lib.PackSeg * n_seg)()
+        i = 0
+        for pk, ps in group:
+            m_total, r0 = sum(pk.rows), 0
+            n_w = len(pk.rows)
+            for j, r in enumerate(pk.rows):
+                g = arr[i]; i += 1
+                g.src, g.dst, g.rows, g.cols = ps[j].data_ptr(), pk.views[j].data_ptr(), r, pk.k
+                if pk._wt is not None:
+                    g.dst_t, g.ld_t = pk._wt.data_ptr() + r0 * pk._wt.element_size(), m_total
+                r0 += r
+            for j in range(n_w, len(pk.views)):              # biases, in the order of pk.views
+                g = arr[i]; i += 1
+                g.src, g.dst, g.rows, g.cols, g.dst_f32 = ps[j].data_ptr(), pk.views[j].data_ptr(), int(pk.views[j].numel()), 1, 1
+            if pk._wt is not None:
+                done_t.add(id(pk))
+        dev = group[0][0].w.device
+        with _lib.on_device(dev):
+            rc = _lib.load().segger_pack_refresh(arr, n_seg, DTYPE_CODE[dt], _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_pack_refresh")
     for pk, key in live:
-        pk.key, pk._wt_fresh = key, False
+        pk.key, pk._wt_fresh = key, id(pk) in done_t
     # the transposed copies the data gradients stream (every pack that has been through a backward): one launch
-    tr = [pk for pk, _ in live if pk._wt is not None and pk.w.element_size() == 2 and pk.w.is_cuda]
+    tr = [pk for pk, _ in live if pk._wt is not None and pk.w.element_size() == 2 and pk.w.is_cuda and not pk._wt_fresh]
     if tr:
         arr = (_lib.TransposeSeg * len(tr))()
         for i, pk in enumerate(tr):

@@ -293,6 +293,15 @@ def test_cached_weight_copies_follow_the_optimizer(cuda, fused):
         before = w1.detach().clone()
         opt.step()
         assert not torch.equal(before, w1.detach())
+    # the refresh itself (one launch, segger_pack_refresh): stacked 16-bit copy, its transpose, the stacked fp32 bias
+    xg = x.clone().requires_grad_(True)
+    ops.linear(xg, (w1, w2), (b1, None)).float().sum().backward()          # (the data gradient makes the transposed copy)
+    opt.step()
+    ops.linear(x, (w1, w2), (b1, None))
+    pk = ops._pack_for((w1, w2), (b1, None))
+    want = torch.cat([w1, w2]).detach().to(torch.bfloat16)
+    assert torch.equal(pk.w, want) and torch.equal(pk.b, torch.cat([b1.detach(), b1.new_zeros(64)]))
+    assert pk._wt is not None and pk._wt_fresh and torch.equal(pk._wt, want.t().contiguous())
     with torch.no_grad():                                # parameters written behind autograd's back need the explicit call
         w1.data.mul_(2.0)
     ops.invalidate_weight_cache()
