@@ -71,27 +71,35 @@ __device__ __forceinline__ void store_tile(const unsigned char* et, T* dst, int6
   }
 }
 
+// 8 waves per workgroup, 2 workgroups per CU (4 waves per SIMD, <= 128 registers per lane): the per-tile work is a
+// dependent chain (coordinate -> sin / cos -> MFMA -> SiLU -> MFMA -> GELU -> stores) that needs the other waves to fill
+// the matrix and transcendental pipes; the biases live in LDS (16 floats per tile and lane) instead of 64 registers
+constexpr int kPmWaves = 8;
 template <typename T, bool TRAIN, bool GELU>
-__global__ __launch_bounds__(256, 2) void posmlp_fwd_kernel(PosMlpParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[kDim * kW0Stride + kDim * kW2Stride + 4 * 32 * kEStride + kHalf * 4];
+__global__ __launch_bounds__(kPmWaves * 64, 2) void posmlp_fwd_kernel(PosMlpParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kDim * kW0Stride + kDim * kW2Stride + kPmWaves * 32 * kEStride +
+                                                            kHalf * 4 + 2 * kDim * 4];
   unsigned char* lw0 = lds;
   unsigned char* lw2 = lds + kDim * kW0Stride;
   unsigned char* le = lw2 + kDim * kW2Stride;
-  float* freqs = reinterpret_cast<float*>(le + 4 * 32 * kEStride);
+  float* freqs = reinterpret_cast<float*>(le + kPmWaves * 32 * kEStride);
+  float* lb0 = freqs + kHalf;
+  float* lb2 = lb0 + kDim;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   {
     const T* w0 = static_cast<const T*>(p.w0);
     const T* w2 = static_cast<const T*>(p.w2);
-    for (int piece = tid; piece < kDim * (kFreq / 8); piece += 256) {
+    for (int piece = tid; piece < kDim * (kFreq / 8); piece += kPmWaves * 64) {
       const int row = piece / (kFreq / 8), col = piece % (kFreq / 8);
       *reinterpret_cast<u32x4*>(lw0 + row * kW0Stride + col * 16) = *reinterpret_cast<const u32x4*>(w0 + row * kFreq + col * 8);
     }
-    for (int piece = tid; piece < kDim * (kDim / 8); piece += 256) {
+    for (int piece = tid; piece < kDim * (kDim / 8); piece += kPmWaves * 64) {
       const int row = piece / (kDim / 8), col = piece % (kDim / 8);
       *reinterpret_cast<u32x4*>(lw2 + row * kW2Stride + col * 16) = *reinterpret_cast<const u32x4*>(w2 + row * kDim + col * 8);
     }
     if (tid < kHalf) freqs[tid] = expf(-p.log_max_period * (float)tid / (float)kHalf);
+    if (tid < kDim) { lb0[tid] = p.b0[tid]; lb2[tid] = p.b2[tid]; }
   }
   __syncthreads();
 
@@ -99,17 +107,6 @@ __global__ __launch_bounds__(256, 2) void posmlp_fwd_kernel(PosMlpParams p) {
   const int64_t n_rows = 2 * p.n;
   const int64_t n_tiles = (n_rows + 31) / 32;
   T* pe = static_cast<T*>(p.pe);
-  // biases of this lane's 32 output columns (ct*32 + 8g + 4h + {0..3}): the same for every tile
-  float b0v[2][16], b2v[2][16];
-#pragma unroll
-  for (int ct = 0; ct < 2; ++ct) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int col = ct * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-      b0v[ct][i] = p.b0[col];
-      b2v[ct][i] = p.b2[col];
-    }
-  }
   // normalised coordinate of this lane's row in tile t (a chain of dependent loads: batch id -> per-graph min / max);
   // the next tile's is requested before this tile's arithmetic starts
   auto coord = [&](int64_t t, bool& ok, int64_t& row_out) -> float {
@@ -122,8 +119,8 @@ __global__ __launch_bounds__(256, 2) void posmlp_fwd_kernel(PosMlpParams p) {
     const float lo = p.mins[2 * g + c], hi = p.maxs[2 * g + c];
     return (p.pos[2 * node + c] - lo) / (hi - lo + p.eps);
   };
-  const int64_t t_step = (int64_t)gridDim.x * 4;
-  int64_t t = (int64_t)blockIdx.x * 4 + wave;
+  const int64_t t_step = (int64_t)gridDim.x * kPmWaves;
+  int64_t t = (int64_t)blockIdx.x * kPmWaves + wave;
   bool valid_n = false; int64_t row_n = 0; float pn_n = 0.f;
   if (t < n_tiles) pn_n = coord(t, valid_n, row_n);
   for (; t < n_tiles; t += t_step) {
@@ -160,19 +157,24 @@ __global__ __launch_bounds__(256, 2) void posmlp_fwd_kernel(PosMlpParams p) {
       }
     }
 
-    // ---- z1 = acc + b0 (lane: data row r, columns ct*32 + 8g + 4h + {0..3}), h1 = SiLU(z1) -------------------------
-    float h1[2][16];
+    // ---- z1 = acc + b0 (lane: data row r, columns ct*32 + 8g + 4h + {0..3}), h1 = SiLU(z1), kept as 16-bit pairs (the
+    //      form the second GEMM's B operand and the optional store want) ---------------------------------------------------
+    uint32_t h1p[2][8];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
         const int col = ct * 32 + 8 * gq + 4 * h;
-        float z[4];
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(lb0 + col);
+        const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
+        float z[4], hq[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          z[j] = acc[ct][4 * gq + j] + b0v[ct][4 * gq + j];
-          h1[ct][4 * gq + j] = z[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z[j]));
+          z[j] = acc[ct][4 * gq + j] + bq[j];
+          hq[j] = z[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z[j]));
         }
+        h1p[ct][2 * gq] = Vec8<T>::pack(hq[0], hq[1]);
+        h1p[ct][2 * gq + 1] = Vec8<T>::pack(hq[2], hq[3]);
         if (TRAIN) {
           uint2 pk;
           pk.x = Vec8<T>::pack(z[0], z[1]);
@@ -191,8 +193,8 @@ __global__ __launch_bounds__(256, 2) void posmlp_fwd_kernel(PosMlpParams p) {
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
             uint2 pk;
-            pk.x = Vec8<T>::pack(h1[ct][4 * gq + 0], h1[ct][4 * gq + 1]);
-            pk.y = Vec8<T>::pack(h1[ct][4 * gq + 2], h1[ct][4 * gq + 3]);
+            pk.x = h1p[ct][2 * gq];
+            pk.y = h1p[ct][2 * gq + 1];
             *reinterpret_cast<uint2*>(et + r * kEStride + (ct * 32 + 8 * gq + 4 * h) * 2) = pk;
           }
         }
@@ -214,8 +216,7 @@ __global__ __launch_bounds__(256, 2) void posmlp_fwd_kernel(PosMlpParams p) {
     for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
       for (int gp = 0; gp < 2; ++gp) {
-        const float* q = &h1[ct][8 * gp];
-        const u32x4 b = {Vec8<T>::pack(q[0], q[1]), Vec8<T>::pack(q[2], q[3]), Vec8<T>::pack(q[4], q[5]), Vec8<T>::pack(q[6], q[7])};
+        const u32x4 b = {h1p[ct][4 * gp], h1p[ct][4 * gp + 1], h1p[ct][4 * gp + 2], h1p[ct][4 * gp + 3]};
         const int base = ct * 32 + 16 * gp + 4 * h;
 #pragma unroll
         for (int c2 = 0; c2 < 2; ++c2) {
@@ -229,7 +230,10 @@ __global__ __launch_bounds__(256, 2) void posmlp_fwd_kernel(PosMlpParams p) {
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc2[ct][i] += b2v[ct][i];
+      for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(lb2 + ct * 32 + 8 * gq + 4 * h);
+        acc2[ct][4 * gq] += bv.x; acc2[ct][4 * gq + 1] += bv.y; acc2[ct][4 * gq + 2] += bv.z; acc2[ct][4 * gq + 3] += bv.w;
+      }
     }
     auto put_tile = [&](bool act) {
 #pragma unroll
@@ -287,15 +291,15 @@ extern "C" int segger_posmlp_fwd(const float* pos, const int64_t* batch, const f
   SEGGER_REQUIRE(aligned16(pe_pre), "segger_posmlp_fwd: pe_pre must be 16-byte aligned");
   PosMlpParams p{pos, batch, mins, maxs, n, eps, logf(max_period), w0, b0, w2, b2, pe, z1, pn, pe_pre, h1};
   const int64_t n_tiles = (2 * n + 31) / 32;
-  int64_t blocks = (n_tiles + 3) / 4;
+  int64_t blocks = (n_tiles + kPmWaves - 1) / kPmWaves;
   if (blocks > 512) blocks = 512;                          // persistent: 2 workgroups per CU
   const bool train = z1 != nullptr;
 #define GO(T)                                                                                                    \
   do {                                                                                                           \
-    if (train && gelu) hipLaunchKernelGGL((posmlp_fwd_kernel<T, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p);        \
-    else if (train) hipLaunchKernelGGL((posmlp_fwd_kernel<T, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p);          \
-    else if (gelu) hipLaunchKernelGGL((posmlp_fwd_kernel<T, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, p);           \
-    else hipLaunchKernelGGL((posmlp_fwd_kernel<T, false, false>), dim3((unsigned)blocks), dim3(256), 0, stream, p);                    \
+    if (train && gelu) hipLaunchKernelGGL((posmlp_fwd_kernel<T, true, true>), dim3((unsigned)blocks), dim3(kPmWaves * 64), 0, stream, p);        \
+    else if (train) hipLaunchKernelGGL((posmlp_fwd_kernel<T, true, false>), dim3((unsigned)blocks), dim3(kPmWaves * 64), 0, stream, p);          \
+    else if (gelu) hipLaunchKernelGGL((posmlp_fwd_kernel<T, false, true>), dim3((unsigned)blocks), dim3(kPmWaves * 64), 0, stream, p);           \
+    else hipLaunchKernelGGL((posmlp_fwd_kernel<T, false, false>), dim3((unsigned)blocks), dim3(kPmWaves * 64), 0, stream, p);                    \
   } while (0)
   if (dtype == SEGGER_BF16) GO(bf16_t); else GO(f16_t);
 #undef GO
