@@ -1,6 +1,6 @@
 import csv,glob,re,collections,sys
 d0=sys.argv[1]; steps=int(sys.argv[2]); top=int(sys.argv[3]) if len(sys.argv)>3 else 30
-f=glob.glob(d0+'/*/*_kernel_trace.csv')[0]
+f=glob.glob(d0+'/**/*_kernel_trace.csv', recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
 rows.sort(key=lambda r:int(r['Start_Timestamp']))
 names=[r['Kernel_Name'] for r in rows]
