@@ -448,7 +448,7 @@ template <typename T, int H, int LPH, bool WPR, bool DIRECT>
 __global__ __launch_bounds__(256, DIRECT ? 2 : SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kernel(GatParams p) {
   using G = Geo<H, LPH>;
   // 4 rows in flight measured -2.6 % on the flagship geometry (H = 2, group-per-row); the other variants would spill
-  constexpr int UD = (!WPR && H == 2) ? SEGGER_DST_UNROLL : 2;
+  constexpr int UD = ((!WPR && H == 2) || DIRECT) ? SEGGER_DST_UNROLL : 2;
   constexpr int GS = G::GS, NG = G::NG, U = UD < GS ? UD : GS, HC = G::HC;
   __shared__ float red[4][2][HC];
   const int64_t blk = xcd_remap(blockIdx.x, p.nblocks_padded, p.nblocks);
