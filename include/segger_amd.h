@@ -384,8 +384,14 @@ typedef struct segger_triplet_args {
                                 caller's zeros; later kernels may add to it), the group's positive row is summed in
                                 registers and added once, negatives add by fp32 atomics -- grad_b is ACCUMULATED INTO
                                 (caller zero-fills it), every embedding row is read once.  C in {32, 64, 96, 128}. */
-  int32_t reserved_;
+  int32_t loss_kind;         /* SEGGER_LOSS_TRIPLET (0) or SEGGER_LOSS_BCE: the BCE variant of the segmentation loss
+                                (lightning_model.py:190-207), BCEWithLogits over the dot-product logits <a, pos> (label 1)
+                                and <a, neg> (label 0), mean over the 2 n_edges logits; margin / eps / contrib unused;
+                                grad_b is always accumulated into (caller zero-fills); with pos_indptr + anchor_unique
+                                the backward is the same one walk over the groups as for the triplet loss */
 } segger_triplet_args;
+#define SEGGER_LOSS_TRIPLET 0
+#define SEGGER_LOSS_BCE 1
 
 /*
  * segger_loss_combine_fwd / _bwd: the loss combination of LitISTEncoder.get_losses (lightning_model.py:136-149,

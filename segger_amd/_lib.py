@@ -122,7 +122,7 @@ class TripletArgs(C.Structure):
         ("grad_a", vp), ("grad_b", vp), ("grad_a_packed", C.c_int32), ("grad_b_packed", C.c_int32),
         ("contrib", vp),
         ("workspace", vp), ("workspace_bytes", C.c_size_t),
-        ("pos_indptr", vp), ("pos_eid", vp), ("anchor_unique", C.c_int32), ("reserved_", C.c_int32),
+        ("pos_indptr", vp), ("pos_eid", vp), ("anchor_unique", C.c_int32), ("loss_kind", C.c_int32),
     ]
 
 

@@ -427,6 +427,138 @@ __global__ __launch_bounds__(256) void triplet_grouped_kernel(TripletParams p) {
   }
 }
 
+// ---- BCE segmentation head (lightning_model.py:190-207): BCEWithLogits over the dot-product logits of the positive
+// edges (label 1) and the sampled negative edges (label 0), mean over both:
+//     loss = 1/(2n) sum_e [ softplus(-<a_e, p_e>) + softplus(<a_e, n_e>) ]
+//     d/d lp = (sigmoid(lp) - 1) / (2n),  d/d ln = sigmoid(ln) / (2n)
+// Same gather / scatter structure as the triplet kernels: 16 lanes per edge, channel pairs 2 gl + 32 k.
+__device__ __forceinline__ float softplus_f(float x) {          // log(1 + e^x), stable
+  return fmaxf(x, 0.f) + log1pf(__expf(-fabsf(x)));
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void bce_edge_kernel(TripletParams p) {
+  __shared__ float wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = p.channels;                              // even (checked by the host)
+  const T* za = static_cast<const T*>(p.za);
+  const T* zb = static_cast<const T*>(p.zb);
+  const int grp = lane >> 4, gl = lane & 15;
+  float acc = 0.f;
+  const int64_t e_base = (int64_t)blockIdx.x * kTripletEdgesPerBlock;
+#pragma unroll 1
+  for (int i = wave * 4 + grp; i < kTripletEdgesPerBlock; i += 16) {
+    const int64_t e = e_base + i;
+    bool ok = e < p.n_edges;                          // group-uniform
+    int64_t ia = ok ? p.src[e] : 0, ip = ok ? p.pos[e] : 0, in = ok ? p.neg[e] : 0;
+    if ((uint64_t)ia >= (uint64_t)p.n_a || (uint64_t)ip >= (uint64_t)p.n_b || (uint64_t)in >= (uint64_t)p.n_b) {
+      ok = false; ia = ip = in = 0;
+    }
+    float lp = 0.f, ln = 0.f;
+    for (int c = 2 * gl; c < C; c += 32) {
+      float a0, a1, p0, p1, n0, n1;
+      load2(za + ia * p.ld_za + c, a0, a1);
+      load2(zb + ip * p.ld_zb + c, p0, p1);
+      load2(zb + in * p.ld_zb + c, n0, n1);
+      lp = fmaf(a0, p0, fmaf(a1, p1, lp));
+      ln = fmaf(a0, n0, fmaf(a1, n1, ln));
+    }
+    lp = lane_block_sum<16>(lp);
+    ln = lane_block_sum<16>(ln);
+    if (!BWD) {
+      if (ok && gl == 0) acc += softplus_f(-lp) + softplus_f(ln);
+    } else if (ok) {
+      const float sc = p.scale_dev ? p.scale * p.scale_dev[0] : p.scale;
+      const float dlp = (sigmoid_f(lp) - 1.0f) * sc, dln = sigmoid_f(ln) * sc;
+      for (int c = 2 * gl; c < C; c += 32) {
+        float a0, a1, p0, p1, n0, n1;
+        load2(za + ia * p.ld_za + c, a0, a1);
+        load2(zb + ip * p.ld_zb + c, p0, p1);
+        load2(zb + in * p.ld_zb + c, n0, n1);
+        grad_add2<T>(p.ga, p.ga_packed, ia * C + c, dlp * p0 + dln * n0, dlp * p1 + dln * n1);
+        grad_add2<T>(p.gb, p.gb_packed, ip * C + c, dlp * a0, dlp * a1);
+        grad_add2<T>(p.gb, p.gb_packed, in * C + c, dln * a0, dln * a1);
+      }
+    }
+  }
+  if (!BWD) {
+    acc = wave_sum(acc);
+    if (lane == 0) wsum[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) p.partial[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  }
+}
+
+// backward with unique anchors, one workgroup per positive row (as triplet_grouped_kernel): anchor rows stored, the
+// positive row summed in registers and added once, negatives by fp32 atomics
+template <typename T, int KP>
+__global__ __launch_bounds__(256) void bce_grouped_kernel(TripletParams p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int grp = lane >> 4, gl = lane & 15;
+  constexpr int C = 32 * KP;
+  const int64_t j = blockIdx.x;
+  const T* za = static_cast<const T*>(p.za);
+  const T* zb = static_cast<const T*>(p.zb);
+  float* gb = static_cast<float*>(p.gb);
+  const int64_t beg = p.pos_indptr[j] + 4 * wave, end = p.pos_indptr[j + 1];
+  if (beg >= end) return;                               // wave-uniform
+  const float sc = p.scale_dev ? p.scale * p.scale_dev[0] : p.scale;
+  float pj[KP][2], acc[KP][2];
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+    load2(zb + j * p.ld_zb + 2 * gl + 32 * k, pj[k][0], pj[k][1]);
+    acc[k][0] = 0.f; acc[k][1] = 0.f;
+  }
+  for (int64_t s0 = beg; s0 < end; s0 += 16) {
+    const int64_t s = s0 + grp;
+    bool ok = s < end;
+    const int64_t e = ok ? (int64_t)p.pos_eid[s] : 0;
+    int64_t ia = ok ? p.src[e] : 0, in = ok ? p.neg[e] : 0;
+    if ((ok && p.pos[e] != j) || (uint64_t)ia >= (uint64_t)p.n_a || (uint64_t)in >= (uint64_t)p.n_b) { ok = false; ia = in = 0; }
+    float av[KP][2], nv[KP][2];
+    float lp = 0.f, ln = 0.f;
+#pragma unroll
+    for (int k = 0; k < KP; ++k) {
+      load2(za + ia * p.ld_za + 2 * gl + 32 * k, av[k][0], av[k][1]);
+      load2(zb + in * p.ld_zb + 2 * gl + 32 * k, nv[k][0], nv[k][1]);
+      lp = fmaf(av[k][0], pj[k][0], fmaf(av[k][1], pj[k][1], lp));
+      ln = fmaf(av[k][0], nv[k][0], fmaf(av[k][1], nv[k][1], ln));
+    }
+    lp = lane_block_sum<16>(lp);
+    ln = lane_block_sum<16>(ln);
+    if (ok) {                                            // group-uniform
+      const float dlp = (sigmoid_f(lp) - 1.0f) * sc, dln = sigmoid_f(ln) * sc;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
+        acc[k][0] = fmaf(dlp, av[k][0], acc[k][0]); acc[k][1] = fmaf(dlp, av[k][1], acc[k][1]);
+        const float g0 = dlp * pj[k][0] + dln * nv[k][0], g1 = dlp * pj[k][1] + dln * nv[k][1];
+        const int64_t ea = ia * C + 2 * gl + 32 * k;
+        bool stored = false;
+        if constexpr (sizeof(T) == 2) {
+          if (p.ga_packed) {
+            *reinterpret_cast<uint32_t*>(static_cast<T*>(p.ga) + ea) = Vec8<T>::pack(g0, g1);
+            stored = true;
+          }
+        }
+        if (!stored) *reinterpret_cast<float2*>(static_cast<float*>(p.ga) + ea) = float2{g0, g1};
+        atomicAdd(gb + in * C + 2 * gl + 32 * k, dln * av[k][0]);
+        atomicAdd(gb + in * C + 2 * gl + 32 * k + 1, dln * av[k][1]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KP; ++k) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float v = acc[k][q];
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (grp == 0) atomicAdd(gb + j * C + 2 * gl + 32 * k + q, v);
+    }
+  }
+}
+
 // C == 64 fast path: a lane owns 4 consecutive channels (one 8-byte load per row for 16-bit embeddings, 16 bytes
 // for fp32), 16 lanes per triplet, 4 triplets per wave-iteration; the backward issues two packed (or four fp32)
 // atomics per row and lane.
@@ -704,6 +836,45 @@ static int triplet_common(const segger_triplet_args* a, bool bwd, hipStream_t st
     }
   }
   dim3 grid((unsigned)nb), block(256);
+  if (a->loss_kind == SEGGER_LOSS_BCE) {
+    // BCE head: mean over the 2 n logits; 4-byte pair loads
+    const size_t es1 = a->dtype == SEGGER_F32 ? 4 : 2;
+    SEGGER_REQUIRE(a->channels % 2 == 0 && (a->ld_za * es1) % 4 == 0 && (a->ld_zb * es1) % 4 == 0 &&
+                       ((uintptr_t)a->z_a % 8) == 0 && ((uintptr_t)a->z_b % 8) == 0,
+                   "segger_triplet (BCE): even channel count and 8-byte aligned rows");
+    SEGGER_REQUIRE(!a->contrib, "segger_triplet (BCE): contrib is a triplet-loss option");
+    p.scale *= 0.5f;
+    const bool grouped = bwd && a->anchor_unique && p.pos_indptr && a->channels % 32 == 0 && a->channels <= 128 &&
+                         ((uintptr_t)a->grad_a % 8) == 0;
+    p.skip_pos = 0;                                     // (the two-kernel positive route is a triplet-loss option)
+#define BCE(T)                                                                                                    \
+    do {                                                                                                          \
+      if (grouped) {                                                                                              \
+        const dim3 gg((unsigned)a->n_b);                                                                          \
+        switch (a->channels / 32) {                                                                               \
+          case 1: hipLaunchKernelGGL((bce_grouped_kernel<T, 1>), gg, block, 0, stream, p); break;                 \
+          case 2: hipLaunchKernelGGL((bce_grouped_kernel<T, 2>), gg, block, 0, stream, p); break;                 \
+          case 3: hipLaunchKernelGGL((bce_grouped_kernel<T, 3>), gg, block, 0, stream, p); break;                 \
+          default: hipLaunchKernelGGL((bce_grouped_kernel<T, 4>), gg, block, 0, stream, p); break;                \
+        }                                                                                                         \
+      } else if (bwd) hipLaunchKernelGGL((bce_edge_kernel<T, true>), grid, block, 0, stream, p);                  \
+      else hipLaunchKernelGGL((bce_edge_kernel<T, false>), grid, block, 0, stream, p);                            \
+    } while (0)
+    SEGGER_REQUIRE(a->n_b < 0x7fffffffLL, "segger_triplet (BCE): too many rows in z_b");
+    switch (a->dtype) {
+      case SEGGER_F32:  BCE(float); break;
+      case SEGGER_BF16: BCE(bf16_t); break;
+      case SEGGER_F16:  BCE(f16_t); break;
+      default: set_error("segger_triplet: unknown dtype %d", a->dtype); return SEGGER_EINVAL;
+    }
+#undef BCE
+    SEGGER_LAUNCH_CHECK("bce kernels");
+    if (!bwd && a->loss) {
+      hipLaunchKernelGGL(triplet_finish_kernel, dim3(1), dim3(256), 0, stream, p.partial, nb, 0.5f / (float)a->n_edges, a->loss);
+      SEGGER_LAUNCH_CHECK("triplet_finish_kernel");
+    }
+    return SEGGER_OK;
+  }
   if (bwd && a->anchor_unique && p.pos_indptr) {
     // one walk over the groups does everything (see triplet_grouped_kernel); grad_b is accumulated into
     const size_t es0 = a->dtype == SEGGER_F32 ? 4 : 2;

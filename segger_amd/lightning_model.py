@@ -174,6 +174,10 @@ class LitISTEncoder(_Base):
             return ops.triplet_edge_loss(z_tx, z_bd, src_pos, dst_pos, dst_neg, self._sg_margin, eps=1e-6,
                                          pos_groups=g.by_dst, anchors_unique=g.src_unique)
         # BCE on dot-product logits (:190-207); unique/inverse in the reference only dedups gathers
+        if z_tx.is_cuda and z_tx.shape[1] % 2 == 0 and z_tx.dtype == z_bd.dtype:
+            g = edge_graph(batch_cache(batch), TX_BD, batch[TX_BD].edge_index, z_tx.size(0), num_bd,
+                           need_by_src="lazy" if torch.is_grad_enabled() else False, validate="deferred")
+            return ops.bce_edge_loss(z_tx, z_bd, src_pos, dst_pos, dst_neg, pos_groups=g.by_dst, anchors_unique=g.src_unique)
         src = torch.cat([src_pos, src_pos]).long()
         dst = torch.cat([dst_pos, dst_neg]).long()
         logits = (z_tx.float()[src] * z_bd.float()[dst]).sum(dim=-1)
@@ -200,7 +204,7 @@ class LitISTEncoder(_Base):
         if bd_mask is None:
             bd_mask = cache[mkey] = bm & (bc >= 0)
         u_tx, u_bd = uniforms if uniforms is not None else (None, None)
-        if (self.fused_loss_head and self._sg_loss_type == 'triplet' and embeddings['tx'].is_cuda
+        if (self.fused_loss_head and embeddings['tx'].is_cuda and embeddings['tx'].shape[1] % 2 == 0
                 and embeddings['tx'].shape[0] > 0 and embeddings['bd'].shape[0] > 0):
             return self._losses_fused(batch, embeddings, tx_mask, bd_mask, u_tx, u_bd, dst_neg)
         loss_tx = self.loss_tx.forward_masked(embeddings['tx'], batch['tx']['cluster'], tx_mask, batch_cache(batch),
@@ -251,7 +255,7 @@ class LitISTEncoder(_Base):
                 wdev.clear()
             b = wdev[(key, dev)] = torch.tensor(key, dtype=torch.float32, device=dev)
         spec = ops.LossHeadSpec((ix_tx["anchors"], pos, neg, self.loss_tx.margin, self.loss_tx.eps),
-                                (bpos, bneg, dp, dn, ix_bd["weight"], 1e-8), sg)
+                                (bpos, bneg, dp, dn, ix_bd["weight"], 1e-8), sg, sg_kind=self._sg_loss_type)
         out = ops.loss_head(z_tx, z_bd, ix_tx["head_a"], b, spec)
         return out[0], out[1], out[2], out[3]
 

@@ -420,8 +420,9 @@ def edge_cos_argmax(by_src: EdgeCSR, z_src: Tensor, z_dst: Tensor, *, dst_index:
 # --------------------------------------------------------------------------
 # Triplet margin loss over edges
 # --------------------------------------------------------------------------
-def _triplet_args(src, pos, neg, za, zb, margin, eps):
+def _triplet_args(src, pos, neg, za, zb, margin, eps, kind: str = "triplet"):
     a = _lib.TripletArgs()
+    a.loss_kind = {"triplet": 0, "bce": 1}[kind]
     a.src, a.pos, a.neg, a.n_edges = src.data_ptr(), pos.data_ptr(), neg.data_ptr(), int(src.numel())
     c = int(za.shape[1])
     a.z_a, a.ld_za = _rows(za, c, "z_a")
@@ -439,7 +440,7 @@ class _TripletEdgeLoss(torch.autograd.Function):
     (loss_tx); one gradient buffer receives all three contributions."""
 
     @staticmethod
-    def forward(ctx, za, zb, src, pos, neg, margin, eps, pos_groups, anchors_unique=False):
+    def forward(ctx, za, zb, src, pos, neg, margin, eps, pos_groups, anchors_unique=False, kind="triplet"):
         same = zb is None
         zb_ = za if same else zb
         _lib.require_cuda(za, zb_, src)
@@ -448,7 +449,7 @@ class _TripletEdgeLoss(torch.autograd.Function):
         if za.dtype != zb_.dtype or za.dtype not in DTYPE_CODE:
             raise TypeError("triplet_edge_loss: z_a / z_b must share a supported dtype")
         src, pos, neg = (t.to(torch.int64).contiguous() for t in (src, pos, neg))
-        a = _triplet_args(src, pos, neg, za, zb_, margin, eps)
+        a = _triplet_args(src, pos, neg, za, zb_, margin, eps, kind)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         ws_bytes = lib.segger_triplet_workspace_bytes(a.n_edges)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -458,7 +459,7 @@ class _TripletEdgeLoss(torch.autograd.Function):
         _lib.check(rc, "segger_triplet_fwd")
         ctx.save_for_backward(za, zb_, src, pos, neg)
         ctx.cfg = (margin, eps, same)
-        ctx.pos_groups, ctx.anchors_unique = pos_groups, anchors_unique
+        ctx.pos_groups, ctx.anchors_unique, ctx.kind = pos_groups, anchors_unique, kind
         return loss[0]
 
     @staticmethod
@@ -467,7 +468,7 @@ class _TripletEdgeLoss(torch.autograd.Function):
         margin, eps, same = ctx.cfg
         lib = _lib.load()
         dev = za.device
-        a = _triplet_args(src, pos, neg, za, zb, margin, eps)
+        a = _triplet_args(src, pos, neg, za, zb, margin, eps, ctx.kind)
         # anchor-matrix rows collect a handful of terms: packed 16-bit atomics straight into a gradient of the
         # embeddings' dtype; a separate (boundary) matrix sums dozens of terms per row and stays fp32
         # (small batches measured no gain from the packed variant: they keep fp32 atomics)
@@ -486,7 +487,7 @@ class _TripletEdgeLoss(torch.autograd.Function):
             # every row of grad_b; the uniformly sampled negatives add themselves with (uncontended) fp32 atomics
             uniq = ctx.anchors_unique
             uniq = bool(uniq() if callable(uniq) else uniq) and za.shape[1] % 32 == 0 and za.shape[1] <= 128
-            gb = (torch.zeros if uniq else torch.empty)(zb.shape, dtype=torch.float32, device=dev)
+            gb = (torch.zeros if (uniq or ctx.kind == "bce") else torch.empty)(zb.shape, dtype=torch.float32, device=dev)
             a.grad_b = gb.data_ptr()
             a.pos_indptr, a.pos_eid = pg.indptr.data_ptr(), (pg.eid.data_ptr() if pg.n_edges else None)
             a.anchor_unique = int(uniq)
@@ -498,7 +499,7 @@ class _TripletEdgeLoss(torch.autograd.Function):
         with _lib.on_device(dev):
             rc = lib.segger_triplet_bwd(C.byref(a), _lib.stream_ptr(dev))
         _lib.check(rc, "segger_triplet_bwd")
-        return ga.to(za.dtype), (None if same else gb.to(zb.dtype)), None, None, None, None, None, None, None
+        return ga.to(za.dtype), (None if same else gb.to(zb.dtype)), None, None, None, None, None, None, None, None
 
 
 def triplet_edge_loss(za: Tensor, zb: Optional[Tensor], src: Tensor, pos: Tensor, neg: Tensor,
@@ -514,7 +515,20 @@ def triplet_edge_loss(za: Tensor, zb: Optional[Tensor], src: Tensor, pos: Tensor
         zb = None
     if pos_groups is not None and (zb is None or pos_groups.n_rows != zb.shape[0] or pos_groups.n_edges != src.numel()):
         raise ValueError("triplet_edge_loss: pos_groups does not describe these triplets")
-    return _TripletEdgeLoss.apply(za, zb, src, pos, neg, float(margin), float(eps), pos_groups, anchors_unique)
+    return _TripletEdgeLoss.apply(za, zb, src, pos, neg, float(margin), float(eps), pos_groups, anchors_unique, "triplet")
+
+
+def bce_edge_loss(za: Tensor, zb: Tensor, src: Tensor, pos: Tensor, neg: Tensor, pos_groups: Optional[EdgeCSR] = None,
+                  anchors_unique=False) -> Tensor:
+    """The BCE variant of the segmentation loss (reference lightning_model.py:190-207): ``BCEWithLogitsLoss`` over
+    ``cat(<za[src], zb[pos]>, <za[src], zb[neg]>)`` with labels ``cat(1, 0)``, one kernel forward and one backward
+    (``segger_triplet_fwd / _bwd`` with ``loss_kind = SEGGER_LOSS_BCE``).  ``pos_groups`` / ``anchors_unique`` as in
+    :func:`triplet_edge_loss`."""
+    if za.shape[1] % 2:
+        raise ValueError("bce_edge_loss: even channel count")
+    if pos_groups is not None and (pos_groups.n_rows != zb.shape[0] or pos_groups.n_edges != src.numel()):
+        raise ValueError("bce_edge_loss: pos_groups does not describe these edges")
+    return _TripletEdgeLoss.apply(za, zb, src, pos, neg, 0.0, 0.0, pos_groups, anchors_unique, "bce")
 
 
 class _MetricLoss(torch.autograd.Function):
@@ -572,8 +586,8 @@ class LossHeadSpec:
     (bool, or a callable asked in the backward, e.g. ``EdgeGraph.src_unique``): no transcript is the anchor of two
     triplets -- the backward then walks the groups once and stores the anchors' gradient rows."""
 
-    def __init__(self, tx, bd, sg):
-        self.tx, self.bd, self.sg = tx, bd, sg
+    def __init__(self, tx, bd, sg, sg_kind: str = "triplet"):
+        self.tx, self.bd, self.sg, self.sg_kind = tx, bd, sg, sg_kind      # sg_kind "bce": margin / eps unused
 
 
 class _LossHead(torch.autograd.Function):
@@ -628,13 +642,14 @@ class _LossHead(torch.autograd.Function):
                 sg = tuple(i64(t) for t in (src, spos, sneg))
                 if pg is not None and (pg.n_rows != nb or pg.n_edges != sg[0].numel()):
                     raise ValueError("loss_head: pos_groups does not describe the segmentation triplets")
-                sa = _triplet_args(*sg, z_tx, z_bd, float(smargin), float(seps))
+                sa = _triplet_args(*sg, z_tx, z_bd, float(smargin), float(seps), spec.sg_kind)
                 ws = torch.empty(lib.segger_triplet_workspace_bytes(sa.n_edges), dtype=torch.uint8, device=dev)
                 sa.loss, sa.workspace, sa.workspace_bytes = None, ws.data_ptr(), ws.numel()
                 _lib.check(lib.segger_triplet_fwd(C.byref(sa), stream), "segger_triplet_fwd")
                 keep.append(ws)
                 if sa.n_edges:
-                    parts[2], counts[2], scales[2] = ws.data_ptr(), lib.segger_triplet_partial_count(sa.n_edges), 1.0 / sa.n_edges
+                    parts[2], counts[2] = ws.data_ptr(), lib.segger_triplet_partial_count(sa.n_edges)
+                    scales[2] = (0.5 if spec.sg_kind == "bce" else 1.0) / sa.n_edges
             out = torch.empty(4, dtype=torch.float32, device=dev)
             # the three means from their per-block partial sums and the weighted total: one launch
             _lib.check(lib.segger_loss_combine_partials_fwd(parts, counts, scales, a.data_ptr(), b.data_ptr(), 3,
@@ -667,13 +682,14 @@ class _LossHead(torch.autograd.Function):
         if pg is not None and len(spec.sg) > 6 and c % 32 == 0 and c <= 128:
             uniq = spec.sg[6]
             uniq = bool(uniq() if callable(uniq) else uniq)
-        gb = (torch.empty if (pg is not None and not uniq) else torch.zeros)(z_bd.shape, dtype=torch.float32, device=dev)
+        gb = (torch.empty if (pg is not None and not uniq and spec.sg_kind != "bce") else torch.zeros)(
+            z_bd.shape, dtype=torch.float32, device=dev)
         stream = _lib.stream_ptr(dev)
         with _lib.on_device(dev):
             _lib.check(lib.segger_loss_combine_bwd(g_out.data_ptr(), a.data_ptr(), b.data_ptr(), 3, graw.data_ptr(), stream),
                        "segger_loss_combine_bwd")
             if sg is not None:          # first: with pos_groups its positive side WRITES every row of gb
-                sa = _triplet_args(*sg, z_tx, z_bd, float(spec.sg[3]), float(spec.sg[4]))
+                sa = _triplet_args(*sg, z_tx, z_bd, float(spec.sg[3]), float(spec.sg[4]), spec.sg_kind)
                 sa.grad_a, sa.grad_a_packed, sa.grad_b, sa.grad_b_packed = ga.data_ptr(), int(packed), gb.data_ptr(), 0
                 if pg is not None:
                     sa.pos_indptr, sa.pos_eid = pg.indptr.data_ptr(), (pg.eid.data_ptr() if pg.n_edges else None)

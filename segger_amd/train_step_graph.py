@@ -75,8 +75,6 @@ class GraphedTrainStep:
         self.split = grad_sync is not None or grad_bucket is not None
         if grad_bucket is not None:
             grad_bucket._ensure()                             # the flat buffer must exist before anything is captured
-        if lit_model._sg_loss_type != "triplet":
-            raise NotImplementedError("the graphed step covers the (default) triplet segmentation loss")
         if lit_model.loss_tx is None or lit_model.loss_bd is None:
             raise RuntimeError("call setup() (or set_similarities) before training")
         if not all(g.get("capturable", False) for g in optimizer.param_groups):
@@ -258,7 +256,8 @@ class GraphedTrainStep:
             (pos, neg), (bpos, bneg, dp, dn), dst_neg = fixed["tx"], fixed["bd"], fixed["dst_neg"]
         spec = ops.LossHeadSpec((self._iota, pos, neg, lit.loss_tx.margin, lit.loss_tx.eps),
                                 (bpos, bneg, dp, dn, self.bd_weight, 1e-8),
-                                (self.sg_src, self.sg_pos, dst_neg, lit._sg_margin, 1e-6, self.g_tb.by_dst, True))
+                                (self.sg_src, self.sg_pos, dst_neg, lit._sg_margin, 1e-6, self.g_tb.by_dst, True),
+                                sg_kind=lit._sg_loss_type)
         out = ops.loss_head(z["tx"], z["bd"], self.head_a, self.scal[3:6], spec)
         if self.defer_sums:                                   # ~30 partial sums of the backward as one launch
             with ops.deferred_reductions(self.dev):

@@ -128,6 +128,38 @@ def test_triplet_backward_in_one_walk_over_the_groups(oracle, cuda, dtype, C, pa
     assert torch.allclose(b2.grad.float(), db.grad.float(), rtol=rtol, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("C", [64, 32, 22])
+@pytest.mark.parametrize("route", ["atomics", "grouped"])
+def test_bce_edge_loss(oracle, cuda, dtype, C, route, monkeypatch):
+    """The BCE variant of the segmentation loss (lightning_model.py:190-207) as one kernel each way: BCEWithLogits over
+    the positive / sampled-negative dot products, against the float64 oracle; "grouped": unique anchors, one walk over
+    the by-destination groups (anchor rows stored); C = 22: not a multiple of 32 -> the per-edge kernel with atomics."""
+    from segger_amd import ops
+    from segger_amd.graph import csr_from_coo
+    monkeypatch.setattr(ops, "_CONTRIB_MIN_EDGES", 0 if dtype != torch.float32 and route == "grouped" else 1 << 60)
+    g = torch.Generator().manual_seed(3 + C)
+    n_tx, n_bd, E = 2600, 35, 2000
+    z_tx = torch.randn(n_tx, C, generator=g).to(dtype)          # (not normalised: logits of a few units either way)
+    z_bd = (torch.randn(n_bd, C, generator=g) * 0.5).to(dtype)
+    src = torch.randperm(n_tx, generator=g)[:E] if route == "grouped" else torch.randint(0, n_tx, (E,), generator=g)
+    dst = torch.randint(0, n_bd, (E,), generator=g)
+    dst[dst == 7] = 8
+    neg = (dst + torch.randint(1, n_bd, (E,), generator=g)) % n_bd
+    a, b = z_tx.double().requires_grad_(True), z_bd.double().requires_grad_(True)
+    ref = oracle.segmentation_loss(a, b, torch.stack([src, dst]), neg, "bce")
+    (ref * 0.37).backward()
+    da, db = z_tx.to(cuda).requires_grad_(True), z_bd.to(cuda).requires_grad_(True)
+    groups = csr_from_coo(dst.to(cuda), src.to(cuda), n_bd, n_tx, validate=False) if route == "grouped" else None
+    loss = ops.bce_edge_loss(da, db, src.to(cuda), dst.to(cuda), neg.to(cuda), pos_groups=groups,
+                             anchors_unique=route == "grouped")
+    (loss * 0.37).backward()
+    assert abs(loss.item() - ref.item()) < 2e-5 * max(1.0, abs(ref.item()))
+    rtol, atol = (1e-5, 1e-7) if dtype == torch.float32 else (1e-2, 4e-6)
+    assert torch.allclose(da.grad.cpu().double(), a.grad, rtol=rtol, atol=atol)
+    assert torch.allclose(db.grad.cpu().double(), b.grad, rtol=rtol, atol=atol)
+
+
 def test_masked_losses_equal_the_gathered_form(cuda):
     """loss_tx / loss_bd under a mask (no compaction, no host sync: the selector works under the mask, the fused
     triplet kernel skips the unmasked anchors) equal TripletLoss / MetricLoss on ``embeddings[mask], labels[mask]`` --

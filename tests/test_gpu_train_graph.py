@@ -8,9 +8,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _model(spec, dev, dtype):
+def _model(spec, dev, dtype, **kw):
     from tests.test_gpu_model import build
-    m, _, b, _ = build(spec, dev, dtype=dtype)
+    m, _, b, _ = build(spec, dev, dtype=dtype, **kw)
     m.train()
     m._max_epochs_override, m.current_epoch = 20, 12
     return m, b.to(dev)
@@ -54,12 +54,13 @@ def _pad_draws(step, d):
                 dst_neg=pad(d["dst_neg"], s["e_tb"], -1))
 
 
+@pytest.mark.parametrize("sg_loss_type", ["triplet", "bce"])
 @pytest.mark.parametrize("capture", [False, True])
-def test_graphed_step_gradients_equal_eager_step(cuda, capture):
+def test_graphed_step_gradients_equal_eager_step(cuda, capture, sg_loss_type):
     from segger_amd.synthetic import SyntheticSpec
     from segger_amd.train_step_graph import GraphedTrainStep, step_bucket
     spec = SyntheticSpec(n_tx=5000, n_bd=170, k_tx=7, seed=31)
-    m, bg = _model(spec, cuda, torch.float32)
+    m, bg = _model(spec, cuda, torch.float32, sg_loss_type=sg_loss_type)
     torch.manual_seed(5)
     d = _fixed_draws(m, bg)
     m2 = copy.deepcopy(m)
