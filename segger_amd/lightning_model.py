@@ -6,8 +6,8 @@ build it from the same CLI-parsed arguments -- over the HIP kernels:
 
 * ``forward``       -> :class:`segger_amd.ist_encoder.ISTEncoder`
 * ``predict_step``  -> fused cosine / arg-max / assignment kernel (``:275-293``)
-* segmentation loss -> fused triplet kernel (``:178-187``); the BCE variant
-  (``:190-207``) keeps torch ops on the device embeddings.
+* segmentation loss -> fused triplet kernel (``:178-187``) / fused BCE kernel
+  (``:190-207``; torch ops only on the CPU or for an odd channel count).
 
 ``lightning`` is used when importable; otherwise a minimal stand-in base class
 provides ``log`` / ``trainer`` / ``current_epoch`` / ``device`` so the module
