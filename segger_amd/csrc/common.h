@@ -36,7 +36,8 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 
 // ------------------------------------------------- fp32 projections (csrc/linear_f32.hip) ---
 int linear_f32_launch(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t n_rows,
-                      int k_in, int m_out, hipStream_t stream);
+                      int k_in, int m_out, hipStream_t stream, const float* rowbias = nullptr, const int32_t* rowidx = nullptr,
+                      int64_t ld_rb = 0);
 size_t wgrad_f32_workspace_bytes(int64_t n_rows, int m_out, int k_in);
 int wgrad_f32_launch(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, int64_t n_rows, int m_out, int k_in,
                      float* partial, int64_t* n_slabs, hipStream_t stream);

@@ -295,10 +295,13 @@ extern "C" int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void*
   SEGGER_REQUIRE(x && w && y, "segger_linear_fwd: NULL pointer");
   SEGGER_REQUIRE(aligned16(x) && aligned16(w) && aligned16(y), "segger_linear_fwd: pointers must be 16-byte aligned");
   if (dtype == SEGGER_F32) {       // fp32 storage: exact-fp32 MFMA kernel (csrc/linear_f32.hip); plain projection only
-    SEGGER_REQUIRE(!rowbias && !rowidx, "segger_linear_fwd_rowbias: the per-row table form is 16-bit only");
+    SEGGER_REQUIRE(!rowbias == !rowidx, "segger_linear_fwd_rowbias: rowbias and rowidx go together");
+    SEGGER_REQUIRE(!rowbias || (aligned16(rowbias) && ld_rb >= m_out && ld_rb % 4 == 0),
+                   "segger_linear_fwd_rowbias: the fp32 table needs 16-byte aligned rows of at least m_out elements");
     SEGGER_REQUIRE(ldx >= k_in && ldy >= m_out && ldx % 4 == 0 && ldy % 4 == 0 && (!bias || aligned16(bias)),
                    "segger_linear_fwd: fp32 rows (and the bias) must be 16-byte aligned");
-    return linear_f32_launch(x, ldx, w, bias, y, ldy, n_rows, k_in, m_out, (hipStream_t)stream);
+    return linear_f32_launch(x, ldx, w, bias, y, ldy, n_rows, k_in, m_out, (hipStream_t)stream,
+                             static_cast<const float*>(rowbias), rowidx, ld_rb);
   }
   SEGGER_REQUIRE(ldx >= k_in && ldy >= m_out && (ldx * 2) % 16 == 0 && (ldy * 2) % 16 == 0,
                  "segger_linear_fwd: bad leading dimension");

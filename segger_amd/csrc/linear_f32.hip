@@ -30,6 +30,9 @@ struct LinF32Params {
   float* y; int64_t ldy;
   int64_t n_rows;
   int m_out;
+  // optional per-row additive term: y[row, :] += rowbias[rowidx[row], :] (fp32 table, row stride ld_rb): the per-gene
+  // table form of the first layer (ops.embed_linear), as in linear.hip
+  const float* rowbias; const int32_t* rowidx; int64_t ld_rb;
 };
 
 // A workgroup (4 waves) owns 128 rows and produces all M columns: X is read once.  A wave keeps its 32 rows as B-operand
@@ -102,6 +105,7 @@ __global__ __launch_bounds__(256, K <= 256 ? 2 : 1) void linear_f32_kernel(LinF3
     }
     if (row_ok) {
       float* yr = p.y + row * p.ldy + c0;
+      const float* tr = p.rowbias ? p.rowbias + (int64_t)p.rowidx[row] * p.ld_rb + c0 : nullptr;
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
 #pragma unroll
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(256, K <= 256 ? 2 : 1) void linear_f32_kernel(LinF3
             const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + c0 + col);
             v = v + b;
           }
+          if (tr) v = v + *reinterpret_cast<const f32x4*>(tr + col);
           *reinterpret_cast<f32x4*>(yr + col) = v;
         }
       }
@@ -335,9 +340,10 @@ void launch_wgrad_f32(const WgF32Params& p, int64_t grid, hipStream_t stream) {
 
 // (declared in common.h for csrc/linear.hip and csrc/linear_wgrad.hip, which dispatch on the dtype)
 int linear_f32_launch(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t n_rows,
-                      int k_in, int m_out, hipStream_t stream) {
+                      int k_in, int m_out, hipStream_t stream, const float* rowbias, const int32_t* rowidx, int64_t ld_rb) {
   LinF32Params p{static_cast<const float*>(x), ldx, static_cast<const float*>(w), bias, static_cast<float*>(y), ldy,
-                 n_rows, m_out};
+                 n_rows, m_out, rowbias, rowidx, ld_rb};
+  if (rowbias && k_in == 384) { set_error("segger_linear_fwd_rowbias (fp32): k_in 64, 128 or 256"); return SEGGER_EUNSUPPORTED; }
   const int64_t nb = (n_rows + 127) / 128;
   if (nb > 0x7fffffffLL) { set_error("segger_linear_fwd: too many rows"); return SEGGER_EUNSUPPORTED; }
   dim3 grid((unsigned)nb), block(256);

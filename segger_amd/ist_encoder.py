@@ -382,7 +382,7 @@ class ISTEncoder(Module):
                 m_first = sum(int(w.shape[0]) for w in (first[TX_TX].lin_l.weight, first[TX_TX].lin_r.weight,
                                                         first[TX_BD].lin_l.weight))
                 probe = ops.EmbedInput(emb.weight, x_dict["tx"], x_bd[:0, : self.in_channels], None)
-                split = (self.split_first_layer and dt != torch.float32
+                split = (self.split_first_layer
                          and x_dict["tx"].shape[0] >= self.split_first_layer_min_rows
                          and ops.embed_linear_supported(probe, m_first))
             # ONE embedder call for both node types (the reference calls it per type, ist_encoder.py:314-318): graph ids

@@ -53,14 +53,18 @@ def main():
     gathered = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     steps = float(next(iter(opt.state.values()))["step"])
-    print(json.dumps({"rank": rank, "own": sum(k is not None for k in sched), "steps_per_epoch": len(sched),
+    rec = json.dumps({"rank": rank, "own": sum(k is not None for k in sched), "steps_per_epoch": len(sched),
                       "adam_steps": steps, "epochs": epochs, "captures": trainer.n_captures,
                       "finite": bool(torch.isfinite(flat).all()), "flat_ptr_stable": bucket.flat.data_ptr() == flat_ptr0,
                       "grads_are_views": all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
                                              for p, v in zip(bucket.params, bucket.views)),
                       "max_param_diff": max(float((g - flat).abs().max()) for g in gathered),
-                      "first": sum(losses[: len(losses) // epochs]), "last": sum(losses[-(len(losses) // epochs):])}),
-          flush=True)
+                      "first": sum(losses[: len(losses) // epochs]), "last": sum(losses[-(len(losses) // epochs):])})
+    out_dir = os.environ.get("DP_WORKER_OUT")       # one file per rank: two ranks' stdout lines can interleave
+    if out_dir:
+        with open(os.path.join(out_dir, f"rank{rank}.json"), "w") as fh:
+            fh.write(rec)
+    print(rec, flush=True)
     dist.destroy_process_group()
 
 

@@ -168,13 +168,13 @@ def test_graphed_trainer_data_parallel(cuda, tmp_path):
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DP_WORKER_OUT=str(tmp_path))
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port),
                         os.path.join(root, "tests", "dp_graphed_worker.py")],
                        capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    recs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    recs = [json.loads(open(os.path.join(str(tmp_path), f"rank{k}.json")).read()) for k in range(2)]
     assert sorted(x["rank"] for x in recs) == [0, 1]
     assert {x["own"] for x in recs} == {recs[0]["steps_per_epoch"], recs[0]["steps_per_epoch"] - 1}   # one empty step
     for x in recs:
