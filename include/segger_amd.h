@@ -389,6 +389,11 @@ typedef struct segger_triplet_args {
                                 and <a, neg> (label 0), mean over the 2 n_edges logits; margin / eps / contrib unused;
                                 grad_b is always accumulated into (caller zero-fills); with pos_indptr + anchor_unique
                                 the backward is the same one walk over the groups as for the triplet loss */
+  void* grad_a_rows;         /* bwd, optional (triplet loss): [n_a, C] in the format of grad_a.  For triplets whose anchor is
+                                their own index (src[e] == e or skipped, n_edges == n_a: loss_tx, where every row anchors one
+                                triplet) the anchor's term of triplet e is STORED into row e (zeros when the triplet is
+                                inactive or skipped) instead of added atomically; grad_a / grad_b then receive only the
+                                positive / negative terms.  The consumer adds the two matrices (segger_l2norm_bwd2). */
 } segger_triplet_args;
 #define SEGGER_LOSS_TRIPLET 0
 #define SEGGER_LOSS_BCE 1
@@ -625,6 +630,10 @@ int segger_l2norm_fwd(const void* y, int64_t ld_y, int64_t n, int32_t channels, 
                       int32_t dtype, segger_stream_t stream);
 int segger_l2norm_bwd(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, int64_t n, int32_t channels,
                       float eps, void* gy, int64_t ld_gy, int32_t dtype, segger_stream_t stream);
+/* the same with the incoming gradient given as the sum of two matrices gz + gz2 (gz2 may be NULL): the loss head hands
+ * the anchors' stored rows and the atomically accumulated rows over separately (segger_triplet_args.grad_a_rows) */
+int segger_l2norm_bwd2(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, const void* gz2, int64_t ld_gz2, int64_t n,
+                       int32_t channels, float eps, void* gy, int64_t ld_gy, int32_t dtype, segger_stream_t stream);
 /* out[s, :] = sum of the rows x[seg_rows[seg_ptr[s] : seg_ptr[s+1]], :] in fp32 (deterministic, no atomics): the
  * scatter-add of per-edge rows into a small table, e.g. the boundary-side gradient of the triplet loss
  * (lightning_model.py:182-187 autograd).  seg_ptr / seg_rows = indptr / col of segger_csr_from_coo(row = segment id of

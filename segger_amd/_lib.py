@@ -123,6 +123,7 @@ class TripletArgs(C.Structure):
         ("contrib", vp),
         ("workspace", vp), ("workspace_bytes", C.c_size_t),
         ("pos_indptr", vp), ("pos_eid", vp), ("anchor_unique", C.c_int32), ("loss_kind", C.c_int32),
+        ("grad_a_rows", vp),
     ]
 
 
@@ -171,6 +172,8 @@ EXPORTS = {
     "segger_reductions_pending": (C.c_int, []),
     "segger_reductions_flush": (C.c_int, [vp]),
     "segger_linear_wgrad_dx_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "segger_l2norm_bwd2": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_float, vp, C.c_int64,
+                                     C.c_int32, vp]),
     "segger_pack_refresh": (C.c_int, [vp, C.c_int32, C.c_int32, vp]),
     "segger_dropout_bits_many": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_float, vp, vp]),
     "segger_step_advance": (C.c_int, [vp, C.c_int64, vp, vp]),

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void emb_finish_kernel(const float* __restrict
 // ---------------------------------------------------------------------------------------------
 template <typename T, int LPC, bool BWD>
 __global__ __launch_bounds__(256) void l2norm_kernel(const T* __restrict__ y, int64_t ld_y, const T* __restrict__ gz, int64_t ld_gz,
-                                                    int64_t n, float eps, T* __restrict__ out, int64_t ld_out) {
+                                                    int64_t n, float eps, T* __restrict__ out, int64_t ld_out,
+                                                    const T* __restrict__ gz2 = nullptr, int64_t ld_gz2 = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   constexpr int RPW = 64 / LPC;
   const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * RPW + lane / LPC;
@@ -217,6 +218,12 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const T* __restrict__ y, in
   } else {
     float g[8];
     Vec8<T>::load(gz + row * ld_gz + c0, g);
+    if (gz2) {                                           // the incoming gradient arrives as the sum of two matrices
+      float g2[8];
+      Vec8<T>::load(gz2 + row * ld_gz2 + c0, g2);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] += g2[k];
+    }
     float dot = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) dot = fmaf(v[k] * inv, g[k], dot);
@@ -230,12 +237,12 @@ __global__ __launch_bounds__(256) void l2norm_kernel(const T* __restrict__ y, in
 
 template <typename T, bool BWD>
 int launch_l2norm(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, int64_t n, int C, float eps, void* out,
-                  int64_t ld_out, hipStream_t stream) {
+                  int64_t ld_out, hipStream_t stream, const void* gz2 = nullptr, int64_t ld_gz2 = 0) {
 #define GO(LPC)                                                                                                      \
   {                                                                                                                  \
     const int64_t rpb = 4 * (64 / LPC);                                                                              \
     hipLaunchKernelGGL((l2norm_kernel<T, LPC, BWD>), dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, stream,    \
-                       (const T*)y, ld_y, (const T*)gz, ld_gz, n, eps, (T*)out, ld_out);                             \
+                       (const T*)y, ld_y, (const T*)gz, ld_gz, n, eps, (T*)out, ld_out, (const T*)gz2, ld_gz2);      \
   }
   switch (C) {
     case 8: GO(1) break;
@@ -523,14 +530,24 @@ extern "C" int segger_l2norm_fwd(const void* y, int64_t ld_y, int64_t n, int32_t
   return SEGGER_OK;
 }
 
-extern "C" int segger_l2norm_bwd(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, int64_t n, int32_t channels,
-                                 float eps, void* gy, int64_t ld_gy, int32_t dtype, segger_stream_t stream) {
+extern "C" int segger_l2norm_bwd2(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, const void* gz2, int64_t ld_gz2,
+                                  int64_t n, int32_t channels, float eps, void* gy, int64_t ld_gy, int32_t dtype,
+                                  segger_stream_t stream) {
   SEGGER_REQUIRE(n >= 0 && channels > 0, "segger_l2norm_bwd: bad sizes");
   if (n == 0) return SEGGER_OK;
-  SEGGER_REQUIRE(y && gz && gy && aligned16(y) && aligned16(gz) && aligned16(gy), "segger_l2norm_bwd: NULL or misaligned pointer");
+  SEGGER_REQUIRE(y && gz && gy && aligned16(y) && aligned16(gz) && aligned16(gy) && aligned16(gz2),
+                 "segger_l2norm_bwd: NULL or misaligned pointer");
+  const size_t es = esize(dtype);
+  SEGGER_REQUIRE((ld_y * es) % 16 == 0 && (ld_gz * es) % 16 == 0 && (ld_gy * es) % 16 == 0 && (!gz2 || (ld_gz2 * es) % 16 == 0),
+                 "segger_l2norm_bwd: bad leading dimension");
   DISPATCH_DTYPE(dtype,
-                 return (launch_l2norm<float, true>(y, ld_y, gz, ld_gz, n, channels, eps, gy, ld_gy, (hipStream_t)stream)),
-                 return (launch_l2norm<bf16_t, true>(y, ld_y, gz, ld_gz, n, channels, eps, gy, ld_gy, (hipStream_t)stream)),
-                 return (launch_l2norm<f16_t, true>(y, ld_y, gz, ld_gz, n, channels, eps, gy, ld_gy, (hipStream_t)stream)))
+                 return (launch_l2norm<float, true>(y, ld_y, gz, ld_gz, n, channels, eps, gy, ld_gy, (hipStream_t)stream, gz2, ld_gz2)),
+                 return (launch_l2norm<bf16_t, true>(y, ld_y, gz, ld_gz, n, channels, eps, gy, ld_gy, (hipStream_t)stream, gz2, ld_gz2)),
+                 return (launch_l2norm<f16_t, true>(y, ld_y, gz, ld_gz, n, channels, eps, gy, ld_gy, (hipStream_t)stream, gz2, ld_gz2)))
   return SEGGER_OK;
+}
+
+extern "C" int segger_l2norm_bwd(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, int64_t n, int32_t channels,
+                                 float eps, void* gy, int64_t ld_gy, int32_t dtype, segger_stream_t stream) {
+  return segger_l2norm_bwd2(y, ld_y, gz, ld_gz, nullptr, 0, n, channels, eps, gy, ld_gy, dtype, stream);
 }

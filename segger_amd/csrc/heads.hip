@@ -147,6 +147,7 @@ struct TripletParams {
   void* contrib;          // bwd, optional: [n_edges][2][C] fp32 -- (-d/d pos, +d/d neg) per triplet INSTEAD of gb atomics
   const int64_t* pos_indptr; const int32_t* pos_eid;   // bwd, optional: triplets grouped by positive row
   int skip_pos;           // bwd: the positive side of gb is written by triplet_pos_kernel
+  void* ga_rows;          // bwd, optional: the anchor's own term of triplet e is STORED into row e of this matrix
 };
 
 // gradient accumulation into one row: fp32 atomics, or -- for 16-bit embeddings -- packed 2-channel atomics in the
@@ -238,6 +239,35 @@ __global__ __launch_bounds__(256) void triplet_kernel(TripletParams p) {
           if (active) grad_add2<T>(p.ga, p.ga_packed, ia * C + c, dp0 - dn0, dp1 - dn1);
           *reinterpret_cast<float2*>(row + c) = float2{-dp0, -dp1};
           *reinterpret_cast<float2*>(row + C + c) = float2{dn0, dn1};
+        }
+      }
+    } else if (p.ga_rows != nullptr) {
+      // anchors are the rows themselves (src[e] == e: loss_tx): the anchor term needs no atomic -- row e of ga_rows is
+      // WRITTEN (zeros for an inactive / skipped triplet; every row of the matrix is some triplet's), only the
+      // positive / negative terms, which land on arbitrary rows, add atomically into ga == gb
+      if (e < p.n_edges && e < p.n_a) {
+        const bool active = ok && l > 0.f;
+        const float sc = p.scale_dev ? p.scale * p.scale_dev[0] : p.scale;
+        const float ip_ = active && dap > 0.f ? sc / dap : 0.f;
+        const float in_ = active && dan > 0.f ? sc / dan : 0.f;
+        for (int c = 2 * gl; c < C; c += 32) {
+          const float a0 = load1(za + ia * p.ld_za + c), a1 = load1(za + ia * p.ld_za + c + 1);
+          const float dp0 = (a0 - load1(zb + ip * p.ld_zb + c) + p.eps) * ip_;
+          const float dp1 = (a1 - load1(zb + ip * p.ld_zb + c + 1) + p.eps) * ip_;
+          const float dn0 = (a0 - load1(zb + in * p.ld_zb + c) + p.eps) * in_;
+          const float dn1 = (a1 - load1(zb + in * p.ld_zb + c + 1) + p.eps) * in_;
+          bool stored = false;
+          if constexpr (sizeof(T) == 2) {
+            if (p.ga_packed) {
+              *reinterpret_cast<uint32_t*>(static_cast<T*>(p.ga_rows) + e * C + c) = Vec8<T>::pack(dp0 - dn0, dp1 - dn1);
+              stored = true;
+            }
+          }
+          if (!stored) *reinterpret_cast<float2*>(static_cast<float*>(p.ga_rows) + e * C + c) = float2{dp0 - dn0, dp1 - dn1};
+          if (active) {
+            if (!p.skip_pos) grad_add2<T>(p.gb, p.gb_packed, ip * C + c, -dp0, -dp1);
+            grad_add2<T>(p.gb, p.gb_packed, in * C + c, dn0, dn1);
+          }
         }
       }
     } else if (ok && l > 0.f) {
@@ -812,7 +842,7 @@ static int triplet_common(const segger_triplet_args* a, bool bwd, hipStream_t st
   TripletParams p{a->src, a->pos, a->neg, a->n_edges, a->z_a, a->ld_za, a->z_b, a->ld_zb, a->n_a, a->n_b, a->channels, a->margin, a->eps,
                   static_cast<float*>(a->workspace), 0.f, nullptr, a->grad_a, a->grad_b,
                   a->grad_a_packed, a->grad_b_packed, bwd ? a->contrib : nullptr,
-                  bwd ? a->pos_indptr : nullptr, bwd ? a->pos_eid : nullptr, 0};
+                  bwd ? a->pos_indptr : nullptr, bwd ? a->pos_eid : nullptr, 0, bwd ? a->grad_a_rows : nullptr};
   if (!bwd) {
     const size_t need = segger_triplet_workspace_bytes(a->n_edges);
     if (!a->workspace || a->workspace_bytes < need) {
@@ -827,6 +857,9 @@ static int triplet_common(const segger_triplet_args* a, bool bwd, hipStream_t st
                    "segger_triplet_bwd: packed gradient buffers need a 16-bit dtype and an even channel count");
     SEGGER_REQUIRE(!(a->grad_a == a->grad_b) || a->grad_a_packed == a->grad_b_packed,
                    "segger_triplet_bwd: one shared gradient buffer cannot be both packed and fp32");
+    SEGGER_REQUIRE(!a->grad_a_rows || (a->channels % 2 == 0 && !a->contrib && a->loss_kind == SEGGER_LOSS_TRIPLET &&
+                                       a->n_edges == a->n_a && ((uintptr_t)a->grad_a_rows % 8) == 0),
+                   "segger_triplet_bwd: grad_a_rows needs an even channel count, one triplet per row of z_a, no contrib");
     p.scale = a->grad_scale / (float)a->n_edges;
     p.scale_dev = a->grad_scale_dev;
     if (p.pos_indptr) {

@@ -255,7 +255,8 @@ class LitISTEncoder(_Base):
                 wdev.clear()
             b = wdev[(key, dev)] = torch.tensor(key, dtype=torch.float32, device=dev)
         spec = ops.LossHeadSpec((ix_tx["anchors"], pos, neg, self.loss_tx.margin, self.loss_tx.eps),
-                                (bpos, bneg, dp, dn, ix_bd["weight"], 1e-8), sg, sg_kind=self._sg_loss_type)
+                                (bpos, bneg, dp, dn, ix_bd["weight"], 1e-8), sg, sg_kind=self._sg_loss_type,
+                                tx_anchors_are_rows=True)
         out = ops.loss_head(z_tx, z_bd, ix_tx["head_a"], b, spec)
         return out[0], out[1], out[2], out[3]
 

@@ -586,8 +586,11 @@ class LossHeadSpec:
     (bool, or a callable asked in the backward, e.g. ``EdgeGraph.src_unique``): no transcript is the anchor of two
     triplets -- the backward then walks the groups once and stores the anchors' gradient rows."""
 
-    def __init__(self, tx, bd, sg, sg_kind: str = "triplet"):
+    def __init__(self, tx, bd, sg, sg_kind: str = "triplet", tx_anchors_are_rows: bool = False):
         self.tx, self.bd, self.sg, self.sg_kind = tx, bd, sg, sg_kind      # sg_kind "bce": margin / eps unused
+        # loss_tx's anchors are arange(n_tx) (possibly with -1 positives = skipped): lets the backward STORE the anchors'
+        # gradient rows (loss_head, when z_tx comes straight out of ops.l2_normalize)
+        self.tx_anchors_are_rows = bool(tx_anchors_are_rows)
 
 
 class _LossHead(torch.autograd.Function):
@@ -598,7 +601,9 @@ class _LossHead(torch.autograd.Function):
     matrix -- no per-loss zero fill, cast and add, and no chain of 0-dim torch ops around the weighted sum."""
 
     @staticmethod
-    def forward(ctx, z_tx, z_bd, a, b, spec: LossHeadSpec):
+    def forward(ctx, z_tx, z_bd, a, b, spec: LossHeadSpec, y_tx=None, eps_tx=0.0):
+        # y_tx (optional): z_tx == l2_normalize(y_tx, eps_tx) is then a CONSTANT here and the gradient is returned for y_tx
+        # (anchor rows stored + normalisation backward inside this node)
         _lib.require_cuda(z_tx, z_bd, a, b)
         lib = _lib.load()
         dev, dt = z_tx.device, z_tx.dtype
@@ -656,7 +661,7 @@ class _LossHead(torch.autograd.Function):
                                                             out.data_ptr(), stream), "segger_loss_combine_partials_fwd")
         ctx.keep = keep                                      # (the partial sums are read by the launch above)
         ctx.save_for_backward(z_tx, z_bd, a, b, *tx, *bd, *(sg or ()))
-        ctx.spec = spec
+        ctx.spec, ctx.y_tx, ctx.eps_tx = spec, y_tx, float(eps_tx)
         return out
 
     @staticmethod
@@ -676,7 +681,9 @@ class _LossHead(torch.autograd.Function):
         # 16-bit atomics straight into a gradient of the embeddings' dtype on large batches; boundary rows sum dozens
         # of terms and stay fp32 (+ one cast)
         packed = dt in (torch.bfloat16, torch.float16) and c % 2 == 0 and tx[0].numel() >= _CONTRIB_MIN_EDGES
+        y_tx = ctx.y_tx
         ga = torch.zeros(z_tx.shape, dtype=dt if packed else torch.float32, device=dev)
+        ga_rows = torch.empty_like(ga) if y_tx is not None else None      # every row written by loss_tx's kernel
         pg = spec.sg[5] if spec.sg is not None else None
         uniq = False
         if pg is not None and len(spec.sg) > 6 and c % 32 == 0 and c <= 128:
@@ -704,14 +711,38 @@ class _LossHead(torch.autograd.Function):
             ta.grad_a = ta.grad_b = ga.data_ptr()
             ta.grad_a_packed = ta.grad_b_packed = int(packed)
             ta.grad_scale, ta.grad_scale_dev = 1.0, graw[0:1].data_ptr()
+            if ga_rows is not None:
+                ta.grad_a_rows = ga_rows.data_ptr()
             _lib.check(lib.segger_triplet_bwd(C.byref(ta), stream), "segger_triplet_bwd")
-        return (ga if packed else ga.to(dt)), gb.to(dt), None, None, None
+            if ga_rows is not None:
+                # d loss / d y_tx = normalisation backward of (ga + ga_rows), read as two matrices
+                g1, g2 = (ga, ga_rows) if ga.dtype == dt else (ga.to(dt), ga_rows.to(dt))
+                gy = torch.empty_like(y_tx)
+                yp, ldy = _rows(y_tx, c, "y_tx")
+                _lib.check(lib.segger_l2norm_bwd2(yp, ldy, g1.data_ptr(), c, g2.data_ptr(), c, int(y_tx.shape[0]), c, ctx.eps_tx,
+                                                  gy.data_ptr(), c, DTYPE_CODE[dt], stream), "segger_l2norm_bwd2")
+                return None, gb.to(dt), None, None, None, gy, None
+        return (ga if packed else ga.to(dt)), gb.to(dt), None, None, None, None, None
+
+
+USE_ANCHOR_ROWS = True       # tools flip it: False = loss_tx's anchor terms by atomics at fp32 storage as well
 
 
 def loss_head(z_tx: Tensor, z_bd: Tensor, a: Tensor, b: Tensor, spec: LossHeadSpec) -> Tensor:
     """-> float32[4] = (a0 * loss_tx, a1 * loss_bd, a2 * loss_sg, sum_i b_i * (the three)): the three losses of
     ``LitISTEncoder.get_losses`` and their weighted sum as one autograd node (see :class:`_LossHead`).  ``a`` / ``b``:
     float32[3] on the device."""
+    pre = getattr(z_tx, "_segger_prenorm", None)
+    # (fp32 storage only: there loss_tx's backward is bound by 12 fp32 atomic instructions per triplet, a third of them the
+    # anchor's -- 1.19 -> 0.8 ms at C2; with 16-bit embeddings the packed atomics are cheap enough that the second matrix
+    # the normalisation backward then reads costs what the stores save: 13.40 vs 13.42 ms per step)
+    if (USE_ANCHOR_ROWS and z_tx.dtype == torch.float32
+            and spec.tx_anchors_are_rows and pre is not None and pre[0].requires_grad and torch.is_grad_enabled()
+            and z_tx.shape[1] % 8 == 0 and pre[0].shape == z_tx.shape and pre[0].dtype == z_tx.dtype
+            and spec.tx[0].numel() == z_tx.shape[0]):
+        # z_tx is the output of ops.l2_normalize: treat it as a constant and send the gradient to its input -- the anchors'
+        # rows are then stored, not added atomically, and the normalisation backward reads the two matrices
+        return _LossHead.apply(z_tx.detach(), z_bd, a, b, spec, pre[0], pre[1])
     return _LossHead.apply(z_tx, z_bd, a, b, spec)
 
 
@@ -1663,6 +1694,8 @@ class _L2Norm(torch.autograd.Function):
 def l2_normalize(y: Tensor, eps: float = 1e-12) -> Tensor:
     """F.normalize(y, dim=-1) for [n, C] with C in {8,16,32,64,128}; other widths use torch."""
     if y.dim() == 2 and y.shape[1] in (8, 16, 32, 64, 128) and y.dtype in DTYPE_CODE:
-        return _L2Norm.apply(y, float(eps))
+        z = _L2Norm.apply(y, float(eps))
+        z._segger_prenorm = (y, float(eps))          # (read by ops.loss_head, which may differentiate through y directly)
+        return z
     _lib.require_cuda(y)
     return torch.nn.functional.normalize(y.float(), dim=-1, eps=eps).to(y.dtype)

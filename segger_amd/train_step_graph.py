@@ -257,7 +257,7 @@ class GraphedTrainStep:
         spec = ops.LossHeadSpec((self._iota, pos, neg, lit.loss_tx.margin, lit.loss_tx.eps),
                                 (bpos, bneg, dp, dn, self.bd_weight, 1e-8),
                                 (self.sg_src, self.sg_pos, dst_neg, lit._sg_margin, 1e-6, self.g_tb.by_dst, True),
-                                sg_kind=lit._sg_loss_type)
+                                sg_kind=lit._sg_loss_type, tx_anchors_are_rows=True)
         out = ops.loss_head(z["tx"], z["bd"], self.head_a, self.scal[3:6], spec)
         if self.defer_sums:                                   # ~30 partial sums of the backward as one launch
             with ops.deferred_reductions(self.dev):
