@@ -1695,7 +1695,8 @@ def l2_normalize(y: Tensor, eps: float = 1e-12) -> Tensor:
     """F.normalize(y, dim=-1) for [n, C] with C in {8,16,32,64,128}; other widths use torch."""
     if y.dim() == 2 and y.shape[1] in (8, 16, 32, 64, 128) and y.dtype in DTYPE_CODE:
         z = _L2Norm.apply(y, float(eps))
-        z._segger_prenorm = (y, float(eps))          # (read by ops.loss_head, which may differentiate through y directly)
+        if torch.is_grad_enabled() and y.requires_grad:
+            z._segger_prenorm = (y, float(eps))      # (read by ops.loss_head, which may differentiate through y directly)
         return z
     _lib.require_cuda(y)
     return torch.nn.functional.normalize(y.float(), dim=-1, eps=eps).to(y.dtype)
