@@ -286,7 +286,8 @@ class LitISTEncoder(_Base):
         max_sim, _, seg_idx, _ = ops.edge_cos_argmax(
             g.by_src, z_tx, z_bd, dst_index=batch['bd']['index'], min_similarity=min_similarity)
         mask = batch['tx']['predict_mask']
-        out = (batch['tx']['index'][mask], seg_idx[mask], max_sim[mask], batch['tx']['x'][mask])
+        keep = mask.nonzero(as_tuple=True)[0]          # ONE compaction (one sync) for the four outputs, not one each
+        out = (batch['tx']['index'][keep], seg_idx[keep], max_sim[keep], batch['tx']['x'][keep])
         out = tuple(t.cpu() for t in out)
         flush_validation()                 # the copies above synchronised: surface a bad edge_index of this batch now
         return out
