@@ -160,6 +160,48 @@ def test_bce_edge_loss(oracle, cuda, dtype, C, route, monkeypatch):
     assert torch.allclose(db.grad.cpu().double(), b.grad, rtol=rtol, atol=atol)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_loss_head_anchor_rows_equal_atomic_anchors(cuda, dtype, monkeypatch):
+    """fp32 storage: loss_tx's anchor terms are STORED into a second gradient matrix (segger_triplet_args.grad_a_rows) and
+    the l2-normalisation backward reads the sum of the two (segger_l2norm_bwd2) -- the loss head then differentiates
+    through the un-normalised embeddings directly.  Same losses, same gradient of the un-normalised rows as the route
+    with atomic anchors through ops.l2_normalize's own backward; masked rows (-1 positives) and a transcript that is
+    nobody's positive / negative included.  bf16: the switch is a no-op by design (packed atomics kept)."""
+    from segger_amd import ops
+    from segger_amd.graph import csr_from_coo
+    g = torch.Generator().manual_seed(21)
+    n, nb, c, e = 3000, 40, 64, 1500
+    y0 = torch.randn(n, c, generator=g).to(dtype)
+    zb0 = torch.nn.functional.normalize(torch.randn(nb, c, generator=g), dim=-1).to(dtype)
+    pos = torch.randint(0, n, (n,), generator=g); pos[::7] = -1
+    neg = torch.randint(0, n, (n,), generator=g)
+    bpos, bneg = torch.randint(0, nb, (nb,), generator=g), torch.randint(0, nb, (nb,), generator=g)
+    dp, dn, w = torch.rand(nb, generator=g), torch.rand(nb, generator=g), torch.full((nb,), 1.0 / nb)
+    src = torch.randperm(n, generator=g)[:e]
+    dst = torch.randint(0, nb, (e,), generator=g)
+    dneg = (dst + torch.randint(1, nb, (e,), generator=g)) % nb
+    groups = csr_from_coo(dst.to(cuda), src.to(cuda), nb, n, validate=False)
+    a = torch.tensor([1.3, 1.0, 0.7], device=cuda)
+    b = torch.tensor([0.5, 0.2, 0.3], device=cuda)
+    out = {}
+    for rows in (True, False):
+        monkeypatch.setattr(ops, "USE_ANCHOR_ROWS", rows)
+        y = y0.to(cuda).requires_grad_(True)
+        zb = zb0.to(cuda).requires_grad_(True)
+        z = ops.l2_normalize(y)
+        spec = ops.LossHeadSpec((torch.arange(n, device=cuda), pos.to(cuda), neg.to(cuda), 0.3, 1e-6),
+                                (bpos.to(cuda), bneg.to(cuda), dp.to(cuda), dn.to(cuda), w.to(cuda), 1e-8),
+                                (src.to(cuda), dst.to(cuda), dneg.to(cuda), 0.4, 1e-6, groups, True), tx_anchors_are_rows=True)
+        res = ops.loss_head(z, zb, a, b, spec)
+        (res[3] * 1.7 + res[0]).backward()
+        out[rows] = (res.detach().clone(), y.grad.clone(), zb.grad.clone())
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(out[True][0], out[False][0], rtol=1e-6, atol=1e-7)
+    scale = out[False][1].float().abs().max().item()
+    assert (out[True][1].float() - out[False][1].float()).abs().max().item() <= tol * scale + 1e-9
+    assert torch.allclose(out[True][2].float(), out[False][2].float(), rtol=1e-5, atol=1e-7)
+
+
 def test_masked_losses_equal_the_gathered_form(cuda):
     """loss_tx / loss_bd under a mask (no compaction, no host sync: the selector works under the mask, the fused
     triplet kernel skips the unmasked anchors) equal TripletLoss / MetricLoss on ``embeddings[mask], labels[mask]`` --
