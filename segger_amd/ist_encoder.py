@@ -93,9 +93,13 @@ class Positional2dEmbedder(Module):
         routes that keep the GELU in autograd."""
         n = pos.shape[0]
         fd = self.frequency_embedding_size
-        if batch is not None and fd % 16 == 0:
+        if (batch is not None or pos.is_cuda) and fd % 16 == 0:
             # fused: per-graph min/max (one pass) -> normalise + sinusoid written straight in `dtype`
-            if num_graphs is None:
+            # (no batch vector = one graph, and the reference normalises it WITHOUT the epsilon, ist_encoder.py:62-64)
+            eps_n = 1e-8 if batch is not None else 0.0
+            if batch is None:
+                num_graphs = 1
+            elif num_graphs is None:
                 num_graphs = int(batch.max()) + 1 if batch.numel() else 0
             l0, l2 = self.mlp[0], self.mlp[2]
             use_fused = (self.fused and pos.is_cuda and l0.bias is not None and l2.bias is not None
@@ -106,8 +110,8 @@ class Positional2dEmbedder(Module):
                 # sinusoid + Linear + SiLU + Linear in one kernel: the [2n, 256] feature matrix is generated in
                 # registers (and stored once for the weight gradient when training) instead of written and re-read
                 return ops.posmlp(pos, batch, mins, maxs, l0.weight, l0.bias, l2.weight, l2.bias, dtype,
-                                  eps=1e-8, max_period=10000.0, gelu=gelu, return_pre=return_pre and gelu)
-            freq = ops.posfreq(pos, batch, mins, maxs, fd, dtype, eps=1e-8, max_period=10000.0)
+                                  eps=eps_n, max_period=10000.0, gelu=gelu, return_pre=return_pre and gelu)
+            freq = ops.posfreq(pos, batch, mins, maxs, fd, dtype, eps=eps_n, max_period=10000.0)
         else:
             pos = self.normalize(pos, batch, num_graphs)
             freq = sinusoidal_embedding(pos.flatten(), fd, max_period=10000).reshape(n, 2, fd).to(dtype)
