@@ -414,6 +414,17 @@ def main():
             except Exception as e:  # noqa: BLE001
                 log(f"[bench] roofline_other incomplete: {type(e).__name__}: {e}")
                 extra["error"] = f"{type(e).__name__}: {e}"
+            tr2 = os.path.join(ROOT, "profiles", "hbm_traffic_other.json")
+            if os.path.exists(tr2):      # HBM bytes per launch of these kernel classes by PMC (separate runs, same sizes)
+                try:
+                    meas2 = json.load(open(tr2))
+                    if meas2.get("workload", {}).get("n_tx") == args.n_tx and args.dtype == meas2["workload"].get("dtype"):
+                        for k_, v_ in meas2.items():
+                            if k_ in extra and isinstance(v_, (int, float)):
+                                extra[k_]["traffic"] = v_
+                                extra[k_]["traffic_source"] = "profiles/hbm_traffic_other.json (rocprofv3 --pmc, separate runs)"
+                except Exception:  # noqa: BLE001
+                    pass
 
     # ---- secondary figure: inference-only edge scoring (predict_step) on the same tile ----------------
     predict = None
