@@ -682,15 +682,22 @@ class _LossHead(torch.autograd.Function):
         # of terms and stay fp32 (+ one cast)
         packed = dt in (torch.bfloat16, torch.float16) and c % 2 == 0 and tx[0].numel() >= _CONTRIB_MIN_EDGES
         y_tx = ctx.y_tx
-        ga = torch.zeros(z_tx.shape, dtype=dt if packed else torch.float32, device=dev)
-        ga_rows = torch.empty_like(ga) if y_tx is not None else None      # every row written by loss_tx's kernel
         pg = spec.sg[5] if spec.sg is not None else None
         uniq = False
         if pg is not None and len(spec.sg) > 6 and c % 32 == 0 and c <= 128:
             uniq = spec.sg[6]
             uniq = bool(uniq() if callable(uniq) else uniq)
-        gb = (torch.empty if (pg is not None and not uniq and spec.sg_kind != "bce") else torch.zeros)(
-            z_bd.shape, dtype=torch.float32, device=dev)
+        gb_written = pg is not None and not uniq and spec.sg_kind != "bce"       # (the two-kernel route writes every row)
+        # both gradient matrices out of ONE zero-filled buffer (one fill launch instead of two)
+        ga_dt = dt if packed else torch.float32
+        na = z_tx.numel() * (2 if packed else 4)
+        na = (na + 255) // 256 * 256
+        nbb = 0 if gb_written else z_bd.numel() * 4
+        zbuf = torch.zeros(na + nbb, dtype=torch.uint8, device=dev)
+        ga = zbuf[:z_tx.numel() * (2 if packed else 4)].view(ga_dt).view(z_tx.shape)
+        gb = (torch.empty(z_bd.shape, dtype=torch.float32, device=dev) if gb_written
+              else zbuf[na:].view(torch.float32).view(z_bd.shape))
+        ga_rows = torch.empty_like(ga) if y_tx is not None else None      # every row written by loss_tx's kernel
         stream = _lib.stream_ptr(dev)
         with _lib.on_device(dev):
             _lib.check(lib.segger_loss_combine_bwd(g_out.data_ptr(), a.data_ptr(), b.data_ptr(), 3, graw.data_ptr(), stream),
