@@ -1176,9 +1176,10 @@ def _copy_groups(dsts, srcs) -> None:
 
 @torch.no_grad()
 def _refresh_stale_packs(requester: "_Pack") -> None:
-    """Refresh every pack whose parameters changed since it was filled, in one multi-tensor copy per dtype (+ one
-    launch for the transposed copies).  During a hipGraph capture only the packs of the active :class:`pack_scope`
-    (or, without one, only ``requester``) are touched: see ``_PACK_SCOPE``."""
+    """Refresh every pack whose parameters changed since it was filled: ONE launch for all 16-bit packs on the GPU
+    (``segger_pack_refresh``: casts into the stacked buffers, their transposed copies, the bias copies); anything else
+    by one multi-tensor copy per dtype + one launch for the transposed copies.  During a hipGraph capture only the
+    packs of the active :class:`pack_scope` (or, without one, only ``requester``) are touched: see ``_PACK_SCOPE``."""
     scope = _PACK_SCOPE[-1] if _PACK_SCOPE else None
     capturing = requester.w.is_cuda and torch.cuda.is_current_stream_capturing()
     dsts, srcs, live, one_launch = [], [], [], []
