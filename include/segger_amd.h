@@ -156,6 +156,12 @@ typedef struct segger_gatv2_fwd_args {
 } segger_gatv2_fwd_args;
 
 int segger_gatv2_fwd(const segger_gatv2_fwd_args* args, segger_stream_t stream);
+/* Two edge types of one HeteroConv layer (ist_encoder.py:109-134: tx-neighbors-tx and tx-belongs-bd) in ONE launch: the
+ * few thousand short blocks of the high-degree edge type `b` (wave per destination row) run beside the blocks of the
+ * low-degree edge type `a` (lane group per row) instead of as a latency-bound launch of their own.  Same arguments as
+ * two segger_gatv2_fwd calls; falls back to two launches when the pair is not (group-per-row, wave-per-row) of one
+ * specialised geometry and storage type, or when attention weights are requested. */
+int segger_gatv2_fwd_pair(const segger_gatv2_fwd_args* a, const segger_gatv2_fwd_args* b, segger_stream_t stream);
 
 /*
  * Backward of the above (replaces autograd through the PyG ops).  Two atomic-free

@@ -174,6 +174,7 @@ EXPORTS = {
     "segger_linear_wgrad_dx_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "segger_l2norm_bwd2": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_float, vp, C.c_int64,
                                      C.c_int32, vp]),
+    "segger_gatv2_fwd_pair": (C.c_int, [vp, vp, vp]),
     "segger_pack_refresh": (C.c_int, [vp, C.c_int32, C.c_int32, vp]),
     "segger_dropout_bits_many": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_float, vp, vp]),
     "segger_step_advance": (C.c_int, [vp, C.c_int64, vp, vp]),

@@ -147,7 +147,9 @@ using namespace segger;
 
 #define CHECK_RC(expr) do { int _rc = (expr); if (_rc != SEGGER_OK) return _rc; } while (0)
 
-extern "C" int segger_gatv2_fwd(const segger_gatv2_fwd_args* a, segger_stream_t stream) {
+// argument checks + kernel parameters of one forward; *empty = nothing to launch
+static int fwd_params(const segger_gatv2_fwd_args* a, GatParams& p, bool* empty) {
+  *empty = false;
   SEGGER_REQUIRE(a != nullptr, "segger_gatv2_fwd: args is NULL");
   SEGGER_REQUIRE(a->heads > 0 && a->channels > 0, "segger_gatv2_fwd: heads/channels must be positive");
   const int hc = a->heads * a->channels;
@@ -156,7 +158,7 @@ extern "C" int segger_gatv2_fwd(const segger_gatv2_fwd_args* a, segger_stream_t 
   SEGGER_REQUIRE(a->att != nullptr, "segger_gatv2_fwd: att is NULL");
   SEGGER_REQUIRE(a->negative_slope >= 0.f && a->negative_slope <= 1.f, "segger_gatv2_fwd: negative_slope must be in [0,1]");
   SEGGER_REQUIRE(a->dropout_p >= 0.f && a->dropout_p < 1.f, "segger_gatv2_fwd: dropout_p must be in [0,1)");
-  if (a->by_dst.n_rows == 0) return SEGGER_OK;
+  if (a->by_dst.n_rows == 0) { *empty = true; return SEGGER_OK; }
   CHECK_RC(check_rows("x_r", a->x_r, a->ld_xr, a->dtype, hc));
   CHECK_RC(check_rows("out", a->out, a->ld_out, a->dtype, hc));
   if (a->by_dst.n_edges > 0) CHECK_RC(check_rows("x_l", a->x_l, a->ld_xl, a->dtype, hc));
@@ -166,7 +168,7 @@ extern "C" int segger_gatv2_fwd(const segger_gatv2_fwd_args* a, segger_stream_t 
   }
   SEGGER_REQUIRE(!((a->dropout_p > 0.f && !a->keep_bits) || a->alpha) || a->by_dst.n_edges == 0 || a->by_dst.eid != nullptr,
                  "segger_gatv2_fwd: by_dst.eid is required for dropout (without keep_bits) / alpha output");
-  GatParams p{};
+  p = GatParams{};
   p.indptr = a->by_dst.indptr; p.col = a->by_dst.col; p.eid = a->by_dst.eid; p.order = a->by_dst.row_order;
   p.n_rows = a->by_dst.n_rows; p.n_edges = a->by_dst.n_edges;
   p.xl = a->x_l; p.ld_xl = a->ld_xl; p.xr = a->x_r; p.ld_xr = a->ld_xr;
@@ -176,7 +178,39 @@ extern "C" int segger_gatv2_fwd(const segger_gatv2_fwd_args* a, segger_stream_t 
   p.bits = a->alpha ? nullptr : a->keep_bits;
   p.slope = a->negative_slope; p.apply_gelu = a->apply_gelu; p.rows_per_wave_iter = 1;
   set_dropout(p, a->dropout_p, a->seed, a->seed_dev);
+  return SEGGER_OK;
+}
+
+extern "C" int segger_gatv2_fwd(const segger_gatv2_fwd_args* a, segger_stream_t stream) {
+  GatParams p;
+  bool empty = false;
+  CHECK_RC(fwd_params(a, p, &empty));
+  if (empty) return SEGGER_OK;
   return launch(Pass::Fwd, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), (hipStream_t)stream);
+}
+
+extern "C" int segger_gatv2_fwd_pair(const segger_gatv2_fwd_args* a, const segger_gatv2_fwd_args* b, segger_stream_t stream) {
+  GatParams pa, pb;
+  bool ea = false, eb = false;
+  CHECK_RC(fwd_params(a, pa, &ea));
+  CHECK_RC(fwd_params(b, pb, &eb));
+  // one launch when `a` is a low-degree (group-per-row) and `b` a high-degree (wave-per-row) edge type of the same
+  // specialised geometry and storage type and neither asks for attention weights; otherwise two launches
+  const bool one = !ea && !eb && a->dtype == b->dtype && a->heads == b->heads && a->channels == b->channels &&
+                   gatv2_has_specialised(a->heads, a->channels) && !use_wave_per_row(a->by_dst) &&
+                   use_wave_per_row(b->by_dst) && !a->alpha && !b->alpha;
+  if (!one) {
+    if (!ea) CHECK_RC(launch(Pass::Fwd, pa, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), (hipStream_t)stream));
+    if (!eb) CHECK_RC(launch(Pass::Fwd, pb, b->dtype, b->heads, b->channels, use_wave_per_row(b->by_dst), (hipStream_t)stream));
+    return SEGGER_OK;
+  }
+  switch (a->dtype) {
+    case SEGGER_F32:  return gatv2_launch_fwd_pair_f32(pa, pb, a->heads, a->channels, (hipStream_t)stream);
+    case SEGGER_BF16: return gatv2_launch_fwd_pair_bf16(pa, pb, a->heads, a->channels, (hipStream_t)stream);
+    case SEGGER_F16:  return gatv2_launch_fwd_pair_f16(pa, pb, a->heads, a->channels, (hipStream_t)stream);
+  }
+  set_error("gatv2: unknown dtype %d", a->dtype);
+  return SEGGER_EINVAL;
 }
 
 extern "C" size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads, int32_t channels) {

@@ -62,7 +62,36 @@ int launch_one(GatParams& p, hipStream_t stream) {
   return SEGGER_OK;
 }
 
+#if SEGGER_INST_PASS == 0
+template <int H, int LPH>
+int launch_pair(GatParams& a, GatParams& b, hipStream_t stream) {
+  using G = Geo<H, LPH>;
+  a.nblocks = (a.n_rows + 4 * G::NG - 1) / (4 * G::NG);           // group-per-row
+  b.nblocks = (b.n_rows + 3) / 4;                                   // wave-per-row
+  a.nblocks_padded = pad_to_xcd(a.nblocks);
+  b.nblocks_padded = pad_to_xcd(b.nblocks);
+  const int64_t grid = a.nblocks_padded + b.nblocks_padded;
+  if (grid == 0) return SEGGER_OK;
+  if (grid > 0x7fffffffLL) { set_error("gatv2: too many blocks"); return SEGGER_EUNSUPPORTED; }
+  hipLaunchKernelGGL((gatv2_fwd_pair_kernel<INST_T, H, LPH>), dim3((unsigned)grid), dim3(256), 0, stream, a, b);
+  SEGGER_LAUNCH_CHECK("gatv2 pair launch");
+  return SEGGER_OK;
+}
+#endif
+
 }  // namespace
+
+#if SEGGER_INST_PASS == 0
+#define INST_PAIR_CAT2(a) gatv2_launch_fwd_pair_##a
+#define INST_PAIR_CAT(a) INST_PAIR_CAT2(a)
+int INST_PAIR_CAT(INST_TN)(GatParams& a, GatParams& b, int heads, int channels, hipStream_t stream) {
+#define X(H, LPH) if (heads == H && channels == LPH * 8) return launch_pair<H, LPH>(a, b, stream);
+  SEGGER_GEOMETRIES(X)
+#undef X
+  set_error("gatv2: heads=%d channels=%d has no specialised kernel", heads, channels);
+  return SEGGER_EUNSUPPORTED;
+}
+#endif
 
 int INST_NAME(GatParams& p, int heads, int channels, bool wpr, hipStream_t stream) {
 #define X(H, LPH)                                      \

@@ -296,10 +296,10 @@ __device__ __forceinline__ void load_att(const float* att, int ch0, float slope,
 // Forward
 // ============================================================================
 template <typename T, int H, int LPH, bool WPR>
-__global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatParams p) {
+__device__ __forceinline__ void gatv2_fwd_body(const GatParams& p, int64_t bid) {
   using G = Geo<H, LPH>;
   constexpr int GS = G::GS, NG = G::NG, U = SEGGER_FWD_UNROLL < GS ? SEGGER_FWD_UNROLL : GS;
-  const int64_t blk = xcd_remap(blockIdx.x, p.nblocks_padded, p.nblocks);
+  const int64_t blk = xcd_remap(bid, p.nblocks_padded, p.nblocks);
   if (blk < 0) return;
   const LaneGeo L = lane_geo<G>();
   const int h = L.h, ch0 = L.ch0;
@@ -430,6 +430,21 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
       p.alpha[id * H + h] = a;
     }
   }
+}
+
+template <typename T, int H, int LPH, bool WPR>
+__global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatParams p) {
+  gatv2_fwd_body<T, H, LPH, WPR>(p, blockIdx.x);
+}
+
+// Two edge types of one hetero layer in ONE launch: the blocks of `b` (wave-per-row: tx-belongs-bd, a few thousand short
+// latency-bound blocks) are dispatched first and run beside the blocks of `a` (group-per-row: tx-neighbors-tx) instead
+// of as a 30 us launch of their own.  b.nblocks_padded is a multiple of the XCD count, so the XCD-contiguous block map of
+// `a` is unchanged.
+template <typename T, int H, int LPH>
+__global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_pair_kernel(GatParams a, GatParams b) {
+  if ((int64_t)blockIdx.x < b.nblocks_padded) gatv2_fwd_body<T, H, LPH, true>(b, blockIdx.x);
+  else gatv2_fwd_body<T, H, LPH, false>(a, (int64_t)blockIdx.x - b.nblocks_padded);
 }
 
 // ============================================================================

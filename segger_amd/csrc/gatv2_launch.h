@@ -35,6 +35,10 @@ SEGGER_DECL_LAUNCH(gatv2_launch_bwd_src_f32)
 SEGGER_DECL_LAUNCH(gatv2_launch_bwd_src_bf16)
 SEGGER_DECL_LAUNCH(gatv2_launch_bwd_src_f16)
 #undef SEGGER_DECL_LAUNCH
+// forward of two edge types in one launch: `a` group-per-row, `b` wave-per-row (gatv2_fwd_pair_kernel)
+int gatv2_launch_fwd_pair_f32(GatParams& a, GatParams& b, int heads, int channels, hipStream_t stream);
+int gatv2_launch_fwd_pair_bf16(GatParams& a, GatParams& b, int heads, int channels, hipStream_t stream);
+int gatv2_launch_fwd_pair_f16(GatParams& a, GatParams& b, int heads, int channels, hipStream_t stream);
 
 // any other (heads, channels <= 512): one wave per row, element loads (gatv2_generic.hip)
 bool gatv2_has_specialised(int heads, int channels);
