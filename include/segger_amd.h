@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEGGER_ABI_VERSION 13
+#define SEGGER_ABI_VERSION 14
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -220,6 +220,15 @@ typedef struct segger_gatv2_bwd_args {
 
 size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads, int32_t channels);
 int segger_gatv2_bwd(const segger_gatv2_bwd_args* args, segger_stream_t stream);
+/* The backward of both edge types of one HeteroConv layer (ist_encoder.py:109-134 under autograd): `a` a two-pass edge
+ * type (tx-neighbors-tx), `b` a one-pass one (src_unique: tx-belongs-bd) whose grad_xl is the matrix `a` zero-fills
+ * (a->zero_rows_out == b->grad_xl with b->grad_xl_zeroed set, or neither set).  Same results as segger_gatv2_bwd(a)
+ * followed by segger_gatv2_bwd(b).  For batches of at most SEGGER_BWD_PAIR_MAX_ROWS source nodes (environment
+ * override of the same name, read once) of one specialised geometry and storage type, with a's destinations and b's
+ * sources indexing the same nodes, the zero fill moves into a's DESTINATION pass and a's source pass shares ONE launch
+ * with b's destination pass (b's few hundred latency-bound blocks run beside a's); otherwise the two calls run as they
+ * are. */
+int segger_gatv2_bwd_pair(const segger_gatv2_bwd_args* a, const segger_gatv2_bwd_args* b, segger_stream_t stream);
 /*
  * segger_dropout_bits: the attention-dropout mask of n_seeds layers as bit planes over the slots of one CSR view:
  *   bits[l * plane_stride + slot] = sum_h keep(eid[slot], h; seeds[l] + *seed_dev) << h        (heads <= 8)

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
@@ -175,6 +175,7 @@ EXPORTS = {
     "segger_l2norm_bwd2": (C.c_int, [vp, C.c_int64, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_float, vp, C.c_int64,
                                      C.c_int32, vp]),
     "segger_gatv2_fwd_pair": (C.c_int, [vp, vp, vp]),
+    "segger_gatv2_bwd_pair": (C.c_int, [vp, vp, vp]),
     "segger_pack_refresh": (C.c_int, [vp, C.c_int32, C.c_int32, vp]),
     "segger_dropout_bits_many": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_float, vp, vp]),
     "segger_step_advance": (C.c_int, [vp, C.c_int64, vp, vp]),

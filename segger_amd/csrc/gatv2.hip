@@ -221,8 +221,16 @@ extern "C" size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads,
   return (size_t)(blocks + kSlabSplits) * 2 * heads * channels * sizeof(float);
 }
 
-extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+// ---- backward in phases (shared by segger_gatv2_bwd and segger_gatv2_bwd_pair) ------------------------------
+namespace {
+struct BwdState {
+  GatParams p;
+  bool direct = false, specialised = false;
+  int64_t n_dst = 0, n_src = 0, n_edges = 0;
+};
+
+// argument checks + the parameters both passes share
+int bwd_prepare(const segger_gatv2_bwd_args* a, BwdState& s) {
   SEGGER_REQUIRE(a != nullptr, "segger_gatv2_bwd: args is NULL");
   SEGGER_REQUIRE(a->heads > 0 && a->channels > 0, "segger_gatv2_bwd: heads/channels must be positive");
   const int hc = a->heads * a->channels;
@@ -260,8 +268,13 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
     set_error("segger_gatv2_bwd: workspace %zu < %zu bytes", a->workspace_bytes, need);
     return SEGGER_EWORKSPACE;
   }
+  SEGGER_REQUIRE(!a->zero_rows_out || (!direct && specialised),
+                 "segger_gatv2_bwd: zero_rows_out needs the two-pass backward of a specialised geometry");
+  if (a->zero_rows_out && n_src > 0) CHECK_RC(check_rows("zero_rows_out", a->zero_rows_out, a->ld_zero, a->dtype, hc));
 
-  GatParams p{};
+  s.direct = direct; s.specialised = specialised; s.n_dst = n_dst; s.n_src = n_src; s.n_edges = n_edges;
+  GatParams& p = s.p;
+  p = GatParams{};
   p.xl = a->x_l; p.ld_xl = a->ld_xl; p.xr = a->x_r; p.ld_xr = a->ld_xr;
   p.att = a->att; p.bias = a->bias;
   p.pre = const_cast<void*>(a->pre); p.ld_pre = a->ld_pre; p.lse = const_cast<float*>(a->lse);
@@ -270,52 +283,129 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
   p.slab = static_cast<float*>(a->workspace);
   p.slope = a->negative_slope; p.apply_gelu = a->apply_gelu;
   set_dropout(p, a->dropout_p, a->seed, a->seed_dev);
+  return SEGGER_OK;
+}
 
-  // ---- destination side ------------------------------------------------------
+// parameters of the destination-side pass (rows = destinations)
+void bwd_dst_params(const segger_gatv2_bwd_args* a, BwdState& s) {
+  GatParams& p = s.p;
   p.indptr = a->by_dst.indptr; p.col = a->by_dst.col; p.eid = a->by_dst.eid; p.order = a->by_dst.row_order;
-  p.n_rows = n_dst; p.n_edges = n_edges; p.rows_per_wave_iter = bwd_row_iters(n_dst);
+  p.n_rows = s.n_dst; p.n_edges = s.n_edges; p.rows_per_wave_iter = bwd_row_iters(s.n_dst);
   p.bits = a->keep_bits_dst;
-  p.direct_gxl = direct ? 1 : 0;
-  SEGGER_REQUIRE(!a->zero_rows_out || (!direct && specialised),
-                 "segger_gatv2_bwd: zero_rows_out needs the two-pass backward of a specialised geometry");
-  if (a->zero_rows_out && n_src > 0) CHECK_RC(check_rows("zero_rows_out", a->zero_rows_out, a->ld_zero, a->dtype, hc));
-  if (direct && n_src > 0 && !a->grad_xl_zeroed) {
-    // sources without an out-edge keep a zero gradient; the others are stored by the destination pass
-    // (rows are 16-byte aligned multiples of 16 bytes: checked above.  hipMemset2DAsync measured 0.19 ms for
-    // 1M x 256 B at pitch 768; this kernel 0.05 ms)
-    const size_t es = elem_size(a->dtype);
-    const int64_t pieces = (int64_t)hc * es / 16, total = n_src * pieces;
-    hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-                       static_cast<char*>(a->grad_xl), (int64_t)a->ld_gxl * (int64_t)es, pieces, total);
-    SEGGER_LAUNCH_CHECK("zero_rows_kernel");
-  }
-  if (n_dst > 0) {
-    GenericOut gen; gen.grad_att = a->grad_att; gen.grad_bias = a->grad_bias;
-    CHECK_RC(launch(Pass::BwdDst, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), stream, gen));
-    if (specialised) {
-    const int width = 2 * hc;
-    if (!defer_reduce(ReduceSeg{p.slab, p.nblocks, width, hc, a->grad_att, a->grad_bias, p.slab + p.nblocks * width})) {
-    float* part = p.slab + p.nblocks * width;          // behind the per-block slabs
-    hipLaunchKernelGGL(slab_reduce_stage1, dim3((width + 63) / 64, kSlabSplits), dim3(256), 0, stream,
-                       p.slab, p.nblocks, width, part);
-    hipLaunchKernelGGL(slab_reduce_stage2, dim3((width + 255) / 256), dim3(256), 0, stream,
-                       part, width, hc, a->grad_att, a->grad_bias);
-    SEGGER_LAUNCH_CHECK("slab_reduce kernels");
-    }
-    }
-  } else {
-    SEGGER_HIP(hipMemsetAsync(a->grad_att, 0, hc * sizeof(float), stream));
-    if (a->grad_bias) SEGGER_HIP(hipMemsetAsync(a->grad_bias, 0, hc * sizeof(float), stream));
-  }
-  // ---- source side -----------------------------------------------------------
-  if (direct) return SEGGER_OK;
+  p.direct_gxl = s.direct ? 1 : 0;
+  p.zero_rows = nullptr; p.ld_zero = 0;
+}
+
+// parameters of the source-side pass (rows = sources)
+void bwd_src_params(const segger_gatv2_bwd_args* a, BwdState& s) {
+  GatParams& p = s.p;
   p.direct_gxl = 0;
   p.indptr = a->by_src.indptr; p.col = a->by_src.col; p.eid = a->by_src.eid; p.order = a->by_src.row_order;
   p.bits = a->keep_bits_src;
-  p.n_rows = n_src; p.rows_per_wave_iter = 1;
+  p.n_rows = s.n_src; p.rows_per_wave_iter = 1;
   p.zero_rows = a->zero_rows_out; p.ld_zero = a->ld_zero;
-  if (n_src > 0) CHECK_RC(launch(Pass::BwdSrc, p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_src), stream));
+}
+
+// the one-pass form's own zero fill: sources without an out-edge keep a zero gradient, the others are stored by the
+// destination pass (rows are 16-byte aligned multiples of 16 bytes: checked above.  hipMemset2DAsync measured 0.19 ms
+// for 1M x 256 B at pitch 768; this kernel 0.05 ms)
+int bwd_zero_fill(const segger_gatv2_bwd_args* a, const BwdState& s, hipStream_t stream) {
+  const size_t es = elem_size(a->dtype);
+  const int64_t pieces = (int64_t)a->heads * a->channels * es / 16, total = s.n_src * pieces;
+  hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                     static_cast<char*>(a->grad_xl), (int64_t)a->ld_gxl * (int64_t)es, pieces, total);
+  SEGGER_LAUNCH_CHECK("zero_rows_kernel");
   return SEGGER_OK;
+}
+
+// grad_att / grad_bias from the per-block slabs a destination pass (s.p still holds its block count) left behind
+int bwd_reduce_slab(const segger_gatv2_bwd_args* a, const BwdState& s, hipStream_t stream) {
+  if (!s.specialised) return SEGGER_OK;                   // the generic kernels write grad_att / grad_bias themselves
+  const GatParams& p = s.p;
+  const int hc = a->heads * a->channels, width = 2 * hc;
+  float* part = p.slab + p.nblocks * width;              // behind the per-block slabs
+  if (defer_reduce(ReduceSeg{p.slab, p.nblocks, width, hc, a->grad_att, a->grad_bias, part})) return SEGGER_OK;
+  hipLaunchKernelGGL(slab_reduce_stage1, dim3((width + 63) / 64, kSlabSplits), dim3(256), 0, stream,
+                     p.slab, p.nblocks, width, part);
+  hipLaunchKernelGGL(slab_reduce_stage2, dim3((width + 255) / 256), dim3(256), 0, stream,
+                     part, width, hc, a->grad_att, a->grad_bias);
+  SEGGER_LAUNCH_CHECK("slab_reduce kernels");
+  return SEGGER_OK;
+}
+
+int bwd_no_destinations(const segger_gatv2_bwd_args* a, hipStream_t stream) {
+  const int hc = a->heads * a->channels;
+  SEGGER_HIP(hipMemsetAsync(a->grad_att, 0, hc * sizeof(float), stream));
+  if (a->grad_bias) SEGGER_HIP(hipMemsetAsync(a->grad_bias, 0, hc * sizeof(float), stream));
+  return SEGGER_OK;
+}
+
+// largest tx-neighbors-tx source count for which segger_gatv2_bwd_pair merges the launches (what it saves is a fixed
+// ~5 us per layer: the launch of a kernel that is latency-bound at these sizes)
+int64_t bwd_pair_max_rows() {
+  static const int64_t v = [] {
+    const char* e = getenv("SEGGER_BWD_PAIR_MAX_ROWS");
+    return e ? (int64_t)atoll(e) : (int64_t)SEGGER_BWD_PAIR_MAX_ROWS;
+  }();
+  return v;
+}
+}  // namespace
+
+extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BwdState s;
+  CHECK_RC(bwd_prepare(a, s));
+  // ---- destination side ------------------------------------------------------
+  bwd_dst_params(a, s);
+  if (s.direct && s.n_src > 0 && !a->grad_xl_zeroed) CHECK_RC(bwd_zero_fill(a, s, stream));
+  if (s.n_dst > 0) {
+    GenericOut gen; gen.grad_att = a->grad_att; gen.grad_bias = a->grad_bias;
+    CHECK_RC(launch(Pass::BwdDst, s.p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), stream, gen));
+    CHECK_RC(bwd_reduce_slab(a, s, stream));
+  } else {
+    CHECK_RC(bwd_no_destinations(a, stream));
+  }
+  // ---- source side -----------------------------------------------------------
+  if (s.direct) return SEGGER_OK;
+  bwd_src_params(a, s);
+  if (s.n_src > 0) CHECK_RC(launch(Pass::BwdSrc, s.p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_src), stream));
+  return SEGGER_OK;
+}
+
+extern "C" int segger_gatv2_bwd_pair(const segger_gatv2_bwd_args* a, const segger_gatv2_bwd_args* b, segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  BwdState sa, sb;
+  CHECK_RC(bwd_prepare(a, sa));
+  CHECK_RC(bwd_prepare(b, sb));
+  // one launch for a's source pass and b's one-pass destination pass when: a is a two-pass, group-per-row edge type
+  // and b a one-pass, wave-per-row one of the same specialised geometry and storage type; both non-empty; b's grad_xl
+  // is the matrix a was asked to zero-fill (or a was asked for none and b's is not zeroed yet) and a's destinations
+  // index the same nodes as b's sources -- a's DESTINATION pass then zero-fills it, since its source pass now runs
+  // beside b's stores; and the batch is small enough for the merger to pay (bwd_pair_max_rows)
+  const bool zero_by_a = a->zero_rows_out ? (a->zero_rows_out == b->grad_xl && a->ld_zero == b->ld_gxl && b->grad_xl_zeroed)
+                                          : !b->grad_xl_zeroed;
+  const bool one = !sa.direct && sb.direct && a->dtype == b->dtype && a->heads == b->heads && a->channels == b->channels &&
+                   sa.specialised && sa.n_dst > 0 && sa.n_src > 0 && sb.n_dst > 0 && sb.n_src > 0 && sa.n_dst == sb.n_src &&
+                   !use_wave_per_row(a->by_dst) && !use_wave_per_row(a->by_src) && use_wave_per_row(b->by_dst) &&
+                   zero_by_a && sa.n_src <= bwd_pair_max_rows();
+  if (!one) {
+    CHECK_RC(segger_gatv2_bwd(a, stream_));
+    return segger_gatv2_bwd(b, stream_);
+  }
+  bwd_dst_params(a, sa);
+  sa.p.zero_rows = b->grad_xl; sa.p.ld_zero = b->ld_gxl;
+  CHECK_RC(launch(Pass::BwdDst, sa.p, a->dtype, a->heads, a->channels, false, stream));
+  CHECK_RC(bwd_reduce_slab(a, sa, stream));
+  bwd_src_params(a, sa);
+  sa.p.zero_rows = nullptr; sa.p.ld_zero = 0;
+  bwd_dst_params(b, sb);
+  switch (a->dtype) {
+    case SEGGER_F32:  CHECK_RC(gatv2_launch_bwd_src_dst_pair_f32(sa.p, sb.p, a->heads, a->channels, stream)); break;
+    case SEGGER_BF16: CHECK_RC(gatv2_launch_bwd_src_dst_pair_bf16(sa.p, sb.p, a->heads, a->channels, stream)); break;
+    case SEGGER_F16:  CHECK_RC(gatv2_launch_bwd_src_dst_pair_f16(sa.p, sb.p, a->heads, a->channels, stream)); break;
+    default: set_error("gatv2: unknown dtype %d", a->dtype); return SEGGER_EINVAL;
+  }
+  return bwd_reduce_slab(b, sb, stream);
 }
 
 extern "C" int segger_gatv2_has_specialised(int32_t heads, int32_t channels) {

@@ -81,6 +81,35 @@ int launch_pair(GatParams& a, GatParams& b, hipStream_t stream) {
 
 }  // namespace
 
+#if SEGGER_INST_PASS == 2
+namespace {
+template <int H, int LPH>
+int launch_src_dst_pair(GatParams& a, GatParams& b, hipStream_t stream) {
+  using G = Geo<H, LPH>;
+  a.nblocks = (a.n_rows + 4 * G::NG - 1) / (4 * G::NG);           // source pass, group-per-row, one row batch per wave
+  const int64_t per_b = 4 * (int64_t)b.rows_per_wave_iter;        // one-pass destination pass, wave-per-row
+  b.nblocks = (b.n_rows + per_b - 1) / per_b;
+  a.nblocks_padded = pad_to_xcd(a.nblocks);
+  b.nblocks_padded = pad_to_xcd(b.nblocks);
+  const int64_t grid = a.nblocks_padded + b.nblocks_padded;
+  if (grid == 0) return SEGGER_OK;
+  if (grid > 0x7fffffffLL) { set_error("gatv2: too many blocks"); return SEGGER_EUNSUPPORTED; }
+  hipLaunchKernelGGL((gatv2_bwd_src_dst_pair_kernel<INST_T, H, LPH>), dim3((unsigned)grid), dim3(256), 0, stream, a, b);
+  SEGGER_LAUNCH_CHECK("gatv2 backward pair launch");
+  return SEGGER_OK;
+}
+}  // namespace
+#define INST_BPAIR_CAT2(a) gatv2_launch_bwd_src_dst_pair_##a
+#define INST_BPAIR_CAT(a) INST_BPAIR_CAT2(a)
+int INST_BPAIR_CAT(INST_TN)(GatParams& a, GatParams& b, int heads, int channels, hipStream_t stream) {
+#define X(H, LPH) if (heads == H && channels == LPH * 8) return launch_src_dst_pair<H, LPH>(a, b, stream);
+  SEGGER_GEOMETRIES(X)
+#undef X
+  set_error("gatv2: heads=%d channels=%d has no specialised kernel", heads, channels);
+  return SEGGER_EUNSUPPORTED;
+}
+#endif
+
 #if SEGGER_INST_PASS == 0
 #define INST_PAIR_CAT2(a) gatv2_launch_fwd_pair_##a
 #define INST_PAIR_CAT(a) INST_PAIR_CAT2(a)

@@ -109,6 +109,13 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
+// The kernel bodies are functions (two of them can share a launch: gatv2_*_pair_kernel) and take the parameter block BY
+// VALUE: handed over by const reference the fp32 source pass came out of the register allocator 32 % slower (2.70 vs
+// 2.04 ms for the C2 backward pair, same instruction mix; tools/build_variant.sh A/B), by value all three storage types
+// match the bodies written directly into the kernels.
+#ifndef SEGGER_BODY_PARAM
+#define SEGGER_BODY_PARAM const GatParams
+#endif
 constexpr int kDppRowRor0 = 0x120;   // row_ror:n
 
 // Row walker shared by the three kernels.  Calls body(valid[U], nbr[U], eid[U])
@@ -296,7 +303,7 @@ __device__ __forceinline__ void load_att(const float* att, int ch0, float slope,
 // Forward
 // ============================================================================
 template <typename T, int H, int LPH, bool WPR>
-__device__ __forceinline__ void gatv2_fwd_body(const GatParams& p, int64_t bid) {
+__device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid) {
   using G = Geo<H, LPH>;
   constexpr int GS = G::GS, NG = G::NG, U = SEGGER_FWD_UNROLL < GS ? SEGGER_FWD_UNROLL : GS;
   const int64_t blk = xcd_remap(bid, p.nblocks_padded, p.nblocks);
@@ -459,14 +466,14 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_pair_kernel(G
 // boundary), so grad_xl[i] has a single term and this pass stores it itself -- no by-source view, no source pass.
 // The caller zero-fills grad_xl first (sources without an out-edge).
 // (the direct form keeps 8 more values per lane live: it is built for 2 waves per SIMD instead of spilling)
-template <typename T, int H, int LPH, bool WPR, bool DIRECT>
-__global__ __launch_bounds__(256, DIRECT ? 2 : SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kernel(GatParams p) {
+template <typename T, int H, int LPH, bool WPR, bool DIRECT, int UFORCE = 0>
+__device__ __forceinline__ void gatv2_bwd_dst_body(SEGGER_BODY_PARAM p, int64_t bid) {
   using G = Geo<H, LPH>;
   // 4 rows in flight measured -2.6 % on the flagship geometry (H = 2, group-per-row); the other variants would spill
-  constexpr int UD = ((!WPR && H == 2) || DIRECT) ? SEGGER_DST_UNROLL : 2;
+  constexpr int UD = UFORCE ? UFORCE : ((!WPR && H == 2) || DIRECT) ? SEGGER_DST_UNROLL : 2;
   constexpr int GS = G::GS, NG = G::NG, U = UD < GS ? UD : GS, HC = G::HC;
   __shared__ float red[4][2][HC];
-  const int64_t blk = xcd_remap(blockIdx.x, p.nblocks_padded, p.nblocks);
+  const int64_t blk = xcd_remap(bid, p.nblocks_padded, p.nblocks);
   if (blk < 0) return;
   const LaneGeo L = lane_geo<G>();
   const int h = L.h, ch0 = L.ch0;
@@ -523,6 +530,12 @@ __global__ __launch_bounds__(256, DIRECT ? 2 : SEGGER_BWD_DST_WAVES) void gatv2_
     D = lane_block_sum<LPH>(D);
     const bool writer = row_ok && L.lane_on && (!WPR || L.grp == 0);
     if (writer) {
+      if (p.zero_rows) {             // zero row of another matrix indexed by THESE rows (the pair form of the backward)
+        f32x2 z[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = splat(0.f);
+        store_pairs(static_cast<T*>(p.zero_rows) + row * p.ld_zero + ch0, z);
+      }
       store_pairs(static_cast<T*>(p.gpre) + row * p.ld_gp + ch0, g);
       if (head_leader)      // (lse, D) side by side: the source pass fetches both with one 8-byte load per (edge, head)
         *reinterpret_cast<float2*>(p.dsum + (row * H + h) * 2) = float2{lse, D};
@@ -628,15 +641,20 @@ __global__ __launch_bounds__(256, DIRECT ? 2 : SEGGER_BWD_DST_WAVES) void gatv2_
   }
 }
 
+template <typename T, int H, int LPH, bool WPR, bool DIRECT>
+__global__ __launch_bounds__(256, DIRECT ? 2 : SEGGER_BWD_DST_WAVES) void gatv2_bwd_dst_kernel(GatParams p) {
+  gatv2_bwd_dst_body<T, H, LPH, WPR, DIRECT>(p, blockIdx.x);
+}
+
 // ============================================================================
 // Backward, source side:  grad_xl   (rows = sources, col = destinations)
 //   grad_xl[i] = sum_j keep/(1-p) * a_ij * g[j]  +  att * (c1 * sum_j de_ij + c2 * sum_j de_ij * sgn(t_ij))
 // ============================================================================
 template <typename T, int H, int LPH, bool WPR>
-__global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kernel(GatParams p) {
+__device__ __forceinline__ void gatv2_bwd_src_body(SEGGER_BODY_PARAM p, int64_t bid) {
   using G = Geo<H, LPH>;
   constexpr int GS = G::GS, NG = G::NG, U = SEGGER_SRC_UNROLL < GS ? SEGGER_SRC_UNROLL : GS;
-  const int64_t blk = xcd_remap(blockIdx.x, p.nblocks_padded, p.nblocks);
+  const int64_t blk = xcd_remap(bid, p.nblocks_padded, p.nblocks);
   if (blk < 0) return;
   const LaneGeo L = lane_geo<G>();
   const int h = L.h, ch0 = L.ch0;
@@ -747,6 +765,22 @@ __global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kerne
       store_pairs(static_cast<T*>(p.zero_rows) + row * p.ld_zero + ch0, z);
     }
   }
+}
+
+template <typename T, int H, int LPH, bool WPR>
+__global__ __launch_bounds__(256, SEGGER_BWD_SRC_WAVES) void gatv2_bwd_src_kernel(GatParams p) {
+  gatv2_bwd_src_body<T, H, LPH, WPR>(p, blockIdx.x);
+}
+
+// The source pass of one edge type (`a`: tx-neighbors-tx, group-per-row) and the ONE-PASS destination pass of another
+// (`b`: tx-belongs-bd, wave-per-row, DIRECT) in one launch: b's few hundred latency-bound blocks go first and run beside
+// a's.  Built for the source pass's 3 waves per SIMD with the one-pass body at 2 rows in flight (it spills ~24 registers
+// there, which a 13 us kernel does not notice; at the one-pass form's own 2 waves per SIMD the merged launch measured
+// +0.5 % on the captured 1M-edge step, as built -1.6 %).  Used for small batches only (SEGGER_BWD_PAIR_MAX_ROWS).
+template <typename T, int H, int LPH>
+__global__ __launch_bounds__(256, 3) void gatv2_bwd_src_dst_pair_kernel(GatParams a, GatParams b) {
+  if ((int64_t)blockIdx.x < b.nblocks_padded) gatv2_bwd_dst_body<T, H, LPH, true, true, 2>(b, blockIdx.x);
+  else gatv2_bwd_src_body<T, H, LPH, false>(a, (int64_t)blockIdx.x - b.nblocks_padded);
 }
 
 }  // namespace segger

@@ -18,6 +18,11 @@ static inline int bwd_row_iters(int64_t n_rows) {
   return (int)(it < 1 ? 1 : (it > kBwdRowIters ? kBwdRowIters : it));
 }
 
+// segger_gatv2_bwd_pair merges launches up to this many source rows of the two-pass edge type
+#ifndef SEGGER_BWD_PAIR_MAX_ROWS
+#define SEGGER_BWD_PAIR_MAX_ROWS 262144
+#endif
+
 // (heads, channels/8) combinations with a specialised kernel
 #define SEGGER_GEOMETRIES(X) \
   X(1, 4) X(2, 4) X(3, 4) X(4, 4) \
@@ -39,6 +44,10 @@ SEGGER_DECL_LAUNCH(gatv2_launch_bwd_src_f16)
 int gatv2_launch_fwd_pair_f32(GatParams& a, GatParams& b, int heads, int channels, hipStream_t stream);
 int gatv2_launch_fwd_pair_bf16(GatParams& a, GatParams& b, int heads, int channels, hipStream_t stream);
 int gatv2_launch_fwd_pair_f16(GatParams& a, GatParams& b, int heads, int channels, hipStream_t stream);
+// source pass of `a` (group-per-row) + one-pass destination pass of `b` (wave-per-row, DIRECT) in one launch
+int gatv2_launch_bwd_src_dst_pair_f32(GatParams& a, GatParams& b, int heads, int channels, hipStream_t stream);
+int gatv2_launch_bwd_src_dst_pair_bf16(GatParams& a, GatParams& b, int heads, int channels, hipStream_t stream);
+int gatv2_launch_bwd_src_dst_pair_f16(GatParams& a, GatParams& b, int heads, int channels, hipStream_t stream);
 
 // any other (heads, channels <= 512): one wave per row, element loads (gatv2_generic.hip)
 bool gatv2_has_specialised(int heads, int channels);

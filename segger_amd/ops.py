@@ -167,6 +167,9 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
     _lib.check(rc, "segger_gatv2_fwd")
 
 
+_FWD_PAIR = 1                   # (0: always two segger_gatv2_fwd calls -- A/B switch of tools/bench_step.py)
+
+
 def gatv2_fwd_pair_launch(first: dict, second: dict) -> None:
     """Two forwards of one hetero layer in ONE launch (``segger_gatv2_fwd_pair``): ``first`` the low-degree edge type
     (tx-neighbors-tx), ``second`` the high-degree one (tx-belongs-bd); each a dict of :func:`gatv2_fwd_launch`'s
@@ -174,8 +177,12 @@ def gatv2_fwd_pair_launch(first: dict, second: dict) -> None:
     a, keep_a = _gat_fwd_args(**first)
     b, keep_b = _gat_fwd_args(**second)
     dev = first["xl"].device
+    lib = _lib.load()
     with _lib.on_device(dev):
-        rc = _lib.load().segger_gatv2_fwd_pair(C.byref(a), C.byref(b), _lib.stream_ptr(dev))
+        if _FWD_PAIR:
+            rc = lib.segger_gatv2_fwd_pair(C.byref(a), C.byref(b), _lib.stream_ptr(dev))
+        else:
+            rc = lib.segger_gatv2_fwd(C.byref(a), _lib.stream_ptr(dev)) or lib.segger_gatv2_fwd(C.byref(b), _lib.stream_ptr(dev))
     _lib.check(rc, "segger_gatv2_fwd_pair")
 
 
@@ -210,13 +217,47 @@ def _gat_fwd_args(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
 
 def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optional[Tensor],
                      heads: int, channels: int, grad_out: Tensor, pre: Tensor, lse: Tensor,
-                     grad_xl: Tensor, grad_xr: Tensor, *, apply_gelu: bool, negative_slope: float = 0.2,
-                     dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tuple] = None,
-                     zero_rows_out: Optional[Tensor] = None, grad_xl_zeroed: bool = False) -> Tuple[Tensor, Tensor]:
+                     grad_xl: Tensor, grad_xr: Tensor, **kw) -> Tuple[Tensor, Tensor]:
     """Writes grad_xl / grad_xr (views allowed); returns (grad_att[HC], grad_bias[HC]) fp32.  ``zero_rows_out``: a
     second [n_src, HC] matrix the source pass zero-fills on its way (ignored -> ``False`` comes back in
     ``gatv2_bwd_launch.zero_filled`` when this edge type runs the one-pass form or the generic kernels);
     ``grad_xl_zeroed``: the one-pass form may skip its own zero fill."""
+    a, gparams, keep = _gat_bwd_args(g, xl, xr, att, bias, heads, channels, grad_out, pre, lse, grad_xl, grad_xr, **kw)
+    with _lib.on_device(xl.device):
+        rc = _lib.load().segger_gatv2_bwd(C.byref(a), _lib.stream_ptr(xl.device))
+    _lib.check(rc, "segger_gatv2_bwd")
+    return gparams[0], gparams[1]
+
+
+_BWD_PAIR = 1                   # (0: always two segger_gatv2_bwd calls -- A/B switch of tools/ab_graphed.py)
+
+
+def gatv2_bwd_pair_launch(first: tuple, first_kw: dict, second: tuple, second_kw: dict):
+    """The backward of both edge types of one hetero layer through ``segger_gatv2_bwd_pair``: ``first`` the two-pass
+    edge type (tx-neighbors-tx), ``second`` the one-pass one (tx-belongs-bd), each the positional / keyword arguments
+    of :func:`gatv2_bwd_launch`.  ``second``'s ``grad_xl`` is the matrix ``first`` zero-fills (``zero_rows_out``); the
+    library merges the source pass of ``first`` with the destination pass of ``second`` for small batches and runs the
+    two backward passes one after the other otherwise.  -> ((grad_att, grad_bias) of first, of second)."""
+    a, gp_a, keep_a = _gat_bwd_args(*first, **first_kw)
+    zeroed = gatv2_bwd_launch.zero_filled
+    b, gp_b, keep_b = _gat_bwd_args(*second, grad_xl_zeroed=zeroed, **second_kw)
+    dev = first[1].device
+    lib = _lib.load()
+    with _lib.on_device(dev):
+        if _BWD_PAIR:
+            rc = lib.segger_gatv2_bwd_pair(C.byref(a), C.byref(b), _lib.stream_ptr(dev))
+        else:
+            rc = lib.segger_gatv2_bwd(C.byref(a), _lib.stream_ptr(dev)) or lib.segger_gatv2_bwd(C.byref(b), _lib.stream_ptr(dev))
+    _lib.check(rc, "segger_gatv2_bwd_pair")
+    return (gp_a[0], gp_a[1]), (gp_b[0], gp_b[1])
+
+
+def _gat_bwd_args(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optional[Tensor],
+                  heads: int, channels: int, grad_out: Tensor, pre: Tensor, lse: Tensor,
+                  grad_xl: Tensor, grad_xr: Tensor, *, apply_gelu: bool, negative_slope: float = 0.2,
+                  dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tuple] = None,
+                  zero_rows_out: Optional[Tensor] = None, grad_xl_zeroed: bool = False):
+    """-> (segger_gatv2_bwd_args, gparams [2, HC] fp32, the tensors the struct points at)."""
     _lib.require_cuda(xl, xr, grad_out)
     lib = _lib.load()
     hc = heads * channels
@@ -264,10 +305,7 @@ def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
     _defer_keep(ws, gparams)
-    with _lib.on_device(dev):
-        rc = lib.segger_gatv2_bwd(C.byref(a), _lib.stream_ptr(dev))
-    _lib.check(rc, "segger_gatv2_bwd")
-    return gparams[0], gparams[1]
+    return a, gparams, (vecs, grad_out, grad_pre, dsum, ws)
 
 
 class _GatV2Aggregate(torch.autograd.Function):
@@ -380,15 +418,16 @@ class _HeteroGatLayer(torch.autograd.Function):
         # the stacked projection gradient on the way, so the one-pass tx-belongs-bd backward needs no fill of its own.
         # (Running tx-belongs-bd on a second stream beside it was measured in round 3: the kernels do overlap, but the
         # small one then takes 10x longer and the big ones 3-7 % longer -- same total)
-        gatt_tt, gbias_tt = gatv2_bwd_launch(
-            g_tt, xp_tx[:, :hc], xp_tx[:, hc:2 * hc], att_tt, bias_tt, heads, channels, gy_tx, pre_tx, lse_tx,
-            gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc], apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tt,
-            keep_bits=ctx.bits[0], zero_rows_out=gxp_tx[:, 2 * hc:])
-        zeroed = gatv2_bwd_launch.zero_filled
-        gatt_tb, gbias_tb = gatv2_bwd_launch(
-            g_tb, xp_tx[:, 2 * hc:], xp_bd, att_tb, bias_tb, heads, channels, gy_bd, pre_bd, lse_bd,
-            gxp_tx[:, 2 * hc:], gxp_bd, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb,
-            keep_bits=ctx.bits[1], grad_xl_zeroed=zeroed)
+        # For small batches the library goes one step further (segger_gatv2_bwd_pair): the tx-neighbors-tx DESTINATION
+        # pass does the zero fill and its source pass shares a launch with the tx-belongs-bd pass.
+        (gatt_tt, gbias_tt), (gatt_tb, gbias_tb) = gatv2_bwd_pair_launch(
+            (g_tt, xp_tx[:, :hc], xp_tx[:, hc:2 * hc], att_tt, bias_tt, heads, channels, gy_tx, pre_tx, lse_tx,
+             gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc]),
+            dict(apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tt, keep_bits=ctx.bits[0],
+                 zero_rows_out=gxp_tx[:, 2 * hc:]),
+            (g_tb, xp_tx[:, 2 * hc:], xp_bd, att_tb, bias_tb, heads, channels, gy_bd, pre_bd, lse_bd,
+             gxp_tx[:, 2 * hc:], gxp_bd),
+            dict(apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb, keep_bits=ctx.bits[1]))
         r = lambda gt, ref: gt.reshape(ref.shape).to(ref.dtype) if ref is not None else None
         return (gxp_tx, gxp_bd, r(gatt_tt, att_tt), r(gbias_tt, bias_tt), r(gatt_tb, att_tb), r(gbias_tb, bias_tb),
                 None, None, None, None, None, None, None, None, None, None, None, None)

@@ -264,6 +264,81 @@ def test_unique_sources_need_no_by_source_view(oracle, cuda, dtype, H, C, n_src,
     assert not dup.src_unique() and dup.by_src is not None
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("H,C,n_tx,n_bd,k,frac", [(2, 64, 3000, 40, 6, 0.9), (2, 64, 900, 300, 5, 0.5), (4, 32, 700, 9, 4, 1.0),
+                                                  (1, 32, 500, 6, 3, 0.8), (5, 16, 300, 5, 4, 0.9)])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_hetero_layer_pair_launches_equal_single_edge_types(cuda, dtype, H, C, n_tx, n_bd, k, frac, p):
+    """One hetero layer (ist_encoder.py:109-134: tx-neighbors-tx + tx-belongs-bd) through the merged launches
+    (segger_gatv2_fwd_pair; segger_gatv2_bwd_pair: zero fill in the tx-neighbors-tx destination pass, its source pass in
+    one launch with the tx-belongs-bd pass) against the two edge types run one by one: the same kernels' bodies, so the
+    per-row results agree to the last bit or two; (900, 300) has too few transcripts per boundary for the wave-per-row form and
+    (5, 16) no specialised kernel -- both take the library's two-call route."""
+    from segger_amd import ops
+    from segger_amd.graph import build_edge_graph
+    g = torch.Generator().manual_seed(n_tx + k)
+    hc = H * C
+    dst = torch.arange(n_tx).repeat_interleave(k)
+    src = torch.randint(0, n_tx, (n_tx * k,), generator=g)
+    ei_tt = torch.stack([src, dst])
+    members = torch.randperm(n_tx, generator=g)[: int(frac * n_tx)]             # each transcript in at most one boundary
+    ei_tb = torch.stack([members, torch.randint(0, n_bd, (members.numel(),), generator=g)])
+    g_tt = build_edge_graph(ei_tt.to(cuda), n_tx, n_tx)
+    g_tb = build_edge_graph(ei_tb.to(cuda), n_tx, n_bd, need_by_src="lazy")
+    xp_tx = torch.randn(n_tx, 3 * hc, generator=g).to(dtype)
+    xp_bd = torch.randn(n_bd, hc, generator=g).to(dtype)
+    vec = lambda s_: torch.randn(hc, generator=g) * s_
+    att_tt, bias_tt, att_tb, bias_tb = vec(0.3), vec(0.1), vec(0.3), vec(0.1)
+    w_tx, w_bd = torch.randn(n_tx, hc, generator=g).to(cuda), torch.randn(n_bd, hc, generator=g).to(cuda)
+    bits_tt = bits_tb = None
+    if p > 0:
+        bits_tt = (ops.dropout_bits(g_tt.by_dst, H, p, [11])[0], ops.dropout_bits(g_tt.by_src, H, p, [11])[0])
+        bits_tb = (ops.dropout_bits(g_tb.by_dst, H, p, [12])[0], None)
+
+    def leaves():
+        return [t.to(cuda).requires_grad_(True) for t in (xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb)]
+
+    def merged():
+        L = leaves()
+        y_tx, y_bd, _ = ops.hetero_gat_layer(*L, g_tt, g_tb, H, C, dropout_p=p, seed_tt=11, seed_tb=12,
+                                             bits_tt=bits_tt, bits_tb=bits_tb)
+        ((y_tx.float() * w_tx).sum() + (y_bd.float() * w_bd).sum()).backward()
+        return [y_tx.detach(), y_bd.detach()] + [t.grad for t in L]
+
+    def one_by_one():
+        L = leaves()
+        xp, xb = L[0], L[1]
+        y_tx = ops.gatv2_aggregate(xp[:, :hc], xp[:, hc:2 * hc], L[2], L[3], g_tt, H, C, apply_gelu=True, dropout_p=p,
+                                   seed=11, keep_bits=bits_tt)
+        y_bd = ops.gatv2_aggregate(xp[:, 2 * hc:], xb, L[4], L[5], g_tb, H, C, apply_gelu=True, dropout_p=p, seed=12,
+                                   keep_bits=bits_tb)
+        ((y_tx.float() * w_tx).sum() + (y_bd.float() * w_bd).sum()).backward()
+        return [y_tx.detach(), y_bd.detach()] + [t.grad for t in L]
+
+    def rows_same(x, y, i):
+        # the merged backward builds the tx-belongs-bd pass at 2 rows in flight instead of 4: the compiler contracts /
+        # orders a few fp32 operations differently, so allow the last bit (fp32) or one rounding flip (16-bit storage)
+        rt = 2e-6 if dtype == torch.float32 else 2.0 ** -7
+        assert torch.allclose(x.float(), y.float(), rtol=rt, atol=rt * float(y.float().abs().max()) * 0.25 + 1e-9), \
+            f"tensor {i} differs: {(x.float() - y.float()).abs().max()}"
+
+    a, b = merged(), one_by_one()
+    for i, (x, y) in enumerate(zip(a[:2], b[:2])):            # outputs: the same kernel bodies
+        assert torch.equal(x, y), f"output {i} differs: {(x.float() - y.float()).abs().max()}"
+    for i, (x, y) in enumerate(zip(a[2:4], b[2:4])):          # the row gradients
+        rows_same(x, y, i)
+    for i, (x, y) in enumerate(zip(a[4:], b[4:])):            # att / bias gradients: block partials may regroup an fp32 sum
+        assert (x - y).abs().max() <= 1e-5 * y.abs().max() + 1e-5, f"parameter gradient {i}"
+    if ops._BWD_PAIR:                                         # and the switch really selects the two-call route
+        ops._BWD_PAIR = 0
+        try:
+            c = merged()
+        finally:
+            ops._BWD_PAIR = 1
+        for i, (x, y) in enumerate(zip(a[:4], c[:4])):
+            rows_same(x, y, i)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("H,C,n_src,n_dst,E", [(2, 64, 300, 257, 3000), (2, 64, 50, 7, 1500), (4, 32, 64, 40, 900), (3, 64, 90, 50, 400)])
 def test_dropout_bit_planes_equal_the_hash(cuda, dtype, H, C, n_src, n_dst, E):

@@ -1,4 +1,4 @@
-"""Times the three GATv2 kernels on the C2 tile (tx-neighbors-tx, bf16, H=2, C=64)."""
+"""Times the three GATv2 kernels on the C2 tile (tx-neighbors-tx, H=2, C=64; DTYPE=bf16|f16|f32)."""
 import sys, os, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from segger_amd import ops, TX_TX
@@ -19,13 +19,14 @@ g = build_edge_graph(ei, n, n)
 if os.environ.get('ORDER', '1') == '0':          # A/B of the degree-balanced visiting order
     g.by_dst.order = g.by_src.order = None
 H, C = 2, 64; hc = H * C
+dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[os.environ.get('DTYPE', 'bf16')]
 gen = torch.Generator(device=dev).manual_seed(0)
-xp = torch.randn(n, 3 * hc, device=dev, generator=gen).bfloat16()
+xp = torch.randn(n, 3 * hc, device=dev, generator=gen).to(dt)
 att = torch.randn(hc, device=dev, generator=gen) * 0.3
 bias = torch.zeros(hc, device=dev)
-out = torch.empty(n, hc, dtype=torch.bfloat16, device=dev); pre = torch.empty_like(out)
+out = torch.empty(n, hc, dtype=dt, device=dev); pre = torch.empty_like(out)
 lse = torch.empty(n, H, device=dev)
-gy = torch.randn(n, hc, device=dev, generator=gen).bfloat16(); gxp = torch.empty_like(xp)
+gy = torch.randn(n, hc, device=dev, generator=gen).to(dt); gxp = torch.empty_like(xp)
 p = float(os.environ.get('DROP', 0.0))
 bits = None
 if os.environ.get('BITS', '0') == '1' and p > 0:    # dropout mask as precomputed bit planes (ops.dropout_bits)
@@ -37,4 +38,4 @@ def t(fn, it=20):
     torch.cuda.synchronize(); a = torch.cuda.Event(True); e = torch.cuda.Event(True); a.record()
     for _ in range(it): fn()
     e.record(); torch.cuda.synchronize(); return a.elapsed_time(e) / it
-print(mode, os.path.basename(os.environ.get('SEGGER_AMD_LIB', 'default')), 'bits', os.environ.get('BITS', '0'), 'drop', p, 'fwd %.3f ms  bwd(dst+src) %.3f ms' % (t(fwd), t(bwd)), flush=True)
+print(os.environ.get('DTYPE', 'bf16'), mode, os.path.basename(os.environ.get('SEGGER_AMD_LIB', 'default')), 'bits', os.environ.get('BITS', '0'), 'drop', p, 'fwd %.3f ms  bwd(dst+src) %.3f ms' % (t(fwd), t(bwd)), flush=True)
