@@ -129,6 +129,54 @@ def test_graphed_trainer_replays_learn_and_draw_afresh(cuda):
     assert torch.isfinite(z["tx"].float()).all()
 
 
+def test_graphed_training_under_manual_optimisation(cuda):
+    """``LitISTEncoder.enable_graphed_training()``: ``training_step`` itself replays the captured step (Lightning's manual
+    optimisation: the trainer runs neither backward nor optimizer.step) -- driven here the way ``Trainer.fit`` drives a
+    module with ``automatic_optimization = False``; parameters and losses equal a ``GraphedTrainer`` used directly."""
+    import types
+    from segger_amd.synthetic import SyntheticSpec
+    from segger_amd.train_step_graph import GraphedTrainer
+    spec = SyntheticSpec(n_tx=20000, n_bd=600, k_tx=6, seed=41)
+    m, bg = _model(spec, cuda, torch.bfloat16)
+    twin, init = copy.deepcopy(m), copy.deepcopy(m)
+    # the reference's flow: Trainer.fit -> configure_optimizers -> training_step per batch
+    assert m.automatic_optimization
+    m.enable_graphed_training(granularity=1.5)
+    assert not m.automatic_optimization
+    opt = m.configure_optimizers()
+    assert all(g["capturable"] for g in opt.param_groups)
+    m.trainer = types.SimpleNamespace(optimizers=[opt], max_epochs=20, datamodule=None)
+    direct = GraphedTrainer(twin, twin.configure_optimizers(capturable=True), granularity=1.5)
+    for i in range(4):
+        loss = m.training_step(bg, i)
+        ref = direct.step(bg).clone()
+        # the first step is the same arithmetic on the same weights; later ones differ by the order of the loss
+        # gradients' atomic adds (and Adam turns a last-bit difference of a near-zero gradient into +-lr)
+        same = torch.equal if i == 0 else (lambda x, y: torch.allclose(x, y, rtol=2e-2, atol=1e-4))
+        assert loss.requires_grad is False and same(loss, ref[3])
+        for j, name in enumerate(("loss_tx", "loss_bd", "loss_sg")):
+            assert same(m.logged[f"train:{name}"], ref[j])
+    # (two GraphedTrainers on twins differ by ~1e-3 in up to a third of the near-zero-gradient parameters after four
+    # Adam steps: compare the distance between the twins with the distance travelled)
+    moved = apart = 0.0
+    with torch.no_grad():
+        for (k, a), (_, b), (_, c) in zip(m.named_parameters(), twin.named_parameters(), init.named_parameters()):
+            apart += float((a - b).abs().sum())
+            moved += float((a - c).abs().sum())
+    assert moved > 0.0 and apart < 0.3 * moved
+    assert float(opt.state[next(iter(m.parameters()))]["step"]) == 4.0
+    # switched on too late (the trainer already holds a non-capturable Adam): a clear error, not a capture failure
+    late = copy.deepcopy(twin)
+    late._graphed_trainer = None
+    late.trainer = types.SimpleNamespace(optimizers=[torch.optim.Adam(late.parameters(), lr=1e-3)], max_epochs=20)
+    late.enable_graphed_training()
+    with pytest.raises(RuntimeError, match="capturable"):
+        late.training_step(bg, 0)
+    # and off again: the eager step with autograd
+    late.enable_graphed_training(False)
+    assert late.automatic_optimization and late.training_step(bg, 0).requires_grad
+
+
 def test_graphed_step_degenerate_batches(cuda):
     """No tx-belongs-bd edge at all, and nothing inside the margin mask: the step must replay, report zero for the
     terms that have no triplets, and leave finite parameters."""
