@@ -136,8 +136,11 @@ __device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const 
   static_assert(GS % U == 0, "group size must be a multiple of the edge unroll");
   for (int64_t e0 = beg; e0 < end; e0 += CHUNK) {
     const int me = WPR ? lane : gl;
+    // slots of this chunk that hold an edge (32-bit: the per-slot validity tests are one v_cmp_lt_i32 each instead of a
+    // 64-bit add + compare)
+    const int rem = (int)(end - e0 < (int64_t)CHUNK ? end - e0 : (int64_t)CHUNK);
     int myc = 0, myeid = 0;
-    if (e0 + me < end) {
+    if (me < rem) {
       myc = col[e0 + me];
       if constexpr (META == kMetaEid) myeid = eid[e0 + me];
       if constexpr (META == kMetaBits) myeid = bits[e0 + me];
@@ -146,14 +149,13 @@ __device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const 
     for (int t = 0; t < GS; t += U) {
       // wave-per-row: uniform over the wave (end is); group-per-row: uniform over the group,
       // and every id a group reads lives in its own lanes
-      if ((WPR ? e0 + (int64_t)t * NG : e0 + t) >= end) break;
+      if ((WPR ? t * NG : t) >= rem) break;
       bool valid[U];
       int nbr[U], ed[U];
       static_for<U>([&](auto u_c) {
         constexpr int u = decltype(u_c)::value;
         const int T = t + u;
-        const int64_t e = WPR ? (e0 + (int64_t)T * NG + grp) : (e0 + T);
-        valid[u] = e < end;
+        valid[u] = (WPR ? T * NG + grp : T) < rem;
         if constexpr (kDpp) {
           nbr[u] = dpp_i<kDppRowBcast0 + u>(myc);
           ed[u] = NEED_EID ? dpp_i<kDppRowBcast0 + u>(myeid) : 0;
