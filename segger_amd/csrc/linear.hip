@@ -211,8 +211,134 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
   }
 }
 
+// ---- resident-W form for large row counts ----------------------------------------------------------------------
+// The chunked kernel above keeps four 128-row blocks per CU, each of which lives ~25 us for ~3 us of matrix work: two
+// barriers per 64-column chunk, W re-committed to LDS per chunk and block, the X fragments loaded with nothing to
+// overlap.  Bytes in flight per CU / block lifetime is what bounds it (4.3 TB/s of stores with the loads taken out,
+// 1.97 TB/s of loads with the stores taken out: `EXP_NOLOAD` / `EXP_NOSTORE` builds, round 3).  For n >= ~10^5 rows
+// and K * M small enough, ONE persistent workgroup per CU holds the whole W in LDS (384 x 128 bf16 = 102 KB with the
+// conflict-free row stride) and its 12 waves walk 32-row tiles on their own: no barrier after the W load, the next
+// tile's X fragments requested before the current tile's MFMAs, the epilogue tile wave-private.  NCH (chunks of 64
+// output columns) is a template parameter so that the chunk loop is straight-line code: the wait for the prefetched
+// X fragments is then vmcnt(4 * NCH) -- the tile's output stores stay in flight (gfx9 counts stores in vmcnt).
+constexpr int kResWaves = 12;
+constexpr int kResMaxOut = 384;
+
+template <typename T, int K, int NCH>
+__global__ __launch_bounds__(kResWaves * 64, 1) void linear_res_kernel(LinearParams p, int64_t n_tiles) {
+  constexpr int NK = K / 16;
+  constexpr int WSTRIDE = K * 2 + 16;
+  constexpr int ESTRIDE = kChunk * 2 + 16;
+  constexpr int M = NCH * kChunk;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[M * WSTRIDE + kResWaves * 32 * ESTRIDE];
+  __shared__ __attribute__((aligned(16))) float lds_bias[M];
+  unsigned char* lds_w = lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  unsigned char* et = lds + M * WSTRIDE + wave * 32 * ESTRIDE;
+  const T* __restrict__ x = static_cast<const T*>(p.x);
+  const T* __restrict__ w = static_cast<const T*>(p.w);
+  T* __restrict__ y = static_cast<T*>(p.y);
+
+  for (int piece = tid; piece < M * K / 8; piece += kResWaves * 64) {
+    const int wrow = piece / (K / 8), wcol = piece % (K / 8);
+    *reinterpret_cast<u32x4*>(lds_w + wrow * WSTRIDE + wcol * 16) = *reinterpret_cast<const u32x4*>(w + (int64_t)wrow * K + wcol * 8);
+  }
+  for (int i = tid; i < M; i += kResWaves * 64) lds_bias[i] = p.bias ? p.bias[i] : 0.f;
+  __syncthreads();
+
+  const int64_t stride = (int64_t)gridDim.x * kResWaves;
+  int64_t tile = (int64_t)blockIdx.x * kResWaves + wave;          // at any time the grid covers one contiguous run of tiles
+  const int64_t n_full = p.n_rows / 32;                           // tiles without a missing row
+
+  auto x_load = [&](u32x4 (&dst)[NK], int64_t t) {
+    int64_t row = t * 32 + r;
+    if (row >= p.n_rows) row = p.n_rows - 1;                      // clamp: loaded, never stored
+    const T* xr = x + row * p.ldx + 8 * h;
+#pragma unroll
+    for (int s = 0; s < NK; ++s) dst[s] = *reinterpret_cast<const u32x4*>(xr + 16 * s);
+  };
+
+  u32x4 xb[NK], xn[NK];
+  if (tile < n_tiles) x_load(xn, tile);
+
+  auto do_tile = [&](auto full_c, const int64_t t) {
+    constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+    for (int s = 0; s < NK; ++s) xb[s] = xn[s];
+    if (t + stride < n_tiles) x_load(xn, t + stride);             // under this tile's MFMAs
+    const int64_t row0 = t * 32;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int c0 = c * kChunk;
+      f32x16 acc[2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+      }
+#pragma unroll
+      for (int s = 0; s < NK; ++s) {
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const u32x4 a = *reinterpret_cast<const u32x4*>(lds_w + (c0 + ct * 32 + r) * WSTRIDE + (16 * s + 8 * h) * 2);
+          acc[ct] = Mfma<T>::run(a, xb[s], acc[ct]);
+        }
+      }
+      // epilogue through the wave's own LDS tile (LDS operations of one wave execute in order: no barrier)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int col = ct * 32 + 8 * g + 4 * h;
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(lds_bias + c0 + col);
+          uint2 pk;
+          pk.x = Vec8<T>::pack(acc[ct][4 * g + 0] + bv.x, acc[ct][4 * g + 1] + bv.y);
+          pk.y = Vec8<T>::pack(acc[ct][4 * g + 2] + bv.z, acc[ct][4 * g + 3] + bv.w);
+          *reinterpret_cast<uint2*>(et + r * ESTRIDE + col * 2) = pk;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int er = 8 * i + (lane >> 3), piece = lane & 7;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(et + er * ESTRIDE + piece * 16);
+        const int64_t row = row0 + er;
+        if (FULL || row < p.n_rows) *reinterpret_cast<u32x4*>(y + row * p.ldy + c0 + piece * 8) = v;
+      }
+    }
+  };
+  // full tiles: unconditional stores (events the wait-count analysis can count on); the one partial tile afterwards
+#pragma unroll 1
+  for (; tile < n_full; tile += stride) do_tile(std::true_type{}, tile);
+  if (tile < n_tiles) do_tile(std::false_type{}, tile);
+}
+
+template <typename T>
+int launch_linear_res(const LinearParams& p, int k_in, hipStream_t stream, bool* done) {
+  *done = false;
+  static const int n_cu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n;
+  }();
+  const int64_t n_tiles = (p.n_rows + 31) / 32;
+  // worth it only when every wave of the persistent grid gets a few tiles
+  if (n_cu <= 0 || p.rowbias || p.gate || n_tiles < (int64_t)n_cu * kResWaves * 2) return SEGGER_OK;
+  dim3 grid((unsigned)n_cu), block(kResWaves * 64);
+#define RES_CASE(KK, NN) \
+  if (k_in == KK && p.m_out == NN * kChunk) { \
+    hipLaunchKernelGGL((linear_res_kernel<T, KK, NN>), grid, block, 0, stream, p, n_tiles); \
+    SEGGER_LAUNCH_CHECK("linear_res_kernel"); *done = true; return SEGGER_OK; }
+  RES_CASE(128, 6) RES_CASE(128, 2) RES_CASE(128, 1) RES_CASE(64, 6) RES_CASE(64, 2) RES_CASE(64, 1)
+#undef RES_CASE
+  return SEGGER_OK;
+}
+
 template <typename T>
 int launch_linear(const LinearParams& p, int k_in, hipStream_t stream) {
+  bool done = false;
+  const int rc = launch_linear_res<T>(p, k_in, stream, &done);
+  if (rc != SEGGER_OK || done) return rc;
   const int64_t nb = (p.n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
   if (nb > 0x7fffffffLL) { set_error("segger_linear_fwd: too many rows"); return SEGGER_EUNSUPPORTED; }
   dim3 grid((unsigned)nb), block(256);

@@ -24,6 +24,32 @@ def test_linear_forward(cuda, dtype, k, m, n):
     assert ((y.float() - ref).abs() <= rel * ref.abs() + 1e-3).all()
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("k,m", [(128, 384), (128, 128), (128, 64), (64, 384), (64, 64)])
+@pytest.mark.parametrize("n", [262_144, 300_007])          # >= 2 tiles per wave of the persistent grid; 300007: partial last tile
+def test_linear_forward_resident_weights(cuda, dtype, k, m, n):
+    """Large row counts take the persistent resident-W kernel (linear_res_kernel): same arithmetic as the chunked kernel
+    -- checked bit for bit against small-n launches over slices, which take the chunked one -- with and without
+    bias, on a strided input view, rows behind the output intact."""
+    from segger_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(n + k + m)
+    big = torch.randn(n, k + 64, device=cuda, generator=g).to(dtype)
+    x = big[:, 64:]                                        # row stride k + 64
+    w = (torch.randn(m, k, device=cuda, generator=g) / k ** 0.5).to(dtype)
+    b = torch.randn(m, device=cuda, generator=g)
+    guard = torch.full((n + 64, m), 7.0, device=cuda, dtype=dtype)        # rows behind the output must stay untouched
+    y = ops.linear_fwd_launch(x, w, b, out=guard[:n])
+    assert torch.equal(guard[n:], torch.full((64, m), 7.0, device=cuda, dtype=dtype))
+    ref = x.float() @ w.float().t() + b
+    rel = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -10
+    assert ((y.float() - ref).abs() <= rel * ref.abs() + 1e-3).all()
+    for lo in (0, 131_072 + 17, n - 5000):                 # chunked kernel on slices (n < the persistent threshold)
+        sl = slice(lo, lo + 5000)
+        assert torch.equal(ops.linear_fwd_launch(x[sl], w, b), y[sl])
+    y0 = ops.linear_fwd_launch(x, w, None)
+    assert torch.equal(ops.linear_fwd_launch(x[-4133:], w, None), y0[-4133:])
+
+
 @pytest.mark.parametrize("k,m", [(64, 64), (128, 64), (128, 384), (256, 384), (384, 256), (384, 128), (256, 64), (64, 128)])
 @pytest.mark.parametrize("n", [1, 127, 128, 1000, 4133])
 def test_linear_forward_fp32(cuda, k, m, n):
