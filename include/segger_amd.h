@@ -504,7 +504,9 @@ int segger_segment_minmax(const float* pos, const int64_t* batch, int64_t n, int
  * Replaces the cuBLAS GEMMs behind PyG's Linear for GATv2Conv.lin_l / lin_r
  * (constructed at src/segger/models/ist_encoder.py:111-124), HeteroDictLinear
  * (ist_encoder.py:282-286,328) and, called with w = W^T, their data gradients.
- * Every workgroup owns 128 rows and ALL m_out columns, so x is read from HBM once.
+ * Every workgroup owns 128 rows and ALL m_out columns, so x is read from HBM once.  From ~2*10^5 rows on, for
+ * k_in in {64, 128} and m_out in {64, 128, 384}, one persistent workgroup per CU keeps the whole w in LDS and its waves
+ * walk 32-row tiles independently (same arithmetic, bit-identical results).
  *   dtype: SEGGER_BF16 / SEGGER_F16 (x, w, y); bias fp32 or NULL; fp32 accumulation.
  *   k_in in {64, 128, 256, 384}; m_out a multiple of 64; w contiguous [m_out, k_in].
  * segger_linear_supported() tells the host whether a shape is covered (others go to
