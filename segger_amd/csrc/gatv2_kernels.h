@@ -174,6 +174,98 @@ __device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const 
   }
 }
 
+// The same walk with the gathers of batch t + 1 issued BEFORE the arithmetic of batch t (two register buffers, the
+// batch loop unrolled by two so that the buffer index is a compile-time constant).  issue(buf, nbr[U]) starts the
+// gathers of a batch into buffer `buf`; compute(buf, meta, valid[U], ed[U]) consumes it.  The prefetch is
+// unconditional straight-line code: behind the last batch of a chunk it fetches rows the batch does not use (ids past
+// the row's end are 0 or ids of the same chunk: valid rows, cache hits) -- a conditional load would be an event the
+// compiler's wait-count analysis cannot count on, and the wait for the current buffer would become vmcnt(0), i.e. wait
+// for the prefetch as well.  Why: every row has the same length, so the waves of a CU run in phase -- all issue their
+// gathers, all wait for the texture addresser to work through them (~16 cycles per 1-KB gather, ~1000 cycles per
+// round and CU), all compute.  With the gathers compiled out the forward takes 0.50 ms instead of 0.66, with every
+// gather an L1 hit (`GRAPH=band`) still 0.655: it is this serialisation, not latency, that the prefetch overlaps.
+template <int GS, bool WPR, int META, int U, typename Issue, typename Compute>
+__device__ __forceinline__ void walk_row_prefetch(const int32_t* __restrict__ col, const void* __restrict__ meta,
+                                                  int64_t beg, int64_t end, int lane, int grp, int gl,
+                                                  Issue&& issue, Compute&& compute) {
+  constexpr bool NEED_EID = META != kMetaNone;
+  const int32_t* __restrict__ eid = static_cast<const int32_t*>(meta);
+  const uint8_t* __restrict__ bits = static_cast<const uint8_t*>(meta);
+  constexpr int NG = 64 / GS;
+  constexpr int CHUNK = WPR ? 64 : GS;
+  constexpr bool kDpp = !WPR && GS == 16 && 2 * U <= 16;
+  static_assert(GS % U == 0, "group size must be a multiple of the edge unroll");
+  using B0 = std::integral_constant<int, 0>;
+  using B1 = std::integral_constant<int, 1>;
+  for (int64_t e0 = beg; e0 < end; e0 += CHUNK) {
+    const int me = WPR ? lane : gl;
+    const int rem = (int)(end - e0 < (int64_t)CHUNK ? end - e0 : (int64_t)CHUNK);
+    int myc = 0, myeid = 0;
+    if (me < rem) {
+      myc = col[e0 + me];
+      if constexpr (META == kMetaEid) myeid = eid[e0 + me];
+      if constexpr (META == kMetaBits) myeid = bits[e0 + me];
+    }
+    // ids of the batch `ahead` (0 or 1) batches behind position t of the chunk (DPP: the id register has been rotated
+    // by t lanes, so the batch at t + ahead * U sits in lanes ahead * U .. ahead * U + U - 1 of every row)
+    auto ids = [&](auto ahead_c, int t, int (&nbr)[U]) {
+      constexpr int ahead = decltype(ahead_c)::value;
+      static_for<U>([&](auto u_c) {
+        constexpr int u = decltype(u_c)::value;
+        if constexpr (kDpp) {
+          nbr[u] = dpp_i<kDppRowBcast0 + ahead * U + u>(myc);
+        } else {
+          const int T = t + ahead * U + u;
+          const int slot = WPR ? (T * NG + grp) : (grp * GS + T);
+          nbr[u] = __builtin_amdgcn_ds_bpermute(slot << 2, myc);      // (slot taken mod 64: some lane's id or 0)
+        }
+      });
+    };
+    auto batch = [&](auto buf_c, int t) {                 // validity / per-edge side information of the batch at t, then its arithmetic
+      bool valid[U];
+      int ed[U];
+      static_for<U>([&](auto u_c) {
+        constexpr int u = decltype(u_c)::value;
+        const int T = t + u;
+        valid[u] = (WPR ? T * NG + grp : T) < rem;
+        if constexpr (kDpp) {
+          ed[u] = NEED_EID ? dpp_i<kDppRowBcast0 + u>(myeid) : 0;
+        } else {
+          const int slot = WPR ? (T * NG + grp) : (grp * GS + T);
+          ed[u] = NEED_EID ? __builtin_amdgcn_ds_bpermute(slot << 2, myeid) : 0;
+        }
+      });
+      compute(buf_c, std::integral_constant<int, META>{}, valid, ed);
+      if constexpr (kDpp) {
+        myc = dpp_i<kDppRowRor0 + 16 - U>(myc);           // lane i <- lane i+U
+        if constexpr (NEED_EID) myeid = dpp_i<kDppRowRor0 + 16 - U>(myeid);
+      }
+    };
+    // the chunk's ids / side bytes must have landed before the loop: left pending, the loop head (which merges "id loads
+    // newest" from the entry with "prefetch newest" from the back edge) waits vmcnt(0) in every iteration
+    asm volatile("" ::"v"(myc), "v"(myeid));
+    int nb[U];
+    ids(B0{}, 0, nb);
+    issue(B0{}, nb);
+#pragma unroll 1
+    for (int t = 0; ; t += 2 * U) {
+      // sched_barrier: the machine scheduler otherwise sinks the prefetch below the arithmetic it is meant to overlap
+      ids(B1{}, t, nb);                                   // batch t + U (rows it may not need: see above)
+      issue(B1{}, nb);
+      __builtin_amdgcn_sched_barrier(0);
+      batch(B0{}, t);
+      __builtin_amdgcn_sched_barrier(0);
+      if ((WPR ? (t + U) * NG : t + U) >= rem) break;     // group-uniform (wave-uniform in wave-per-row mode)
+      ids(B1{}, t + U, nb);                               // batch t + 2U
+      issue(B0{}, nb);
+      __builtin_amdgcn_sched_barrier(0);
+      batch(B1{}, t + U);
+      __builtin_amdgcn_sched_barrier(0);
+      if ((WPR ? (t + 2 * U) * NG : t + 2 * U) >= rem) break;
+    }
+  }
+}
+
 // ----------------------------------------------------------------------------
 // Arithmetic layout.  The kernels are VALU-bound (rocprofv3: VALU ~95 % busy,
 // HBM traffic 1/4 of the algorithmic bytes), so the inner loops are written for
@@ -340,12 +432,17 @@ __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid)
   float m = -INFINITY, s = 0.f;                       // online softmax state
 
   const int hbit = 1 << h;
-  auto body = [&](auto meta_c, const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
-    constexpr int META = decltype(meta_c)::value;
-    if (!valid[0]) return;                            // wave-per-row tail (group-uniform)
-    Raw8<T> raw[U];
+  Raw8<T> rawbuf[2][U];                               // gathered rows of the batch in work and of the next one
+  auto issue = [&](auto buf_c, const int (&nbr)[U]) {
+    constexpr int B = decltype(buf_c)::value;
 #pragma unroll
-    for (int u = 0; u < U; ++u) raw[u].load(row_ptr(xl, nbr[u], ld_xl));   // invalid slots read row 0
+    for (int u = 0; u < U; ++u) rawbuf[B][u].load(row_ptr(xl, nbr[u], ld_xl));   // invalid slots read row 0 / a row of the chunk
+  };
+  auto body = [&](auto buf_c, auto meta_c, const bool (&valid)[U], const int (&ed)[U]) {
+    constexpr int META = decltype(meta_c)::value;
+    constexpr int B = decltype(buf_c)::value;
+    if (!valid[0]) return;                            // wave-per-row tail (group-uniform)
+    Raw8<T> (&raw)[U] = rawbuf[B];
     float e[U];
     float mx = m;
 #pragma unroll
@@ -383,11 +480,11 @@ __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid)
     }
   };
   if (want_alpha || (dropout && !p.bits))
-    walk_row<GS, WPR, kMetaEid, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+    walk_row_prefetch<GS, WPR, kMetaEid, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, issue, body);
   else if (dropout)
-    walk_row<GS, WPR, kMetaBits, U>(p.col, p.bits, beg, end, L.lane, L.grp, L.gl, body);
+    walk_row_prefetch<GS, WPR, kMetaBits, U>(p.col, p.bits, beg, end, L.lane, L.grp, L.gl, issue, body);
   else
-    walk_row<GS, WPR, kMetaNone, U>(p.col, nullptr, beg, end, L.lane, L.grp, L.gl, body);
+    walk_row_prefetch<GS, WPR, kMetaNone, U>(p.col, nullptr, beg, end, L.lane, L.grp, L.gl, issue, body);
 
   if constexpr (WPR) {
     // merge the NG groups' online-softmax states
