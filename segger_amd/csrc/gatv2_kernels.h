@@ -479,12 +479,20 @@ __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid)
       for (int i = 0; i < 4; ++i) acc[i] = pk_fma(w2, v[i], acc[i]);
     }
   };
-  if (want_alpha || (dropout && !p.bits))
-    walk_row_prefetch<GS, WPR, kMetaEid, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, issue, body);
-  else if (dropout)
-    walk_row_prefetch<GS, WPR, kMetaBits, U>(p.col, p.bits, beg, end, L.lane, L.grp, L.gl, issue, body);
-  else
-    walk_row_prefetch<GS, WPR, kMetaNone, U>(p.col, nullptr, beg, end, L.lane, L.grp, L.gl, issue, body);
+  // 16-bit storage: the next batch's rows are requested before this batch's arithmetic.  fp32 rows take twice the
+  // registers (the second buffer spills 20-65 of them at 4 waves per SIMD): plain walk, one buffer.
+  auto plain = [&](auto meta_c, const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
+    issue(std::integral_constant<int, 0>{}, nbr);
+    body(std::integral_constant<int, 0>{}, meta_c, valid, ed);
+  };
+  auto walk = [&](auto meta_c, const void* meta) {
+    constexpr int META = decltype(meta_c)::value;
+    if constexpr (sizeof(T) == 2) walk_row_prefetch<GS, WPR, META, U>(p.col, meta, beg, end, L.lane, L.grp, L.gl, issue, body);
+    else walk_row<GS, WPR, META, U>(p.col, meta, beg, end, L.lane, L.grp, L.gl, plain);
+  };
+  if (want_alpha || (dropout && !p.bits)) walk(std::integral_constant<int, kMetaEid>{}, p.eid);
+  else if (dropout) walk(std::integral_constant<int, kMetaBits>{}, p.bits);
+  else walk(std::integral_constant<int, kMetaNone>{}, nullptr);
 
   if constexpr (WPR) {
     // merge the NG groups' online-softmax states
