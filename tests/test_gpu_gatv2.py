@@ -267,7 +267,7 @@ def test_unique_sources_need_no_by_source_view(oracle, cuda, dtype, H, C, n_src,
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("H,C,n_tx,n_bd,k,frac", [(2, 64, 3000, 40, 6, 0.9), (2, 64, 900, 300, 5, 0.5), (4, 32, 700, 9, 4, 1.0),
                                                   (1, 32, 500, 6, 3, 0.8), (5, 16, 300, 5, 4, 0.9)])
-@pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("p", [0.0, 0.3, -0.3])          # -0.3: dropout 0.3 by the counter hash (no precomputed bit planes)
 def test_hetero_layer_pair_launches_equal_single_edge_types(cuda, dtype, H, C, n_tx, n_bd, k, frac, p):
     """One hetero layer (ist_encoder.py:109-134: tx-neighbors-tx + tx-belongs-bd) through the merged launches
     (segger_gatv2_fwd_pair; segger_gatv2_bwd_pair: zero fill in the tx-neighbors-tx destination pass, its source pass in
@@ -291,7 +291,8 @@ def test_hetero_layer_pair_launches_equal_single_edge_types(cuda, dtype, H, C, n
     att_tt, bias_tt, att_tb, bias_tb = vec(0.3), vec(0.1), vec(0.3), vec(0.1)
     w_tx, w_bd = torch.randn(n_tx, hc, generator=g).to(cuda), torch.randn(n_bd, hc, generator=g).to(cuda)
     bits_tt = bits_tb = None
-    if p > 0:
+    use_bits, p = p > 0, abs(p)
+    if use_bits:
         bits_tt = (ops.dropout_bits(g_tt.by_dst, H, p, [11])[0], ops.dropout_bits(g_tt.by_src, H, p, [11])[0])
         bits_tb = (ops.dropout_bits(g_tb.by_dst, H, p, [12])[0], None)
 
