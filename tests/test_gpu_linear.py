@@ -48,6 +48,10 @@ def test_linear_forward_resident_weights(cuda, dtype, k, m, n):
         assert torch.equal(ops.linear_fwd_launch(x[sl], w, b), y[sl])
     y0 = ops.linear_fwd_launch(x, w, None)
     assert torch.equal(ops.linear_fwd_launch(x[-4133:], w, None), y0[-4133:])
+    # a column window of a wider matrix as the output (row stride m + 128): the columns beside it stay untouched
+    wide = torch.full((n, m + 128), 3.0, device=cuda, dtype=dtype)
+    ops.linear_fwd_launch(x, w, b, out=wide[:, 64:64 + m])
+    assert torch.equal(wide[:, 64:64 + m], y) and bool((wide[:, :64] == 3.0).all()) and bool((wide[:, 64 + m:] == 3.0).all())
 
 
 @pytest.mark.parametrize("k,m", [(64, 64), (128, 64), (128, 384), (256, 384), (384, 256), (384, 128), (256, 64), (64, 128)])
