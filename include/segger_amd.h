@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SEGGER_ABI_VERSION 14
+#define SEGGER_ABI_VERSION 15
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -294,6 +294,27 @@ typedef struct {
                                 rebase ids while they are copied; 0 for float segments */
 } segger_stage_seg;
 int segger_stage(const segger_stage_seg* segs, int32_t n_segs, segger_stream_t stream);
+
+/*
+ * segger_adam_step: torch.optim.Adam.step() (lightning_model.py:300-303: Adam(lr), default betas / eps, no weight decay,
+ * no amsgrad) for n_tensors fp32 parameter tensors at once, on the optimizer's OWN state tensors (exp_avg, exp_avg_sq and
+ * the per-tensor fp32 step counter of a capturable torch Adam), so checkpoints and an eager optimizer.step() stay
+ * interchangeable:   step += 1;  exp_avg = lerp(exp_avg, grad, 1 - beta1);  exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) grad^2;
+ * param -= lr / (1 - beta1^step) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps).
+ * Two launches per 64 tensors (counters, then all elements) instead of torch's three multi-tensor launches per step.
+ * lr / betas / eps are doubles as torch holds them (1 - beta and beta^step are evaluated in double, the rest in fp32).
+ * tensors is a HOST array (copied into the kernel arguments); zero-sized tensors only advance their counter.
+ */
+typedef struct segger_adam_tensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  float* step;               /* device scalar, fp32 (torch's capturable step counter) */
+  int64_t numel;
+} segger_adam_tensor;
+int segger_adam_step(const segger_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2, double eps,
+                     segger_stream_t stream);
 
 /* segger_transpose_many: dst [cols, rows] = src [rows, cols]^T for n_segs contiguous 16-bit matrices in one launch:
  * the W^T copies the data-gradient GEMMs (dX = dY W on segger_linear_fwd) need after every optimizer step. */

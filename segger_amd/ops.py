@@ -873,6 +873,48 @@ _FILLS = {"const": _lib.FILL_CONST, "tile": _lib.FILL_TILE, "div": _lib.FILL_DIV
           "ramp": _lib.FILL_RAMP}
 
 
+def adam_step(opt) -> bool:
+    """``optimizer.step()`` of a plain capturable ``torch.optim.Adam`` through ``segger_adam_step``: every parameter tensor
+    in two launches, on the optimizer's own state tensors (checkpoints and eager ``optimizer.step()`` calls stay
+    interchangeable).  -> False, nothing done, when the optimizer is anything else (amsgrad, weight decay, maximize, a
+    tensor learning rate, non-fp32 or non-contiguous parameters, state not created yet): the caller then runs
+    ``optimizer.step()`` itself."""
+    if type(opt) is not torch.optim.Adam:
+        return False
+    jobs = []
+    for g in opt.param_groups:
+        if (g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") or g.get("differentiable")
+                or not g.get("capturable") or isinstance(g["lr"], Tensor)):
+            return False
+        rows = []
+        for p in g["params"]:
+            if p.grad is None:
+                continue
+            st = opt.state.get(p)
+            if not st or "exp_avg" not in st:
+                return False
+            ts = (p, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"])
+            if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts) or p.grad.is_sparse:
+                return False
+            rows.append(ts)
+        jobs.append((g, rows))
+    lib = _lib.load()
+    for g, rows in jobs:
+        if not rows:
+            continue
+        arr = (_lib.AdamTensor * len(rows))()
+        for a, (p, gr, m, v, st) in zip(arr, rows):
+            a.param, a.grad, a.exp_avg, a.exp_avg_sq, a.step, a.numel = (p.data_ptr(), gr.data_ptr(), m.data_ptr(),
+                                                                         v.data_ptr(), st.data_ptr(), p.numel())
+        dev = rows[0][0].device
+        b1, b2 = g["betas"]
+        with _lib.on_device(dev):
+            rc = lib.segger_adam_step(arr, len(rows), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+                                      _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_adam_step")
+    return True
+
+
 def float_bits(x: float) -> int:
     """The int whose low 32 bits are the fp32 pattern of ``x`` (a ``const`` fill of a float buffer)."""
     import struct

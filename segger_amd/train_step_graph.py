@@ -62,6 +62,9 @@ def step_bucket(batch, granularity: float = 1.06, floor: int = 256) -> Dict[str,
             "graphs": up(int(getattr(batch, "num_graphs", 1)), 1)}
 
 
+USE_ADAM_KERNEL = True       # (False: torch's fused Adam inside the captured step -- A/B switch)
+
+
 class GraphedTrainStep:
     """The captured step of ONE shape bucket (see :class:`GraphedTrainer` for the per-batch dispatch).  A batch is
     written into the bucket's static buffers by ONE launch (``ops.stage`` -> ``segger_stage``): node features, the three
@@ -231,7 +234,13 @@ class GraphedTrainStep:
     # ------------------------------------------------------------------------------------------- the step
     def _run(self) -> None:
         self._run_grads()
-        self.opt.step()
+        self._opt_step()
+
+    def _opt_step(self) -> None:
+        """Adam on the hand-written kernel (two launches for all tensors; torch's fused multi-tensor Adam takes three and
+        ~40 us for the encoder's 60 small tensors); any other optimizer steps itself."""
+        if not (USE_ADAM_KERNEL and ops.adam_step(self.opt)):
+            self.opt.step()
 
     def _run_grads(self) -> None:
         lit, enc, s = self.lit, self.lit.model, self.sizes
@@ -357,7 +366,7 @@ class GraphedTrainStep:
                             self.grad_bucket.pack()
                     self.graph_opt = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self.graph_opt, pool=self.graph.pool()):
-                        self.opt.step()
+                        self._opt_step()
             # the graph holds raw pointers into these buffers: they must outlive it whatever happens to the cache
             self._pack_refs = [(pk, pk.w, pk.b, pk._wt) for pk in ops.packs_of(aliases)]
             self._grads = [p.grad for p in self._params]

@@ -230,3 +230,39 @@ def test_graphed_trainer_data_parallel(cuda, tmp_path):
         assert x["flat_ptr_stable"] and x["grads_are_views"]        # persistent flat buffer, .grad = its slices
         assert x["adam_steps"] == x["epochs"] * x["steps_per_epoch"]
         assert x["last"] < x["first"]
+
+
+def test_adam_kernel_matches_torch_adam(cuda):
+    """ops.adam_step (segger_adam_step: all tensors in two launches, on torch's own state tensors) against
+    torch.optim.Adam(fused, capturable) on the same gradients: parameters and both moments agree to fp32 rounding over
+    several steps, the step counters are torch's, odd sizes / an unused parameter / a zero-sized tensor included; an
+    optimizer it does not cover is declined."""
+    from segger_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(5)
+    shapes = [(384, 128), (128,), (1, 2, 64), (7,), (3, 5), (0,), (64, 130), (1,)]
+    ps_a = [torch.randn(s, device=cuda, generator=g).requires_grad_(True) for s in shapes]
+    ps_b = [p.detach().clone().requires_grad_(True) for p in ps_a]
+    unused_a, unused_b = (torch.zeros(5, device=cuda, requires_grad=True) for _ in range(2))
+    oa = torch.optim.Adam(ps_a + [unused_a], lr=1e-3, fused=True, capturable=True)
+    ob = torch.optim.Adam(ps_b + [unused_b], lr=1e-3, fused=True, capturable=True)
+    for step in range(6):
+        grads = [torch.randn(s, device=cuda, generator=g) * (10.0 ** (step % 3 - 1)) for s in shapes]
+        for p, q, gr in zip(ps_a, ps_b, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        if step == 0:
+            assert not ops.adam_step(oa)              # no state yet: declined, torch creates it
+            oa.step()
+        else:
+            assert ops.adam_step(oa)
+        ob.step()
+        for p, q in zip(ps_a, ps_b):
+            sa, sb = oa.state[p], ob.state[q]
+            assert float(sa["step"]) == float(sb["step"]) == step + 1
+            for x, y in ((p, q), (sa["exp_avg"], sb["exp_avg"]), (sa["exp_avg_sq"], sb["exp_avg_sq"])):
+                # one fp32 ulp of the operands (the lerp cancels: an exp_avg near zero from terms of order 1)
+                scale = float(y.abs().max()) if y.numel() else 0.0
+                assert torch.allclose(x, y, rtol=2e-6, atol=5e-7 * scale + 1e-12), (step, tuple(p.shape))
+        assert unused_a.grad is None and len(oa.state.get(unused_a, {})) == 0
+    assert not ops.adam_step(torch.optim.Adam(ps_a, lr=1e-3, weight_decay=0.1, fused=True, capturable=True))
+    assert not ops.adam_step(torch.optim.AdamW(ps_a, lr=1e-3, fused=True, capturable=True))
+    assert not ops.adam_step(torch.optim.Adam(ps_a, lr=1e-3))          # not capturable: host-side step counters

@@ -7,6 +7,7 @@ from segger_amd import LitISTEncoder, ops
 from segger_amd.fov import build_fov_batches
 from segger_amd.synthetic import SyntheticSpec
 from segger_amd.train_step_graph import GraphedTrainer
+from segger_amd import train_step_graph as tsg
 
 dev = torch.device("cuda:0")
 spec = SyntheticSpec(n_tx=int(os.environ.get("N_TX", 10_000_000)), n_bd=int(os.environ.get("N_BD", 100_000)), k_tx=15, seed=0)
@@ -19,11 +20,12 @@ for item in os.environ.get("VARIANTS", "base:").split(";"):
     variants.append((name, dict(kv.split("=") for kv in fl.split(",") if kv)))
 for rnd in range(int(os.environ.get("ROUNDS", 2))):
     for name, fl in variants:
-        for k, v in defaults.items():
-            setattr(ops, k, v)
+        for (mod, k), v in defaults.items():
+            setattr(mod, k, v)
         for k, v in fl.items():
-            defaults.setdefault(k, getattr(ops, k))
-            setattr(ops, k, type(getattr(ops, k))(int(v)))
+            mod = ops if hasattr(ops, k) else tsg          # (switches of segger_amd.ops or of segger_amd.train_step_graph)
+            defaults.setdefault((mod, k), getattr(mod, k))
+            setattr(mod, k, type(getattr(mod, k))(int(v)))
         torch.manual_seed(0)
         m = LitISTEncoder(n_genes=spec.n_genes, in_channels=128)
         m.model._materialize_bd(spec.bd_dim, "cpu")
