@@ -340,9 +340,14 @@ class LitISTEncoder(_Base):
         return out
 
     def configure_optimizers(self, capturable: bool = False) -> torch.optim.Optimizer:
-        """Adam as in the reference (lightning_model.py:300-303).  ``capturable`` (not in the reference): keep the
-        step counters on the device so that ``train_step_graph.GraphedTrainStep`` can capture ``optimizer.step()``."""
+        """Adam as in the reference (lightning_model.py:300-303).  On the GPU it is ``segger_amd.optim.Adam`` -- a
+        ``torch.optim.Adam`` (same state and ``state_dict``) with device-side step counters whose ``step()`` runs the
+        hand-written update kernel; ``capturable`` is kept for old call sites (always on there)."""
         params = list(self.parameters())
         fused = bool(params) and all(p.is_cuda for p in params)     # one multi-tensor kernel on the GPU
-        capturable = capturable or self._graphed_kw is not None     # enable_graphed_training(): Adam is part of the graph
-        return torch.optim.Adam(params, lr=self.learning_rate, fused=fused, capturable=bool(capturable and fused))
+        if fused:
+            # on the GPU: device-side step counters always, and the update on the hand-written kernel (optim.Adam is a
+            # torch.optim.Adam: same state, same state_dict; falls through to torch's step for anything it does not cover)
+            from .optim import Adam
+            return Adam(params, lr=self.learning_rate, fused=True, capturable=True)
+        return torch.optim.Adam(params, lr=self.learning_rate)

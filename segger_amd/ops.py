@@ -879,7 +879,8 @@ def adam_step(opt) -> bool:
     interchangeable).  -> False, nothing done, when the optimizer is anything else (amsgrad, weight decay, maximize, a
     tensor learning rate, non-fp32 or non-contiguous parameters, state not created yet): the caller then runs
     ``optimizer.step()`` itself."""
-    if type(opt) is not torch.optim.Adam:
+    from .optim import Adam as _Adam
+    if type(opt) not in (torch.optim.Adam, _Adam):   # (not subclasses in general: torch's AdamW is one)
         return False
     jobs = []
     for g in opt.param_groups:
