@@ -24,7 +24,10 @@ __global__ __launch_bounds__(256) void minmax_init_kernel(float* mins, float* ma
   if (i < n2) { mins[i] = INFINITY; maxs[i] = -INFINITY; }
 }
 
-constexpr int kNodesPerThread = 16;
+// nodes per thread: 4 for tile batches (more workgroups, shorter per-thread chains), 16 from 256 k nodes on (fewer
+// same-address atomics)
+constexpr int kNodesSmall = 4, kNodesLarge = 16;
+constexpr int64_t kNodesLargeFrom = 262144;
 
 struct MM { float lx, ly, hx, hy; };
 
@@ -36,6 +39,7 @@ __device__ __forceinline__ void flush(float* mins, float* maxs, int64_t g, const
 // Graph ids of a PyG Batch are sorted, so a block's contiguous chunk of nodes
 // nearly always belongs to one graph: lanes accumulate privately, a wave whose
 // lanes all hold the same graph reduces with shuffles and issues 4 atomics.
+template <int kNodesPerThread>
 __global__ __launch_bounds__(256) void segment_minmax_kernel(const float* __restrict__ pos, const int64_t* __restrict__ batch,
                                                             int64_t n, int64_t n_graphs, float* mins, float* maxs) {
   const int64_t base = (int64_t)blockIdx.x * (256 * kNodesPerThread);
@@ -126,10 +130,13 @@ extern "C" int segger_segment_minmax_ex(const float* pos, const int64_t* batch, 
   if (!(flags & SEGGER_MINMAX_INITIALISED))
     hipLaunchKernelGGL(minmax_init_kernel, dim3(gb), dim3(256), 0, stream, mins, maxs, n2);
   if (n > 0) {
-    const int64_t per = 256 * kNodesPerThread;
+    const int64_t per = 256 * (n >= kNodesLargeFrom ? kNodesLarge : kNodesSmall);
     const int64_t nb = (n + per - 1) / per;
     SEGGER_REQUIRE(nb < 0x7fffffffLL, "segger_segment_minmax: too many nodes");
-    hipLaunchKernelGGL(segment_minmax_kernel, dim3((unsigned)nb), dim3(256), 0, stream, pos, batch, n, n_graphs, mins, maxs);
+    if (n >= kNodesLargeFrom)
+      hipLaunchKernelGGL(segment_minmax_kernel<kNodesLarge>, dim3((unsigned)nb), dim3(256), 0, stream, pos, batch, n, n_graphs, mins, maxs);
+    else
+      hipLaunchKernelGGL(segment_minmax_kernel<kNodesSmall>, dim3((unsigned)nb), dim3(256), 0, stream, pos, batch, n, n_graphs, mins, maxs);
   }
   if (!(flags & SEGGER_MINMAX_KEEP_EMPTY))
     hipLaunchKernelGGL(minmax_fixup_kernel, dim3(gb), dim3(256), 0, stream, mins, maxs, n2);
