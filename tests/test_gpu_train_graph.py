@@ -266,3 +266,39 @@ def test_adam_kernel_matches_torch_adam(cuda):
     assert not ops.adam_step(torch.optim.Adam(ps_a, lr=1e-3, weight_decay=0.1, fused=True, capturable=True))
     assert not ops.adam_step(torch.optim.AdamW(ps_a, lr=1e-3, fused=True, capturable=True))
     assert not ops.adam_step(torch.optim.Adam(ps_a, lr=1e-3))          # not capturable: host-side step counters
+
+
+def test_optim_adam_is_a_drop_in_torch_adam(cuda):
+    """segger_amd.optim.Adam (what configure_optimizers returns on the GPU): a closure is evaluated once and its loss
+    returned (Lightning's automatic optimisation calls step(closure)), the weight-cache hook fires, and the state
+    dict moves to and from a plain torch.optim.Adam."""
+    from segger_amd.optim import Adam
+    g = torch.Generator(device=cuda).manual_seed(9)
+    w = torch.randn(64, 32, device=cuda, generator=g).requires_grad_(True)
+    x = torch.randn(128, 32, device=cuda, generator=g)
+    opt = Adam([w], lr=1e-2, fused=True, capturable=True)
+    assert isinstance(opt, torch.optim.Adam)
+    calls = []
+
+    def closure():
+        calls.append(1)
+        opt.zero_grad(set_to_none=True)
+        loss = (x @ w.t()).square().mean()
+        loss.backward()
+        return loss
+
+    losses = [float(opt.step(closure).detach()) for _ in range(5)]  # step 1 through torch (creates the state), then the kernel
+    assert len(calls) == 5 and losses[-1] < losses[0]
+    assert float(opt.state[w]["step"]) == 5.0
+    # state dict -> plain torch Adam on a copy: the next step agrees
+    w2 = w.detach().clone().requires_grad_(True)
+    ref = torch.optim.Adam([w2], lr=1e-2, fused=True, capturable=True)
+    ref.load_state_dict(copy.deepcopy(opt.state_dict()))     # (load_state_dict keeps tensors that already fit: no aliasing wanted here)
+    gr = torch.randn(64, 32, device=cuda, generator=g)
+    w.grad, w2.grad = gr.clone(), gr.clone()
+    opt.step(); ref.step()
+    assert torch.allclose(w, w2, rtol=2e-6, atol=2e-6) and float(ref.state[w2]["step"]) == 6.0     # (one ulp of values ~ 3)
+    # and back
+    opt2 = Adam([w], lr=1e-2, fused=True, capturable=True)
+    opt2.load_state_dict(copy.deepcopy(ref.state_dict()))
+    assert float(opt2.state[w]["step"]) == 6.0 and torch.equal(opt2.state[w]["exp_avg"], ref.state[w2]["exp_avg"])
