@@ -39,6 +39,22 @@ JSON line:
       strong-scaling speed-up.  `census` is an all-reduced one-hot of the ranks (all ones <=> RCCL saw N ranks).
       At N = 1, `strong.graphed` {value, ms_per_step, epoch_s, shape_buckets} repeats the epoch with every training
       step replayed as one hipGraph (segger_amd.train_step_graph).
+  untimed_setup {csr_build_ms, uncached_step_ms, first_step_ms}, csr_build_ms
+      what the timed region leaves out: it replays ONE resident batch whose sorted edge views (both CSR views of the 15M
+      tx-neighbors-tx edges + tx-belongs-bd by destination), sampler indices and masks are cached on the batch
+  auroc {what, tile, n_edges, positives, dtype {f32, bf16, f16: {hip, oracle, delta, max_abs_score_diff, ...}}, met,
+         fov_tiles {tiles, n_edges, oracle_seconds, dtype {...}, met}}
+      (N = 1)  the "AUROC vs ref" half of the metric: tx-neighbors-bd candidate edges ranked by cosine score
+      (lightning_model.py:275-279), HIP path vs the CPU oracle with identical weights: the cpu_baseline leg's C2/10 tile
+      with its seed-0 weights, and `--auroc-tiles` (8) seeded random tiles of the 50M-tx FOV with the weights the timed
+      epochs left behind.  Bar: delta <= 1e-3 in every dtype.
+  c5 {dtype "f16", edges_per_s, ms, buckets, packed_batches {...}, predict_tiles {...}}
+      (N = 1)  BASELINE config 5 on the resident 50M-tx FOV: GraphedPredictorPool sweeps (first sweep captures, second is
+      timed) over the partition's packed batches and over the reference's overlapping prediction tiles
+      (tile_dataset.py:218-246); `spot_check` compares assignments with the eager predict_step on 4 tiles.
+      (The 100M-tx run of the same code: tools/fov_stream.py, profiles/r0N_fov_100m_e16M.json.)
+  default_dropin {ms_per_step, value, batches, dtype "f32"}
+      (N = 1)  what INTEGRATION.md's import swap alone gives: fp32 storage, eager steps, 1M-edge batches (100 of the FOV's)
 """
 from __future__ import annotations
 
@@ -197,16 +213,18 @@ def host_threads():
     return max(1, min(n, 16))           # the GPU box gives 16 cores per GPU
 
 
-def cpu_baseline(sample_tx=100_000, sample_bd=1_000, k=15, n_warm=2, n_reps=5, label="C2/10"):
+def cpu_baseline(sample_tx=100_000, sample_bd=1_000, k=15, n_warm=2, n_reps=5, label="C2/10", auroc_ctx=None):
     """The oracle (pure-torch CPU restatement of the PyG path, fp32) timed on the
     host cores over a bounded sample of the same workload (C2/10): fwd + seg loss + bwd,
-    2 warm-ups + the median of 5 repetitions."""
+    2 warm-ups + the median of 5 repetitions.  ``auroc_ctx`` (a dict): filled with the tile, the seed-0 weights, the
+    oracle's cosine scores of every tx-neighbors-bd edge (one more forward, no grad) and the edge labels, for
+    :func:`auroc_vs_oracle`."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import segger_oracle as O
     from segger_amd.synthetic import SyntheticSpec, make_graph
     from segger_amd import LitISTEncoder
     spec = SyntheticSpec(n_tx=sample_tx, n_bd=sample_bd, k_tx=k, seed=123)
-    b = make_graph(spec)
+    b, aux = make_graph(spec, return_aux=True)
     torch.manual_seed(0)
     m = LitISTEncoder(n_genes=spec.n_genes, in_channels=128)
     m.model._materialize_bd(spec.bd_dim, "cpu")
@@ -232,6 +250,12 @@ def cpu_baseline(sample_tx=100_000, sample_bd=1_000, k=15, n_warm=2, n_reps=5, l
         log(f"[bench] cpu_baseline[{label}] step {ts[-1]:.2f}s")
     reps = len(ts)
     dt = sorted(ts)[len(ts) // 2]
+    if auroc_ctx is not None:
+        with torch.no_grad():
+            z = O.ist_encoder_forward(sd, b.x_dict, b.edge_index_dict, b.pos_dict, b.batch_dict, n_heads=2)
+            auroc_ctx.update(batch=b, spec=spec, label=aux["label"], state_dict={k_: v.detach() for k_, v in sd.items()},
+                             oracle_scores=O.edge_scores(z["tx"], z["bd"], b[O.TX_NB_BD].edge_index).float(),
+                             tile=f"{sample_tx}-tx / {sample_bd}-nuclei k={k} tile ({label}), seed-0 weights")
     etb = int(ei.shape[1])
     mp_edges = 4 * (int(b[O.TX_TX].edge_index.shape[1]) + etb)
     cpu_model = "unknown"
@@ -251,6 +275,194 @@ def cpu_baseline(sample_tx=100_000, sample_bd=1_000, k=15, n_warm=2, n_reps=5, l
     }
 
 
+_DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+
+
+@torch.no_grad()
+def hip_edge_scores(model, batch, dtype):
+    """Cosine score of every tx-neighbors-bd candidate edge (reference lightning_model.py:275-279) on the HIP path
+    at storage ``dtype``: encoder forward (eval) + ``segger_edge_cos_argmax`` with the per-edge similarities kept."""
+    from segger_amd import TX_NB_BD, ops
+    from segger_amd.graph import batch_cache, edge_graph
+    keep, model.model.compute_dtype = model.model.compute_dtype, dtype
+    try:
+        z = model.forward(batch)
+        ei = batch[TX_NB_BD].edge_index
+        g = edge_graph(batch_cache(batch), TX_NB_BD, ei, batch["tx"].num_nodes, batch["bd"].num_nodes, need_by_dst=False)
+        _, _, _, sim = ops.edge_cos_argmax(g.by_src, z["tx"], z["bd"], return_sim=True)
+    finally:
+        model.model.compute_dtype = keep
+    return sim.float()
+
+
+def _auroc_entry(scores_hip, scores_oracle, labels, a_oracle):
+    from segger_amd.metrics import auroc
+    a = auroc(scores_hip, labels)
+    d = (scores_hip - scores_oracle).abs()
+    return {"hip": a, "oracle": a_oracle, "delta": abs(a - a_oracle), "max_abs_score_diff": float(d.max()),
+            "mean_abs_score_diff": float(d.mean())}
+
+
+def auroc_vs_oracle(ctx, dev, trained=None):
+    """The AUROC half of the headline metric (BASELINE.json: "AUROC vs ref"): the HIP encoder with the oracle's own
+    seed-0 weights on the oracle's own C2/10 tile, candidate edges ranked by cosine score against label = "the
+    candidate is the transcript's true nucleus" (SURVEY.md 8(d)); bar |dAUROC| <= 1e-3.  The oracle's scores come from
+    the ``cpu_baseline`` leg (checker only).  ``trained``: the benchmark model after its timed steps -- the same tile
+    scored once more by both sides with THOSE weights (untrained weights rank at chance, AUROC 0.50)."""
+    from segger_amd import LitISTEncoder
+    from segger_amd.metrics import auroc
+    spec, b = ctx["spec"], ctx["batch"].to(dev)
+    m = LitISTEncoder(n_genes=spec.n_genes, in_channels=128)
+    m.model._materialize_bd(spec.bd_dim, "cpu")
+    m.load_state_dict(ctx["state_dict"], strict=True)
+    m = m.to(dev).eval()
+    lab = ctx["label"].to(dev)
+    s_or = ctx["oracle_scores"].to(dev)
+    a_or = auroc(s_or, lab)
+    out = {"what": "edge-AUROC of tx-neighbors-bd cosine scores, HIP path vs the CPU oracle (fp32), identical weights "
+                   "and inputs; bar: delta <= 1e-3", "tile": ctx["tile"], "n_edges": int(lab.numel()),
+           "positives": int(lab.sum()), "dtype": {}}
+    for name in ("f32", "bf16", "f16"):
+        out["dtype"][name] = _auroc_entry(hip_edge_scores(m, b, _DT[name]), s_or, lab, a_or)
+    out["met"] = all(v["delta"] <= 1e-3 for v in out["dtype"].values())
+    if trained is not None:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import segger_oracle as O
+        sd = {k: v.detach().float().cpu() for k, v in trained.state_dict().items()}
+        bc = ctx["batch"]
+        torch.set_num_threads(host_threads())
+        with torch.no_grad():
+            z = O.ist_encoder_forward(sd, bc.x_dict, bc.edge_index_dict, bc.pos_dict, bc.batch_dict, n_heads=2)
+            s_tr = O.edge_scores(z["tx"], z["bd"], bc[O.TX_NB_BD].edge_index).float().to(dev)
+        a_tr = auroc(s_tr, lab)
+        was_training = trained.training
+        trained.eval()
+        out["trained_weights"] = {"what": "same tile, weights of the benchmark model after its timed C2 steps and FOV epochs",
+                                  "dtype": {n: _auroc_entry(hip_edge_scores(trained, b, _DT[n]), s_tr, lab, a_tr)
+                                            for n in ("f32", "bf16", "f16")}}
+        trained.train(was_training)
+        out["met"] = out["met"] and all(v["delta"] <= 1e-3 for v in out["trained_weights"]["dtype"].values())
+    return out
+
+
+def fov_tiles_auroc(model, part, dev, n_tiles=8, seed=1):
+    """The same check on ``n_tiles`` seeded random tiles of the resident 50M-transcript FOV with the weights the timed
+    epochs left behind (tiles are independent graphs, so a random sample of tiles is an unbiased estimate of the FOV's
+    edge ranking quality): oracle fp32 forward on the host per tile, HIP f32 / bf16 / f16 on the device."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import segger_oracle as O
+    from segger_amd import TX_NB_BD
+    from segger_amd.metrics import auroc
+    was_training = model.training
+    model.eval()
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(seed)
+    usable = [t for t in range(len(part)) if int(part.node_sizes["bd"][t]) > 1 and int(part.edge_sizes[TX_NB_BD][t]) > 0]
+    sample = [usable[i] for i in torch.randperm(len(usable), generator=g)[:n_tiles].tolist()]
+    scores = {k: [] for k in ("oracle",) + tuple(_DT)}
+    labels = []
+    torch.set_num_threads(host_threads())
+    t_or = 0.0
+    for t in sample:
+        b = part.tile(t)
+        ei = b[TX_NB_BD].edge_index
+        labels.append(b["bd"]["index"][ei[1]].long() == b["tx"]["cell"][ei[0]])
+        for name, dt in _DT.items():
+            scores[name].append(hip_edge_scores(model, b, dt))
+        bc = b.to("cpu")
+        t1 = time.perf_counter()
+        with torch.no_grad():
+            zr = O.ist_encoder_forward(sd, bc.x_dict, bc.edge_index_dict, bc.pos_dict, bc.batch_dict, n_heads=2)
+        t_or += time.perf_counter() - t1
+        scores["oracle"].append(O.edge_scores(zr["tx"], zr["bd"], bc[TX_NB_BD].edge_index).float().to(dev))
+    model.train(was_training)
+    lab = torch.cat(labels)
+    cat = {k: torch.cat(v) for k, v in scores.items()}
+    a_or = auroc(cat["oracle"], lab)
+    out = {"what": f"{len(sample)} seeded random tiles of the resident FOV, weights as the timed epochs left them",
+           "tiles": sample, "n_edges": int(lab.numel()), "positives": int(lab.sum()), "oracle_seconds": t_or, "dtype": {}}
+    for name in _DT:
+        out["dtype"][name] = _auroc_entry(cat[name], cat["oracle"], lab, a_or)
+    out["met"] = all(v["delta"] <= 1e-3 for v in out["dtype"].values())
+    return out
+
+
+def c5_record(model, part, batches, data, tiling, bd_dim, dev, margin=10.0, spot_tiles=4):
+    """BASELINE config 5 (inference-only edge scoring, fp16, hipGraph-captured batched predict) on the resident FOV:
+    ``GraphedPredictorPool`` sweeps, one ``segger_stage`` launch + one graph replay per batch, no host sync inside a
+    sweep, one mask compaction at its end; the first sweep captures one graph per shape bucket, the second is timed.
+    ``packed_batches``: the partition's packed tile batches (intra-tile edges, every transcript exactly once);
+    ``predict_tiles``: the reference's prediction tiles (tile_dataset.py:218-246: bounding box + margin,
+    ``predict_mask`` = inside the tile proper).  Assignments of ``spot_tiles`` tiles are compared with the eager
+    ``predict_step`` of the same tile (same fp16 kernels: equal up to the order of ties)."""
+    from segger_amd import TX_NB_BD
+    from segger_amd.inference import GraphedPredictorPool
+    from segger_amd.tiles import PredictTileIndex
+    keep_dt, was_training = model.model.compute_dtype, model.training
+    model.eval()
+    model.model.compute_dtype = torch.float16
+    out = {"dtype": "f16"}
+    try:
+        def sweep(pool, items, get):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            dev_out = [pool.predict_device(get(i)) for i in items]       # nothing waits for the GPU in here
+            mask = torch.cat([o[4] for o in dev_out])
+            res = tuple(torch.cat([o[i] for o in dev_out])[mask] for i in range(4))
+            torch.cuda.synchronize()
+            return time.perf_counter() - t, res
+
+        def spot_check(pool, items, get):
+            agree = n = 0
+            step = max(len(items) // max(spot_tiles, 1), 1)
+            for i in list(items)[::step][:spot_tiles]:
+                b = get(i)
+                idx_g, seg_g, sim_g, _ = pool.predict(b)
+                idx_e, seg_e, sim_e, _ = model.predict_step(b, 0)
+                same_rows = torch.equal(idx_g, idx_e)
+                agree += int(((seg_g == seg_e) | ((sim_g - sim_e).abs() < 2e-3)).sum()) if same_rows else 0
+                n += int(idx_e.numel())
+            return {"tiles": spot_tiles, "rows": n, "assignments_equal_to_eager": agree / max(n, 1)}
+
+        ep_sizes = part.edge_sizes[TX_NB_BD].tolist()
+        ep_packed = sum(ep_sizes[t] for ids in batches for t in ids)
+        pool = GraphedPredictorPool(model, bd_dim)
+        t_cap, _ = sweep(pool, range(len(batches)), lambda i: part.batch(batches[i]))
+        t_run, res = sweep(pool, range(len(batches)), lambda i: part.batch(batches[i]))
+        out["packed_batches"] = {"batches": len(batches), "buckets": len(pool.buckets), "capture_sweep_s": t_cap,
+                                 "seconds": t_run, "ms_per_batch": t_run / max(len(batches), 1) * 1e3,
+                                 "edges_scored": ep_packed, "edges_per_s": ep_packed / t_run,
+                                 "transcripts_out": int(res[0].numel()),
+                                 "spot_check": spot_check(pool, range(len(batches)), lambda i: part.batch(batches[i]))}
+        del res, pool
+        if data is not None:
+            t = time.perf_counter()
+            pti = PredictTileIndex(data, tiling, margin=margin)
+            torch.cuda.synchronize()
+            t_index = time.perf_counter() - t
+            pool = GraphedPredictorPool(model, bd_dim)
+            t_cap, _ = sweep(pool, range(len(pti)), lambda i: pti[i])
+            t_run, res = sweep(pool, range(len(pti)), lambda i: pti[i])
+            ep_tiles = 0
+            for i in list(range(len(pti)))[:: max(len(pti) // 16, 1)][:16]:      # candidate edges per tile: a 16-tile sample
+                ep_tiles += int(pti[i][TX_NB_BD].edge_index.shape[1])
+            ep_est = ep_tiles / 16 * len(pti)
+            out["predict_tiles"] = {"tiles": len(pti), "margin_um": margin, "buckets": len(pool.buckets),
+                                    "index_build_s": t_index, "capture_sweep_s": t_cap, "seconds": t_run,
+                                    "ms_per_tile": t_run / max(len(pti), 1) * 1e3,
+                                    "transcripts_out": int(res[0].numel()),
+                                    "transcripts_per_s": int(res[0].numel()) / t_run,
+                                    "edges_scored_estimate": ep_est, "edges_per_s": ep_est / t_run,
+                                    "spot_check": spot_check(pool, range(len(pti)), lambda i: pti[i])}
+            del res, pool, pti
+        p = out["packed_batches"]
+        out.update({"edges_per_s": p["edges_per_s"], "ms": p["seconds"] * 1e3, "buckets": p["buckets"]})
+    finally:
+        model.model.compute_dtype = keep_dt
+        model.train(was_training)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,6 +480,9 @@ def main():
     ap.add_argument("--strong-n-bd", type=int, default=500_000)
     ap.add_argument("--strong-edges-per-batch", type=int, default=1_000_000,
                     help="segger's edges_per_batch default (data_module.py:158)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the config-5 record (fp16 hipGraph predict sweeps over the FOV)")
+    ap.add_argument("--no-default-dropin", action="store_true", help="skip the fp32 + eager + 1M-edge-batch record")
+    ap.add_argument("--auroc-tiles", type=int, default=8, help="FOV tiles scored by the oracle for auroc.fov_tiles")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     args = ap.parse_args()
@@ -325,8 +540,13 @@ def main():
         opt.step()
         return loss
 
-    for _ in range(args.warmup):
+    torch.cuda.synchronize()
+    t_first = time.perf_counter()
+    for w in range(args.warmup):
         loss = step()
+        if w == 0:                       # the very first step: library load, lazy inits, allocator, both CSR sorts, samplers
+            torch.cuda.synchronize()
+            t_first = time.perf_counter() - t_first
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -348,6 +568,32 @@ def main():
         etb_all, ett_all, ep_all = float(etb), float(ett), float(ep)
     loss_val = float(loss.detach())
     del loss
+
+    # ---- what the timed region leaves out: it replays ONE resident batch, whose sorted edge views, sampler indices,
+    # rows-by-gene grouping and loss masks were built by the first warm-up step and are cached on the batch ------------
+    untimed = None
+    if rank == 0:
+        from segger_amd.graph import build_edge_graph
+        n_tx_, n_bd_ = spec.n_tx, spec.n_bd
+
+        def build_views():
+            build_edge_graph(batch[TX_TX].edge_index, n_tx_, n_tx_, need_by_src=True, validate="deferred")
+            build_edge_graph(batch[TX_BD].edge_index, n_tx_, n_bd_, need_by_src="lazy", validate="deferred")
+        ms_csr = time_kernel(build_views, iters=3, warm=1)
+        batch_cache(batch).clear()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        ms_uncached = (time.perf_counter() - t) * 1e3
+        untimed = {"csr_build_ms": ms_csr, "uncached_step_ms": ms_uncached,
+                   "first_step_ms": t_first * 1e3 if args.warmup else None,
+                   "note": "csr_build_ms: COO -> both sorted views of tx-neighbors-tx (15M edges) + the by-destination "
+                           "view of tx-belongs-bd (segger_csr_from_coo; PyG consumes COO directly); uncached_step_ms: "
+                           "one whole step on the same batch with its per-batch cache dropped (sorts, loss samplers' "
+                           "indices, rows-by-gene grouping, masks rebuilt) = what a NEW tile costs once; first_step_ms: "
+                           "the very first step of the process (lazy inits and allocator warm-up on top)"}
+        log(f"[bench] untimed per-batch setup: {untimed}")
 
     # ---- roofline of the dominant kernel: tx-neighbors-tx aggregation, forward -------------------
     roof, extra = None, {}
@@ -467,6 +713,7 @@ def main():
 
     # ---- strong scaling: ONE fixed FOV streamed as packed tile batches over all ranks (BASELINE config 4) ----
     strong = None
+    auroc_fov = c5 = default_dropin = None
     if not args.no_strong:
         from segger_amd.dp import seed_rank, strong_scaling_epoch
         from segger_amd.fov import batch_weights, build_fov_batches
@@ -477,7 +724,12 @@ def main():
         torch.cuda.empty_cache()
         t = time.perf_counter()
         sspec = SyntheticSpec(n_tx=args.strong_n_tx, n_bd=args.strong_n_bd, k_tx=args.k, seed=0)
-        part, batches, saux, tiling = build_fov_batches(sspec, dev, edges_per_batch=args.strong_edges_per_batch)
+        fov_data = None
+        if world == 1 and not args.no_c5:        # the c5 record's prediction tiles are cut from the un-partitioned FOV
+            part, batches, saux, tiling, fov_data = build_fov_batches(sspec, dev, edges_per_batch=args.strong_edges_per_batch,
+                                                                      keep_data=True)
+        else:
+            part, batches, saux, tiling = build_fov_batches(sspec, dev, edges_per_batch=args.strong_edges_per_batch)
         torch.cuda.synchronize()
         n_tiles_all = len(tiling)
         log(f"[bench r{rank}] fixed FOV: {args.strong_n_tx} tx -> {n_tiles_all} tiles, {len(batches)} batches "
@@ -530,6 +782,33 @@ def main():
             "ms_per_step": rec["epoch_s"] / max(rec["steps_per_rank"], 1) * 1e3,
             "resident": resident,
             "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30})
+        # ---- the out-of-the-box configuration: INTEGRATION.md's one-line import swap gives fp32 storage (ist_encoder.py:281
+        # default), eager steps under automatic optimisation (cli/segment.py:400-405), 1M-edge batches (data_module.py:158)
+        if rank == 0 and world == 1 and not args.no_default_dropin:
+            try:
+                model.model.compute_dtype = torch.float32
+                n_dd = min(100, len(batches))
+                for k in range(3):
+                    strong_step(k, k)
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for k in range(n_dd):
+                    strong_step(k, k)
+                torch.cuda.synchronize()
+                d_dd = (time.perf_counter() - t) / n_dd
+                etb_dd = sum(units_of[k][0] for k in range(n_dd))
+                default_dropin = {"ms_per_step": d_dd * 1e3, "value": 2.0 * etb_dd / (d_dd * n_dd), "unit": "edges/s",
+                                  "batches": n_dd, "dtype": "f32",
+                                  "what": "what the import swap alone gives: fp32 storage, eager training_step + backward "
+                                          "+ optimizer.step() per batch (Lightning's automatic optimisation), "
+                                          f"<= {args.strong_edges_per_batch}-edge batches of the resident FOV; "
+                                          "LitISTEncoder.fast() switches to bf16 storage + captured steps "
+                                          "(strong.graphed)"}
+                log(f"[bench] default_dropin: {default_dropin}")
+            except Exception as e:  # noqa: BLE001  (secondary figure, single process)
+                default_dropin = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                model.model.compute_dtype = dtype
         # the same epoch with every step replayed as ONE hipGraph (segger_amd.train_step_graph); with several ranks as
         # two graphs around the all-reduce of the persistent flat gradient buffer.  The ranks decide TOGETHER whether to
         # run it: each first takes two captured steps with NO collective (pre-flight; rolled back), then all vote
@@ -570,12 +849,36 @@ def main():
         del trainer
         if rank == 0:
             log(f"[bench] strong: {strong}")
-        del part, batches
+        # ---- AUROC vs the oracle on tiles of this FOV, and config 5 on it (single process only) -----------------------
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            try:
+                auroc_fov = fov_tiles_auroc(model, part, dev, n_tiles=args.auroc_tiles)
+                log(f"[bench] auroc (FOV tiles): {auroc_fov}")
+            except Exception as e:  # noqa: BLE001
+                auroc_fov = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0 and world == 1 and not args.no_c5:
+            try:
+                c5 = c5_record(model, part, batches, fov_data, tiling, sspec.bd_dim, dev)
+                c5["workload"] = (f"C5 on the resident {args.strong_n_tx}-tx FOV (the 100M-tx run: tools/fov_stream.py, "
+                                  f"profiles/): fp16, hipGraph-captured batched predict")
+                log(f"[bench] c5: {c5}")
+            except Exception as e:  # noqa: BLE001
+                c5 = {"error": f"{type(e).__name__}: {e}"}
+        del part, batches, fov_data
 
     cpu = None
+    auroc = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        torch.cuda.empty_cache()
         try:
-            cpu = cpu_baseline()
+            ctx = {}
+            cpu = cpu_baseline(auroc_ctx=ctx)
+            try:
+                auroc = auroc_vs_oracle(ctx, dev, trained=model)
+                log(f"[bench] auroc (C2/10 tile): {auroc}")
+            except Exception as e:  # noqa: BLE001
+                auroc = {"error": f"{type(e).__name__}: {e}"}
+            del ctx
             # the CPU figure for the default regime -- one packed 1M-edge batch (~50k tx, k = 15)
             cpu["default_batch"] = cpu_baseline(sample_tx=50_000, sample_bd=500, n_warm=1, n_reps=3,
                                                 label="one 1M-edge batch (segger's edges_per_batch default)")
@@ -597,9 +900,12 @@ def main():
                                    f"attention dropout {'off' if args.no_dropout else '0.2'}",
                        "tiles_per_step": world, "parallelism": f"dp{world}"},
             "mp_edges_per_s": n_layers * (ett_all + etb_all) * args.steps / dt,
-            "loss": loss_val,
+            "loss": loss_val, "untimed_setup": untimed,
+            "csr_build_ms": None if untimed is None else untimed["csr_build_ms"],
             "roofline": roof, "roofline_other": extra, "cpu_baseline": cpu, "predict": predict,
             "f32": f32, "strong": strong,
+            "auroc": None if auroc is None else dict(auroc, fov_tiles=auroc_fov),
+            "c5": c5, "default_dropin": default_dropin,
             "strong_value": None if not strong else strong.get("value"),
             "strong_graphed_value": None if not strong or not strong.get("graphed") else strong["graphed"].get("value"),
         }

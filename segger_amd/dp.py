@@ -25,9 +25,12 @@ class FlatGradBucket:
     buffer with ONE multi-tensor copy and re-points every ``.grad`` at its slice of it; ``all_reduce_mean`` then runs
     ONE collective on the buffer and divides by the world size in place -- three launches, no allocation, and no copy
     back: the optimizer reads the averaged slices.  The buffer is allocated once (same address every step; a captured
-    optimizer graph may read it).  With a single rank ``all_reduce_mean`` does nothing at all."""
+    optimizer graph may read it).  With a single rank ``all_reduce_mean`` does nothing at all -- unless
+    ``force_collective`` is set: then the one-rank communicator is exercised too (a world-1 mean is the identity; how the
+    RCCL path is tested on a one-GPU box)."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], force_collective: bool = False):
+        self.force_collective = bool(force_collective)
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -69,12 +72,13 @@ class FlatGradBucket:
         for p, v in zip(self.params, self.views):
             p.grad = v
 
-    def all_reduce_mean(self, group=None, packed: bool = False) -> None:
-        """``packed``: the caller has already run :meth:`pack` / :meth:`zero` (e.g. inside a captured graph)."""
+    def all_reduce_mean(self, group=None, packed: bool = False, force: Optional[bool] = None) -> None:
+        """``packed``: the caller has already run :meth:`pack` / :meth:`zero` (e.g. inside a captured graph).
+        ``force`` (default: ``self.force_collective``): run pack + collective + divide on a one-rank group too."""
         if not (dist.is_available() and dist.is_initialized()):
             return
         world = dist.get_world_size(group)
-        if world == 1:
+        if world == 1 and not (self.force_collective if force is None else force):
             return
         if not packed:
             self.pack()

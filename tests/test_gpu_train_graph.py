@@ -232,6 +232,39 @@ def test_graphed_trainer_data_parallel(cuda, tmp_path):
         assert x["last"] < x["first"]
 
 
+def test_rccl_one_rank_communicator(cuda, tmp_path):
+    """RCCL on this one GPU (task 2a): a one-rank ``nccl`` group runs every collective of bench.py / dp.py
+    (same dtypes and reduce ops), an eager step through the forced flat-bucket all-reduce, and 20 captured steps in the
+    data-parallel form -- two graphs around the all-reduce -- against the single-graph trainer.  A world-1 mean is the
+    identity: the exchange must not change one bit of the flat gradient buffer; the two trainers agree as two runs of
+    one trainer do (the loss kernels add with float atomics, so even those differ in the last bits).  The worker is a
+    fresh process whose first GPU call is ``init_process_group(device_id=...)``."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(str(tmp_path), "rccl.json")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0",
+               WORLD_SIZE="1", LOCAL_RANK="0", RCCL_WORKER_OUT=out)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_world1_worker.py")],
+                       capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    x = json.loads(open(out).read())
+    assert x["backend"] == "nccl" and x["world"] == 1
+    assert x["collectives_identity"]
+    assert x["eager_calls"] == 1 and x["eager_bits_changed"] == 0 and x["grads_are_views"]
+    assert x["split_calls"] == 20 and x["split_bits_changed"] == 0          # one exchange per step, the identity
+    assert x["split_two_graphs"] and x["single_graph"]
+    assert x["adam_steps"] == [0.0, 20.0] and x["finite"]
+    assert x["max_loss_diff"] < 2e-2 and x["max_param_diff"] < 2e-2 * max(x["param_scale"], 1.0)
+    assert x["loss_first_last"][1] < x["loss_first_last"][0]
+
+
 def test_adam_kernel_matches_torch_adam(cuda):
     """ops.adam_step (segger_adam_step: all tensors in two launches, on torch's own state tensors) against
     torch.optim.Adam(fused, capturable) on the same gradients: parameters and both moments agree to fp32 rounding over
