@@ -36,6 +36,13 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: only what is declared between this push and the pop at the end of the
+ * header -- the C entry points -- reaches its dynamic symbol table (a definition takes the visibility of its first
+ * declaration); the C++ launchers behind them (namespace segger) stay internal. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define SEGGER_ABI_VERSION 15
 
 enum segger_status {
@@ -698,6 +705,10 @@ size_t segger_knn_workspace_bytes(int64_t n_points, int32_t nx, int32_t ny);
 int segger_knn_grid(const float* points, int64_t n_points, const float* queries, int64_t n_queries, int32_t k,
                     float max_dist, float x0, float y0, float cell, int32_t nx, int32_t ny,
                     int32_t* nbr, float* dist, void* workspace, size_t workspace_bytes, segger_stream_t stream);
+
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,19 @@ int hip_fail(hipError_t e, const char* what);
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Compute units of the CURRENT device, cached per device id (a process may drive several GPUs: a persistent grid sized
+// from whichever device asked first would be wrong on a heterogeneous node).  0 = unknown.
+inline int device_cu_count() {
+  static int cache[64] = {};            // written once per device with the same value: a benign race
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+  if (dev < 64 && cache[dev] > 0) return cache[dev];
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+  if (dev < 64 && n > 0) cache[dev] = n;
+  return n;
+}
+
 // ------------------------------------------------- fp32 projections (csrc/linear_f32.hip) ---
 int linear_f32_launch(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t n_rows,
                       int k_in, int m_out, hipStream_t stream, const float* rowbias = nullptr, const int32_t* rowidx = nullptr,
@@ -47,13 +60,14 @@ int wgrad_f32_launch(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x,
 // Between segger_reductions_defer_begin() and segger_reductions_flush() (csrc/reduce.hip) the kernels that leave
 // per-workgroup partial sums (weight gradients, grad_att / grad_bias slabs) queue their final sum here instead of
 // launching it; defer_reduce() returns false when nothing is being deferred (or the sum is too long for one pass,
-// or the table is full) and the caller launches its own reduction as usual.
+// or the table is full, or the producer runs on another device / stream than the bracket's) and the caller launches its
+// own reduction as usual.
 struct ReduceSeg {
   const float* partial; int64_t n_slabs; int64_t width; int64_t split; float* out0; float* out1;
   float* scratch;      // >= kReduceGroups * width floats behind the partials (sums longer than one pass go through it)
 };
 constexpr int kReduceGroups = 32;
-bool defer_reduce(const ReduceSeg& seg);
+bool defer_reduce(const ReduceSeg& seg, hipStream_t stream);
 
 constexpr int kWave = 64;
 constexpr int kNumXcd = 8;

@@ -324,7 +324,7 @@ int bwd_reduce_slab(const segger_gatv2_bwd_args* a, const BwdState& s, hipStream
   const GatParams& p = s.p;
   const int hc = a->heads * a->channels, width = 2 * hc;
   float* part = p.slab + p.nblocks * width;              // behind the per-block slabs
-  if (defer_reduce(ReduceSeg{p.slab, p.nblocks, width, hc, a->grad_att, a->grad_bias, part})) return SEGGER_OK;
+  if (defer_reduce(ReduceSeg{p.slab, p.nblocks, width, hc, a->grad_att, a->grad_bias, part}, stream)) return SEGGER_OK;
   hipLaunchKernelGGL(slab_reduce_stage1, dim3((width + 63) / 64, kSlabSplits), dim3(256), 0, stream,
                      p.slab, p.nblocks, width, part);
   hipLaunchKernelGGL(slab_reduce_stage2, dim3((width + 255) / 256), dim3(256), 0, stream,

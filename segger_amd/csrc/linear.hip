@@ -316,11 +316,7 @@ __global__ __launch_bounds__(kResWaves * 64, 1) void linear_res_kernel(LinearPar
 template <typename T>
 int launch_linear_res(const LinearParams& p, int k_in, hipStream_t stream, bool* done) {
   *done = false;
-  static const int n_cu = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-    return n;
-  }();
+  const int n_cu = device_cu_count();           // per device (common.h)
   const int64_t n_tiles = (p.n_rows + 31) / 32;
   // worth it only when every wave of the persistent grid gets a few tiles
   if (n_cu <= 0 || p.rowbias || p.gate || n_tiles < (int64_t)n_cu * kResWaves * 2) return SEGGER_OK;

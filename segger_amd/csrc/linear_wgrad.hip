@@ -877,7 +877,7 @@ namespace segger {
 namespace {
 int reduce_partials(float* partial, int64_t grid, int m_out, int k_in, float* grad_w, float* grad_b, hipStream_t stream) {
   const int64_t width = (int64_t)m_out * k_in + m_out;
-  if (defer_reduce(ReduceSeg{partial, grid, width, (int64_t)m_out * k_in, grad_w, grad_b, partial + grid * width}))
+  if (defer_reduce(ReduceSeg{partial, grid, width, (int64_t)m_out * k_in, grad_w, grad_b, partial + grid * width}, stream))
     return SEGGER_OK;
   if (grid <= kSinglePassSlabs) {
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((width + 255) / 256)), dim3(256), 0, stream, partial, grid,

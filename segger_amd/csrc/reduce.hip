@@ -22,6 +22,9 @@ constexpr int64_t kOnePassSlabs = 128;          // longer sums first fold into k
 struct ReduceBatch { int n; ReduceSeg seg[kMaxSegs]; };
 static ReduceBatch g_batch;
 static bool g_active = false;
+static int g_device = -1;                       // the device that opened the bracket
+static hipStream_t g_stream = nullptr;          // the stream of the first producer that queued a sum
+static bool g_stream_set = false;
 static std::mutex g_mu;
 
 __global__ __launch_bounds__(256) void reduce_many_kernel(ReduceBatch b) {
@@ -60,9 +63,15 @@ __global__ __launch_bounds__(256) void reduce_many_fold_kernel(ReduceBatch b) {
 
 }  // namespace
 
-bool defer_reduce(const ReduceSeg& seg) {
+bool defer_reduce(const ReduceSeg& seg, hipStream_t stream) {
   std::lock_guard<std::mutex> lock(g_mu);
   if (!g_active || g_batch.n >= kMaxSegs || (seg.n_slabs > kOnePassSlabs && seg.scratch == nullptr)) return false;
+  // the table belongs to ONE device and ONE stream (the bracket's): a backward of another model on another GPU or
+  // stream of this process must not leave its sum to a flush that runs elsewhere -- it launches its own
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != g_device) return false;
+  if (!g_stream_set) { g_stream = stream; g_stream_set = true; }
+  else if (stream != g_stream) return false;
   g_batch.seg[g_batch.n++] = seg;
   return true;
 }
@@ -74,7 +83,9 @@ using namespace segger;
 extern "C" int segger_reductions_defer_begin(void) {
   std::lock_guard<std::mutex> lock(g_mu);
   SEGGER_REQUIRE(!g_active, "segger_reductions_defer_begin: already deferring (flush first)");
+  SEGGER_HIP(hipGetDevice(&g_device));
   g_active = true;
+  g_stream_set = false;
   g_batch.n = 0;
   return SEGGER_OK;
 }
@@ -89,6 +100,11 @@ extern "C" int segger_reductions_flush(segger_stream_t stream) {
   SEGGER_REQUIRE(g_active, "segger_reductions_flush: nothing is being deferred");
   g_active = false;
   if (g_batch.n == 0) return SEGGER_OK;
+  if (g_stream_set && g_stream != (hipStream_t)stream) {
+    g_batch.n = 0;
+    set_error("segger_reductions_flush: the queued sums were produced on another stream than the one given");
+    return SEGGER_EINVAL;
+  }
   // sums of more than kOnePassSlabs partials: one launch folds them all into kReduceGroups groups each (their scratch),
   // and the final launch sums those groups like any short sum
   ReduceBatch longs; longs.n = 0;

@@ -122,7 +122,9 @@ class deferred_reductions:
         global _DEFER_KEEP
         if _DEFER_KEEP is not None:
             raise RuntimeError("deferred_reductions does not nest")
-        _lib.check(_lib.load().segger_reductions_defer_begin(), "segger_reductions_defer_begin")
+        with _lib.on_device(self.device):        # the table is pinned to the device current HERE and to the stream of the
+            rc = _lib.load().segger_reductions_defer_begin()     # first producer: a backward elsewhere sums for itself
+        _lib.check(rc, "segger_reductions_defer_begin")
         _DEFER_KEEP = []
         return self
 
@@ -881,6 +883,11 @@ def adam_step(opt) -> bool:
     ``optimizer.step()`` itself."""
     from .optim import Adam as _Adam
     if type(opt) not in (torch.optim.Adam, _Adam):   # (not subclasses in general: torch's AdamW is one)
+        return False
+    # torch's AMP contract for fused optimizers (``_step_supports_amp_scaling``): ``GradScaler.step`` skips its own unscale /
+    # inf check and hands both to the optimizer as ``grad_scale`` / ``found_inf``.  The kernel reads neither: torch's fused
+    # step does the scaled, skippable update.
+    if getattr(opt, "grad_scale", None) is not None or getattr(opt, "found_inf", None) is not None:
         return False
     jobs = []
     for g in opt.param_groups:

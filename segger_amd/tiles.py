@@ -370,6 +370,21 @@ class TilePartition:
                     add(v)
         return total
 
+    def checksum(self) -> int:
+        """A cheap fingerprint of every integer store batches hand out views of (edge lists, sorted views): equal before
+        and after an epoch <=> no consumer wrote through a view.  One reduction per tensor + one sync: debug / tests."""
+        total = 0
+        tensors = [st["edge_index"] for st in self.data._edges.values()]
+        for views in (getattr(self, "_csr", None) or {}).values():
+            for side in views.values():
+                tensors += list(side.values())
+        for i, t in enumerate(tensors):
+            if t.numel():
+                f = t.reshape(-1)
+                total += (i + 1) * (int(f.sum(dtype=torch.int64)) + 3 * int(f[::2].sum(dtype=torch.int64))
+                                    + 7 * int(f[1::3].sum(dtype=torch.int64)))
+        return total & ((1 << 62) - 1)
+
     def add_node_attr(self, node_type: str, name: str, value: Tensor, permuted: bool = False) -> None:
         self.data[node_type][name] = value if permuted else value.index_select(0, self.node_perm[node_type])
 
@@ -383,7 +398,13 @@ class TilePartition:
 
     def batch(self, tile_ids: Sequence[int]) -> HeteroBatch:
         """The collated batch of the given tiles (== PyG ``Batch.from_data_list([tile(i) ...])`` for the
-        fields of the contract): node slices concatenated, edge ids rebased, ``batch`` = graph id."""
+        fields of the contract): node slices concatenated, edge ids rebased, ``batch`` = graph id.
+
+        READ-ONLY: a single-tile batch is made of VIEWS of the slide-level stores (node attributes, ``edge_index``, and --
+        after :meth:`build_csr` -- the sorted views' ``indptr`` / ``col`` / ``eid``): no launch, no copy per batch.  An
+        in-place edit by a consumer (``edge_index.add_``, a self-loop transform, ``sort_``) would corrupt the tile for
+        every later epoch and every shard; clone what you need to change.  :meth:`checksum` lets a test or a debug run
+        assert that nobody did."""
         tile_ids = [int(t) + (self.num_tiles if t < 0 else 0) for t in tile_ids]
         for t in tile_ids:
             if not 0 <= t < self.num_tiles:

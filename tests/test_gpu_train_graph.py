@@ -165,6 +165,32 @@ def test_graphed_training_under_manual_optimisation(cuda):
             moved += float((a - c).abs().sum())
     assert moved > 0.0 and apart < 0.3 * moved
     assert float(opt.state[next(iter(m.parameters()))]["step"]) == 4.0
+    # Lightning's manual optimisation counts global_step through hooks its loop installs on the LightningOptimizer wrapper
+    # (lightning/pytorch/loops/optimization/manual.py: _on_before_step / _on_after_step -> optim_step_progress); the
+    # replay steps the raw optimizer, so training_step must fire them itself -- else global_step stays 0, ModelCheckpoint
+    # never saves and max_steps never ends the fit
+    class Progress:
+        ready = completed = 0
+
+    class Wrapper:                                          # the slice of LightningOptimizer the path touches
+        def __init__(self, optimizer, prog):
+            self.optimizer = optimizer
+            self._on_before_step = lambda: setattr(prog, "ready", prog.ready + 1)
+            self._on_after_step = lambda: setattr(prog, "completed", prog.completed + 1)
+    prog = Progress()
+    m.trainer = types.SimpleNamespace(optimizers=[Wrapper(opt, prog)], max_epochs=20, datamodule=None)
+    for i in range(3):
+        m.training_step(bg, i)
+    assert (prog.ready, prog.completed) == (3, 3)
+    # no hooks on the wrapper: the loop's progress tracker is advanced directly
+    class Tracker(Progress):
+        def increment_ready(self): self.ready += 1
+        def increment_completed(self): self.completed += 1
+    trk = Tracker()
+    loop = types.SimpleNamespace(epoch_loop=types.SimpleNamespace(manual_optimization=types.SimpleNamespace(optim_step_progress=trk)))
+    m.trainer = types.SimpleNamespace(optimizers=[opt], max_epochs=20, datamodule=None, fit_loop=loop)
+    m.training_step(bg, 0)
+    assert (trk.ready, trk.completed) == (1, 1)
     # switched on too late (the trainer already holds a non-capturable Adam): a clear error, not a capture failure
     late = copy.deepcopy(twin)
     late._graphed_trainer = None
@@ -299,6 +325,37 @@ def test_adam_kernel_matches_torch_adam(cuda):
     assert not ops.adam_step(torch.optim.Adam(ps_a, lr=1e-3, weight_decay=0.1, fused=True, capturable=True))
     assert not ops.adam_step(torch.optim.AdamW(ps_a, lr=1e-3, fused=True, capturable=True))
     assert not ops.adam_step(torch.optim.Adam(ps_a, lr=1e-3))          # not capturable: host-side step counters
+
+
+def test_optim_adam_honours_the_grad_scaler_contract(cuda):
+    """torch hands a FUSED optimizer the loss scale and the inf flag instead of unscaling itself
+    (``_step_supports_amp_scaling``: ``GradScaler.step`` sets ``optimizer.grad_scale`` / ``found_inf``).  The hand-written
+    kernel reads neither, so ``optim.Adam`` must leave such a step to torch: same parameters as
+    ``torch.optim.Adam(fused=True)`` under the same scaler, and a step with an inf gradient is skipped."""
+    from segger_amd.optim import Adam
+    g = torch.Generator(device=cuda).manual_seed(3)
+    w0 = torch.randn(48, 32, device=cuda, generator=g)
+    x = torch.randn(64, 32, device=cuda, generator=g)
+    runs = {}
+    for name, cls in (("ours", Adam), ("torch", torch.optim.Adam)):
+        w = w0.clone().requires_grad_(True)
+        opt = cls([w], lr=1e-2, fused=True, capturable=True)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0, growth_interval=1000)
+        for step in range(5):
+            opt.zero_grad(set_to_none=True)
+            loss = (x @ w.t()).square().mean()
+            scaler.scale(loss).backward()
+            if step == 3:
+                w.grad[0, 0] = float("inf")              # the scaler must skip this step and halve the scale
+            before = w.detach().clone()
+            scaler.step(opt)
+            scaler.update()
+            if step == 3:
+                assert torch.equal(w.detach(), before), name
+        runs[name] = (w.detach().clone(), float(opt.state[w]["step"]), scaler.get_scale())
+    assert runs["ours"][1] == runs["torch"][1] == 4.0 and runs["ours"][2] == runs["torch"][2] == 512.0
+    assert torch.allclose(runs["ours"][0], runs["torch"][0], rtol=1e-6, atol=1e-7)
+    assert not torch.equal(runs["ours"][0], w0)
 
 
 def test_optim_adam_is_a_drop_in_torch_adam(cuda):

@@ -23,6 +23,19 @@ def header_abi_version():
     return int(re.search(r"#define\s+SEGGER_ABI_VERSION\s+(\d+)", src).group(1))
 
 
+def test_library_exports_only_the_c_entry_points():
+    """The dynamic symbol table of the built library is exactly the header's declarations: no C++ launcher
+    (``_ZN6segger...``), no kernel handle, no rocPRIM template (csrc/exports.map + -fvisibility=hidden)."""
+    import shutil
+    import subprocess
+    from segger_amd import _lib
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    syms = sorted(ln.split()[-1] for ln in out.splitlines() if ln.strip())
+    assert syms == header_functions(), [s_ for s_ in syms if s_ not in header_functions()][:5]
+    assert not any("_ZN6segger" in s_ for s_ in syms)
+
+
 def test_library_exports_every_declared_symbol():
     from segger_amd import _lib
     lib = _lib.load()                      # loads without a GPU; no compute call is made

@@ -249,3 +249,20 @@ def test_shard_keeps_only_its_tiles_and_batches_match(graph):
     assert part.shard([]).num_tiles == 0
     with pytest.raises(IndexError):
         part.shard([0, 0])
+
+
+def test_single_tile_batches_are_read_only_views_and_the_checksum_sees_a_write(graph):
+    """A single-tile batch hands out VIEWS of the slide-level stores (no copy per batch): `TilePartition.checksum()` is
+    unchanged by an epoch of batches and changes when a consumer edits an edge list in place (the contract is
+    documented on `TilePartition.batch`; this is the cheap regression check)."""
+    part = T.partition_by_tiling(graph, T.SquareTiling(all_pos(graph), 25.0), margin=2.0)
+    before = part.checksum()
+    for t in range(len(part)):
+        b = part.tile(t)
+        ei = b[("tx", "neighbors", "tx")].edge_index
+        if ei.numel():
+            assert ei.data_ptr() >= part.data[("tx", "neighbors", "tx")].edge_index.data_ptr()     # a view, not a copy
+    assert part.checksum() == before
+    t = next(t for t in range(len(part)) if part.tile(t)[("tx", "neighbors", "tx")].edge_index.numel())
+    part.tile(t)[("tx", "neighbors", "tx")].edge_index.add_(1)           # what a consumer must NOT do
+    assert part.checksum() != before
