@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 15
+#define SEGGER_ABI_VERSION 16
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -507,6 +507,56 @@ size_t segger_triplet_workspace_bytes(int64_t n_edges);
 int segger_triplet_fwd(const segger_triplet_args* args, segger_stream_t stream);
 int segger_triplet_bwd(const segger_triplet_args* args, segger_stream_t stream);
 
+/*
+ * segger_loss_head_fwd / _bwd: LitISTEncoder.get_losses after the sampling (lightning_model.py:151-213: loss_tx =
+ * TripletLoss, loss_bd = MetricLoss (models/triplet_loss.py:128-204), loss_sg = TripletMarginLoss or BCEWithLogits on the
+ * tx-belongs-bd edges (:167-207), weighted sum :210-211) as ONE launch each way (csrc/loss_head.hip).  Same arithmetic as
+ * segger_triplet_* / segger_metric_* / segger_loss_combine_*, which remain for other shapes.
+ *   loss_tx triplets are (t, tx_pos[t], tx_neg[t]), t < n_tx (rows of z_tx; tx_pos[t] < 0 skips t; mean over n_tx);
+ *   loss_bd as segger_metric_fwd over the rows of z_bd;  loss_sg over n_sg triplets (sg_src -> z_tx, sg_pos / sg_neg -> z_bd;
+ *   sg_pos < 0 skips; mean over n_sg, or over 2 n_sg logits for SEGGER_LOSS_BCE).
+ *   out[0..2] = a[i] * loss_i, out[3] = sum_i b[i] out[i]  (a, b: float[3] on the device, as segger_loss_combine_fwd).
+ * Forward, with tx_w / tx_state / tx_next / tx_hot_id / tx_hot_acc given (a training step): per loss_tx triplet the reciprocal
+ *   distances of ACTIVE triplets (tx_w [n_tx, 2], 0 = inactive) and the chains of contributions per target row: tx_state
+ *   int32 [2 n_tx + 4] = per row (chain head, contribution count), then the hot-row counter -- the CALLER ZERO-FILLS it
+ *   before every forward launch (a chain walk is bounded whatever it holds: a stale buffer gives wrong numbers, never a
+ *   spinning kernel); tx_next int32 [2 n_tx]; a row that receives more than 64 contributions (skewed draws: few members of a
+ *   much-drawn cluster in the batch) is "hot": tx_hot_id int32 [n_tx + segger_loss_head_max_hot_rows(n_tx)] and tx_hot_acc fp32 [segger_loss_head_max_hot_rows(n_tx),
+ *   C] hold its accumulator (no initialisation needed).  With grad_bd given the launch zero-fills it; with grad_out
+ *   (float[4], d / d out) given it also writes grad_raw[3], the scale factors of the three backward terms
+ *   (segger_loss_combine_bwd's result).
+ * Backward: grad_tx [n_tx, C] (dtype of the embeddings) is WRITTEN, every row once, no atomics: row r = its anchor term of
+ *   loss_tx + the positive / negative terms of the triplets chained to r + the anchor term of the segmentation triplet
+ *   sg_of_tx[r] (int32 [n_tx], -1 = none: requires that no transcript anchors two segmentation triplets; NULL = the
+ *   segmentation loss contributes nothing to grad_tx, the caller adds it); with y_tx given (z_tx = y_tx / max(|y_tx|,
+ *   norm_eps) row-wise) the row is pushed through that normalisation's backward and grad_tx is d / d y_tx.  Hot rows are
+ *   accumulated with fp32 atomics by the groups of the contributing triplets and finished by the last contributor.
+ *   grad_bd [n_bd, C] fp32 is ACCUMULATED INTO (zero-filled by the forward): metric loss, segmentation positives (summed
+ *   per boundary over sg_pos_indptr [n_bd + 1] / sg_pos_eid [n_sg], the triplets grouped by positive row) and negatives.
+ * workspace: segger_loss_head_workspace_bytes() (per-block partial sums); ticket: one int32 that is ZERO before the first
+ *   launch and that every launch leaves zero (last-block detection) -- keep one per stream.  C in {32, 64, 128}.
+ */
+typedef struct segger_loss_head_args {
+  const void* z_tx; int64_t ld_ztx; int64_t n_tx;
+  const void* z_bd; int64_t ld_zbd; int64_t n_bd;
+  int32_t channels, dtype;
+  const int64_t* tx_pos; const int64_t* tx_neg; float tx_margin, tx_eps;
+  const int64_t* bd_pos; const int64_t* bd_neg; const float* bd_dpos; const float* bd_dneg; const float* bd_w; float bd_eps;
+  int32_t sg_kind;
+  const int64_t* sg_src; const int64_t* sg_pos; const int64_t* sg_neg; int64_t n_sg; float sg_margin, sg_eps;
+  const int64_t* sg_pos_indptr; const int32_t* sg_pos_eid; const int32_t* sg_of_tx;
+  const float* a; const float* b; const float* grad_out; float* out; float* grad_raw;
+  float* tx_w; int32_t* tx_state; int32_t* tx_next; int32_t* tx_hot_id; float* tx_hot_acc;
+  const void* y_tx; int64_t ld_ytx; float norm_eps; int32_t reserved_;
+  void* grad_tx; int64_t ld_gtx; float* grad_bd;
+  void* workspace; size_t workspace_bytes; int32_t* ticket;
+} segger_loss_head_args;
+size_t segger_loss_head_workspace_bytes(int64_t n_tx, int64_t n_bd, int64_t n_sg);
+int64_t segger_loss_head_max_hot_rows(int64_t n_tx);
+int segger_loss_head_supported(int32_t channels, int32_t dtype);
+int segger_loss_head_fwd(const segger_loss_head_args* args, segger_stream_t stream);
+int segger_loss_head_bwd(const segger_loss_head_args* args, segger_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Positional embedder, stage 1: per-graph min / max of node positions.
  * Replaces the Python loop over graphs in Positional2dEmbedder.forward
@@ -675,6 +725,16 @@ int segger_l2norm_fwd(const void* y, int64_t ld_y, int64_t n, int32_t channels, 
                       int32_t dtype, segger_stream_t stream);
 int segger_l2norm_bwd(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, int64_t n, int32_t channels,
                       float eps, void* gy, int64_t ld_gy, int32_t dtype, segger_stream_t stream);
+/* segger_l2norm_many: up to 4 row normalisations in ONE launch (both node types of the encoder's tail, ist_encoder.py:331-332;
+ * the boundary side's backward from the loss head's fp32 gradient).  Per segment: gz == NULL -> out = y / max(|y|, eps);
+ * otherwise out = d / d y from the incoming gradient gz ([n, C] in the embeddings' dtype, or fp32 when gz_f32 != 0). */
+typedef struct segger_l2norm_seg {
+  const void* y; int64_t ld_y; int64_t n;
+  void* out; int64_t ld_out;
+  const void* gz; int64_t ld_gz; int32_t gz_f32; int32_t reserved_;
+} segger_l2norm_seg;
+int segger_l2norm_many(const segger_l2norm_seg* segs, int32_t n_segs, int32_t channels, float eps, int32_t dtype,
+                       segger_stream_t stream);
 /* the same with the incoming gradient given as the sum of two matrices gz + gz2 (gz2 may be NULL): the loss head hands
  * the anchors' stored rows and the atomically accumulated rows over separately (segger_triplet_args.grad_a_rows) */
 int segger_l2norm_bwd2(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, const void* gz2, int64_t ld_gz2, int64_t n,

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
@@ -132,6 +132,29 @@ class TripletArgs(C.Structure):
     ]
 
 
+class L2NormSeg(C.Structure):
+    _fields_ = [("y", vp), ("ld_y", C.c_int64), ("n", C.c_int64), ("out", vp), ("ld_out", C.c_int64),
+                ("gz", vp), ("ld_gz", C.c_int64), ("gz_f32", C.c_int32), ("reserved_", C.c_int32)]
+
+
+class LossHeadArgs(C.Structure):
+    _fields_ = [
+        ("z_tx", vp), ("ld_ztx", C.c_int64), ("n_tx", C.c_int64),
+        ("z_bd", vp), ("ld_zbd", C.c_int64), ("n_bd", C.c_int64),
+        ("channels", C.c_int32), ("dtype", C.c_int32),
+        ("tx_pos", vp), ("tx_neg", vp), ("tx_margin", C.c_float), ("tx_eps", C.c_float),
+        ("bd_pos", vp), ("bd_neg", vp), ("bd_dpos", vp), ("bd_dneg", vp), ("bd_w", vp), ("bd_eps", C.c_float),
+        ("sg_kind", C.c_int32),
+        ("sg_src", vp), ("sg_pos", vp), ("sg_neg", vp), ("n_sg", C.c_int64), ("sg_margin", C.c_float), ("sg_eps", C.c_float),
+        ("sg_pos_indptr", vp), ("sg_pos_eid", vp), ("sg_of_tx", vp),
+        ("a", vp), ("b", vp), ("grad_out", vp), ("out", vp), ("grad_raw", vp),
+        ("tx_w", vp), ("tx_state", vp), ("tx_next", vp), ("tx_hot_id", vp), ("tx_hot_acc", vp),
+        ("y_tx", vp), ("ld_ytx", C.c_int64), ("norm_eps", C.c_float), ("reserved_", C.c_int32),
+        ("grad_tx", vp), ("ld_gtx", C.c_int64), ("grad_bd", vp),
+        ("workspace", vp), ("workspace_bytes", C.c_size_t), ("ticket", vp),
+    ]
+
+
 # every symbol include/segger_amd.h declares: name -> (restype, argtypes)
 EXPORTS = {
     "segger_abi_version": (C.c_int, []),
@@ -206,6 +229,12 @@ EXPORTS = {
                                         C.c_size_t, vp]),
     "segger_colsum_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "segger_colsum": (C.c_int, [vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, vp, C.c_size_t, vp]),
+    "segger_l2norm_many": (C.c_int, [C.POINTER(L2NormSeg), C.c_int32, C.c_int32, C.c_float, C.c_int32, vp]),
+    "segger_loss_head_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64, C.c_int64]),
+    "segger_loss_head_max_hot_rows": (C.c_int64, [C.c_int64]),
+    "segger_loss_head_supported": (C.c_int, [C.c_int32, C.c_int32]),
+    "segger_loss_head_fwd": (C.c_int, [C.POINTER(LossHeadArgs), vp]),
+    "segger_loss_head_bwd": (C.c_int, [C.POINTER(LossHeadArgs), vp]),
     "segger_knn_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "segger_knn_grid": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_int32, C.c_int32, vp, vp, vp, C.c_size_t, vp]),

@@ -257,6 +257,48 @@ int launch_l2norm(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, in
   return SEGGER_OK;
 }
 
+// Several row normalisations in one launch (segger_l2norm_many): per segment forward (gz == NULL) or backward, the
+// incoming gradient in the embeddings' dtype or in fp32 (the loss head accumulates the boundary side in fp32).
+constexpr int kL2MaxSegs = 4;
+struct L2Batch { segger_l2norm_seg seg[kL2MaxSegs]; int32_t first_block[kL2MaxSegs + 1]; int32_t n; float eps; };
+
+template <typename T, int LPC>
+__global__ __launch_bounds__(256) void l2norm_many_kernel(L2Batch b) {
+  int s = 0;
+  while (s + 1 < b.n && (int)blockIdx.x >= b.first_block[s + 1]) ++s;
+  const segger_l2norm_seg g = b.seg[s];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int RPW = 64 / LPC;
+  const int64_t row = ((int64_t)(blockIdx.x - b.first_block[s]) * 4 + wave) * RPW + lane / LPC;
+  if (row >= g.n) return;
+  const int c0 = (lane % LPC) * 8;
+  float v[8];
+  Vec8<T>::load(static_cast<const T*>(g.y) + row * g.ld_y + c0, v);
+  float ss = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ss = fmaf(v[k], v[k], ss);
+  const float nrm = sqrtf(lane_block_sum<LPC>(ss));
+  const float inv = 1.0f / fmaxf(nrm, b.eps);
+  T* out = static_cast<T*>(g.out) + row * g.ld_out + c0;
+  if (g.gz == nullptr) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= inv;
+    Vec8<T>::store(out, v);
+    return;
+  }
+  float gr[8];
+  if (g.gz_f32) Vec8<float>::load(static_cast<const float*>(g.gz) + row * g.ld_gz + c0, gr);
+  else Vec8<T>::load(static_cast<const T*>(g.gz) + row * g.ld_gz + c0, gr);
+  float dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dot = fmaf(v[k] * inv, gr[k], dot);
+  dot = lane_block_sum<LPC>(dot);
+  if (nrm < b.eps) dot = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) gr[k] = (gr[k] - v[k] * inv * dot) * inv;
+  Vec8<T>::store(out, gr);
+}
+
 size_t esize(int dtype) { return dtype == SEGGER_F32 ? 4 : 2; }
 
 
@@ -550,4 +592,39 @@ extern "C" int segger_l2norm_bwd2(const void* y, int64_t ld_y, const void* gz, i
 extern "C" int segger_l2norm_bwd(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, int64_t n, int32_t channels,
                                  float eps, void* gy, int64_t ld_gy, int32_t dtype, segger_stream_t stream) {
   return segger_l2norm_bwd2(y, ld_y, gz, ld_gz, nullptr, 0, n, channels, eps, gy, ld_gy, dtype, stream);
+}
+
+extern "C" int segger_l2norm_many(const segger_l2norm_seg* segs, int32_t n_segs, int32_t channels, float eps, int32_t dtype,
+                                  segger_stream_t stream) {
+  SEGGER_REQUIRE(n_segs >= 0 && n_segs <= kL2MaxSegs && (n_segs == 0 || segs), "segger_l2norm_many: 0..4 segments");
+  SEGGER_REQUIRE(channels == 8 || channels == 16 || channels == 32 || channels == 64 || channels == 128,
+                 "segger_l2norm_many: channels=%d not supported (8,16,32,64,128)", channels);
+  const size_t es = esize(dtype);
+  const int lpc = channels / 8;
+  const int64_t rpb = 4 * (64 / lpc);
+  L2Batch b{};
+  b.eps = eps;
+  int64_t blocks = 0;
+  for (int i = 0; i < n_segs; ++i) {
+    const segger_l2norm_seg& g = segs[i];
+    SEGGER_REQUIRE(g.n >= 0, "segger_l2norm_many: segment %d: negative size", i);
+    if (g.n == 0) continue;
+    SEGGER_REQUIRE(g.y && g.out && aligned16(g.y) && aligned16(g.out) && aligned16(g.gz), "segger_l2norm_many: segment %d: NULL or misaligned pointer", i);
+    SEGGER_REQUIRE((g.ld_y * es) % 16 == 0 && (g.ld_out * es) % 16 == 0 && g.ld_y >= channels && g.ld_out >= channels &&
+                       (!g.gz || ((g.ld_gz * (g.gz_f32 ? 4 : es)) % 16 == 0 && g.ld_gz >= channels)),
+                   "segger_l2norm_many: segment %d: bad leading dimension", i);
+    b.seg[b.n] = g;
+    b.first_block[b.n++] = (int32_t)blocks;
+    blocks += (g.n + rpb - 1) / rpb;
+    SEGGER_REQUIRE(blocks < 0x7fffffffLL, "segger_l2norm_many: too many rows");
+  }
+  b.first_block[b.n] = (int32_t)blocks;
+  if (blocks == 0) return SEGGER_OK;
+#define GO(T, LPC) hipLaunchKernelGGL((l2norm_many_kernel<T, LPC>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b)
+#define BY_C(T) switch (lpc) { case 1: GO(T, 1); break; case 2: GO(T, 2); break; case 4: GO(T, 4); break; case 8: GO(T, 8); break; default: GO(T, 16); break; }
+  DISPATCH_DTYPE(dtype, BY_C(float), BY_C(bf16_t), BY_C(f16_t))
+#undef BY_C
+#undef GO
+  SEGGER_LAUNCH_CHECK("l2norm_many_kernel");
+  return SEGGER_OK;
 }

@@ -7,7 +7,7 @@
 
 namespace segger {
 
-constexpr int kStageMaxSegs = 48;        // 48 x 64 B by value in the kernel arguments
+constexpr int kStageMaxSegs = 56;        // 56 x 64 B by value in the kernel arguments (< 4 KiB)
 
 struct StageBatch {
   segger_stage_seg s[kStageMaxSegs];

@@ -449,5 +449,5 @@ class ISTEncoder(Module):
 
         x = self.lin_last(x)
         if self.normalize_embeddings:
-            x = {k: ops.l2_normalize(v) for k, v in x.items()}
+            x = ops.l2_normalize_many(x)                     # both node types in one launch
         return x

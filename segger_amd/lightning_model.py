@@ -258,6 +258,11 @@ class LitISTEncoder(_Base):
             g = edge_graph(cache, TX_BD, batch[TX_BD].edge_index, n_tx, n_bd,
                            need_by_src="lazy" if torch.is_grad_enabled() else False, validate="deferred")
             sg = (src_pos, dst_pos, dst_neg, self._sg_margin, 1e-6, g.by_dst, g.src_unique)
+            # "the segmentation triplet anchored at transcript r": what lets the one-launch loss head gather a transcript's
+            # whole gradient row instead of scattering into it; depends on the edge list only -> kept with the tile set
+            store = cache.get("persistent")
+            keep, okey = (store, "sg_of_tx") if store is not None else (cache, ("sg_of_tx", src_pos.data_ptr(), int(src_pos.numel()), n_tx))
+            of_tx = (lambda: keep.get(okey) if keep.get(okey) is not None else keep.setdefault(okey, ops.anchor_index(src_pos, n_tx)))
         w = self._scheduled_weights(self._w_start, self._w_end)
         key = tuple(float(v) for v in w)
         wdev = self.__dict__.setdefault("_head_weights", {})
@@ -268,7 +273,7 @@ class LitISTEncoder(_Base):
             b = wdev[(key, dev)] = torch.tensor(key, dtype=torch.float32, device=dev)
         spec = ops.LossHeadSpec((ix_tx["anchors"], pos, neg, self.loss_tx.margin, self.loss_tx.eps),
                                 (bpos, bneg, dp, dn, ix_bd["weight"], 1e-8), sg, sg_kind=self._sg_loss_type,
-                                tx_anchors_are_rows=True)
+                                tx_anchors_are_rows=True, sg_of_tx=of_tx if sg is not None else None)
         out = ops.loss_head(z_tx, z_bd, ix_tx["head_a"], b, spec)
         return out[0], out[1], out[2], out[3]
 

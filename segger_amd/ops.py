@@ -652,11 +652,18 @@ class LossHeadSpec:
     (bool, or a callable asked in the backward, e.g. ``EdgeGraph.src_unique``): no transcript is the anchor of two
     triplets -- the backward then walks the groups once and stores the anchors' gradient rows."""
 
-    def __init__(self, tx, bd, sg, sg_kind: str = "triplet", tx_anchors_are_rows: bool = False):
+    def __init__(self, tx, bd, sg, sg_kind: str = "triplet", tx_anchors_are_rows: bool = False, sg_of_tx=None,
+                 tx_state: Optional[Tensor] = None, grad_out_hint: Optional[Tensor] = None):
         self.tx, self.bd, self.sg, self.sg_kind = tx, bd, sg, sg_kind      # sg_kind "bce": margin / eps unused
         # loss_tx's anchors are arange(n_tx) (possibly with -1 positives = skipped): lets the backward STORE the anchors'
         # gradient rows (loss_head, when z_tx comes straight out of ops.l2_normalize)
         self.tx_anchors_are_rows = bool(tx_anchors_are_rows)
+        # one-launch loss head (segger_loss_head_fwd / _bwd): ``sg_of_tx`` int32 [n_tx] = the segmentation triplet anchored
+        # at each transcript row (-1: none; :func:`anchor_index`), or a callable returning it; ``tx_state`` int32
+        # [2 n_tx + 4] a buffer the caller has ALREADY zero-filled (a captured step does that in its staging launch);
+        # ``grad_out_hint`` float32 [4]: the gradient the backward will receive (a training step: e_3) -- the forward then
+        # leaves the three scale factors behind and the backward skips their launch when it is handed that very tensor
+        self.sg_of_tx, self.tx_state, self.grad_out_hint = sg_of_tx, tx_state, grad_out_hint
 
 
 class _LossHead(torch.autograd.Function):
@@ -798,6 +805,207 @@ class _LossHead(torch.autograd.Function):
         return (ga if packed else ga.to(dt)), gb.to(dt), None, None, None, None, None
 
 
+_TICKETS: dict = {}
+
+
+def _ticket(dev) -> Tensor:
+    """The zero-initialised int32 the one-launch loss head counts finished blocks in (every launch leaves it zero);
+    one per device, never freed: captured graphs hold its address."""
+    t = _TICKETS.get(dev)
+    if t is None:
+        t = _TICKETS[dev] = torch.zeros(16, dtype=torch.int32, device=dev)
+    return t
+
+
+@torch.no_grad()
+def anchor_index(src: Tensor, n_rows: int) -> Tensor:
+    """int32 [n_rows]: position in ``src`` of each row (-1: the row is not in ``src``).  For the tx-belongs-bd edge list
+    (every transcript at most once, heterodata.py:147) this is "the segmentation triplet anchored at transcript r"."""
+    inv = torch.full((int(n_rows),), -1, dtype=torch.int32, device=src.device)
+    if src.numel():
+        inv[src.long()] = torch.arange(src.numel(), dtype=torch.int32, device=src.device)
+    return inv
+
+
+ONE_LAUNCH_LOSS_HEAD = True      # tools flip it: False = the round-3 loss head (three kernels + combination each way)
+
+
+def loss_head_fused_supported(z_tx: Tensor, z_bd: Tensor, spec: "LossHeadSpec") -> bool:
+    c = int(z_tx.shape[1])
+    n = int(z_tx.shape[0])
+    return (ONE_LAUNCH_LOSS_HEAD and spec.tx_anchors_are_rows and z_tx.dtype in DTYPE_CODE and z_tx.dtype == z_bd.dtype
+            and bool(_lib.load().segger_loss_head_supported(c, DTYPE_CODE[z_tx.dtype])) and int(z_bd.shape[1]) == c
+            and 0 < n < (1 << 30) and spec.tx[0].numel() == n and z_bd.shape[0] > 0
+            and (spec.sg is None or (len(spec.sg) > 5 and spec.sg[5] is not None)))
+
+
+class _LossHeadFused(torch.autograd.Function):
+    """``LitISTEncoder.get_losses`` after the sampling as ONE launch forward and ONE backward (``segger_loss_head_fwd`` /
+    ``_bwd``, csrc/loss_head.hip).  ``t_tx`` / ``t_bd`` carry the gradient: the embeddings themselves, or -- with
+    ``z_tx`` / ``z_bd`` given as constants -- the matrices they were normalised from (``z = t / max(|t|, eps)``): the
+    transcript side's normalisation backward then happens inside the launch, the boundary side's in a second, tiny one
+    that reads the fp32 gradient directly.  No float atomic touches the transcript matrix (rows are gathered, not
+    scattered), nothing is zero-filled by a launch of its own."""
+
+    @staticmethod
+    def forward(ctx, t_tx, t_bd, a, b, spec: LossHeadSpec, z_tx=None, z_bd=None, eps_tx=0.0, eps_bd=0.0):
+        prenorm = z_tx is not None
+        if not prenorm:
+            z_tx, z_bd = t_tx, t_bd
+        _lib.require_cuda(z_tx, z_bd, a, b)
+        lib = _lib.load()
+        dev, dt = z_tx.device, z_tx.dtype
+        n_tx, c = int(z_tx.shape[0]), int(z_tx.shape[1])
+        n_bd = int(z_bd.shape[0])
+        need = any(ctx.needs_input_grad[:2])
+        a = a.detach().to(torch.float32).contiguous()
+        b = b.detach().to(torch.float32).contiguous()
+        i64 = lambda t: t.to(torch.int64).contiguous()
+        f32 = lambda t: t.to(torch.float32).contiguous()
+        _, pos, neg, margin, eps = spec.tx
+        tx = (i64(pos), i64(neg))
+        bpos, bneg, dp, dn, w, beps = spec.bd
+        bd = (i64(bpos), i64(bneg), f32(dp), f32(dn), f32(w))
+        sg = None
+        if spec.sg is not None:
+            sg = tuple(i64(t) for t in spec.sg[:3])
+        g = _lib.LossHeadArgs()
+        g.z_tx, g.ld_ztx = _rows(z_tx, c, "z_tx")
+        g.z_bd, g.ld_zbd = _rows(z_bd, c, "z_bd")
+        g.n_tx, g.n_bd, g.channels, g.dtype = n_tx, n_bd, c, DTYPE_CODE[dt]
+        g.tx_pos, g.tx_neg, g.tx_margin, g.tx_eps = tx[0].data_ptr(), tx[1].data_ptr(), float(margin), float(eps)
+        g.bd_pos, g.bd_neg, g.bd_dpos, g.bd_dneg, g.bd_w = (t.data_ptr() for t in bd)
+        g.bd_eps = float(beps)
+        g.sg_kind = {"triplet": 0, "bce": 1}[spec.sg_kind]
+        if sg is not None and sg[0].numel():
+            g.sg_src, g.sg_pos, g.sg_neg, g.n_sg = sg[0].data_ptr(), sg[1].data_ptr(), sg[2].data_ptr(), int(sg[0].numel())
+            g.sg_margin, g.sg_eps = float(spec.sg[3]), float(spec.sg[4])
+        g.a, g.b = a.data_ptr(), b.data_ptr()
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        graw = torch.empty(3, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.segger_loss_head_workspace_bytes(n_tx, n_bd, int(g.n_sg)), dtype=torch.uint8, device=dev)
+        g.out, g.grad_raw, g.workspace, g.workspace_bytes = out.data_ptr(), graw.data_ptr(), ws.data_ptr(), ws.numel()
+        g.ticket = _ticket(dev).data_ptr()
+        hint = spec.grad_out_hint
+        state = None
+        if need:
+            tx_w = torch.empty((n_tx, 2), dtype=torch.float32, device=dev)
+            head = spec.tx_state
+            if head is None:
+                head = torch.zeros(2 * n_tx + 4, dtype=torch.int32, device=dev)
+            elif head.dtype != torch.int32 or head.numel() < 2 * n_tx + 4 or not head.is_contiguous():
+                raise ValueError("loss_head: tx_state must be a contiguous int32 [2 n_tx + 4] tensor (zero-filled)")
+            n_hot = int(lib.segger_loss_head_max_hot_rows(n_tx))
+            nxt = torch.empty(2 * n_tx + n_tx + n_hot, dtype=torch.int32, device=dev)        # chain links | hot ids + arrivals
+            hot_acc = torch.empty((n_hot, c), dtype=torch.float32, device=dev)
+            gbd = torch.empty((n_bd, c), dtype=torch.float32, device=dev)
+            g.tx_w, g.tx_state, g.tx_next, g.grad_bd = tx_w.data_ptr(), head.data_ptr(), nxt.data_ptr(), gbd.data_ptr()
+            g.tx_hot_id, g.tx_hot_acc = nxt[2 * n_tx:].data_ptr(), hot_acc.data_ptr()
+            if hint is not None:
+                hint = hint.detach()
+                if hint.dtype != torch.float32 or hint.numel() != 4 or not hint.is_contiguous() or hint.device != dev:
+                    raise ValueError("loss_head: grad_out_hint must be a contiguous float32 [4] tensor on the embeddings' device")
+                g.grad_out = hint.data_ptr()
+            state = (tx_w, head, nxt, gbd, graw, hot_acc)
+        with _lib.on_device(dev):
+            rc = lib.segger_loss_head_fwd(C.byref(g), _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_loss_head_fwd")
+        if need:
+            ctx.save_for_backward(t_tx, t_bd, z_tx, z_bd, a, b, *tx, *bd, *(sg or ()))
+            ctx.spec, ctx.state, ctx.prenorm, ctx.eps = spec, state, prenorm, (float(eps_tx), float(eps_bd))
+            ctx.hint = hint if need else None
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        t_tx, t_bd, z_tx, z_bd, a, b = ctx.saved_tensors[:6]
+        tx = ctx.saved_tensors[6:8]
+        bd = ctx.saved_tensors[8:13]
+        spec = ctx.spec
+        sg = ctx.saved_tensors[13:16] if spec.sg is not None else None
+        tx_w, head, nxt, gbd, graw, hot_acc = ctx.state
+        lib = _lib.load()
+        dev, dt = z_tx.device, z_tx.dtype
+        n_tx, c = int(z_tx.shape[0]), int(z_tx.shape[1])
+        n_bd = int(z_bd.shape[0])
+        stream = _lib.stream_ptr(dev)
+        g_out = g_out.detach().to(torch.float32).contiguous()
+        # the segmentation triplets' anchor terms ride in the row walk when no transcript anchors two of them
+        pg = spec.sg[5] if spec.sg is not None else None
+        uniq, of_tx = False, None
+        if sg is not None and sg[0].numel():
+            uniq = spec.sg[6] if len(spec.sg) > 6 else False
+            uniq = bool(uniq() if callable(uniq) else uniq)
+            if uniq:
+                of_tx = spec.sg_of_tx() if callable(spec.sg_of_tx) else spec.sg_of_tx
+                if of_tx is None:
+                    of_tx = anchor_index(sg[0], n_tx)
+                if of_tx.dtype != torch.int32 or of_tx.numel() < n_tx or not of_tx.is_contiguous():
+                    raise ValueError("loss_head: sg_of_tx must be a contiguous int32 [n_tx] tensor")
+        fuse_norm = ctx.prenorm and (sg is None or not sg[0].numel() or uniq)
+        g = _lib.LossHeadArgs()
+        g.z_tx, g.ld_ztx = _rows(z_tx, c, "z_tx")
+        g.z_bd, g.ld_zbd = _rows(z_bd, c, "z_bd")
+        g.n_tx, g.n_bd, g.channels, g.dtype = n_tx, n_bd, c, DTYPE_CODE[dt]
+        g.tx_pos, g.tx_neg, g.tx_margin, g.tx_eps = tx[0].data_ptr(), tx[1].data_ptr(), float(spec.tx[3]), float(spec.tx[4])
+        g.bd_pos, g.bd_neg, g.bd_dpos, g.bd_dneg, g.bd_w = (t.data_ptr() for t in bd)
+        g.bd_eps = float(spec.bd[5])
+        g.sg_kind = {"triplet": 0, "bce": 1}[spec.sg_kind]
+        if sg is not None and sg[0].numel():
+            if pg.n_rows != n_bd or pg.n_edges != sg[0].numel():
+                raise ValueError("loss_head: pos_groups does not describe the segmentation triplets")
+            g.sg_src, g.sg_pos, g.sg_neg, g.n_sg = sg[0].data_ptr(), sg[1].data_ptr(), sg[2].data_ptr(), int(sg[0].numel())
+            g.sg_margin, g.sg_eps = float(spec.sg[3]), float(spec.sg[4])
+            g.sg_pos_indptr, g.sg_pos_eid = pg.indptr.data_ptr(), (pg.eid.data_ptr() if pg.n_edges else None)
+            g.sg_of_tx = _lib.ptr(of_tx)
+        g.a, g.b, g.grad_raw = a.data_ptr(), b.data_ptr(), graw.data_ptr()
+        out_dummy = torch.empty(4, dtype=torch.float32, device=dev)
+        g.out = out_dummy.data_ptr()
+        g.tx_w, g.tx_state, g.tx_next, g.grad_bd = tx_w.data_ptr(), head.data_ptr(), nxt.data_ptr(), gbd.data_ptr()
+        g.tx_hot_id, g.tx_hot_acc = nxt[2 * n_tx:].data_ptr(), hot_acc.data_ptr()
+        ws = torch.empty(lib.segger_loss_head_workspace_bytes(n_tx, n_bd, int(g.n_sg)), dtype=torch.uint8, device=dev)
+        g.workspace, g.workspace_bytes, g.ticket = ws.data_ptr(), ws.numel(), _ticket(dev).data_ptr()
+        gtx = torch.empty((n_tx, c), dtype=dt, device=dev)
+        g.grad_tx, g.ld_gtx = gtx.data_ptr(), c
+        if fuse_norm:
+            g.y_tx, g.ld_ytx = _rows(t_tx, c, "y_tx")
+            g.norm_eps = ctx.eps[0]
+        with _lib.on_device(dev):
+            if ctx.hint is None or g_out.data_ptr() != ctx.hint.data_ptr():      # (else the forward left the factors behind)
+                _lib.check(lib.segger_loss_combine_bwd(g_out.data_ptr(), a.data_ptr(), b.data_ptr(), 3, graw.data_ptr(), stream),
+                           "segger_loss_combine_bwd")
+            _lib.check(lib.segger_loss_head_bwd(C.byref(g), stream), "segger_loss_head_bwd")
+            if sg is not None and sg[0].numel() and not uniq:
+                # a transcript anchors two segmentation triplets (never in segger's data): their anchor terms by atomics
+                # on top of the rows just written, the boundary side having been done by the launch above
+                sa = _triplet_args(*sg, z_tx, z_bd, float(spec.sg[3]), float(spec.sg[4]), spec.sg_kind)
+                scratch = torch.zeros((n_bd, c), dtype=torch.float32, device=dev)      # (its boundary side is discarded)
+                sa.grad_a, sa.grad_a_packed = gtx.data_ptr(), int(dt != torch.float32)
+                sa.grad_b, sa.grad_b_packed = scratch.data_ptr(), 0
+                sa.grad_scale, sa.grad_scale_dev = 1.0, graw[2:3].data_ptr()
+                _lib.check(lib.segger_triplet_bwd(C.byref(sa), stream), "segger_triplet_bwd")
+            if ctx.prenorm:
+                # boundary side (and, in the rare case above, the transcript side) through the normalisation's backward
+                gy_bd = torch.empty((n_bd, c), dtype=dt, device=dev)
+                segs = (_lib.L2NormSeg * 2)()
+                n_seg = 0
+                yb, ldb = _rows(t_bd, c, "y_bd")
+                segs[0].y, segs[0].ld_y, segs[0].n, segs[0].out, segs[0].ld_out = yb, ldb, n_bd, gy_bd.data_ptr(), c
+                segs[0].gz, segs[0].ld_gz, segs[0].gz_f32 = gbd.data_ptr(), c, 1
+                n_seg = 1
+                if not fuse_norm:
+                    gy_tx = torch.empty((n_tx, c), dtype=dt, device=dev)
+                    yt, ldt = _rows(t_tx, c, "y_tx")
+                    segs[1].y, segs[1].ld_y, segs[1].n, segs[1].out, segs[1].ld_out = yt, ldt, n_tx, gy_tx.data_ptr(), c
+                    segs[1].gz, segs[1].ld_gz, segs[1].gz_f32 = gtx.data_ptr(), c, 0
+                    n_seg = 2
+                    gtx = gy_tx
+                # (the two eps are the same number in the encoder; the launch takes one)
+                _lib.check(lib.segger_l2norm_many(segs, n_seg, c, ctx.eps[1], DTYPE_CODE[dt], stream), "segger_l2norm_many")
+                return gtx, gy_bd, None, None, None, None, None, None, None
+        return gtx, gbd.to(dt), None, None, None, None, None, None, None
+
+
 USE_ANCHOR_ROWS = True       # tools flip it: False = loss_tx's anchor terms by atomics at fp32 storage as well
 
 
@@ -805,6 +1013,14 @@ def loss_head(z_tx: Tensor, z_bd: Tensor, a: Tensor, b: Tensor, spec: LossHeadSp
     """-> float32[4] = (a0 * loss_tx, a1 * loss_bd, a2 * loss_sg, sum_i b_i * (the three)): the three losses of
     ``LitISTEncoder.get_losses`` and their weighted sum as one autograd node (see :class:`_LossHead`).  ``a`` / ``b``:
     float32[3] on the device."""
+    if loss_head_fused_supported(z_tx, z_bd, spec):
+        pt, pb = getattr(z_tx, "_segger_prenorm", None), getattr(z_bd, "_segger_prenorm", None)
+        ok = lambda z, p: (p is not None and p[0].requires_grad and p[0].shape == z.shape and p[0].dtype == z.dtype)
+        if torch.is_grad_enabled() and ok(z_tx, pt) and ok(z_bd, pb) and pt[1] == pb[1]:
+            # both embeddings come straight out of the row normalisation: they are constants here and the gradient goes
+            # to its inputs (the transcript side's normalisation backward inside the launch)
+            return _LossHeadFused.apply(pt[0], pb[0], a, b, spec, z_tx.detach(), z_bd.detach(), pt[1], pb[1])
+        return _LossHeadFused.apply(z_tx, z_bd, a, b, spec)
     pre = getattr(z_tx, "_segger_prenorm", None)
     # (fp32 storage only: there loss_tx's backward is bound by 12 fp32 atomic instructions per triplet, a third of them the
     # anchor's -- 1.19 -> 0.8 ms at C2; with 16-bit embeddings the packed atomics are cheap enough that the second matrix
@@ -1811,6 +2027,71 @@ class _L2Norm(torch.autograd.Function):
                                        _lib.stream_ptr(y.device))
         _lib.check(rc, "segger_l2norm_bwd")
         return gy, None
+
+
+class _L2NormMany(torch.autograd.Function):
+    """Row normalisation of several matrices in ONE launch each way (``segger_l2norm_many``)."""
+
+    @staticmethod
+    def forward(ctx, eps, *ys):
+        lib = _lib.load()
+        c, dt, dev = int(ys[0].shape[1]), ys[0].dtype, ys[0].device
+        zs = [torch.empty((int(y.shape[0]), c), dtype=dt, device=dev) for y in ys]
+        segs = (_lib.L2NormSeg * len(ys))()
+        for sg, y, z in zip(segs, ys, zs):
+            sg.y, sg.ld_y = _rows(y, c, "y")
+            sg.n, sg.out, sg.ld_out = int(y.shape[0]), z.data_ptr(), c
+        with _lib.on_device(dev):
+            rc = lib.segger_l2norm_many(segs, len(ys), c, eps, DTYPE_CODE[dt], _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_l2norm_many")
+        ctx.save_for_backward(*ys)
+        ctx.eps = eps
+        return tuple(zs)
+
+    @staticmethod
+    def backward(ctx, *gzs):
+        ys = ctx.saved_tensors
+        lib = _lib.load()
+        c, dt, dev = int(ys[0].shape[1]), ys[0].dtype, ys[0].device
+        segs = (_lib.L2NormSeg * len(ys))()
+        outs, keep, k = [], [], 0
+        for y, gz in zip(ys, gzs):
+            if gz is None:
+                outs.append(None)
+                continue
+            if gz.dtype not in (dt, torch.float32):
+                gz = gz.to(dt)
+            if gz.dim() != 2 or (gz.shape[0] > 1 and gz.stride(1) != 1):
+                gz = gz.contiguous()
+            gy = torch.empty((int(y.shape[0]), c), dtype=dt, device=dev)
+            sg = segs[k]; k += 1
+            sg.y, sg.ld_y = _rows(y, c, "y")
+            sg.n, sg.out, sg.ld_out = int(y.shape[0]), gy.data_ptr(), c
+            sg.gz, sg.ld_gz = _rows(gz, c, "gz")
+            sg.gz_f32 = int(gz.dtype == torch.float32 and dt != torch.float32)
+            outs.append(gy); keep.append(gz)
+        if k:
+            with _lib.on_device(dev):
+                rc = lib.segger_l2norm_many(segs, k, c, ctx.eps, DTYPE_CODE[dt], _lib.stream_ptr(dev))
+            _lib.check(rc, "segger_l2norm_many")
+        return (None,) + tuple(outs)
+
+
+def l2_normalize_many(ys: dict, eps: float = 1e-12) -> dict:
+    """``{k: F.normalize(v, dim=-1)}`` for up to four [n_k, C] matrices of one width and dtype in ONE launch (both node
+    types of the encoder's tail, ist_encoder.py:331-332); anything else goes through :func:`l2_normalize` per entry."""
+    vals = list(ys.values())
+    if (1 < len(vals) <= 4 and all(v.dim() == 2 and v.is_cuda for v in vals) and vals[0].shape[1] in (8, 16, 32, 64, 128)
+            and vals[0].dtype in DTYPE_CODE and all(v.shape[1] == vals[0].shape[1] and v.dtype == vals[0].dtype for v in vals)
+            and all(v.shape[0] > 0 for v in vals)):
+        zs = _L2NormMany.apply(float(eps), *vals)
+        out = {}
+        for k, y, z in zip(ys, vals, zs):
+            if torch.is_grad_enabled() and y.requires_grad:
+                z._segger_prenorm = (y, float(eps))
+            out[k] = z
+        return out
+    return {k: l2_normalize(v, eps) for k, v in ys.items()}
 
 
 def l2_normalize(y: Tensor, eps: float = 1e-12) -> Tensor:

@@ -111,6 +111,9 @@ class GraphedTrainStep:
         by_gene_col = z(nt, dtype=i32)
         self.by_gene = EdgeCSR(z(self.n_genes + 1, dtype=i64), by_gene_col, by_gene_col, self.n_genes, nt)
         self.sg_src, self.sg_pos = z(etb, dtype=i64), z(etb, dtype=i64)
+        # one-launch loss head: the segmentation triplet anchored at each transcript row (-1: none) and the rows'
+        # contribution chains (heads + counts), zero-filled by the staging launch of every step
+        self.sg_of_tx, self.tx_state = z(nt, dtype=i32), z(2 * nt + 4, dtype=i32)
 
         def sampler_index(selector, n):
             k = int(selector.similarity.shape[0])
@@ -201,6 +204,9 @@ class GraphedTrainStep:
         if by_gene is None:
             by_gene = keep["tx_by_gene"] = ops.rows_by_id(tx["x"], self.n_genes)
         ei = batch[TX_BD].edge_index
+        of_tx = keep.get("sg_of_tx")
+        if of_tx is None:
+            of_tx = keep["sg_of_tx"] = ops.anchor_index(ei[0], n_tx)
         w = lit._scheduled_weights(lit._w_start, lit._w_end)
         fb = ops.float_bits
         dummies = ("mod", n_tx, nt - n_tx)                    # dummy transcripts, round robin
@@ -216,6 +222,7 @@ class GraphedTrainStep:
             (self.by_gene.col, by_gene.col, "div", n_tx, 1, 0),
             # segmentation triplets: padded ones carry -1 and are skipped by the kernels
             (self.sg_src, ei[0], *dummies, 0), (self.sg_pos, ei[1], "const", -1, 0, 0),
+            (self.sg_of_tx, of_tx, "const", -1, 0, 0), (self.tx_state, None, "const", 0, 0, 0),
             (self.bd_weight, ix_bd["weight"], "const", 0, 0, 0),
             (self.n_bd, None, "const", n_bd, 0, 0),
             (self.minmax[0], None, "const", fb(float("inf")), 0, 0), (self.minmax[1], None, "const", fb(float("-inf")), 0, 0),
@@ -266,7 +273,8 @@ class GraphedTrainStep:
         spec = ops.LossHeadSpec((self._iota, pos, neg, lit.loss_tx.margin, lit.loss_tx.eps),
                                 (bpos, bneg, dp, dn, self.bd_weight, 1e-8),
                                 (self.sg_src, self.sg_pos, dst_neg, lit._sg_margin, 1e-6, self.g_tb.by_dst, True),
-                                sg_kind=lit._sg_loss_type, tx_anchors_are_rows=True)
+                                sg_kind=lit._sg_loss_type, tx_anchors_are_rows=True, sg_of_tx=self.sg_of_tx,
+                                tx_state=self.tx_state, grad_out_hint=self._e_loss)
         out = ops.loss_head(z["tx"], z["bd"], self.head_a, self.scal[3:6], spec)
         if self.defer_sums:                                   # ~30 partial sums of the backward as one launch
             with ops.deferred_reductions(self.dev):
@@ -288,6 +296,7 @@ class GraphedTrainStep:
             ref = [None if p.grad is None else p.grad.detach().clone() for p in self._params]
             with torch.no_grad():
                 self.lit.model._step_dev.copy_(keep[3])       # same dropout masks and sampler draws again
+                self.tx_state.zero_()                         # (what the staging launch does before every step)
             self.defer_sums = True
             self._run_grads()
             names = {id(p): n for n, p in self.lit.model.named_parameters()}
@@ -308,6 +317,7 @@ class GraphedTrainStep:
                     break
             if why:
                 self.defer_sums = False
+                self.tx_state.zero_()
                 import warnings
                 warnings.warn("GraphedTrainStep: a parameter gradient is consumed inside the backward pass "
                               f"({why}); partial sums are launched where they are produced (more kernel nodes)")
@@ -352,6 +362,7 @@ class GraphedTrainStep:
                 self._warm_up(keep)
             torch.cuda.current_stream().wait_stream(side)
             self._restore(keep)                               # ... which must not count as a training step
+            self.tx_state.zero_()                             # (the warm-up's forward left its chains: staged state again)
             aliases = list(self._alias.values())
             ops.invalidate_weights(aliases)                   # the captured step starts with the weight refresh ...
             self.graph = torch.cuda.CUDAGraph()
