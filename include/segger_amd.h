@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 16
+#define SEGGER_ABI_VERSION 17
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -264,6 +264,26 @@ int segger_dropout_bits_many(const segger_bits_job* jobs, int32_t n_jobs, int32_
                              const uint64_t* seed_dev, segger_stream_t stream);
 int segger_step_advance(int64_t* step, int64_t inc, int64_t* copy, segger_stream_t stream);
 
+/* segger_step_draws: ALL random draws of one training step in one launch -- the bit planes of up to four edge views
+ * (segger_dropout_bits_many), up to two cluster-aware triplet samplers (segger_triplet_sample: loss_tx and loss_bd,
+ * models/triplet_loss.py:83-125, with the kernel's own counter-based uniforms) and the negative boundaries of the
+ * segmentation loss (segger_sample_negatives, lightning_model.py:167-176).  Same streams, same results as the separate
+ * calls with the same seeds; every job reads the device word seed_dev. */
+typedef struct segger_sample_job {
+  const int64_t* lab; int64_t n; int32_t n_clusters; int32_t reserved_;
+  const float* cdf_pos; const float* cdf_neg; const int64_t* counts; const int64_t* offsets; const int64_t* members;
+  uint64_t seed; const float* dists; int64_t* pos; int64_t* neg; float* d_pos; float* d_neg;
+} segger_sample_job;
+typedef struct segger_step_draws_args {
+  const segger_bits_job* bits; int32_t n_bits; int32_t heads; float dropout_p; int32_t n_samplers;
+  segger_sample_job samplers[2];
+  const int64_t* neg_pos; int64_t neg_n; int64_t neg_n_b; const int64_t* neg_n_b_dev; uint64_t neg_seed; int64_t* neg_out;
+  const uint64_t* seed_dev;
+  float* const* advance; int32_t n_advance; int32_t reserved_;   /* HOST array of up to 64 device floats: *advance[i] += 1 (Adam's
+                                                                    step counters, see segger_adam_step_ex) */
+} segger_step_draws_args;
+int segger_step_draws(const segger_step_draws_args* args, segger_stream_t stream);
+
 /* 1 when (heads, channels) runs on the specialised kernels (channels in {32,64}, heads in 1..4), 0 = generic kernels */
 int segger_gatv2_has_specialised(int32_t heads, int32_t channels);
 
@@ -322,6 +342,13 @@ typedef struct segger_adam_tensor {
 } segger_adam_tensor;
 int segger_adam_step(const segger_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2, double eps,
                      segger_stream_t stream);
+/* segger_adam_step_ex: the same with (a) flags & SEGGER_ADAM_STEPS_ADVANCED: the step counters have been advanced already
+ * (segger_step_draws does it at the head of a captured training step: nothing in between reads them) -- one launch instead
+ * of two; (b) counter != NULL: *counter += counter_inc by the update launch's first workgroup -- the device-side dropout /
+ * sampling counter of the step that ends here (nothing reads it after the backward). */
+#define SEGGER_ADAM_STEPS_ADVANCED 1
+int segger_adam_step_ex(const segger_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2, double eps,
+                        int32_t flags, int64_t* counter, int64_t counter_inc, segger_stream_t stream);
 
 /* segger_transpose_many: dst [cols, rows] = src [rows, cols]^T for n_segs contiguous 16-bit matrices in one launch:
  * the W^T copies the data-gradient GEMMs (dX = dY W on segger_linear_fwd) need after every optimizer step. */
@@ -533,8 +560,11 @@ int segger_triplet_bwd(const segger_triplet_args* args, segger_stream_t stream);
  *   accumulated with fp32 atomics by the groups of the contributing triplets and finished by the last contributor.
  *   grad_bd [n_bd, C] fp32 is ACCUMULATED INTO (zero-filled by the forward): metric loss, segmentation positives (summed
  *   per boundary over sg_pos_indptr [n_bd + 1] / sg_pos_eid [n_sg], the triplets grouped by positive row) and negatives.
- * workspace: segger_loss_head_workspace_bytes() (per-block partial sums); ticket: one int32 that is ZERO before the first
- *   launch and that every launch leaves zero (last-block detection) -- keep one per stream.  C in {32, 64, 128}.
+ * workspace: segger_loss_head_workspace_bytes() (per-block partial sums; the forward is TWO launches: the loss kernel and a
+ *   one-workgroup launch that adds the partial sums in a fixed order -- a last-block-by-ticket form paid a whole-L2
+ *   write-back per block for its device-scope release: 0.76 of 0.90 ms at 10^6 rows); ticket: unused (kept for layout).
+ *   C in {32, 64, 128}.  Worth it below ~10^5 transcript rows (a captured 1M-edge step); at 10^6 rows the forward's chain
+ *   atomics (4 returning atomics per triplet) make it slower than the kernel-by-kernel head (profiles/r04_loss_head_modes_c2.txt).
  */
 typedef struct segger_loss_head_args {
   const void* z_tx; int64_t ld_ztx; int64_t n_tx;
@@ -607,6 +637,18 @@ int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void* w, const f
                               int64_t ld_rb, const int32_t* rowidx, void* y, int64_t ldy, int64_t n_rows, int32_t k_in,
                               int32_t m_out, int32_t dtype, segger_stream_t stream);
 
+/* segger_linear_fwd_pair: two such projections with the same k_in and dtype as ONE launch -- a hetero layer projects its
+ * transcripts ([lin_l | lin_r | lin_l], ist_encoder.py:109-134 through HeteroConv) and its ~10^2-10^3 boundaries (lin_r)
+ * in the same step, and lin_last maps both node types (ist_encoder.py:282-286,328); the small one's blocks ride in the
+ * large one's grid instead of paying a launch of their own (a large `a` takes its persistent resident-W launch and `b` its
+ * own; fp32: two launches).  Same arithmetic as segger_linear_fwd, bit-identical results. */
+typedef struct segger_linear_args {
+  const void* x; int64_t ldx; const void* w; const float* bias; void* y; int64_t ldy; int64_t n_rows; int32_t m_out;
+  int32_t reserved_;
+} segger_linear_args;
+int segger_linear_fwd_pair(const segger_linear_args* a, const segger_linear_args* b, int32_t k_in, int32_t dtype,
+                           segger_stream_t stream);
+
 /*
  * segger_linear_wgrad: the parameter gradients of the same projections,
  *     grad_w[M, K] = dY[n, M]^T * X[n, K]      grad_b[M] = sum_n dY[n, :]       (fp32 outputs)
@@ -640,6 +682,18 @@ int segger_linear_wgrad_dx(const void* dy, int64_t ld_dy, const void* x, int64_t
                            int32_t m_out, int32_t k_in, int32_t dtype, float* grad_w, float* grad_b, void* dx,
                            int64_t ld_dx, const void* gelu_gate, int64_t ld_gate, void* workspace, size_t workspace_bytes,
                            segger_stream_t stream);
+/* segger_linear_wgrad_pair: the backward passes of TWO projections with the same k_in and dtype as one launch -- what
+ * segger_linear_fwd_pair is to the forward: a hetero layer's transcript-side and boundary-side projections, lin_last of both
+ * node types; the small side's one or two workgroups ride in the large side's grid.  With w_t / dx given on both sides the
+ * one-pass form (segger_linear_wgrad_dx), with both NULL the weight / bias gradients only (segger_linear_wgrad).  Same
+ * arithmetic and workspaces as the single calls (bit-identical results); shape pairs without a paired kernel, fp32 and
+ * empty sides run as two launches. */
+typedef struct segger_wgrad_args {
+  const void* dy; int64_t ld_dy; const void* x; int64_t ld_x; const void* w_t; int64_t n_rows; int32_t m_out; int32_t reserved_;
+  float* grad_w; float* grad_b; void* dx; int64_t ld_dx; void* workspace; size_t workspace_bytes;
+} segger_wgrad_args;
+int segger_linear_wgrad_pair(const segger_wgrad_args* a, const segger_wgrad_args* b, int32_t k_in, int32_t dtype,
+                             segger_stream_t stream);
 
 /*
  * Deferred partial sums.  segger_linear_wgrad / _wgrad_dx / segger_posmlp_wgrad and segger_gatv2_bwd finish with a small

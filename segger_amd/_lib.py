@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
@@ -116,6 +116,19 @@ class BitsJob(C.Structure):
                 ("bits", vp), ("plane_stride", C.c_int64)]
 
 
+class SampleJob(C.Structure):
+    _fields_ = [("lab", vp), ("n", C.c_int64), ("n_clusters", C.c_int32), ("reserved_", C.c_int32),
+                ("cdf_pos", vp), ("cdf_neg", vp), ("counts", vp), ("offsets", vp), ("members", vp),
+                ("seed", C.c_uint64), ("dists", vp), ("pos", vp), ("neg", vp), ("d_pos", vp), ("d_neg", vp)]
+
+
+class StepDrawsArgs(C.Structure):
+    _fields_ = [("bits", vp), ("n_bits", C.c_int32), ("heads", C.c_int32), ("dropout_p", C.c_float), ("n_samplers", C.c_int32),
+                ("samplers", SampleJob * 2),
+                ("neg_pos", vp), ("neg_n", C.c_int64), ("neg_n_b", C.c_int64), ("neg_n_b_dev", vp), ("neg_seed", C.c_uint64),
+                ("neg_out", vp), ("seed_dev", vp), ("advance", vp), ("n_advance", C.c_int32), ("reserved_", C.c_int32)]
+
+
 class TripletArgs(C.Structure):
     _fields_ = [
         ("src", vp), ("pos", vp), ("neg", vp), ("n_edges", C.c_int64),
@@ -155,6 +168,17 @@ class LossHeadArgs(C.Structure):
     ]
 
 
+class LinearArgs(C.Structure):
+    _fields_ = [("x", vp), ("ldx", C.c_int64), ("w", vp), ("bias", vp), ("y", vp), ("ldy", C.c_int64),
+                ("n_rows", C.c_int64), ("m_out", C.c_int32), ("reserved_", C.c_int32)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("dy", vp), ("ld_dy", C.c_int64), ("x", vp), ("ld_x", C.c_int64), ("w_t", vp), ("n_rows", C.c_int64),
+                ("m_out", C.c_int32), ("reserved_", C.c_int32), ("grad_w", vp), ("grad_b", vp), ("dx", vp),
+                ("ld_dx", C.c_int64), ("workspace", vp), ("workspace_bytes", C.c_size_t)]
+
+
 # every symbol include/segger_amd.h declares: name -> (restype, argtypes)
 EXPORTS = {
     "segger_abi_version": (C.c_int, []),
@@ -170,6 +194,7 @@ EXPORTS = {
     "segger_coo_unique": (C.c_int, [vp, C.c_int64, C.c_int64, vp, vp, vp]),
     "segger_stage": (C.c_int, [C.POINTER(StageSeg), C.c_int32, vp]),
     "segger_adam_step": (C.c_int, [C.POINTER(AdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, vp]),
+    "segger_adam_step_ex": (C.c_int, [C.POINTER(AdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp, C.c_int64, vp]),
     "segger_transpose_many": (C.c_int, [C.POINTER(TransposeSeg), C.c_int32, vp]),
     "segger_posmlp_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "segger_posmlp_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp,
@@ -187,6 +212,8 @@ EXPORTS = {
     "segger_segment_minmax": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp, vp]),
     "segger_linear_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "segger_linear_fwd": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32, vp]),
+    "segger_linear_fwd_pair": (C.c_int, [C.POINTER(LinearArgs), C.POINTER(LinearArgs), C.c_int32, C.c_int32, vp]),
+    "segger_linear_wgrad_pair": (C.c_int, [C.POINTER(WgradArgs), C.POINTER(WgradArgs), C.c_int32, C.c_int32, vp]),
     "segger_linear_fwd_silu_grad": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                               C.c_int32, vp]),
     "segger_linear_fwd_rowbias": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int64, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
@@ -208,6 +235,7 @@ EXPORTS = {
     "segger_pack_refresh": (C.c_int, [vp, C.c_int32, C.c_int32, vp]),
     "segger_dropout_bits_many": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_float, vp, vp]),
     "segger_step_advance": (C.c_int, [vp, C.c_int64, vp, vp]),
+    "segger_step_draws": (C.c_int, [C.POINTER(StepDrawsArgs), vp]),
     "segger_segment_minmax_ex": (C.c_int, [vp, vp, C.c_int64, C.c_int64, vp, vp, C.c_int32, vp]),
     "segger_triplet_partial_count": (C.c_int64, [C.c_int64]),
     "segger_loss_combine_partials_fwd": (C.c_int, [vp, vp, vp, vp, vp, C.c_int32, vp, vp]),

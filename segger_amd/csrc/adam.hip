@@ -18,6 +18,7 @@ struct AdamBatch {
   int32_t first_block[kAdamMaxTensors + 1];       // prefix sums of the tensors' block counts
   int32_t n;
   double lr, beta1, beta2, eps;                   // torch keeps them as Python floats and evaluates 1 - beta, beta^step in double
+  int64_t* counter; int64_t counter_inc;          // optional: *counter += counter_inc by the first workgroup (nobody reads it here)
 };
 
 __global__ __launch_bounds__(64) void adam_advance_kernel(AdamBatch b) {
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamBatch b) {
     const int mid = (lo + hi) >> 1;
     if (b.first_block[mid] <= blk) lo = mid; else hi = mid;
   }
+  if (blk == 0 && threadIdx.x == 0 && b.counter != nullptr) *b.counter += b.counter_inc;
   const segger_adam_tensor& t = b.t[lo];
   const int64_t base = (int64_t)(blk - b.first_block[lo]) * kAdamElemsPerBlock;
   // torch/optim/adam.py (capturable, fused=False formulas; the fused kernel evaluates the same expressions in fp32):
@@ -80,7 +82,14 @@ using namespace segger;
 
 extern "C" int segger_adam_step(const segger_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2,
                                 double eps, segger_stream_t stream_) {
+  return segger_adam_step_ex(tensors, n_tensors, lr, beta1, beta2, eps, 0, nullptr, 0, stream_);
+}
+
+extern "C" int segger_adam_step_ex(const segger_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2,
+                                   double eps, int32_t flags, int64_t* counter, int64_t counter_inc, segger_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  const bool advanced = (flags & SEGGER_ADAM_STEPS_ADVANCED) != 0;
+  bool counter_done = counter == nullptr;
   SEGGER_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || tensors), "segger_adam_step: NULL tensor table");
   SEGGER_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0.,
                  "segger_adam_step: lr / betas / eps out of range");
@@ -99,9 +108,13 @@ extern "C" int segger_adam_step(const segger_adam_tensor* tensors, int32_t n_ten
       SEGGER_REQUIRE(blocks < 0x7fffffffLL, "segger_adam_step: too many elements");
     }
     b.first_block[b.n] = (int32_t)blocks;
-    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, stream, b);
-    if (blocks > 0) hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, b);
+    if (!advanced) hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, stream, b);
+    if (blocks > 0) {
+      if (!counter_done) { b.counter = counter; b.counter_inc = counter_inc; counter_done = true; }
+      hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, b);
+    }
     SEGGER_LAUNCH_CHECK("adam kernels");
   }
+  if (!counter_done) return segger_step_advance(counter, counter_inc, nullptr, stream_);     // (nothing to update)
   return SEGGER_OK;
 }

@@ -1,5 +1,6 @@
 // Host launchers for the fused GATv2 kernels (C ABI: include/segger_amd.h).
 #include "gatv2_launch.h"
+#include "draws.h"
 
 namespace segger {
 
@@ -40,42 +41,8 @@ __global__ __launch_bounds__(256) void zero_rows_kernel(char* __restrict__ base,
   *reinterpret_cast<u32x4*>(base + (i / pieces) * pitch + (i % pieces) * 16) = u32x4{0u, 0u, 0u, 0u};
 }
 
-// bits[l][slot] = OR_h keep(eid[slot], h; seed_l) << h for all layers; a thread owns FOUR consecutive slots: one 16-byte
-// load of their edge ids and one 4-byte store per plane (byte stores, one slot per thread, ran at 2.3 TB/s)
-struct BitsParams { const int32_t* eid; int64_t n_edges; int64_t plane_stride; int heads; uint32_t thr; int n_seeds;
-                    int eid_aligned; uint64_t seeds[16]; const uint64_t* seed_dev; uint8_t* bits; };
-constexpr int kMaxBitsJobs = 4;
-struct BitsJobs { BitsParams job[kMaxBitsJobs]; };       // blockIdx.y picks the job (the edge views of one step)
-__device__ __forceinline__ void dropout_bits_body(const BitsParams& p);
-__global__ __launch_bounds__(256) void dropout_bits_kernel(BitsParams p) { dropout_bits_body(p); }
-__global__ __launch_bounds__(256) void dropout_bits_many_kernel(BitsJobs j) { dropout_bits_body(j.job[blockIdx.y]); }
-__device__ __forceinline__ void dropout_bits_body(const BitsParams& p) {
-  const int64_t s0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (s0 >= p.n_edges) return;
-  const bool full = s0 + 3 < p.n_edges;
-  uint32_t e[4] = {0u, 0u, 0u, 0u};
-  if (full && p.eid_aligned) {                          // (a view sliced out of a slide-level sort may start anywhere)
-    const u32x4 v = *reinterpret_cast<const u32x4*>(p.eid + s0);
-    e[0] = v.x; e[1] = v.y; e[2] = v.z; e[3] = v.w;
-  } else {
-    for (int k = 0; k < 4 && s0 + k < p.n_edges; ++k) e[k] = (uint32_t)p.eid[s0 + k];
-  }
-  const uint64_t dev = p.seed_dev ? *p.seed_dev : 0ull;
-  for (int l = 0; l < p.n_seeds; ++l) {
-    const uint64_t mixed = splitmix64(p.seeds[l] + dev);
-    const uint32_t lo = (uint32_t)mixed, hi = (uint32_t)(mixed >> 32);
-    uint32_t word = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      uint32_t b = 0;
-      for (int h = 0; h < p.heads; ++h) b |= (uint32_t)dropout_keep(e[k], p.heads, h, lo, hi, p.thr) << h;
-      word |= b << (8 * k);
-    }
-    uint8_t* plane = p.bits + (int64_t)l * p.plane_stride + s0;
-    if (full) *reinterpret_cast<uint32_t*>(plane) = word;          // (plane_stride % 4 == 0: checked by the host)
-    else for (int k = 0; k < 4 && s0 + k < p.n_edges; ++k) plane[k] = (uint8_t)(word >> (8 * k));
-  }
-}
+__global__ __launch_bounds__(256) void dropout_bits_kernel(BitsParams p) { dropout_bits_body(p, blockIdx.x); }
+__global__ __launch_bounds__(256) void dropout_bits_many_kernel(BitsJobs j) { dropout_bits_body(j.job[blockIdx.y], blockIdx.x); }
 
 namespace {
 
@@ -432,6 +399,22 @@ extern "C" int segger_dropout_bits(const int32_t* eid, int64_t n_edges, int32_t 
   return SEGGER_OK;
 }
 
+namespace segger {
+int fill_bits_params(const segger_bits_job& jb, int heads, float dropout_p, const uint64_t* seed_dev, int i, BitsParams* out) {
+  SEGGER_REQUIRE(jb.n_edges >= 0 && jb.n_seeds > 0 && jb.n_seeds <= 16, "segger_dropout_bits_many: job %d: bad sizes", i);
+  SEGGER_REQUIRE(jb.n_edges == 0 || (jb.eid && jb.bits), "segger_dropout_bits_many: job %d: NULL pointer", i);
+  SEGGER_REQUIRE(jb.plane_stride >= jb.n_edges && jb.plane_stride % 4 == 0 && ((uintptr_t)jb.bits & 3u) == 0,
+                 "segger_dropout_bits_many: job %d: plane_stride must be a multiple of 4 >= n_edges, bits 4-byte aligned", i);
+  BitsParams& p = *out;
+  p = BitsParams{};
+  p.eid = jb.eid; p.n_edges = jb.n_edges; p.plane_stride = jb.plane_stride; p.heads = heads; p.n_seeds = jb.n_seeds;
+  p.seed_dev = seed_dev; p.bits = jb.bits; p.eid_aligned = aligned16(jb.eid) ? 1 : 0;
+  p.thr = (uint32_t)((double)dropout_p * 16777216.0);
+  for (int l = 0; l < jb.n_seeds; ++l) p.seeds[l] = jb.seeds[l];
+  return SEGGER_OK;
+}
+}  // namespace segger
+
 extern "C" int segger_dropout_bits_many(const segger_bits_job* jobs, int32_t n_jobs, int32_t heads, float dropout_p,
                                         const uint64_t* seed_dev, segger_stream_t stream) {
   SEGGER_REQUIRE(jobs && n_jobs > 0 && n_jobs <= kMaxBitsJobs, "segger_dropout_bits_many: 1..4 jobs");
@@ -440,17 +423,9 @@ extern "C" int segger_dropout_bits_many(const segger_bits_job* jobs, int32_t n_j
   BitsJobs all{};
   int64_t most = 0;
   for (int i = 0; i < n_jobs; ++i) {
-    const segger_bits_job& jb = jobs[i];
-    SEGGER_REQUIRE(jb.n_edges >= 0 && jb.n_seeds > 0 && jb.n_seeds <= 16, "segger_dropout_bits_many: job %d: bad sizes", i);
-    SEGGER_REQUIRE(jb.n_edges == 0 || (jb.eid && jb.bits), "segger_dropout_bits_many: job %d: NULL pointer", i);
-    SEGGER_REQUIRE(jb.plane_stride >= jb.n_edges && jb.plane_stride % 4 == 0 && ((uintptr_t)jb.bits & 3u) == 0,
-                   "segger_dropout_bits_many: job %d: plane_stride must be a multiple of 4 >= n_edges, bits 4-byte aligned", i);
-    BitsParams& p = all.job[i];
-    p.eid = jb.eid; p.n_edges = jb.n_edges; p.plane_stride = jb.plane_stride; p.heads = heads; p.n_seeds = jb.n_seeds;
-    p.seed_dev = seed_dev; p.bits = jb.bits; p.eid_aligned = aligned16(jb.eid) ? 1 : 0;
-    p.thr = (uint32_t)((double)dropout_p * 16777216.0);
-    for (int l = 0; l < jb.n_seeds; ++l) p.seeds[l] = jb.seeds[l];
-    if (jb.n_edges > most) most = jb.n_edges;
+    const int rc = fill_bits_params(jobs[i], heads, dropout_p, seed_dev, i, &all.job[i]);
+    if (rc != SEGGER_OK) return rc;
+    if (jobs[i].n_edges > most) most = jobs[i].n_edges;
   }
   if (most == 0) return SEGGER_OK;
   hipLaunchKernelGGL(dropout_bits_many_kernel, dim3((unsigned)((most + 1023) / 1024), (unsigned)n_jobs), dim3(256), 0,

@@ -1,6 +1,7 @@
 // Scoring heads: fused cosine-similarity + per-transcript arg-max + assignment
 // (prediction) and the triplet margin loss over tx-belongs-bd edges (training).
 #include "common.h"
+#include "draws.h"
 
 namespace segger {
 namespace {
@@ -677,58 +678,7 @@ __global__ __launch_bounds__(256) void triplet_finish_kernel(const float* __rest
   if (threadIdx.x == 0) loss[0] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * inv_n;
 }
 
-// ---- cluster-aware triplet sampling (loss_tx / loss_bd), one thread per node -----------------------------------
-struct SampleParams {
-  const int64_t* lab; int64_t n; int n_clusters;
-  const float* cdf_pos; const float* cdf_neg;
-  const int64_t* counts; const int64_t* offsets; const int64_t* members;
-  const float* uniforms; uint32_t seed_lo, seed_hi; uint64_t seed_raw; const uint64_t* seed_dev;
-  const float* dists; int64_t* pos; int64_t* neg; float* d_pos; float* d_neg;
-};
-
-__device__ __forceinline__ float uniform01(uint32_t node, uint32_t draw, uint32_t lo, uint32_t hi) {
-  uint32_t x = (node * 4u + draw) ^ lo;
-  x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16; x ^= hi;
-  x *= 0x9e3779b1u; x ^= x >> 15;
-  return (float)(x >> 8) * (1.0f / 16777216.0f);          // 24 bits: [0, 1)
-}
-
-__global__ __launch_bounds__(256) void triplet_sample_kernel(SampleParams p) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= p.n) return;
-  const int K = p.n_clusters;
-  const int64_t r = p.lab[i];
-  if (r < 0 || r >= K) {                                   // masked-out node: no triplet
-    p.pos[i] = -1; p.neg[i] = -1;
-    if (p.d_pos) { p.d_pos[i] = 0.f; p.d_neg[i] = 0.f; }
-    return;
-  }
-  uint32_t lo = p.seed_lo, hi = p.seed_hi;
-  if (!p.uniforms && p.seed_dev) {
-    const uint64_t mixed = splitmix64(p.seed_raw + *p.seed_dev);
-    lo = (uint32_t)mixed; hi = (uint32_t)(mixed >> 32);
-  }
-  float u[4];
-#pragma unroll
-  for (int d = 0; d < 4; ++d) u[d] = p.uniforms ? p.uniforms[(int64_t)d * p.n + i] : uniform01((uint32_t)i, d, lo, hi);
-  int64_t pick[2];
-  int cl[2];
-#pragma unroll
-  for (int side = 0; side < 2; ++side) {
-    const float* row = (side == 0 ? p.cdf_pos : p.cdf_neg) + r * K;
-    int c = 0;
-    while (c < K - 1 && row[c] < u[2 * side]) ++c;         // first column with cdf >= u (searchsorted, left)
-    const int64_t cnt = p.counts[c];
-    int64_t w = (int64_t)floorf(u[2 * side + 1] * (float)cnt);
-    int64_t slot = p.offsets[c] + w;
-    if (slot >= p.n) slot = p.n - 1;
-    if (slot < 0) slot = 0;
-    pick[side] = p.members[slot];
-    cl[side] = c;
-  }
-  p.pos[i] = pick[0]; p.neg[i] = pick[1];
-  if (p.d_pos) { p.d_pos[i] = p.dists[r * K + cl[0]]; p.d_neg[i] = p.dists[r * K + cl[1]]; }
-}
+__global__ __launch_bounds__(256) void triplet_sample_kernel(SampleParams p) { triplet_sample_body(p, blockIdx.x); }
 
 // ---- MetricLoss on sampled triplets: 16 lanes per node, 4 nodes per wave-iteration ----------------------------------
 struct MetricParams {
@@ -1072,21 +1022,7 @@ extern "C" int segger_triplet_sample(const int64_t* lab, int64_t n, int32_t n_cl
 }
 
 namespace segger {
-__global__ __launch_bounds__(256) void sample_negatives_kernel(const int64_t* pos, int64_t n, int64_t n_b,
-                                                               const int64_t* n_b_dev, uint64_t seed_raw,
-                                                               const uint64_t* seed_dev, int64_t* neg) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= n) return;
-  const int64_t ip = pos[e];
-  if (ip < 0) { neg[e] = -1; return; }
-  if (n_b_dev) n_b = *n_b_dev;
-  if (n_b <= 1) { neg[e] = 0; return; }
-  const uint64_t mixed = splitmix64(seed_raw + (seed_dev ? *seed_dev : 0ull));
-  const float u = uniform01((uint32_t)e, (uint32_t)(e >> 30), (uint32_t)mixed, (uint32_t)(mixed >> 32));
-  int64_t shift = 1 + (int64_t)floorf(u * (float)(n_b - 1));
-  if (shift > n_b - 1) shift = n_b - 1;                    // u * (n_b - 1) may round up to n_b - 1
-  neg[e] = (ip + shift) % n_b;
-}
+__global__ __launch_bounds__(256) void sample_negatives_kernel(NegParams p) { sample_negatives_body(p, blockIdx.x); }
 }  // namespace segger
 
 extern "C" int segger_sample_negatives(const int64_t* pos, int64_t n, int64_t n_b, const int64_t* n_b_dev, uint64_t seed,
@@ -1094,8 +1030,8 @@ extern "C" int segger_sample_negatives(const int64_t* pos, int64_t n, int64_t n_
   SEGGER_REQUIRE(n >= 0 && n_b >= 0, "segger_sample_negatives: negative size");
   if (n == 0) return SEGGER_OK;
   SEGGER_REQUIRE(pos && neg, "segger_sample_negatives: NULL pointer");
-  hipLaunchKernelGGL(sample_negatives_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pos,
-                     n, n_b, n_b_dev, seed, seed_dev, neg);
+  hipLaunchKernelGGL(sample_negatives_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     NegParams{pos, n, n_b, n_b_dev, seed, seed_dev, neg});
   SEGGER_LAUNCH_CHECK("sample_negatives_kernel");
   return SEGGER_OK;
 }

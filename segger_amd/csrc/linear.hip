@@ -54,7 +54,7 @@ struct LinearParams {
 };
 
 template <typename T, int K, bool RB = false, bool SG = false>
-__global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
+__device__ __forceinline__ void linear_fwd_body(const LinearParams p, const int64_t bid) {
   constexpr int NK = K / 16;                       // k-steps
   constexpr int WSTRIDE = K * 2 + 16;              // bytes per LDS row of W
   constexpr int ESTRIDE = kChunk * 2 + 16;         // bytes per LDS row of the epilogue tile
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int64_t row0 = (int64_t)blockIdx.x * kRowsPerBlock + wave * 32;
+  const int64_t row0 = bid * kRowsPerBlock + wave * 32;
   const T* __restrict__ x = static_cast<const T*>(p.x);
   const T* __restrict__ w = static_cast<const T*>(p.w);
   T* __restrict__ y = static_cast<T*>(p.y);
@@ -209,6 +209,20 @@ __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
       if (row < p.n_rows) *reinterpret_cast<u32x4*>(y + row * p.ldy + c0 + piece * 8) = v;
     }
   }
+}
+
+template <typename T, int K, bool RB = false, bool SG = false>
+__global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
+  linear_fwd_body<T, K, RB, SG>(p, blockIdx.x);
+}
+
+// Two projections with the same K in ONE launch: the blocks of `b` (a few: the boundary side of a hetero layer, ~500 rows)
+// are dispatched first and run beside the blocks of `a` instead of as a 7 us launch of their own (a captured 1M-edge
+// training step has six such pairs; same idea as gatv2_fwd_pair_kernel).
+template <typename T, int K>
+__global__ __launch_bounds__(256, 2) void linear_fwd_pair_kernel(LinearParams a, LinearParams b, int nb_b) {
+  if ((int)blockIdx.x < nb_b) linear_fwd_body<T, K>(b, blockIdx.x);
+  else linear_fwd_body<T, K>(a, (int64_t)blockIdx.x - nb_b);
 }
 
 // ---- resident-W form for large row counts ----------------------------------------------------------------------
@@ -371,10 +385,63 @@ int launch_linear(const LinearParams& p, int k_in, hipStream_t stream) {
   return SEGGER_OK;
 }
 
+template <typename T>
+int launch_linear_pair(const LinearParams& a, const LinearParams& b, int k_in, hipStream_t stream) {
+  bool done = false;
+  int rc = launch_linear_res<T>(a, k_in, stream, &done);       // a large `a` goes its own (persistent) way
+  if (rc != SEGGER_OK) return rc;
+  if (done) return launch_linear<T>(b, k_in, stream);
+  const int64_t nb_a = (a.n_rows + kRowsPerBlock - 1) / kRowsPerBlock, nb_b = (b.n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
+  if (nb_a + nb_b > 0x7fffffffLL) { set_error("segger_linear_fwd_pair: too many rows"); return SEGGER_EUNSUPPORTED; }
+  if (nb_a == 0) return launch_linear<T>(b, k_in, stream);
+  if (nb_b == 0) return launch_linear<T>(a, k_in, stream);
+  dim3 grid((unsigned)(nb_a + nb_b)), block(256);
+  switch (k_in) {
+    case 64:  hipLaunchKernelGGL((linear_fwd_pair_kernel<T, 64>), grid, block, 0, stream, a, b, (int)nb_b); break;
+    case 128: hipLaunchKernelGGL((linear_fwd_pair_kernel<T, 128>), grid, block, 0, stream, a, b, (int)nb_b); break;
+    case 256: hipLaunchKernelGGL((linear_fwd_pair_kernel<T, 256>), grid, block, 0, stream, a, b, (int)nb_b); break;
+    case 384: hipLaunchKernelGGL((linear_fwd_pair_kernel<T, 384>), grid, block, 0, stream, a, b, (int)nb_b); break;
+    default:
+      set_error("segger_linear_fwd_pair: k_in=%d not supported (64, 128, 256, 384)", k_in);
+      return SEGGER_EUNSUPPORTED;
+  }
+  SEGGER_LAUNCH_CHECK("linear_fwd_pair_kernel");
+  return SEGGER_OK;
+}
+
 }  // namespace
 }  // namespace segger
 
 using namespace segger;
+
+extern "C" int segger_linear_fwd_pair(const segger_linear_args* a, const segger_linear_args* b, int32_t k_in, int32_t dtype,
+                                      segger_stream_t stream) {
+  SEGGER_REQUIRE(a && b, "segger_linear_fwd_pair: NULL args");
+  const segger_linear_args* both[2] = {a, b};
+  if (dtype == SEGGER_F32) {      // fp32 storage: two launches of the exact-fp32 kernel
+    for (const segger_linear_args* q : both) {
+      const int rc = segger_linear_fwd(q->x, q->ldx, q->w, q->bias, q->y, q->ldy, q->n_rows, k_in, q->m_out, dtype, stream);
+      if (rc != SEGGER_OK) return rc;
+    }
+    return SEGGER_OK;
+  }
+  LinearParams p[2];
+  for (int i = 0; i < 2; ++i) {
+    const segger_linear_args* q = both[i];
+    SEGGER_REQUIRE(q->n_rows >= 0 && q->m_out > 0, "segger_linear_fwd_pair: bad sizes");
+    if (!segger_linear_supported(k_in, q->m_out, dtype)) {
+      set_error("segger_linear_fwd_pair: k_in=%d m_out=%d dtype=%d not supported", k_in, q->m_out, dtype);
+      return SEGGER_EUNSUPPORTED;
+    }
+    SEGGER_REQUIRE(q->n_rows == 0 || (q->x && q->w && q->y), "segger_linear_fwd_pair: NULL pointer");
+    SEGGER_REQUIRE(aligned16(q->x) && aligned16(q->w) && aligned16(q->y), "segger_linear_fwd_pair: pointers must be 16-byte aligned");
+    SEGGER_REQUIRE(q->ldx >= k_in && q->ldy >= q->m_out && (q->ldx * 2) % 16 == 0 && (q->ldy * 2) % 16 == 0,
+                   "segger_linear_fwd_pair: bad leading dimension");
+    p[i] = LinearParams{q->x, q->ldx, q->w, q->bias, q->y, q->ldy, q->n_rows, q->m_out, nullptr, nullptr, 0, nullptr, 0};
+  }
+  return dtype == SEGGER_BF16 ? launch_linear_pair<bf16_t>(p[0], p[1], k_in, (hipStream_t)stream)
+                              : launch_linear_pair<f16_t>(p[0], p[1], k_in, (hipStream_t)stream);
+}
 
 extern "C" int segger_linear_supported(int32_t k_in, int32_t m_out, int32_t dtype) {
   const bool k_ok = k_in == 64 || k_in == 128 || k_in == 256 || k_in == 384;

@@ -127,8 +127,14 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {   // lgkmcnt / e
   __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14));
 }
 
+// The kernel body is a function (two of them can share a launch: wgrad_pair_kernel) and takes the parameter block by
+// value (gatv2_kernels.h: by const reference a body came out of the register allocator slower); `lds` = the workgroup's
+// shared array of at least wgrad_lds_bytes<...>() bytes, 1 KiB aligned; `bid` = the slab this workgroup owns.
+template <int M, int K, int NW, bool GEN, bool DX>
+constexpr int wgrad_lds_bytes() { return WgGeo<M, K, NW, GEN>::LDS + (DX ? 2 * WgGeo<M, K, NW, GEN>::OUT : 0); }
+
 template <typename T, int M, int K, int NW, bool GEN = false, bool DX = false>
-__global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
+__device__ __forceinline__ void wgrad_body(const WgradParams p, const int64_t bid, unsigned char* lds) {
   using G = WgGeo<M, K, NW, GEN>;
   static_assert(!(GEN && DX), "the generated-operand form has no data gradient");
   // wave grid over (M tiles, K tiles); GEN: every wave its own K tiles, so no generated fragment is computed twice
@@ -139,7 +145,6 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
   constexpr int MT = TM / WM, KT = TK / WK;            // 32x32 tiles per wave
   constexpr int SY = G::SY, SX = G::SX, P = G::P, BUF = G::BUF;
   static_assert((kStageRows * SY) % 1024 == 0, "the dY / X boundary must fall on a DMA chunk boundary");
-  __shared__ __attribute__((aligned(1024))) unsigned char lds[G::LDS + (DX ? 2 * G::OUT : 0)];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -150,7 +155,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
   // ---- staging by LDS-DMA through buffer resources based at this workgroup's first row: the source of a piece is
   //      an SGPR base + a per-lane 32-bit offset fixed for the whole kernel + a scalar stage offset; rows past the
   //      end of the matrix (the last, partial stage, and the stages the ring runs ahead of the slab) read as zeros
-  const int64_t s_beg = (int64_t)blockIdx.x * p.stages_per_block;
+  const int64_t s_beg = bid * p.stages_per_block;
   int64_t s_end = s_beg + p.stages_per_block;
   if (s_end > p.n_stages) s_end = p.n_stages;
   const int n_local = (int)(s_end > s_beg ? s_end - s_beg : 0);
@@ -380,7 +385,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
 
   // ---- partial results: acc tile (a, b) element e of lane l is dW[m][k] with
   //      m = 32*(wm*MT + a) + (e & 3) + 8*(e >> 2) + 4*(l >> 5),  k = 32*(wk*KT + b) + (l & 31) -----------------------
-  float* out = p.partial + (int64_t)blockIdx.x * (M * K + M);
+  float* out = p.partial + bid * (M * K + M);
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int a = 0; a < MT; ++a) {
@@ -401,6 +406,23 @@ __global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
       if (h == 0) out[M * K + 32 * (wm * MT + a) + r] = d;
     }
   }
+}
+
+template <typename T, int M, int K, int NW, bool GEN = false, bool DX = false>
+__global__ __launch_bounds__(NW * 64) void wgrad_kernel(WgradParams p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[wgrad_lds_bytes<M, K, NW, GEN, DX>()];
+  wgrad_body<T, M, K, NW, GEN, DX>(p, blockIdx.x, lds);
+}
+
+// Two projections' backward passes (same K, same wave count, both with or both without the data gradient) in ONE launch:
+// the slabs of `b` (the boundary side of a hetero layer: a few hundred rows, one or two workgroups) are dispatched first
+// and run beside the slabs of `a` instead of as a 7-15 us launch of their own (six such pairs in a captured 1M-edge step).
+template <typename T, int MA, int MB, int K, int NW, bool DX>
+__global__ __launch_bounds__(NW * 64) void wgrad_pair_kernel(WgradParams a, WgradParams b, int nb_b) {
+  constexpr int LA = wgrad_lds_bytes<MA, K, NW, false, DX>(), LB = wgrad_lds_bytes<MB, K, NW, false, DX>();
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[LA > LB ? LA : LB];
+  if ((int)blockIdx.x < nb_b) wgrad_body<T, MB, K, NW, false, DX>(b, blockIdx.x, lds);
+  else wgrad_body<T, MA, K, NW, false, DX>(a, (int64_t)blockIdx.x - nb_b, lds);
 }
 
 // ---- the positional embedder's whole backward from ONE read of its incoming gradient (segger_posmlp_bwd) -----------
@@ -871,6 +893,83 @@ extern "C" int segger_linear_wgrad(const void* dy, int64_t ld_dy, const void* x,
   if (rc != SEGGER_OK) return rc;
   SEGGER_LAUNCH_CHECK("wgrad_kernel");
   return reduce_partials(p.partial, grid, m_out, k_in, grad_w, grad_b, stream);
+}
+
+// ---- two backward passes in one launch -----------------------------------------------------------------------------
+namespace segger {
+namespace {
+template <typename T>
+bool launch_wgrad_pair(const WgradParams& a, int ma, int64_t grid_a, const WgradParams& b, int mb, int64_t grid_b, int k,
+                       bool dx, hipStream_t stream) {
+  const dim3 grid((unsigned)(grid_a + grid_b));
+#define PAIR(MA, MB, KK, NWW, DXX)                                                                                     \
+  if (ma == MA && mb == MB && k == KK && dx == DXX) {                                                                  \
+    hipLaunchKernelGGL((wgrad_pair_kernel<T, MA, MB, KK, NWW, DXX>), grid, dim3(NWW * 64), 0, stream, a, b, (int)grid_b); \
+    return true;                                                                                                       \
+  }
+  // the pairs of the default encoder: a hetero layer ([lin_l | lin_r | lin_l] of the transcripts + lin_r of the
+  // boundaries; the first layer reads K = 256 and has no one-pass data gradient) and lin_last of both node types
+  PAIR(384, 128, 128, 8, true) PAIR(384, 128, 256, 8, false) PAIR(64, 64, 128, 4, true)
+  PAIR(384, 128, 128, 8, false) PAIR(64, 64, 128, 4, false)
+#undef PAIR
+  return false;
+}
+}  // namespace
+}  // namespace segger
+
+extern "C" int segger_linear_wgrad_pair(const segger_wgrad_args* a, const segger_wgrad_args* b, int32_t k_in, int32_t dtype,
+                                        segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGGER_REQUIRE(a && b, "segger_linear_wgrad_pair: NULL args");
+  const segger_wgrad_args* both[2] = {a, b};
+  const bool dx = a->w_t != nullptr;
+  auto separately = [&]() -> int {
+    for (const segger_wgrad_args* q : both) {
+      const int rc = q->w_t ? segger_linear_wgrad_dx(q->dy, q->ld_dy, q->x, q->ld_x, q->w_t, q->n_rows, q->m_out, k_in, dtype,
+                                                     q->grad_w, q->grad_b, q->dx, q->ld_dx, nullptr, 0, q->workspace,
+                                                     q->workspace_bytes, stream_)
+                            : segger_linear_wgrad(q->dy, q->ld_dy, q->x, q->ld_x, q->n_rows, q->m_out, k_in, dtype, q->grad_w,
+                                                  q->grad_b, q->workspace, q->workspace_bytes, stream_);
+      if (rc != SEGGER_OK) return rc;
+    }
+    return SEGGER_OK;
+  };
+  if ((dtype != SEGGER_BF16 && dtype != SEGGER_F16) || (b->w_t != nullptr) != dx || a->n_rows <= 0 || b->n_rows <= 0)
+    return separately();
+  WgradParams p[2];
+  int64_t grid[2];
+  for (int i = 0; i < 2; ++i) {
+    const segger_wgrad_args* q = both[i];
+    const bool ok = dx ? segger_linear_wgrad_dx_supported(q->m_out, k_in, dtype) : segger_linear_wgrad_supported(q->m_out, k_in, dtype);
+    if (!ok) return separately();
+    SEGGER_REQUIRE(q->grad_w != nullptr, "segger_linear_wgrad_pair: grad_w is NULL");
+    SEGGER_REQUIRE(q->dy && q->x && (!dx || q->dx), "segger_linear_wgrad_pair: NULL pointer");
+    SEGGER_REQUIRE(aligned16(q->dy) && aligned16(q->x) && aligned16(q->w_t) && aligned16(q->dx),
+                   "segger_linear_wgrad_pair: pointers must be 16-byte aligned");
+    SEGGER_REQUIRE(q->ld_dy >= q->m_out && q->ld_x >= k_in && (q->ld_dy * 2) % 16 == 0 && (q->ld_x * 2) % 16 == 0 &&
+                       (!dx || (q->ld_dx >= k_in && (q->ld_dx * 2) % 16 == 0)), "segger_linear_wgrad_pair: bad leading dimension");
+    const size_t need = segger_linear_wgrad_workspace_bytes(q->n_rows, q->m_out, k_in);
+    if (q->workspace == nullptr || q->workspace_bytes < need) {
+      set_error("segger_linear_wgrad_pair: workspace %zu < %zu bytes", q->workspace_bytes, need);
+      return SEGGER_EWORKSPACE;
+    }
+    grid[i] = grid_for(q->n_rows, q->m_out, k_in, dx);
+    const int64_t stages = (q->n_rows + kStageRows - 1) / kStageRows;
+    const int64_t span = ((stages + grid[i] - 1) / grid[i]) * kStageRows * (q->ld_dy > q->ld_x ? q->ld_dy : q->ld_x) * 2;
+    SEGGER_REQUIRE(span < (int64_t)kOutOfRange, "segger_linear_wgrad_pair: a workgroup's row slab exceeds 1 GiB");
+    p[i] = WgradParams{q->dy, q->ld_dy, q->x, q->ld_x, q->n_rows, stages, (stages + grid[i] - 1) / grid[i],
+                       static_cast<float*>(q->workspace), nullptr, 0.f, q->w_t, q->dx, q->ld_dx, nullptr, 0};
+  }
+  const bool launched = dtype == SEGGER_BF16
+      ? launch_wgrad_pair<bf16_t>(p[0], a->m_out, grid[0], p[1], b->m_out, grid[1], k_in, dx, stream)
+      : launch_wgrad_pair<f16_t>(p[0], a->m_out, grid[0], p[1], b->m_out, grid[1], k_in, dx, stream);
+  if (!launched) return separately();
+  SEGGER_LAUNCH_CHECK("wgrad_pair_kernel");
+  for (int i = 0; i < 2; ++i) {
+    const int rc = reduce_partials(p[i].partial, grid[i], both[i]->m_out, k_in, both[i]->grad_w, both[i]->grad_b, stream);
+    if (rc != SEGGER_OK) return rc;
+  }
+  return SEGGER_OK;
 }
 
 namespace segger {

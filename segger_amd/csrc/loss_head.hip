@@ -5,7 +5,7 @@
 // atomic ceiling (0.33 of the HBM roofline at C2, the furthest-below kernel of the step).  Here:
 //
 //   forward   one grid, three block ranges: loss_tx triplets | loss_bd nodes | loss_sg triplets.  Every block leaves a
-//             partial sum; the LAST block to finish (a ticket counter) adds them in a fixed order, forms the weighted
+//             partial sum; a one-workgroup launch behind it adds them in a fixed order, forms the weighted
 //             total (segger_loss_combine_fwd's arithmetic) and -- the incoming gradient of a training step being known --
 //             the three backward scale factors.  On the way every block zero-fills its slice of the boundary gradient,
 //             and the loss_tx range records, per ACTIVE triplet t = (t, p, n), 1/d(t,p) and 1/d(t,n) and threads t into
@@ -117,7 +117,6 @@ struct LossHeadParams {
 template <typename T, int CPL>
 __global__ __launch_bounds__(256) void loss_head_fwd_kernel(LossHeadParams p) {
   __shared__ float wsum[4];
-  __shared__ int is_last;
   constexpr int C = 16 * CPL;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int grp = lane >> 4, gl = lane & 15, c0 = gl * CPL;
@@ -251,40 +250,46 @@ __global__ __launch_bounds__(256) void loss_head_fwd_kernel(LossHeadParams p) {
   acc = wave_sum(acc);
   if (lane == 0) wsum[wave] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    p.partial[blk] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __threadfence();
-    is_last = atomicAdd(p.ticket, 1) == (int)gridDim.x - 1;
-  }
-  __syncthreads();
-  if (!is_last) return;
-  // the last block: the three means in a fixed order, the weighted total, the backward's scale factors
-  __threadfence();
+  if (threadIdx.x == 0) p.partial[blk] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// The three means in a fixed order, the weighted total and -- the incoming gradient of a training step being known -- the
+// three backward scale factors: one workgroup, launched right behind the forward kernel.  (Round 4 first let the LAST block
+// of the forward do this, found by a ticket counter behind a __threadfence(): on this part a device-scope release writes
+// back the whole L2 of the XCD, once per block -- 0.76 of the forward's 0.90 ms at C2 (22k blocks), 30 of 44 us at 44k rows;
+// tools/bench_loss_head.py, profiles/r04_loss_head_modes_c2.txt.)
+__global__ __launch_bounds__(256) void loss_head_finish_kernel(LossHeadParams p) {
+  __shared__ float wsum[4];
   __shared__ float raw[3];
-  const int lo[3] = {0, p.nb_tx, p.nb_tx + p.nb_bd};
-  const int hi[3] = {p.nb_tx, p.nb_tx + p.nb_bd, p.nb_tx + p.nb_bd + p.nb_sg};
-  const float scale[3] = {p.n_tx > 0 ? 1.0f / (float)p.n_tx : 0.f, 1.0f,
-                          p.n_sg > 0 ? (p.sg_kind == SEGGER_LOSS_BCE ? 0.5f : 1.0f) / (float)p.n_sg : 0.f};
-  for (int r = 0; r < 3; ++r) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {      // (no arrays indexed by r: they would live in scratch memory)
+    const int lo = r == 0 ? 0 : (r == 1 ? p.nb_tx : p.nb_tx + p.nb_bd);
+    const int hi = r == 0 ? p.nb_tx : (r == 1 ? p.nb_tx + p.nb_bd : p.nb_tx + p.nb_bd + p.nb_sg);
+    const float scale = r == 0 ? (p.n_tx > 0 ? 1.0f / (float)p.n_tx : 0.f)
+                      : r == 1 ? 1.0f
+                               : (p.n_sg > 0 ? (p.sg_kind == SEGGER_LOSS_BCE ? 0.5f : 1.0f) / (float)p.n_sg : 0.f);
     float s = 0.f;
-    for (int k = lo[r] + (int)threadIdx.x; k < hi[r]; k += 256) s += __builtin_nontemporal_load(p.partial + k);
+    for (int k = lo + (int)threadIdx.x; k < hi; k += 256) s += p.partial[k];
     s = wave_sum(s);
     if (lane == 0) wsum[wave] = s;
     __syncthreads();
-    if (threadIdx.x == 0) raw[r] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * scale[r];
+    if (threadIdx.x == 0) raw[r] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) * scale;
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     float total = 0.f;
+#pragma unroll
     for (int i = 0; i < 3; ++i) {
       const float t = raw[i] * p.a[i];
       p.out[i] = t;
       total = fmaf(t, p.b[i], total);
     }
     p.out[3] = total;
-    if (p.gout != nullptr && p.graw != nullptr)
+    if (p.gout != nullptr && p.graw != nullptr) {
+#pragma unroll
       for (int i = 0; i < 3; ++i) p.graw[i] = (p.gout[3] * p.b[i] + p.gout[i]) * p.a[i];
-    *p.ticket = 0;                                                // ready for the next launch
+    }
   }
 }
 
@@ -571,7 +576,6 @@ int fill_params(const segger_loss_head_args* a, bool bwd, LossHeadParams* out) {
     set_error("segger_loss_head: workspace %zu < %zu bytes", a->workspace_bytes, need);
     return SEGGER_EWORKSPACE;
   }
-  SEGGER_REQUIRE(a->ticket != nullptr, "segger_loss_head: ticket is NULL (one zero-initialised int32 the launches reset themselves)");
   LossHeadParams p{};
   p.ztx = a->z_tx; p.ld_ztx = a->ld_ztx; p.n_tx = a->n_tx;
   p.zbd = a->z_bd; p.ld_zbd = a->ld_zbd; p.n_bd = a->n_bd;
@@ -632,6 +636,10 @@ int launch(const segger_loss_head_args* a, hipStream_t stream) {
 #undef BY_C
 #undef GO
   SEGGER_LAUNCH_CHECK("loss_head kernel");
+  if (!BWD) {
+    hipLaunchKernelGGL(loss_head_finish_kernel, dim3(1), dim3(256), 0, stream, p);
+    SEGGER_LAUNCH_CHECK("loss_head_finish_kernel");
+  }
   return SEGGER_OK;
 }
 

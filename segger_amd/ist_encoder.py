@@ -35,9 +35,10 @@ NEGATIVE_SLOPE = 0.2       # GATv2Conv default
 
 
 def _layer_seed(seed, which: int):
-    """(2*layer + edge-type slot) with the optional device counter carried along."""
+    """(2*layer + edge-type slot) with the optional device counter carried along; a third entry is a constant added to the
+    seed (a captured step reads the counter BEFORE its end-of-step advance: offset = the advance)."""
     if isinstance(seed, tuple):
-        return (2 * int(seed[0]) + which, seed[1])
+        return (2 * int(seed[0]) + which + (int(seed[2]) if len(seed) > 2 else 0), seed[1])
     return 2 * int(seed) + which
 
 
@@ -229,10 +230,12 @@ class SkipGAT(Module):
         tt, tb = self.conv[TX_TX], self.conv[TX_BD]
         dt = x_tx.dtype
         # one fused projection for the three linear maps that read x_tx (stacked and cast once per optimizer step)
-        proj = ops.embed_linear if isinstance(x_tx, ops.EmbedInput) else ops.linear
-        xp_tx = proj(x_tx, (tt.lin_l.weight, tt.lin_r.weight, tb.lin_l.weight),
-                     (tt.lin_l.bias, tt.lin_r.bias, tb.lin_l.bias))
-        xp_bd = ops.linear(x_bd, tb.lin_r.weight, tb.lin_r.bias)
+        w_tx, b_tx = (tt.lin_l.weight, tt.lin_r.weight, tb.lin_l.weight), (tt.lin_l.bias, tt.lin_r.bias, tb.lin_l.bias)
+        if isinstance(x_tx, ops.EmbedInput):
+            xp_tx = ops.embed_linear(x_tx, w_tx, b_tx)
+            xp_bd = ops.linear(x_bd, tb.lin_r.weight, tb.lin_r.bias)
+        else:                    # both node types' projections in one launch (the boundary side rides in the grid)
+            xp_tx, xp_bd = ops.linear_pair(x_tx, w_tx, b_tx, x_bd, tb.lin_r.weight, tb.lin_r.bias)
         p = tt.dropout if self.training else 0.0
         y_tx, y_bd, alpha = ops.hetero_gat_layer(
             xp_tx, xp_bd, tt.att, tt.bias, tb.att, tb.bias, graphs[TX_TX], graphs[TX_BD],
@@ -260,6 +263,11 @@ class _HeteroDictLinear(Module):
 
     def forward(self, x_dict: Dict[str, Tensor]) -> Dict[str, Tensor]:
         out = {}
+        if len(x_dict) == 2:     # lin_last of both node types: one launch
+            (ka, xa), (kb, xb) = x_dict.items()
+            la, lb = self.lins[ka], self.lins[kb]
+            out[ka], out[kb] = ops.linear_pair(xa, la.weight, la.bias, xb, lb.weight, lb.bias)
+            return out
         for k, x in x_dict.items():
             lin = self.lins[k]
             out[k] = ops.linear(x, lin.weight, lin.bias)
@@ -323,26 +331,37 @@ class ISTEncoder(Module):
         for k in [k for k in state_dict if k.startswith(prefix) and "<bd___contains___tx>" in k]:
             del state_dict[k]
 
-    def _dropout_planes(self, graphs, step):
-        """The attention-dropout masks of all layers as bit planes per CSR view (``ops.dropout_bits_many``): one launch
-        per step; the 12 aggregation launches of the step then test a bit per (edge, head) instead of hashing."""
+    def plane_views(self, graphs, seed_offset: int = 0):
+        """The CSR views whose attention-dropout masks a training step needs as bit planes: [(edge type, side, csr, seeds)]
+        (side 0 = by destination, 1 = by source), or None when the planes do not apply."""
         n_layers = len(self.conv_layers)
         first = self.conv_layers[0]
         if n_layers > 16 or self.n_heads > 8 or not (first.conv[TX_TX].dropout > 0):
             return None
-        p = first.conv[TX_TX].dropout
-        out, views = {}, []
+        views = []
         for which, et in ((0, TX_TX), (1, TX_BD)):
             g = graphs.get(et)
             if g is None or g.by_dst is None:
                 continue
-            seeds = [2 * li + which for li in range(n_layers)]
+            seeds = [2 * li + which + int(seed_offset) for li in range(n_layers)]
             views += [(et, 0, g.by_dst, seeds)] + ([(et, 1, g.by_src, seeds)] if g.by_src is not None else [])
-            out[et] = [None, None]
-        for (et, side, _, _), bits in zip(views, ops.dropout_bits_many([(c, sd) for _, _, c, sd in views], self.n_heads, p,
-                                                                         step)):
-            out[et][side] = bits
+        return views
+
+    @staticmethod
+    def planes_of(views, bits) -> dict:
+        out = {}
+        for (et, side, _, _), b in zip(views, bits):
+            out.setdefault(et, [None, None])[side] = b
         return {et: tuple(v) for et, v in out.items()}
+
+    def _dropout_planes(self, graphs, step):
+        """The attention-dropout masks of all layers as bit planes per CSR view (``ops.dropout_bits_many``): one launch
+        per step; the 12 aggregation launches of the step then test a bit per (edge, head) instead of hashing."""
+        views = self.plane_views(graphs)
+        if views is None:
+            return None
+        p = self.conv_layers[0].conv[TX_TX].dropout
+        return self.planes_of(views, ops.dropout_bits_many([(c, sd) for _, _, c, sd in views], self.n_heads, p, step))
 
     def _pos_embed_pair(self, pos_dict, batch_dict, num_graphs, dt, gelu: bool, graphs):
         """(pe_tx, pe_bd): ``pos_emb`` of both node types, in one call where the batch vectors allow it.  With ``gelu``
@@ -433,7 +452,13 @@ class ISTEncoder(Module):
                                      validate="deferred")     # checked without a host sync (graph.py)
                       for et in (TX_TX, TX_BD) if et in edge_index_dict}
         step = self._step_dev
-        if self.training:
+        seed_off = 0
+        drawn = graphs.get("draws") if self.training else None
+        if drawn is not None:
+            # a captured step made all of its draws up front in one launch (ops.step_draws) from the counter as it stands
+            # and advances it at its end: (planes | None, constant added to every seed)
+            planes, seed_off = drawn
+        elif self.training:
             # every training forward gets its own snapshot of the advanced counter: its backward re-reads THAT word,
             # so a second forward before the first backward (two views, checkpointing, a logging pass) cannot change
             # the masks the first backward regenerates.  Capture-safe: the clone lives in the graph's pool.
@@ -442,10 +467,11 @@ class ISTEncoder(Module):
             else:
                 self._step_dev.add_(256)
                 step = self._step_dev.clone()
-        planes = self._dropout_planes(graphs, step) if self.training else None
+        if drawn is None:
+            planes = self._dropout_planes(graphs, step) if self.training else None
         for li, layer in enumerate(self.conv_layers):
             kb = None if planes is None else {et: (d[li], None if s_ is None else s_[li]) for et, (d, s_) in planes.items()}
-            x = layer(x, edge_index_dict, graphs=graphs, apply_gelu=True, seed=(li, step), keep_bits=kb)   # conv + GELU (:324-325)
+            x = layer(x, edge_index_dict, graphs=graphs, apply_gelu=True, seed=(li, step, seed_off), keep_bits=kb)   # conv + GELU (:324-325)
 
         x = self.lin_last(x)
         if self.normalize_embeddings:

@@ -104,6 +104,68 @@ def step_advance(step: Tensor, inc: int) -> Tensor:
     return snap
 
 
+@torch.no_grad()
+def step_draws(views, heads: int, dropout_p: float, samplers, negatives, seed_dev: Tensor, advance=None):
+    """Every random draw of one training step in ONE launch (``segger_step_draws``): ``views`` = up to four ``(csr, seeds)``
+    of :func:`dropout_bits_many` (or []), ``samplers`` = up to two ``(index, seed)`` of :func:`triplet_sample`, ``negatives``
+    = ``(pos, n_b, n_b_dev, seed)`` of :func:`sample_negatives` or None; all streams read the device word ``seed_dev``;
+    ``advance``: up to 64 fp32 device scalars incremented by one on the way (:func:`adam_step_counters`).
+    -> (planes, [(pos, neg, d_pos, d_neg), ...], negatives | None): what the separate calls return for the same seeds."""
+    if len(views) > 4 or len(samplers) > 2:
+        raise ValueError("step_draws: at most four views and two samplers")
+    _lib.require_cuda(seed_dev)
+    lib = _lib.load()
+    dev = seed_dev.device
+    a = _lib.StepDrawsArgs()
+    keep, planes, draws = [], [], []
+    if views:
+        jobs = (_lib.BitsJob * len(views))()
+        for i, (csr, seeds) in enumerate(views):
+            seeds = [int(v) & 0xFFFFFFFFFFFFFFFF for v in seeds]
+            stride = (csr.n_edges + 15) // 16 * 16
+            out = torch.empty((len(seeds), stride), dtype=torch.uint8, device=dev)
+            arr = (C.c_uint64 * len(seeds))(*seeds)
+            keep.append(arr)
+            jobs[i].eid = csr.eid.data_ptr() if csr.n_edges else None
+            jobs[i].n_edges, jobs[i].n_seeds = csr.n_edges, len(seeds)
+            jobs[i].seeds = C.cast(arr, C.c_void_p)
+            jobs[i].bits, jobs[i].plane_stride = out.data_ptr(), stride
+            planes.append(out[:, :csr.n_edges])
+        keep.append(jobs)
+        a.bits, a.n_bits, a.heads, a.dropout_p = C.cast(jobs, C.c_void_p), len(views), int(heads), float(dropout_p)
+    a.n_samplers = len(samplers)
+    for i, (index, seed) in enumerate(samplers):
+        lab = index["lab"]
+        n = int(lab.numel())
+        pos = torch.empty(n, dtype=torch.int64, device=dev)
+        neg = torch.empty(n, dtype=torch.int64, device=dev)
+        dd = torch.empty((2, n), dtype=torch.float32, device=dev)
+        j = a.samplers[i]
+        j.lab, j.n, j.n_clusters = lab.data_ptr(), n, int(index["n_clusters"])
+        j.cdf_pos, j.cdf_neg = index["cdf_pos_t"].data_ptr(), index["cdf_neg_t"].data_ptr()
+        j.counts, j.offsets, j.members = index["counts"].data_ptr(), index["offsets"].data_ptr(), index["members"].data_ptr()
+        j.seed, j.dists = int(seed) & 0xFFFFFFFFFFFFFFFF, index["dists"].data_ptr()
+        j.pos, j.neg, j.d_pos, j.d_neg = pos.data_ptr(), neg.data_ptr(), dd[0].data_ptr(), dd[1].data_ptr()
+        draws.append((pos, neg, dd[0], dd[1]))
+    out_neg = None
+    if negatives is not None:
+        npos, n_b, n_b_dev, nseed = negatives
+        npos = npos.to(torch.int64).contiguous()
+        out_neg = torch.empty_like(npos)
+        keep.append(npos)
+        a.neg_pos, a.neg_n, a.neg_n_b, a.neg_n_b_dev = npos.data_ptr(), int(npos.numel()), int(n_b), _lib.ptr(n_b_dev)
+        a.neg_seed, a.neg_out = int(nseed) & 0xFFFFFFFFFFFFFFFF, out_neg.data_ptr()
+    a.seed_dev = seed_dev.data_ptr()
+    if advance:
+        ptrs = (C.c_void_p * len(advance))(*[t.data_ptr() for t in advance])
+        keep.append(ptrs)
+        a.advance, a.n_advance = C.cast(ptrs, C.c_void_p), len(advance)
+    with _lib.on_device(dev):
+        rc = lib.segger_step_draws(C.byref(a), _lib.stream_ptr(dev))
+    _lib.check(rc, "segger_step_draws")
+    return planes, draws, out_neg
+
+
 # ---- deferred partial sums (csrc/reduce.hip) ----------------------------------------------------------------
 _DEFER_KEEP: Optional[list] = None
 
@@ -828,6 +890,11 @@ def anchor_index(src: Tensor, n_rows: int) -> Tensor:
 
 
 ONE_LAUNCH_LOSS_HEAD = True      # tools flip it: False = the round-3 loss head (three kernels + combination each way)
+# the one-launch head up to this many transcript rows (a captured 1M-edge step: ~50k): its forward threads loss_tx's
+# contributions into per-row chains with 4 returning atomics per triplet -- 250 us at 10^6 rows against 150 us for the whole
+# kernel-by-kernel forward, and its gathered backward gains only 70 us there (tools/bench_loss_head.py,
+# profiles/r04_loss_head_modes_c2.txt; a variant with the contributions radix-sorted by target row instead: sort 270 us)
+LOSS_HEAD_ONE_LAUNCH_MAX_ROWS = 131072
 
 
 def loss_head_fused_supported(z_tx: Tensor, z_bd: Tensor, spec: "LossHeadSpec") -> bool:
@@ -835,7 +902,7 @@ def loss_head_fused_supported(z_tx: Tensor, z_bd: Tensor, spec: "LossHeadSpec") 
     n = int(z_tx.shape[0])
     return (ONE_LAUNCH_LOSS_HEAD and spec.tx_anchors_are_rows and z_tx.dtype in DTYPE_CODE and z_tx.dtype == z_bd.dtype
             and bool(_lib.load().segger_loss_head_supported(c, DTYPE_CODE[z_tx.dtype])) and int(z_bd.shape[1]) == c
-            and 0 < n < (1 << 30) and spec.tx[0].numel() == n and z_bd.shape[0] > 0
+            and 0 < n <= LOSS_HEAD_ONE_LAUNCH_MAX_ROWS and spec.tx[0].numel() == n and z_bd.shape[0] > 0
             and (spec.sg is None or (len(spec.sg) > 5 and spec.sg[5] is not None)))
 
 
@@ -1091,41 +1158,74 @@ _FILLS = {"const": _lib.FILL_CONST, "tile": _lib.FILL_TILE, "div": _lib.FILL_DIV
           "ramp": _lib.FILL_RAMP}
 
 
-def adam_step(opt) -> bool:
-    """``optimizer.step()`` of a plain capturable ``torch.optim.Adam`` through ``segger_adam_step``: every parameter tensor
-    in two launches, on the optimizer's own state tensors (checkpoints and eager ``optimizer.step()`` calls stay
-    interchangeable).  -> False, nothing done, when the optimizer is anything else (amsgrad, weight decay, maximize, a
-    tensor learning rate, non-fp32 or non-contiguous parameters, state not created yet): the caller then runs
-    ``optimizer.step()`` itself."""
+def _adam_jobs(opt):
+    """[(param group, [(param, grad, exp_avg, exp_avg_sq, step)])] when ``segger_adam_step`` covers ``opt``, else None."""
     from .optim import Adam as _Adam
     if type(opt) not in (torch.optim.Adam, _Adam):   # (not subclasses in general: torch's AdamW is one)
-        return False
+        return None
     # torch's AMP contract for fused optimizers (``_step_supports_amp_scaling``): ``GradScaler.step`` skips its own unscale /
     # inf check and hands both to the optimizer as ``grad_scale`` / ``found_inf``.  The kernel reads neither: torch's fused
     # step does the scaled, skippable update.
     if getattr(opt, "grad_scale", None) is not None or getattr(opt, "found_inf", None) is not None:
-        return False
+        return None
     jobs = []
     for g in opt.param_groups:
         if (g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") or g.get("differentiable")
                 or not g.get("capturable") or isinstance(g["lr"], Tensor)):
-            return False
+            return None
         rows = []
         for p in g["params"]:
             if p.grad is None:
                 continue
             st = opt.state.get(p)
             if not st or "exp_avg" not in st:
-                return False
+                return None
             ts = (p, p.grad, st["exp_avg"], st["exp_avg_sq"], st["step"])
             if not all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in ts) or p.grad.is_sparse:
-                return False
+                return None
             rows.append(ts)
         jobs.append((g, rows))
+    return jobs
+
+
+def adam_step_counters(opt, params=None) -> Optional[list]:
+    """The step counters ``segger_adam_step`` would advance (one fp32 scalar per parameter ``params`` -- default: those with
+    a gradient -- of a covered optimizer whose state exists), at most 64 in ONE parameter group; None otherwise.  A captured
+    step hands them to :func:`step_draws` and then calls ``adam_step(opt, steps_advanced=True)``."""
+    from .optim import Adam as _Adam
+    if type(opt) not in (torch.optim.Adam, _Adam) or len(opt.param_groups) != 1:
+        return None
+    g = opt.param_groups[0]
+    if (g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") or g.get("differentiable")
+            or not g.get("capturable") or isinstance(g["lr"], Tensor)):
+        return None
+    out = []
+    for p in (g["params"] if params is None else params):
+        st = opt.state.get(p)
+        if not st or "step" not in st or not st["step"].is_cuda or st["step"].dtype != torch.float32:
+            return None
+        out.append(st["step"])
+    return out if 0 < len(out) <= 64 else None
+
+
+def adam_step(opt, steps_advanced: bool = False, counter: Optional[Tensor] = None, counter_inc: int = 0) -> bool:
+    """``optimizer.step()`` of a plain capturable ``torch.optim.Adam`` through ``segger_adam_step``: every parameter tensor
+    in two launches, on the optimizer's own state tensors (checkpoints and eager ``optimizer.step()`` calls stay
+    interchangeable).  -> False, nothing done, when the optimizer is anything else (amsgrad, weight decay, maximize, a
+    tensor learning rate, non-fp32 or non-contiguous parameters, state not created yet): the caller then runs
+    ``optimizer.step()`` itself.  ``steps_advanced``: the step counters were advanced already (:func:`adam_step_counters`);
+    ``counter`` (int64[1] on the device): ``counter += counter_inc`` rides in the update launch."""
+    # torch's AMP contract for fused optimizers (``_step_supports_amp_scaling``): ``GradScaler.step`` skips its own unscale /
+    # inf check and hands both to the optimizer as ``grad_scale`` / ``found_inf``.  The kernel reads neither: torch's fused
+    # step does the scaled, skippable update.
+    jobs = _adam_jobs(opt)
+    if jobs is None:
+        return False
+    jobs = [(g, rows) for g, rows in jobs if rows]
+    if (steps_advanced or counter is not None) and len(jobs) != 1:
+        raise RuntimeError("adam_step: advanced counters need exactly one parameter group with gradients")
     lib = _lib.load()
     for g, rows in jobs:
-        if not rows:
-            continue
         arr = (_lib.AdamTensor * len(rows))()
         for a, (p, gr, m, v, st) in zip(arr, rows):
             a.param, a.grad, a.exp_avg, a.exp_avg_sq, a.step, a.numel = (p.data_ptr(), gr.data_ptr(), m.data_ptr(),
@@ -1133,8 +1233,8 @@ def adam_step(opt) -> bool:
         dev = rows[0][0].device
         b1, b2 = g["betas"]
         with _lib.on_device(dev):
-            rc = lib.segger_adam_step(arr, len(rows), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
-                                      _lib.stream_ptr(dev))
+            rc = lib.segger_adam_step_ex(arr, len(rows), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+                                         1 if steps_advanced else 0, _lib.ptr(counter), int(counter_inc), _lib.stream_ptr(dev))
         _lib.check(rc, "segger_adam_step")
     return True
 
@@ -1351,6 +1451,45 @@ def linear_wgrad_dx_launch(gy: Tensor, x: Tensor, wt: Tensor, want_bias: bool = 
     _lib.check(rc, "segger_linear_wgrad_dx")
     _defer_keep(ws, gw, gb)
     return gx, gw, gb
+
+
+def linear_wgrad_pair_launch(sides, dx: bool):
+    """``sides`` = two (gy [n, M], x [n, K], wt [K, M] | None, want_bias) of one K and dtype -> [(gx | None, gw, gb | None)] * 2 from
+    ONE launch (``segger_linear_wgrad_pair``; ``dx``: the one-pass form with the data gradients, else dW / db only)."""
+    lib = _lib.load()
+    dev, dt = sides[0][0].device, sides[0][1].dtype
+    args, outs, keep = [], [], []
+    for gy, x, wt, want_bias in sides:
+        _lib.require_cuda(gy, x)
+        n, m = gy.shape
+        k = x.shape[1]
+        if x.shape[0] != n or gy.dtype != dt or x.dtype != dt:
+            raise ValueError("linear_wgrad_pair: gy / x must share the row count and the dtype")
+        a = _lib.WgradArgs()
+        a.dy, a.ld_dy = _rows(gy, m, "gy")
+        a.x, a.ld_x = _rows(x, k, "x")
+        a.n_rows, a.m_out = n, m
+        gx = None
+        if dx:
+            if wt.dtype != dt or tuple(wt.shape) != (k, m) or not wt.is_contiguous():
+                raise ValueError("linear_wgrad_pair: W^T must be contiguous [K, M] in the activation dtype")
+            gx = torch.empty((n, k), dtype=dt, device=dev)
+            a.w_t, a.dx, a.ld_dx = wt.data_ptr(), gx.data_ptr(), k
+        gw = torch.empty((m, k), dtype=torch.float32, device=dev)
+        gb = torch.empty(m, dtype=torch.float32, device=dev) if want_bias else None
+        ws_bytes = lib.segger_linear_wgrad_workspace_bytes(n, m, k)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        a.grad_w, a.grad_b, a.workspace, a.workspace_bytes = gw.data_ptr(), _lib.ptr(gb), ws.data_ptr(), ws_bytes
+        args.append(a)
+        outs.append((gx, gw, gb))
+        keep.append((ws, gw, gb))
+    with _lib.on_device(dev):
+        rc = lib.segger_linear_wgrad_pair(C.byref(args[0]), C.byref(args[1]), int(sides[0][1].shape[1]), DTYPE_CODE[dt],
+                                          _lib.stream_ptr(dev))
+    _lib.check(rc, "segger_linear_wgrad_pair")
+    for kk in keep:
+        _defer_keep(*kk)
+    return outs
 
 
 def _weight_grad_gemm(gy: Tensor, x: Tensor) -> Tensor:
@@ -1606,56 +1745,166 @@ class _Linear(torch.autograd.Function):
         pk = _pack_for(weights, biases).get(x.dtype, x.device)
         y = linear_fwd_launch(x, pk.w, pk.b)
         ctx.save_for_backward(x)
-        ctx.pack, ctx.n_w = pk, n_w
-        ctx.rows = [int(w.shape[0]) for w in weights]
-        ctx.has_bias = [b is not None for b in biases]
-        # the pack is refreshed IN PLACE after an optimizer step; a backward that runs later than that (not the case in
-        # forward -> backward -> step training) would see the new weights: remember which generation this forward used
-        ctx.w, ctx.wt_of, ctx.w_key = pk.w, pk, pk.key
+        ctx.n_w = n_w
+        _linear_save(ctx, pk, weights, biases)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
-        dt = x.dtype
-        n_w = ctx.n_w
-        if gy.dtype != dt:
-            gy = gy.to(dt)
-        if gy.dim() != 2 or (gy.shape[0] > 1 and gy.stride(1) != 1):
-            gy = gy.contiguous()
-        w = ctx.w
-        m, k = w.shape
-        gx = None
-        want_w = any(ctx.needs_input_grad[2:2 + n_w])
-        want_b = any(h and g for h, g in zip(ctx.has_bias, ctx.needs_input_grad[2 + n_w:]))
-        gw = gb = None
-        if ctx.needs_input_grad[0]:
-            if ctx.wt_of.key != ctx.w_key:
-                raise RuntimeError("the projection weights changed between this forward and its backward "
-                                   "(optimizer step in between?): run backward before stepping")
-            wt = ctx.wt_of.wt                                                   # [K, M]: dX = dY @ W
-            if (FUSED_WGRAD_DX and (want_w or want_b) and x.shape[0] > 0 and linear_wgrad_dx_supported(m, k, dt)):
-                gx, gw, gb = linear_wgrad_dx_launch(gy, x, wt, want_bias=want_b)    # dY read ONCE for dX, dW and db
-            elif linear_supported(m, k, dt):
-                gx = linear_fwd_launch(gy, wt, None)
-            else:
-                gx = gy @ w
-        if gw is not None:
-            pass
-        elif (want_w or want_b) and x.shape[0] > 0 and linear_wgrad_supported(m, k, dt):
-            gw, gb = linear_wgrad_launch(gy, x, want_bias=want_b)       # dY and X read once for both
+        return _linear_backward(ctx, x, gy, ctx.needs_input_grad[0], ctx.needs_input_grad[2:])
+
+
+def _linear_save(ctx, pk, weights, biases) -> None:
+    ctx.pack = pk
+    ctx.rows = [int(w.shape[0]) for w in weights]
+    ctx.has_bias = [b is not None for b in biases]
+    # the pack is refreshed IN PLACE after an optimizer step; a backward that runs later than that (not the case in
+    # forward -> backward -> step training) would see the new weights: remember which generation this forward used
+    ctx.w, ctx.wt_of, ctx.w_key = pk.w, pk, pk.key
+
+
+def _grad_rows(gy: Tensor, dt) -> Tensor:
+    if gy.dtype != dt:
+        gy = gy.to(dt)
+    if gy.dim() != 2 or (gy.shape[0] > 1 and gy.stride(1) != 1):
+        gy = gy.contiguous()
+    return gy
+
+
+def _linear_backward(st, x, gy, need_x: bool, need_params, pre=None) -> tuple:
+    """-> (gx, None, *grads_w, *grads_b) of one projection; ``st`` holds what :func:`_linear_save` left, ``need_params`` =
+    needs_input_grad of its weights then biases; ``pre`` = (gx | None, gw, gb) already computed by a paired launch."""
+    dt = x.dtype
+    n_w = len(st.rows)
+    gy = _grad_rows(gy, dt)
+    w = st.w
+    m, k = w.shape
+    gx = None
+    want_w = any(need_params[:n_w])
+    want_b = any(h and g for h, g in zip(st.has_bias, need_params[n_w:]))
+    gw = gb = None
+    if pre is not None:
+        gx, gw, gb = pre
+    if need_x and gx is None:
+        if st.wt_of.key != st.w_key:
+            raise RuntimeError("the projection weights changed between this forward and its backward "
+                               "(optimizer step in between?): run backward before stepping")
+        wt = st.wt_of.wt                                                   # [K, M]: dX = dY @ W
+        if (FUSED_WGRAD_DX and (want_w or want_b) and x.shape[0] > 0 and linear_wgrad_dx_supported(m, k, dt)):
+            gx, gw, gb = linear_wgrad_dx_launch(gy, x, wt, want_bias=want_b)    # dY read ONCE for dX, dW and db
+        elif linear_supported(m, k, dt):
+            gx = linear_fwd_launch(gy, wt, None)
         else:
-            if want_w:
-                gw = _weight_grad_gemm(gy, x)
-            if want_b:
-                gb = colsum(gy)
-        grads_w, grads_b, r0 = [], [], 0
-        for i, r in enumerate(ctx.rows):
-            grads_w.append(gw[r0:r0 + r] if (gw is not None and ctx.needs_input_grad[2 + i]) else None)
-            grads_b.append(gb[r0:r0 + r] if (gb is not None and ctx.has_bias[i] and ctx.needs_input_grad[2 + n_w + i])
-                           else None)
-            r0 += r
-        return (gx, None) + tuple(grads_w) + tuple(grads_b)
+            gx = gy @ w
+    if gw is not None:
+        pass
+    elif (want_w or want_b) and x.shape[0] > 0 and linear_wgrad_supported(m, k, dt):
+        gw, gb = linear_wgrad_launch(gy, x, want_bias=want_b)       # dY and X read once for both
+    else:
+        if want_w:
+            gw = _weight_grad_gemm(gy, x)
+        if want_b:
+            gb = colsum(gy)
+    grads_w, grads_b, r0 = [], [], 0
+    for i, r in enumerate(st.rows):
+        grads_w.append(gw[r0:r0 + r] if (gw is not None and need_params[i]) else None)
+        grads_b.append(gb[r0:r0 + r] if (gb is not None and st.has_bias[i] and need_params[n_w + i]) else None)
+        r0 += r
+    return (gx, None) + tuple(grads_w) + tuple(grads_b)
+
+
+class _State:
+    pass
+
+
+class _LinearPair(torch.autograd.Function):
+    """Two projections with the same K as one launch (``segger_linear_fwd_pair``): (xa, xb, n_wa, n_wb, *weights_a,
+    *biases_a, *weights_b, *biases_b) -> (ya, yb).  Backward: each side's own :func:`_linear_backward`."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, n_wa, n_wb, *params):
+        pa, pb = params[:2 * n_wa], params[2 * n_wa:]
+        lib = _lib.load()
+        sides, args, outs = [], [], []
+        for x, n_w, pp in ((xa, n_wa, pa), (xb, n_wb, pb)):
+            weights, biases = pp[:n_w], pp[n_w:]
+            pk = _pack_for(weights, biases).get(x.dtype, x.device)
+            st = _State()
+            _linear_save(st, pk, weights, biases)
+            sides.append(st)
+            n, k = x.shape
+            m = int(pk.w.shape[0])
+            y = torch.empty((n, m), dtype=x.dtype, device=x.device)
+            a = _lib.LinearArgs()
+            a.x, a.ldx = _rows(x, k, "x")
+            a.w, a.bias = pk.w.data_ptr(), _lib.ptr(_f32_vec(pk.b, m, "bias"))
+            a.y, a.ldy = _rows(y, m, "y")
+            a.n_rows, a.m_out = n, m
+            args.append(a)
+            outs.append(y)
+        with _lib.on_device(xa.device):
+            rc = lib.segger_linear_fwd_pair(C.byref(args[0]), C.byref(args[1]), int(xa.shape[1]), DTYPE_CODE[xa.dtype],
+                                            _lib.stream_ptr(xa.device))
+        _lib.check(rc, "segger_linear_fwd_pair")
+        ctx.save_for_backward(xa, xb)
+        ctx.sides, ctx.n_w = sides, (n_wa, n_wb)
+        return outs[0], outs[1]
+
+    @staticmethod
+    def backward(ctx, gya, gyb):
+        xa, xb = ctx.saved_tensors
+        n_wa, n_wb = ctx.n_w
+        need = ctx.needs_input_grad
+        na, nb = need[4:4 + 2 * n_wa], need[4 + 2 * n_wa:]
+        pre = (None, None)
+        sts = ctx.sides
+        dt = xa.dtype
+        wants = [any(nn[:len(st.rows)]) or any(h and g for h, g in zip(st.has_bias, nn[len(st.rows):]))
+                 for st, nn in zip(sts, (na, nb))]
+        if (WGRAD_PAIR and all(wants) and gya is not None and gyb is not None and dt in (torch.bfloat16, torch.float16)
+                and xa.shape[0] > 0 and xb.shape[0] > 0):
+            # both sides' backward passes in one launch: with the data gradients when both want them and the one-pass
+            # kernel covers both shapes, else the weight / bias gradients only
+            k = int(xa.shape[1])
+            ms = [int(st.w.shape[0]) for st in sts]
+            dx = (FUSED_WGRAD_DX and need[0] and need[1] and all(linear_wgrad_dx_supported(m, k, dt) for m in ms))
+            if dx or all(linear_wgrad_supported(m, k, dt) for m in ms):
+                for st in sts:
+                    if dx and st.wt_of.key != st.w_key:
+                        raise RuntimeError("the projection weights changed between this forward and its backward "
+                                           "(optimizer step in between?): run backward before stepping")
+                gya, gyb = _grad_rows(gya, dt), _grad_rows(gyb, dt)
+                bias = [any(h and g for h, g in zip(st.has_bias, nn[len(st.rows):])) for st, nn in zip(sts, (na, nb))]
+                pre = linear_wgrad_pair_launch([(gya, xa, sts[0].wt_of.wt if dx else None, bias[0]),
+                                                (gyb, xb, sts[1].wt_of.wt if dx else None, bias[1])], dx)
+        ra = _linear_backward(sts[0], xa, gya, need[0], na, pre[0])
+        rb = _linear_backward(sts[1], xb, gyb, need[1], nb, pre[1])
+        return (ra[0], rb[0], None, None) + ra[2:] + rb[2:]
+
+
+LINEAR_PAIR = True           # tools flip it: False = one launch per projection
+WGRAD_PAIR = True            # ... and per projection backward
+
+
+def linear_pair(xa: Tensor, wa, ba, xb: Tensor, wb, bb) -> Tuple[Tensor, Tensor]:
+    """``(linear(xa, wa, ba), linear(xb, wb, bb))`` -- as ONE launch when both are 2-D activations of the same dtype and
+    width on the MFMA kernels (a hetero layer's transcript and boundary projections, ``lin_last`` of both node types)."""
+    tup = lambda v: tuple(v) if isinstance(v, (list, tuple)) else (v,)
+    wa, ba, wb, bb = tup(wa), tup(ba), tup(wb), tup(bb)
+    ma, mb = sum(int(w.shape[0]) for w in wa), sum(int(w.shape[0]) for w in wb)
+    ok = (LINEAR_PAIR and xa.dim() == 2 and xb.dim() == 2 and xa.is_cuda and xb.is_cuda and xa.dtype == xb.dtype
+          and xa.dtype in (torch.bfloat16, torch.float16)
+          and xa.shape[1] == xb.shape[1] and xa.shape[0] > 0 and xb.shape[0] > 0
+          and len(ba) == len(wa) and len(bb) == len(wb)
+          and linear_supported(xa.shape[1], ma, xa.dtype) and linear_supported(xb.shape[1], mb, xb.dtype))
+    if not ok:
+        return linear(xa, wa, ba), linear(xb, wb, bb)
+    if xa.shape[0] > 1 and xa.stride(1) != 1:
+        xa = xa.contiguous()
+    if xb.shape[0] > 1 and xb.stride(1) != 1:
+        xb = xb.contiguous()
+    return _LinearPair.apply(xa, xb, len(wa), len(wb), *wa, *ba, *wb, *bb)
 
 
 def linear(x: Tensor, weight, bias) -> Tensor:

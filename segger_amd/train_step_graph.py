@@ -63,6 +63,9 @@ def step_bucket(batch, granularity: float = 1.06, floor: int = 256) -> Dict[str,
 
 
 USE_ADAM_KERNEL = True       # (False: torch's fused Adam inside the captured step -- A/B switch)
+MERGED_DRAWS = True          # (False: dropout planes, both samplers and the negatives as launches of their own, the dropout
+                             #  counter advanced at the head of the step, Adam's step counters by a launch of their own)
+STEP_INC = 256               # what a training forward advances the encoder's dropout counter by (ist_encoder.py)
 
 
 class GraphedTrainStep:
@@ -134,6 +137,8 @@ class GraphedTrainStep:
         self._grads: list = []
         self._training: Optional[bool] = None
         self._iota = torch.arange(nt, device=dev)
+        self._late = (0, False)                               # (dropout-counter advance owed to the step's end, Adam's counters advanced)
+        self._warming = False
         # The captured forward runs on ALIASES of the parameters (same storage, distinct autograd leaves).  A leaf's
         # gradient sink (its AccumulateGrad node) belongs to the stream it was created on and lives as long as any
         # autograd graph mentions it: after an eager step whose loss the caller still holds, the parameters' own
@@ -244,26 +249,61 @@ class GraphedTrainStep:
         self._opt_step()
 
     def _opt_step(self) -> None:
-        """Adam on the hand-written kernel (two launches for all tensors; torch's fused multi-tensor Adam takes three and
-        ~40 us for the encoder's 60 small tensors); any other optimizer steps itself."""
-        if not (USE_ADAM_KERNEL and ops.adam_step(self.opt)):
-            self.opt.step()
+        """Adam on the hand-written kernel (two launches for all tensors -- one when the step's first launch advanced the
+        step counters; torch's fused multi-tensor Adam takes three and ~40 us for the encoder's 60 small tensors); any other
+        optimizer steps itself.  The dropout counter a merged-draws step read un-advanced moves on here."""
+        inc, adv = self._late
+        self._late = (0, False)
+        enc = self.lit.model
+        if USE_ADAM_KERNEL and ops.adam_step(self.opt, steps_advanced=adv, counter=enc._step_dev if inc else None,
+                                             counter_inc=inc):
+            return
+        if adv:
+            raise RuntimeError("the step advanced Adam's counters for segger_adam_step, which then refused the optimizer")
+        self.opt.step()
+        if inc:
+            ops.step_advance(enc._step_dev, inc)
 
     def _run_grads(self) -> None:
         lit, enc, s = self.lit, self.lit.model, self.sizes
         nt = s["tx"]
         tx, bd = self.nodes["tx"], self.nodes["bd"]
+        graphs = {TX_TX: self.g_tt, TX_BD: self.g_tb, "tx_by_gene": self.by_gene,
+                  "pos_all": (self.pos_all, self.batch_all), "minmax": self.minmax}
+        fixed = self.draws
+        drawn = None
+        self._late = (0, False)
+        if MERGED_DRAWS and fixed is None:
+            # ALL of the step's random draws in its first launch (ops.step_draws), from the dropout counter as it stands + the
+            # advance it receives at the END of the step (inside Adam's launch): the same masks and triplets as advancing
+            # first.  Adam's step counters move in the same launch (nothing reads them before the update).
+            inc = STEP_INC if enc.training else 0
+            views = enc.plane_views(graphs, seed_offset=inc) if enc.training else None
+            p_drop = enc.conv_layers[0].conv[TX_TX].dropout
+            adv = None
+            # (not while warming up -- that step ends in optimizer.step() -- and not in split mode, whose empty steps replay
+            # Adam's graph without this one)
+            if USE_ADAM_KERNEL and not self._warming and not self.split:
+                adv = ops.adam_step_counters(self.opt, self._params)
+            planes, samples, dst_neg = ops.step_draws(
+                [(c, sd) for _, _, c, sd in views] if views else [], enc.n_heads, p_drop,
+                [(self.ix_tx, 0x7478 + inc), (self.ix_bd, 0x6264 + inc)], (self.sg_pos, 0, self.n_bd, 0x7367 + inc),
+                enc._step_dev, advance=adv)
+            graphs["draws"] = (enc.planes_of(views, planes) if views else None, inc)
+            drawn = (samples, dst_neg)
+            self._late = (inc, adv is not None)
         z = torch.func.functional_call(
             enc, self._alias,
             ({"tx": tx["x"], "bd": bd["x"]}, {TX_TX: None, TX_BD: None}, {"tx": tx["pos"], "bd": bd["pos"]},
              {"tx": tx["batch"], "bd": bd["batch"]}),
-            dict(num_graphs=s["graphs"], graphs={TX_TX: self.g_tt, TX_BD: self.g_tb, "tx_by_gene": self.by_gene,
-                                                 "pos_all": (self.pos_all, self.batch_all), "minmax": self.minmax}))
+            dict(num_graphs=s["graphs"], graphs=graphs))
         step = enc._step_dev                                  # advanced by the forward: a fresh stream per replay
-        fixed = self.draws
         # the three losses on the staged sampler indices and their weighted sum as one autograd node (ops.loss_head):
         # means are taken over the padded rows by the kernels and rescaled to the masked real ones by `head_a`
-        if fixed is None:
+        if drawn is not None:
+            (pos, neg, _, _), (bpos, bneg, dp, dn) = drawn[0]
+            dst_neg = drawn[1]
+        elif fixed is None:
             pos, neg, _, _ = ops.triplet_sample(self.ix_tx, seed=0x7478, seed_dev=step)
             bpos, bneg, dp, dn = ops.triplet_sample(self.ix_bd, seed=0x6264, seed_dev=step)
             # segmentation loss over the real tx-belongs-bd edges (lightning_model.py:167-189): negatives in [0, n_bd_real)
@@ -359,7 +399,11 @@ class GraphedTrainStep:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                     # warm-up: lazy inits, allocator, optimizer state
-                self._warm_up(keep)
+                self._warming = True
+                try:
+                    self._warm_up(keep)
+                finally:
+                    self._warming = False
             torch.cuda.current_stream().wait_stream(side)
             self._restore(keep)                               # ... which must not count as a training step
             self.tx_state.zero_()                             # (the warm-up's forward left its chains: staged state again)

@@ -604,3 +604,48 @@ def test_fused_positional_embedder_matches_unfused_route(cuda, dtype, n):
         assert (a.double() - r64).abs().max().item() <= 1e-2 * scale
     with torch.no_grad():                                    # inference: same values, nothing stored
         assert torch.equal(emb(pos, batch, num_graphs=3, dtype=dtype), pe)
+
+
+def test_step_draws_equal_the_separate_launches(cuda):
+    """segger_step_draws (all random draws of a training step in one launch: bit planes of the edge views, both triplet
+    samplers, the negative boundaries, + the increment of Adam's step counters) against dropout_bits_many, triplet_sample x 2
+    and sample_negatives with the same seeds and the same device seed word: bit-identical."""
+    from segger_amd import ops
+    from segger_amd.graph import csr_from_coo
+    from segger_amd.triplet_loss import FastTripletSelector
+    g = torch.Generator().manual_seed(5)
+    n, nb, e = 5003, 211, 40_007
+    src, dst = torch.randint(0, n, (e,), generator=g), torch.randint(0, n, (e,), generator=g)
+    by_dst = csr_from_coo(dst.to(cuda), src.to(cuda), n, n, validate=False)
+    by_src = csr_from_coo(src.to(cuda), dst.to(cuda), n, n, validate=False)
+    e2 = 1234
+    tb = csr_from_coo(torch.randint(0, nb, (e2,), generator=g).to(cuda), torch.randint(0, n, (e2,), generator=g).to(cuda), nb, n,
+                      validate=False)
+    views = [(by_dst, [0, 2, 4, 6, 8]), (by_src, [0, 2, 4, 6, 8]), (tb, [1, 3, 5, 7, 9])]
+    k = 7
+    sim = torch.rand(k, k, generator=g); sim = (sim + sim.T) / 2
+    sel = FastTripletSelector(sim.to(cuda))
+    lab_tx = torch.randint(0, k, (n,), generator=g).to(cuda)
+    lab_bd = torch.randint(0, k, (nb,), generator=g).to(cuda)
+    ix_tx = sel.build_index(lab_tx, mask=(torch.rand(n, generator=g) > 0.1).to(cuda))
+    ix_bd = sel.build_index(lab_bd, mask=None)
+    sg_pos = torch.randint(0, nb, (e2,), generator=g).to(cuda); sg_pos[-10:] = -1
+    n_bd_dev = torch.tensor([nb], device=cuda)
+    word = torch.tensor([256 * 17], dtype=torch.int64, device=cuda)
+    counters = [torch.full((), float(i), device=cuda) for i in range(5)]
+    planes, samples, negs = ops.step_draws(views, 2, 0.2, [(ix_tx, 0x7478), (ix_bd, 0x6264)], (sg_pos, 0, n_bd_dev, 0x7367), word,
+                                           advance=counters)
+    ref_planes = ops.dropout_bits_many(views, 2, 0.2, word)
+    for a, b in zip(planes, ref_planes):
+        assert torch.equal(a, b)
+    for (ix, seed), got in zip(((ix_tx, 0x7478), (ix_bd, 0x6264)), samples):
+        ref = ops.triplet_sample(ix, seed=seed, seed_dev=word)
+        for a, b in zip(got, ref):
+            assert torch.equal(a, b)
+    assert torch.equal(negs, ops.sample_negatives(sg_pos, 0, n_bd_dev, seed=0x7367, seed_dev=word))
+    assert [float(c) for c in counters] == [1.0, 2.0, 3.0, 4.0, 5.0]
+    # nothing but samplers / nothing but planes
+    _, s2, n2 = ops.step_draws([], 2, 0.0, [(ix_bd, 3)], None, word)
+    assert n2 is None and torch.equal(s2[0][0], ops.triplet_sample(ix_bd, seed=3, seed_dev=word)[0])
+    p3, s3, _ = ops.step_draws(views[:1], 2, 0.5, [], None, word)
+    assert s3 == [] and torch.equal(p3[0], ops.dropout_bits_many(views[:1], 2, 0.5, word)[0])

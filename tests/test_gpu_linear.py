@@ -392,3 +392,33 @@ def test_colsum_empty_and_errors(cuda):
     assert rc != 0 and b"workspace" in lib.segger_last_error()
     rc = lib.segger_colsum(x.data_ptr(), 64, 10, 60, 0, out.data_ptr(), None, 0, _lib.stream_ptr(cuda))
     assert rc != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+@pytest.mark.parametrize("k,ma,mb,na,nb", [(128, 384, 128, 3000, 45), (256, 384, 128, 1001, 130), (128, 64, 64, 257, 7),
+                                            (128, 384, 128, 400_000, 500)])
+def test_linear_pair_equals_two_launches(cuda, dtype, k, ma, mb, na, nb):
+    """segger_linear_fwd_pair (a hetero layer's transcript and boundary projections, lin_last of both node types, as one
+    launch) against two ops.linear calls: outputs bit-identical, all gradients equal (the same backward kernels run).
+    The last case sends the large side to its persistent resident-W launch."""
+    from segger_amd import ops
+    g = torch.Generator().manual_seed(k + ma + na)
+    xa0 = torch.randn(na, k, generator=g).to(dtype)
+    xb0 = torch.randn(nb, k, generator=g).to(dtype)
+    ws = [torch.randn(m, k, generator=g) * 0.05 for m in ([ma // 3] * 3 if ma == 384 else [ma]) + [mb]]
+    bs = [torch.randn(w.shape[0], generator=g) for w in ws]
+    out = {}
+    for pair in (True, False):
+        xa, xb = xa0.to(cuda).requires_grad_(True), xb0.to(cuda).requires_grad_(True)
+        w = [t.to(cuda).requires_grad_(True) for t in ws]
+        b = [t.to(cuda).requires_grad_(True) for t in bs]
+        if pair:
+            ya, yb = ops.linear_pair(xa, w[:-1], b[:-1], xb, w[-1], b[-1])
+        else:
+            ya, yb = ops.linear(xa, w[:-1], b[:-1]), ops.linear(xb, w[-1], b[-1])
+        assert ya.shape == (na, ma) and yb.shape == (nb, mb)
+        (ya.float().square().sum() + yb.float().sum()).backward()
+        out[pair] = [ya.detach(), yb.detach(), xa.grad, xb.grad] + [t.grad for t in w] + [t.grad for t in b]
+    for p_, s_ in zip(out[True], out[False]):
+        assert torch.equal(p_, s_)

@@ -392,3 +392,34 @@ def test_optim_adam_is_a_drop_in_torch_adam(cuda):
     opt2 = Adam([w], lr=1e-2, fused=True, capturable=True)
     opt2.load_state_dict(copy.deepcopy(ref.state_dict()))
     assert float(opt2.state[w]["step"]) == 6.0 and torch.equal(opt2.state[w]["exp_avg"], ref.state[w2]["exp_avg"])
+
+
+def test_merged_draws_step_equals_separate_draws_step(cuda, monkeypatch):
+    """A captured step that makes all its draws in its first launch (ops.step_draws, Adam's counters advanced there, the
+    dropout counter inside Adam's launch at the END of the step) against one that advances first and draws in four launches:
+    same masks, same triplets -- the same loss trajectory up to the order of the loss kernels' float atomics -- and the same
+    counters afterwards."""
+    from segger_amd import tiles as T
+    from segger_amd import train_step_graph as tsg
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=20000, n_bd=600, k_tx=6, seed=41)
+    runs = {}
+    for merged in (True, False):
+        monkeypatch.setattr(tsg, "MERGED_DRAWS", merged)
+        m, bg = _model(spec, cuda, torch.float32)
+        for nt in ("tx", "bd"):
+            del bg[nt]["mask"]
+        tiling = T.SquareTiling(torch.cat([bg["tx"].pos, bg["bd"].pos]).cpu(), 80.0)
+        part = T.partition_by_tiling(bg, tiling, margin=3.0)
+        part.build_csr()
+        batches = [[t] for t in range(len(part)) if part.node_sizes["bd"][t] > 1][:3]
+        opt = m.configure_optimizers(capturable=True)
+        trainer = tsg.GraphedTrainer(m, opt, granularity=1.5)
+        losses = [trainer.step(part.batch(ids)).clone() for _ in range(3) for ids in batches]
+        st = opt.state[next(iter(m.model.conv_layers[1].parameters()))]
+        runs[merged] = (torch.stack(losses), int(m.model._step_dev), float(st["step"]),
+                        torch.cat([p.detach().reshape(-1) for p in m.parameters()]))
+    a, b = runs[True], runs[False]
+    assert a[1] == b[1] == 256 * 9 and a[2] == b[2] == 9.0
+    assert torch.allclose(a[0], b[0], rtol=2e-3, atol=1e-5), (a[0] - b[0]).abs().max()
+    assert (a[3] - b[3]).abs().max().item() <= 2e-3 * b[3].abs().max().item()
