@@ -39,6 +39,20 @@ namespace {
       hipLaunchKernelGGL((gatv2_bwd_dst_kernel<INST_T, H, LPH, WPR, false>), dim3((unsigned)p.nblocks_padded),     \
                          dim3(256), 0, stream, p);                                                                 \
   } while (0)
+#elif SEGGER_INST_PASS == 0 && (defined(EXP_PERSIST) || defined(EXP_EXTRA_STORES))
+// bounding builds of the forward (tools/build_variant.sh): a persistent grid and / or a scratch matrix for the extra stores
+#ifdef EXP_PERSIST
+#define EXP_GRID (p.nblocks_padded < EXP_PERSIST * 256 ? p.nblocks_padded : (int64_t)EXP_PERSIST * 256)
+#else
+#define EXP_GRID p.nblocks_padded
+#endif
+#define INST_LAUNCH(H, LPH, WPR)                                                                                   \
+  do {                                                                                                             \
+    static void* scratch = nullptr; static int64_t scratch_rows = 0;                                               \
+    if (scratch_rows < p.n_rows) { (void)hipMalloc(&scratch, (size_t)p.n_rows * 3 * H * LPH * 8 * 4); scratch_rows = p.n_rows; } \
+    p.gxl = scratch; p.ld_gxl = 3 * H * LPH * 8;                                                                   \
+    hipLaunchKernelGGL((INST_KERNEL<INST_T, H, LPH, WPR>), dim3((unsigned)(EXP_GRID)), dim3(256), 0, stream, p);  \
+  } while (0)
 #else
 #define INST_LAUNCH(H, LPH, WPR) \
   hipLaunchKernelGGL((INST_KERNEL<INST_T, H, LPH, WPR>), dim3((unsigned)p.nblocks_padded), dim3(256), 0, stream, p)

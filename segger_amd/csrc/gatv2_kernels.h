@@ -530,6 +530,12 @@ __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid)
     }
     store_pairs(static_cast<T*>(p.out) + row * p.ld_out + ch0, o);
     if (p.lse && head_leader) p.lse[row * H + h] = lse;
+#ifdef EXP_EXTRA_STORES      // bounding build: the bytes a fused next-layer projection would write from here
+    if (p.gxl) {
+      T* q = static_cast<T*>(p.gxl) + row * p.ld_gxl + ch0;
+      store_pairs(q, o); store_pairs(q + H * LPH * 8, o); store_pairs(q + 2 * H * LPH * 8, o);
+    }
+#endif
   }
 
   if (want_alpha && row_ok && head_leader) {
@@ -548,7 +554,12 @@ __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid)
 
 template <typename T, int H, int LPH, bool WPR>
 __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatParams p) {
+#ifdef EXP_PERSIST           // bounding build: EXP_PERSIST workgroups per CU walk their XCD's row blocks in a loop
+  const int64_t per = p.nblocks_padded / kNumXcd, k = gridDim.x / kNumXcd;
+  for (int64_t i = blockIdx.x / kNumXcd; i < per; i += k) gatv2_fwd_body<T, H, LPH, WPR>(p, i * kNumXcd + blockIdx.x % kNumXcd);
+#else
   gatv2_fwd_body<T, H, LPH, WPR>(p, blockIdx.x);
+#endif
 }
 
 // Two edge types of one hetero layer in ONE launch: the blocks of `b` (wave-per-row: tx-belongs-bd, a few thousand short
