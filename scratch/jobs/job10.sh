@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+python tools/host_phases.py 2>&1 | grep -v Warn | tee gpurun_out/host_phases2.txt
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3

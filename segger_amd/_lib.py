@@ -324,7 +324,15 @@ def on_device(device):
     return torch.cuda.device(device)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr(device) -> int:
+    """hipStream_t of torch's current stream on ``device`` (the raw-handle query: 0.3 us instead of 2.5 us for the Stream
+    object -- an eager 1M-edge step makes ~110 launches and is host-bound)."""
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream
 
 

@@ -44,10 +44,17 @@ class EdgeCSR:
         return int(self.col.shape[0])
 
     def c_struct(self) -> _lib.Csr:
-        return _lib.Csr(self.indptr.data_ptr(),
-                        self.col.data_ptr() if self.n_edges else None,
-                        self.eid.data_ptr() if self.n_edges else None,
-                        self.n_rows, self.n_cols, self.n_edges, _lib.ptr(self.order))
+        # built once per view and kept while the arrays stay the same objects (4 layers x 3 passes ask for it every step)
+        key = (id(self.indptr), id(self.col), id(self.eid), id(self.order), self.n_rows, self.n_cols)
+        hit = self.__dict__.get("_c_struct")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        c = _lib.Csr(self.indptr.data_ptr(),
+                     self.col.data_ptr() if self.n_edges else None,
+                     self.eid.data_ptr() if self.n_edges else None,
+                     self.n_rows, self.n_cols, self.n_edges, _lib.ptr(self.order))
+        self.__dict__["_c_struct"] = (key, c)
+        return c
 
     def balanced_order(self, window: int = ROW_ORDER_WINDOW) -> "EdgeCSR":
         """Attach the visiting order of ``segger_csr_row_order`` (rows of near-equal degree share a wave; computed

@@ -424,12 +424,20 @@ class ISTEncoder(Module):
                 ids = x_dict["tx"]
                 by_gene = graphs.get("tx_by_gene") if graphs is not None else None
                 if by_gene is None and torch.is_grad_enabled() and emb.weight.requires_grad:
-                    key = ("by_gene", ids.data_ptr(), int(ids.shape[0]))
-                    by_gene = cache.get(key) if cache is not None else None
-                    if by_gene is None:
-                        by_gene = ops.rows_by_id(ids, emb.weight.shape[0])
-                        if cache is not None:
-                            cache[key] = by_gene
+                    # batches of a resident partition keep what depends on the tile set only across epochs
+                    # (tiles.TilePartition: cache["persistent"], shared with the captured step's staging)
+                    store = cache.get("persistent") if cache is not None else None
+                    if store is not None:
+                        by_gene = store.get("tx_by_gene")
+                        if by_gene is None or by_gene.n_rows != emb.weight.shape[0] or by_gene.n_edges != ids.shape[0]:
+                            by_gene = store["tx_by_gene"] = ops.rows_by_id(ids, emb.weight.shape[0])
+                    else:
+                        key = ("by_gene", ids.data_ptr(), int(ids.shape[0]))
+                        by_gene = cache.get(key) if cache is not None else None
+                        if by_gene is None:
+                            by_gene = ops.rows_by_id(ids, emb.weight.shape[0])
+                            if cache is not None:
+                                cache[key] = by_gene
                 if split:
                     # keep gelu(cat(E[g], pe)) as its parts: the first layer projects it as T[g] + W_pe gelu(pe)
                     x_tx = ops.EmbedInput(emb.weight, ids.to(torch.int32).contiguous(), pe_tx, by_gene, pre_tx)

@@ -22,12 +22,33 @@ from .graph import EdgeCSR, EdgeGraph
 # --------------------------------------------------------------------------
 def _rows(t: Tensor, width: int, name: str) -> Tuple[int, int]:
     """(data_ptr, row stride in elements) of a [n, width] tensor whose last dim is dense."""
-    if t.dim() != 2 or t.shape[1] != width:
-        raise ValueError(f"{name}: expected [n, {width}], got {tuple(t.shape)}")
-    if t.shape[0] > 1 and t.stride(1) != 1:
-        raise ValueError(f"{name}: last dimension must be contiguous")
-    ld = t.stride(0) if t.shape[0] > 1 else max(width, t.stride(0))
-    return t.data_ptr(), int(ld)
+    sh = t.shape
+    if len(sh) != 2 or sh[1] != width:
+        raise ValueError(f"{name}: expected [n, {width}], got {tuple(sh)}")
+    st = t.stride()
+    if sh[0] > 1:
+        if st[1] != 1:
+            raise ValueError(f"{name}: last dimension must be contiguous")
+        return t.data_ptr(), st[0]
+    return t.data_ptr(), max(width, st[0])
+
+
+import functools
+
+
+@functools.lru_cache(maxsize=None)
+def _has_specialised(heads: int, channels: int) -> bool:
+    return bool(_lib.load().segger_gatv2_has_specialised(heads, channels))
+
+
+@functools.lru_cache(maxsize=4096)
+def _gat_bwd_ws_bytes(n_dst: int, heads: int, channels: int) -> int:
+    return int(_lib.load().segger_gatv2_bwd_workspace_bytes(n_dst, heads, channels))
+
+
+@functools.lru_cache(maxsize=4096)
+def _wgrad_ws_bytes(n: int, m: int, k: int) -> int:
+    return int(_lib.load().segger_linear_wgrad_workspace_bytes(n, m, k))
 
 
 def _seed_parts(seed):
@@ -209,6 +230,8 @@ def _defer_keep(*tensors) -> None:
 def _f32_vec(t: Optional[Tensor], n: int, name: str) -> Optional[Tensor]:
     if t is None:
         return None
+    if t.dtype == torch.float32 and t.numel() == n and t.is_contiguous():
+        return t                                         # (only its data_ptr is used: the common case costs no torch call)
     t = t.detach().reshape(-1)
     if t.numel() != n:
         raise ValueError(f"{name}: expected {n} elements, got {t.numel()}")
@@ -330,12 +353,12 @@ def _gat_bwd_args(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optio
     a = _lib.GatBwdArgs()
     a.by_dst = g.by_dst.c_struct()
     gatv2_bwd_launch.zero_filled = False
-    if g.by_src is None and g.src_unique() and lib.segger_gatv2_has_specialised(heads, channels):
+    if g.by_src is None and g.src_unique() and _has_specialised(heads, channels):
         a.src_unique = 1          # every source has at most one out-edge: the destination pass stores grad_xl itself
         a.grad_xl_zeroed = int(bool(grad_xl_zeroed))
     else:
         a.by_src = g.require_by_src().c_struct()
-        if zero_rows_out is not None and lib.segger_gatv2_has_specialised(heads, channels) and g.n_src > 0:
+        if zero_rows_out is not None and _has_specialised(heads, channels) and g.n_src > 0:
             a.zero_rows_out, a.ld_zero = _rows(zero_rows_out, hc, "zero_rows_out")
             gatv2_bwd_launch.zero_filled = True
     a.x_l, a.ld_xl = _rows(xl, hc, "x_l")
@@ -365,7 +388,7 @@ def _gat_bwd_args(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optio
     a.grad_xr, a.ld_gxr = _rows(grad_xr, hc, "grad_xr")
     gparams = torch.empty((2, hc), dtype=torch.float32, device=dev)
     a.grad_att, a.grad_bias = gparams[0].data_ptr(), gparams[1].data_ptr()
-    ws_bytes = lib.segger_gatv2_bwd_workspace_bytes(n_dst, heads, channels)
+    ws_bytes = _gat_bwd_ws_bytes(n_dst, heads, channels)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
     _defer_keep(ws, gparams)
@@ -1214,7 +1237,9 @@ def adam_step(opt, steps_advanced: bool = False, counter: Optional[Tensor] = Non
     interchangeable).  -> False, nothing done, when the optimizer is anything else (amsgrad, weight decay, maximize, a
     tensor learning rate, non-fp32 or non-contiguous parameters, state not created yet): the caller then runs
     ``optimizer.step()`` itself.  ``steps_advanced``: the step counters were advanced already (:func:`adam_step_counters`);
-    ``counter`` (int64[1] on the device): ``counter += counter_inc`` rides in the update launch."""
+    ``counter`` (int64[1] on the device): ``counter += counter_inc`` rides in the update launch.
+    (Host cost ~135 us per call for 60 tensors, nearly all of it the per-tensor attribute reads; a cached launch table
+    that re-checked pointers and state identity per step measured the same -- tools/host_phases.py.)"""
     # torch's AMP contract for fused optimizers (``_step_supports_amp_scaling``): ``GradScaler.step`` skips its own unscale /
     # inf check and hands both to the optimizer as ``grad_scale`` / ``found_inf``.  The kernel reads neither: torch's fused
     # step does the scaled, skippable update.
@@ -1396,7 +1421,7 @@ def linear_wgrad_launch(gy: Tensor, x: Tensor, want_bias: bool = True) -> Tuple[
     xp, ldx = _rows(x, k, "x")
     gw = torch.empty((m, k), dtype=torch.float32, device=x.device)
     gb = torch.empty(m, dtype=torch.float32, device=x.device) if want_bias else None
-    ws_bytes = lib.segger_linear_wgrad_workspace_bytes(n, m, k)
+    ws_bytes = _wgrad_ws_bytes(n, m, k)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     with _lib.on_device(x.device):
         rc = lib.segger_linear_wgrad(gp, ldg, xp, ldx, n, m, k, DTYPE_CODE[x.dtype], gw.data_ptr(), _lib.ptr(gb),
@@ -1442,7 +1467,7 @@ def linear_wgrad_dx_launch(gy: Tensor, x: Tensor, wt: Tensor, want_bias: bool = 
     gx = torch.empty((n, k), dtype=x.dtype, device=x.device)
     gw = torch.empty((m, k), dtype=torch.float32, device=x.device)
     gb = torch.empty(m, dtype=torch.float32, device=x.device) if want_bias else None
-    ws_bytes = lib.segger_linear_wgrad_workspace_bytes(n, m, k)
+    ws_bytes = _wgrad_ws_bytes(n, m, k)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     with _lib.on_device(x.device):
         rc = lib.segger_linear_wgrad_dx(gp, ldg, xp, ldx, wt.data_ptr(), n, m, k, DTYPE_CODE[x.dtype], gw.data_ptr(),
@@ -1477,7 +1502,7 @@ def linear_wgrad_pair_launch(sides, dx: bool):
             a.w_t, a.dx, a.ld_dx = wt.data_ptr(), gx.data_ptr(), k
         gw = torch.empty((m, k), dtype=torch.float32, device=dev)
         gb = torch.empty(m, dtype=torch.float32, device=dev) if want_bias else None
-        ws_bytes = lib.segger_linear_wgrad_workspace_bytes(n, m, k)
+        ws_bytes = _wgrad_ws_bytes(n, m, k)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         a.grad_w, a.grad_b, a.workspace, a.workspace_bytes = gw.data_ptr(), _lib.ptr(gb), ws.data_ptr(), ws_bytes
         args.append(a)
