@@ -637,6 +637,17 @@ int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void* w, const f
                               int64_t ld_rb, const int32_t* rowidx, void* y, int64_t ldy, int64_t n_rows, int32_t k_in,
                               int32_t m_out, int32_t dtype, segger_stream_t stream);
 
+/* segger_linear_fwd_f32_split: the fp32-storage projection on the bf16 matrix pipe -- every fp32 operand as the sum of three
+ * bf16 numbers, the product as its six leading partial products, each exact in the MFMA's fp32 accumulator
+ * (csrc/linear_f32_split.hip).  An OPT-IN alternative to segger_linear_fwd's exact-fp32 kernel for the same nn.Linear call
+ * sites (ist_encoder.py:111-124,282-286 under a default fp32 Trainer, cli/segment.py:400-405): error ~2^-22 relative to
+ * sum |x||w| instead of fp32 rounding only, at 6/16 of the bf16 MFMA rate instead of the 157 TFLOP/s fp32 pipe.
+ *   x [n, k_in] fp32, y [n, m_out] fp32 (16-byte aligned rows); w3 = bf16 [3][m_out][k_in]: hi = bf16(w), mid = bf16(w - hi),
+ *   lo = bf16(w - hi - mid).  Covered: k_in 128 with m_out a multiple of 64; k_in 384 with m_out 128 (dX = dY W on W^T planes). */
+int segger_linear_fwd_f32_split_supported(int32_t k_in, int32_t m_out);
+int segger_linear_fwd_f32_split(const float* x, int64_t ldx, const void* w3, const float* bias, float* y, int64_t ldy,
+                                int64_t n_rows, int32_t k_in, int32_t m_out, segger_stream_t stream);
+
 /* segger_linear_fwd_pair: two such projections with the same k_in and dtype as ONE launch -- a hetero layer projects its
  * transcripts ([lin_l | lin_r | lin_l], ist_encoder.py:109-134 through HeteroConv) and its ~10^2-10^3 boundaries (lin_r)
  * in the same step, and lin_last maps both node types (ist_encoder.py:282-286,328); the small one's blocks ride in the

@@ -1368,6 +1368,39 @@ def linear_fwd_launch(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Optiona
     return y
 
 
+def f32_split_planes(w: Tensor) -> Tensor:
+    """bf16 [3, M, K]: hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid) of an fp32 matrix (the weight operand of
+    :func:`linear_f32_split_launch`)."""
+    w = w.detach().float()
+    hi = w.bfloat16()
+    r = w - hi.float()
+    mid = r.bfloat16()
+    lo = (r - mid.float()).bfloat16()
+    return torch.stack((hi, mid, lo)).contiguous()
+
+
+def linear_f32_split_supported(k_in: int, m_out: int) -> bool:
+    return bool(_lib.load().segger_linear_fwd_f32_split_supported(int(k_in), int(m_out)))
+
+
+def linear_f32_split_launch(x: Tensor, w3: Tensor, bias: Optional[Tensor]) -> Tensor:
+    """y = x @ w.T + bias for fp32 ``x`` [n, K] on the bf16 matrix pipe (``segger_linear_fwd_f32_split``: three-way bf16
+    split of both operands, six partial products, fp32 accumulation); ``w3`` = :func:`f32_split_planes` of w."""
+    _lib.require_cuda(x, w3)
+    n, k = x.shape
+    m = int(w3.shape[1])
+    if x.dtype != torch.float32 or w3.dtype != torch.bfloat16 or tuple(w3.shape) != (3, m, k) or not w3.is_contiguous():
+        raise ValueError("linear_f32_split: x fp32 [n, K], w3 contiguous bf16 [3, M, K]")
+    xp, ldx = _rows(x, k, "x")
+    y = torch.empty((n, m), dtype=torch.float32, device=x.device)
+    b = _f32_vec(bias, m, "bias")
+    with _lib.on_device(x.device):
+        rc = _lib.load().segger_linear_fwd_f32_split(xp, ldx, w3.data_ptr(), _lib.ptr(b), y.data_ptr(), m, n, k, m,
+                                                     _lib.stream_ptr(x.device))
+    _lib.check(rc, "segger_linear_fwd_f32_split")
+    return y
+
+
 def colsum(x: Tensor) -> Tensor:
     """fp32 column sums of a [n, cols] matrix (row stride allowed): the bias gradient ``grad_out.sum(0)``."""
     _lib.require_cuda(x)
@@ -1643,6 +1676,17 @@ class _Pack:
                 self.key, self._wt_fresh = key, False
         return self
 
+    def planes(self, transposed: bool = False) -> Tensor:
+        """fp32 packs: the bf16 [3, M, K] split of the stacked weight (or [3, K, M] of its transpose) for the opt-in
+        bf16x3 projections (F32_SPLIT), rebuilt when the pack was refreshed."""
+        slot = "_planes_t" if transposed else "_planes"
+        hit = self.__dict__.get(slot)
+        if hit is None or hit[0] != self.key:
+            with torch.no_grad():
+                hit = (self.key, f32_split_planes(self.w.t().contiguous() if transposed else self.w))
+            self.__dict__[slot] = hit
+        return hit[1]
+
     @property
     def wt(self) -> Tensor:                              # [K, M]: dX = dY @ W
         if self._wt is None:
@@ -1768,7 +1812,10 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, n_w, *params):
         weights, biases = params[:n_w], params[n_w:]
         pk = _pack_for(weights, biases).get(x.dtype, x.device)
-        y = linear_fwd_launch(x, pk.w, pk.b)
+        if F32_SPLIT and x.dtype == torch.float32 and linear_f32_split_supported(x.shape[1], pk.w.shape[0]):
+            y = linear_f32_split_launch(x, pk.planes(), pk.b)
+        else:
+            y = linear_fwd_launch(x, pk.w, pk.b)
         ctx.save_for_backward(x)
         ctx.n_w = n_w
         _linear_save(ctx, pk, weights, biases)
@@ -1818,6 +1865,8 @@ def _linear_backward(st, x, gy, need_x: bool, need_params, pre=None) -> tuple:
         wt = st.wt_of.wt                                                   # [K, M]: dX = dY @ W
         if (FUSED_WGRAD_DX and (want_w or want_b) and x.shape[0] > 0 and linear_wgrad_dx_supported(m, k, dt)):
             gx, gw, gb = linear_wgrad_dx_launch(gy, x, wt, want_bias=want_b)    # dY read ONCE for dX, dW and db
+        elif F32_SPLIT and dt == torch.float32 and linear_f32_split_supported(m, k):
+            gx = linear_f32_split_launch(gy, st.wt_of.planes(transposed=True), None)
         elif linear_supported(m, k, dt):
             gx = linear_fwd_launch(gy, wt, None)
         else:
@@ -1908,6 +1957,10 @@ class _LinearPair(torch.autograd.Function):
         return (ra[0], rb[0], None, None) + ra[2:] + rb[2:]
 
 
+# fp32 storage: forward projections and their data gradients as three-way bf16 splits on the bf16 matrix pipe
+# (segger_linear_fwd_f32_split: error within the exact-fp32 kernel's own, 0.77 vs 1.17 ms for 1M x 128 -> 384) instead of the
+# exact-fp32 MFMA.  Off by default: the exact kernels are the parity mode against the fp64 oracle.
+F32_SPLIT = False
 LINEAR_PAIR = True           # tools flip it: False = one launch per projection
 WGRAD_PAIR = True            # ... and per projection backward
 

@@ -422,3 +422,50 @@ def test_linear_pair_equals_two_launches(cuda, dtype, k, ma, mb, na, nb):
         out[pair] = [ya.detach(), yb.detach(), xa.grad, xb.grad] + [t.grad for t in w] + [t.grad for t in b]
     for p_, s_ in zip(out[True], out[False]):
         assert torch.equal(p_, s_)
+
+
+@pytest.mark.parametrize("k,m,n", [(128, 384, 4133), (128, 64, 1), (128, 128, 129), (384, 128, 3001)])
+def test_linear_fp32_split_within_the_exact_kernels_error(cuda, k, m, n):
+    """segger_linear_fwd_f32_split (fp32 operands as three bf16 parts, six partial products on the bf16 MFMA, fp32
+    accumulation) against fp64: its error, relative to sum |x||w| (what fp32 rounding scales with), stays within twice the
+    exact-fp32 MFMA kernel's own and within 4 * 2^-24 * sqrt(K) absolutely; partial last tile, bias, wide dynamic range."""
+    from segger_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(k + m + n)
+    x = torch.randn(n, k, device=cuda, generator=g) * torch.rand(n, 1, device=cuda, generator=g).mul(6).exp()
+    w = torch.randn(m, k, device=cuda, generator=g) / k ** 0.5
+    b = torch.randn(m, device=cuda, generator=g)
+    assert ops.linear_f32_split_supported(k, m)
+    w3 = ops.f32_split_planes(w)
+    assert torch.equal(w3.float().sum(0), w)                  # the three parts add up to the fp32 number exactly
+    y_split = ops.linear_f32_split_launch(x, w3, b)
+    y_exact = ops.linear_fwd_launch(x, w, b)
+    ref = x.double() @ w.double().t() + b.double()
+    bound = x.double().abs() @ w.double().abs().t() + b.double().abs()
+    e_split = ((y_split.double() - ref).abs() / bound).max().item()
+    e_exact = ((y_exact.double() - ref).abs() / bound).max().item()
+    assert e_split <= max(2 * e_exact, 2.0 ** -23), (e_split, e_exact)
+    assert e_split <= 4 * 2.0 ** -24 * k ** 0.5
+
+
+def test_linear_fp32_split_autograd_switch(cuda, monkeypatch):
+    """ops.F32_SPLIT routes the fp32 forward projection and its data gradient through the split kernel; outputs and all
+    gradients agree with the exact route to fp32 rounding."""
+    from segger_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(9)
+    n, k = 5000, 128
+    x0 = torch.randn(n, k, device=cuda, generator=g)
+    ws = [torch.randn(128, k, device=cuda, generator=g) / k ** 0.5 for _ in range(3)]
+    bs = [torch.randn(128, device=cuda, generator=g) for _ in range(3)]
+    gy = torch.randn(n, 384, device=cuda, generator=g)
+    out = {}
+    for split in (False, True):
+        monkeypatch.setattr(ops, "F32_SPLIT", split)
+        x = x0.clone().requires_grad_(True)
+        w = [t.clone().requires_grad_(True) for t in ws]
+        b = [t.clone().requires_grad_(True) for t in bs]
+        y = ops.linear(x, w, b)
+        y.backward(gy)
+        out[split] = [y.detach(), x.grad] + [t.grad for t in w] + [t.grad for t in b]
+    for a, r in zip(out[True], out[False]):
+        assert (a - r).abs().max().item() <= 2e-5 * r.abs().max().item()
+    assert not torch.equal(out[True][0], out[False][0])       # (it did take the other kernel)
