@@ -486,6 +486,9 @@ def main():
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
     args = ap.parse_args()
+    if os.environ.get("SEGGER_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack each N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SEGGER_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -572,7 +575,7 @@ def main():
     # ---- what the timed region leaves out: it replays ONE resident batch, whose sorted edge views, sampler indices,
     # rows-by-gene grouping and loss masks were built by the first warm-up step and are cached on the batch ------------
     untimed = None
-    if rank == 0:
+    if True:     # EVERY rank: the uncached step below contains the gradient all-reduce (rank 0 alone would deadlock the job)
         from segger_amd.graph import build_edge_graph
         n_tx_, n_bd_ = spec.n_tx, spec.n_bd
 
@@ -593,7 +596,10 @@ def main():
                            "one whole step on the same batch with its per-batch cache dropped (sorts, loss samplers' "
                            "indices, rows-by-gene grouping, masks rebuilt) = what a NEW tile costs once; first_step_ms: "
                            "the very first step of the process (lazy inits and allocator warm-up on top)"}
-        log(f"[bench] untimed per-batch setup: {untimed}")
+        if rank == 0:
+            log(f"[bench] untimed per-batch setup: {untimed}")
+        else:
+            untimed = None
 
     # ---- roofline of the dominant kernel: tx-neighbors-tx aggregation, forward -------------------
     roof, extra = None, {}
@@ -725,36 +731,40 @@ def main():
         t = time.perf_counter()
         sspec = SyntheticSpec(n_tx=args.strong_n_tx, n_bd=args.strong_n_bd, k_tx=args.k, seed=0)
         fov_data = None
-        if world == 1 and not args.no_c5:        # the c5 record's prediction tiles are cut from the un-partitioned FOV
-            part, batches, saux, tiling, fov_data = build_fov_batches(sspec, dev, edges_per_batch=args.strong_edges_per_batch,
-                                                                      keep_data=True)
+        torch.cuda.reset_peak_memory_stats()
+        if world > 1:
+            # rank-local generation: every rank derives the same seed-0 FOV, tiling, batch list and schedule (no data-path
+            # collective) but builds only the EDGES of the tiles of the packed batches dp.rank_schedule deals to it --
+            # "spatial tiles shard naturally" (north_star); nodes and a counting pass over all transcripts are replicated
+            from segger_amd.fov import build_fov_shard
+            part, batches, local_batches, _sched, saux, tiling, info = build_fov_shard(
+                sspec, dev, rank, world, edges_per_batch=args.strong_edges_per_batch)
+            weights_all, units_of = info["weights"], info["units"]
+            full_bytes = None
         else:
-            part, batches, saux, tiling = build_fov_batches(sspec, dev, edges_per_batch=args.strong_edges_per_batch)
+            if not args.no_c5:                   # the c5 record's prediction tiles are cut from the un-partitioned FOV
+                part, batches, saux, tiling, fov_data = build_fov_batches(sspec, dev, edges_per_batch=args.strong_edges_per_batch,
+                                                                          keep_data=True)
+            else:
+                part, batches, saux, tiling = build_fov_batches(sspec, dev, edges_per_batch=args.strong_edges_per_batch)
+            weights_all = batch_weights(part, batches)
+            e_tb, e_tt = part.edge_sizes[TX_BD].tolist(), part.edge_sizes[TX_TX].tolist()
+            units_of = {k: (sum(e_tb[t] for t in ids), sum(e_tt[t] for t in ids)) for k, ids in enumerate(batches)}
+            full_bytes = part.resident_bytes()
+            local_batches = dict(enumerate(batches))
         torch.cuda.synchronize()
         n_tiles_all = len(tiling)
+        build_peak = torch.cuda.max_memory_allocated() / 2 ** 30
         log(f"[bench r{rank}] fixed FOV: {args.strong_n_tx} tx -> {n_tiles_all} tiles, {len(batches)} batches "
-            f"in {time.perf_counter() - t:.1f}s")
-        weights_all = batch_weights(part, batches)
-        e_tb, e_tt = part.edge_sizes[TX_BD].tolist(), part.edge_sizes[TX_TX].tolist()
-        units_of = {k: (sum(e_tb[t] for t in ids), sum(e_tt[t] for t in ids)) for k, ids in enumerate(batches)}
-        full_bytes = part.resident_bytes()
-        if world > 1:
-            # shard residency: every rank generated the same seed-0 FOV (no data-path collective), but it keeps only the
-            # tiles of the packed batches dp.rank_schedule deals to it -- "spatial tiles shard naturally" (north_star)
-            from segger_amd.dp import rank_schedule
-            mine = [k for k in rank_schedule(weights_all, world)[rank] if k is not None]
-            tiles_mine = sorted({t for k in mine for t in batches[k]})
-            remap = {t: i for i, t in enumerate(tiles_mine)}
-            local = part.shard(tiles_mine)
-            local_batches = {k: [remap[t] for t in batches[k]] for k in mine}
-            del part
-            part = local
-            torch.cuda.empty_cache()
-        else:
-            local_batches = dict(enumerate(batches))
+            f"in {time.perf_counter() - t:.1f}s ({part.num_tiles} tiles resident, build peak {build_peak:.1f} GiB; "
+            f"{len(local_batches)} own batches, schedule fingerprint {hash(tuple(weights_all)) & 0xffffffff:08x})")
+        torch.cuda.empty_cache()
         torch.cuda.reset_peak_memory_stats()
         resident = {"tiles": part.num_tiles, "tiles_total": n_tiles_all, "bytes": part.resident_bytes(),
-                    "fraction_of_fov": part.resident_bytes() / max(full_bytes, 1)}
+                    "fraction_of_fov": (part.resident_bytes() / max(full_bytes, 1)) if full_bytes
+                    else part.num_tiles / max(n_tiles_all, 1),
+                    "generation": "rank-local (own tiles' edges only)" if world > 1 else "whole FOV",
+                    "build_peak_hbm_gib": build_peak}
         model.set_similarities(saux["tx_similarity"].to(dev), saux["bd_similarity"].to(dev))
         model.train(not args.no_dropout)
         seed_rank(0, rank, model.model)

@@ -201,6 +201,12 @@ def strong_scaling_epoch(batch_weights: Sequence[float], step, units=None, *, sy
     world = dist.get_world_size(group) if on else 1
     rank = dist.get_rank(group) if on else 0
     sched = rank_schedule(batch_weights, world)[rank]
+    if on:      # every rank must take the same number of steps: each one is a collective (a mismatch would deadlock, not fail)
+        n = torch.tensor([len(sched), -len(sched)], dtype=torch.int64, device=device)
+        dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
+        if int(n[0]) != len(sched) or int(-n[1]) != len(sched):
+            raise RuntimeError(f"strong_scaling_epoch: rank {rank} has {len(sched)} steps, others between {int(-n[1])} and "
+                               f"{int(n[0])}: the ranks do not agree on the batch list")
     sync = sync or (lambda: None)
     for k in (sched if warmup < 0 else sched[:warmup]):     # warmup < 0: one whole untimed epoch first
         step(k, 0)

@@ -71,13 +71,10 @@ def _morton_torch(xy: torch.Tensor, lo: float, hi: float) -> torch.Tensor:
     return spread(q[:, 0]) | (spread(q[:, 1]) << 1)
 
 
-def make_fov(spec: SyntheticSpec, device, return_aux: bool = False):
-    """The same generative model as :func:`make_graph`, built ON THE DEVICE for full-FOV sizes (BASELINE
-    configs 3 / 5: 50-100 M transcripts): torch RNG instead of numpy's, and the three edge stores come from the
-    HIP grid kNN (``segger_knn_grid``) instead of a host KD-tree.  Adds ``tx.cell`` (index of the true nucleus),
-    so the label of a candidate edge is ``bd.index[dst] == tx.cell[src]`` in any tile batch."""
-    from .neighbors import knn_grid, knn_to_edge_index
-
+def fov_nodes(spec: SyntheticSpec, device) -> dict:
+    """The NODES of :func:`make_fov` (nuclei, transcripts in Morton order, genes, the similarity matrices): cheap -- 40 bytes
+    per transcript -- next to the edge stores (16 bytes per edge, ~18 edges per transcript), which :func:`fov_edges` builds
+    for all transcripts or for a subset of them."""
     dev = torch.device(device)
     gen = torch.Generator(device=dev).manual_seed(spec.seed)
     Nt, Nb, T, G = spec.n_tx, spec.n_bd, spec.n_types, spec.n_genes
@@ -111,43 +108,91 @@ def make_fov(spec: SyntheticSpec, device, return_aux: bool = False):
     gene = (torch.searchsorted(flat, u + ttype.to(torch.float64), right=True) - ttype * G).clamp_(0, G - 1)
     del u, flat
     gene_cluster = profiles.argmax(0)
-
-    k = min(spec.k_tx, Nt)
-    nbr, _ = knn_grid(pos, k)
-    ett, _ = knn_to_edge_index(nbr, padding_value=Nt)
-    del nbr
-    d_own = (pos - centres[cell]).norm(dim=1)
-    inside = (d_own < spec.belongs_radius).nonzero(as_tuple=False).squeeze(1)
-    etb = torch.stack([inside, cell[inside]])
-    del d_own, inside
-    pk = min(spec.pred_k, Nb)
-    cnb, _ = knn_grid(centres, pk, spec.pred_radius, query=pos)
-    ep, _ = knn_to_edge_index(cnb, padding_value=Nb)
-    del cnb
-
-    b = HeteroBatch(num_graphs=1)
-    tx, bd = b["tx"], b["bd"]
-    tx["x"] = gene.to(torch.int32)
-    tx["pos"] = pos.to(torch.float32)
-    tx["batch"] = torch.zeros(Nt, dtype=torch.long, device=dev)
-    tx["cluster"] = gene_cluster[gene]
-    tx["index"] = torch.arange(Nt, dtype=torch.int64, device=dev)
-    tx["cell"] = cell
-    bd["x"] = bd_x.to(torch.float32)
-    bd["pos"] = centres.to(torch.float32)
-    bd["batch"] = torch.zeros(Nb, dtype=torch.long, device=dev)
-    bd["cluster"] = bd_type.to(torch.int32)
-    bd["index"] = torch.arange(Nb, dtype=torch.int32, device=dev)
-    b[TX_TX]["edge_index"] = ett
-    b[TX_BD]["edge_index"] = etb
-    b[TX_NB_BD]["edge_index"] = ep
-    if not return_aux:
-        return b
     pn = profiles - profiles.mean(1, keepdim=True)
     pn = pn / pn.norm(dim=1, keepdim=True)
     tn = type_mean.double() / type_mean.double().norm(dim=1, keepdim=True)
     aux = {"tx_similarity": (pn @ pn.T).to(torch.float32), "bd_similarity": (tn @ tn.T).to(torch.float32)}
-    return b, aux
+    return dict(centres=centres, bd_type=bd_type, bd_x=bd_x, cell=cell, pos=pos, gene=gene, gene_cluster=gene_cluster, aux=aux)
+
+
+def fov_edges(nodes: dict, spec: SyntheticSpec, sel: Optional[torch.Tensor] = None):
+    """(tx-neighbors-tx, tx-belongs-bd, tx-neighbors-bd) ``edge_index`` tensors [2, E] in GLOBAL node ids, for the query
+    transcripts ``sel`` (ascending int64 ids; None = all): every store lists its edges by ascending source transcript, so
+    the edges of a subset are exactly the corresponding rows of the full stores (a rank of a data-parallel run builds only
+    the edges of its own tiles' transcripts; the grid kNN searches ALL points either way)."""
+    from .neighbors import knn_grid, knn_to_edge_index
+    pos, centres, cell = nodes["pos"], nodes["centres"], nodes["cell"]
+    Nt, Nb = int(pos.shape[0]), int(centres.shape[0])
+    q = pos if sel is None else pos.index_select(0, sel)
+    own = (lambda t: t) if sel is None else (lambda t: sel[t])
+    k = min(spec.k_tx, Nt)
+    nbr, _ = knn_grid(pos, k, query=None if sel is None else q)
+    ett, _ = knn_to_edge_index(nbr, padding_value=Nt)
+    del nbr
+    ett = torch.stack([own(ett[0]), ett[1]])
+    cq = cell if sel is None else cell.index_select(0, sel)
+    d_own = (q - centres[cq]).norm(dim=1)
+    inside = (d_own < spec.belongs_radius).nonzero(as_tuple=False).squeeze(1)
+    etb = torch.stack([own(inside), cq[inside]])
+    del d_own, inside
+    pk = min(spec.pred_k, Nb)
+    cnb, _ = knn_grid(centres, pk, spec.pred_radius, query=q)
+    ep, _ = knn_to_edge_index(cnb, padding_value=Nb)
+    del cnb
+    ep = torch.stack([own(ep[0]), ep[1]])
+    return ett, etb, ep
+
+
+def fov_graph(nodes: dict, edges, tx_ids: Optional[torch.Tensor] = None, bd_ids: Optional[torch.Tensor] = None) -> HeteroBatch:
+    """The HeteroBatch of :func:`make_fov` from its nodes and edge stores -- or, with ``tx_ids`` / ``bd_ids`` (ascending
+    global ids), the subgraph on those nodes: ``edges`` must then connect kept nodes only and come in global ids."""
+    pos, centres, cell, gene = nodes["pos"], nodes["centres"], nodes["cell"], nodes["gene"]
+    dev = pos.device
+    Nt, Nb = int(pos.shape[0]), int(centres.shape[0])
+    pick = lambda t, ids: t if ids is None else t.index_select(0, ids)
+    b = HeteroBatch(num_graphs=1)
+    tx, bd = b["tx"], b["bd"]
+    g = pick(gene, tx_ids)
+    nt = int(g.shape[0])
+    tx["x"] = g.to(torch.int32)
+    tx["pos"] = pick(pos, tx_ids).to(torch.float32)
+    tx["batch"] = torch.zeros(nt, dtype=torch.long, device=dev)
+    tx["cluster"] = nodes["gene_cluster"][g]
+    tx["index"] = torch.arange(Nt, dtype=torch.int64, device=dev) if tx_ids is None else tx_ids.clone()
+    tx["cell"] = pick(cell, tx_ids)
+    bx = pick(nodes["bd_x"], bd_ids)
+    nb = int(bx.shape[0])
+    bd["x"] = bx.to(torch.float32)
+    bd["pos"] = pick(centres, bd_ids).to(torch.float32)
+    bd["batch"] = torch.zeros(nb, dtype=torch.long, device=dev)
+    bd["cluster"] = pick(nodes["bd_type"], bd_ids).to(torch.int32)
+    bd["index"] = (torch.arange(Nb, dtype=torch.int32, device=dev) if bd_ids is None else bd_ids.to(torch.int32))
+    ett, etb, ep = edges
+    if tx_ids is not None or bd_ids is not None:
+        def local(ids, n):
+            if ids is None:
+                return lambda t: t
+            m = torch.full((n,), -1, dtype=torch.int64, device=dev)
+            m[ids] = torch.arange(ids.numel(), device=dev)
+            return lambda t: m[t]
+        lt, lb = local(tx_ids, Nt), local(bd_ids, Nb)
+        ett = torch.stack([lt(ett[0]), lt(ett[1])])
+        etb = torch.stack([lt(etb[0]), lb(etb[1])])
+        ep = torch.stack([lt(ep[0]), lb(ep[1])])
+    b[TX_TX]["edge_index"] = ett
+    b[TX_BD]["edge_index"] = etb
+    b[TX_NB_BD]["edge_index"] = ep
+    return b
+
+
+def make_fov(spec: SyntheticSpec, device, return_aux: bool = False):
+    """The same generative model as :func:`make_graph`, built ON THE DEVICE for full-FOV sizes (BASELINE
+    configs 3 / 5: 50-100 M transcripts): torch RNG instead of numpy's, and the three edge stores come from the
+    HIP grid kNN (``segger_knn_grid``) instead of a host KD-tree.  Adds ``tx.cell`` (index of the true nucleus),
+    so the label of a candidate edge is ``bd.index[dst] == tx.cell[src]`` in any tile batch."""
+    nodes = fov_nodes(spec, device)
+    b = fov_graph(nodes, fov_edges(nodes, spec))
+    return (b, nodes["aux"]) if return_aux else b
 
 
 def make_graph(spec: SyntheticSpec = C1, return_aux: bool = False):

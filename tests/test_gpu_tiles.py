@@ -299,3 +299,57 @@ def test_generic_geometry_trains_on_csr_partition(cuda):
     torch.cuda.synchronize()
     assert torch.isfinite(loss)
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_rank_local_fov_generation_equals_shards_of_the_whole_fov(cuda):
+    """``fov.build_fov_shard`` (a data-parallel rank builds only the edges of its own tiles; nodes and a chunked counting
+    pass are replicated) against ``build_fov_batches`` + ``dp.rank_schedule`` + ``TilePartition.shard`` on the whole FOV:
+    the same batch list and schedule on every rank, and tile for tile the same tensors -- node stores, tile-local edge
+    lists, global permutations, pointer arrays, slide-level sorted views -- bit for bit; its peak memory stays below the
+    whole-FOV route's."""
+    from segger_amd.dp import rank_schedule
+    from segger_amd.fov import batch_weights, build_fov_batches, build_fov_shard
+    spec = SyntheticSpec(n_tx=300_000, n_bd=3_000, k_tx=15, seed=11)
+    kw = dict(tile_nodes=20_000, edges_per_batch=700_000)
+    torch.cuda.synchronize(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    part, batches, aux, tiling = build_fov_batches(spec, cuda, **kw)
+    peak_full = torch.cuda.max_memory_allocated() - base
+    weights = batch_weights(part, batches)
+    world = 3
+    sched = rank_schedule(weights, world)
+    assert len(batches) >= 4 and len(part) >= 9
+    seen = set()
+    for rank in range(world):
+        mine = [k for k in sched[rank] if k is not None]
+        tiles = sorted({t for k in mine for t in batches[k]})
+        ref = part.shard(tiles)
+        torch.cuda.synchronize(); torch.cuda.empty_cache(); torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        loc, b2, local_batches, s2, aux2, tiling2, info = build_fov_shard(spec, cuda, rank, world, count_chunk=70_001, **kw)
+        peak_local = torch.cuda.max_memory_allocated() - base
+        assert b2 == batches and s2 == sched and info["tiles"] == tiles and info["weights"] == weights
+        assert sorted(local_batches) == sorted(mine)
+        assert len(tiling2) == len(tiling) and torch.equal(aux2["tx_similarity"], aux["tx_similarity"])
+        assert loc.num_tiles == ref.num_tiles == len(tiles)
+        for nt in ("tx", "bd"):
+            assert torch.equal(loc.node_indptr[nt], ref.node_indptr[nt]) and torch.equal(loc.node_perm[nt], ref.node_perm[nt])
+            assert set(loc.data[nt].keys()) == set(ref.data[nt].keys())
+            for a, v in ref.data[nt].items():
+                if isinstance(v, torch.Tensor):
+                    assert torch.equal(loc.data[nt][a], v), (nt, a)
+        for et in ETS:
+            assert torch.equal(loc.edge_indptr[et], ref.edge_indptr[et]), et
+            assert torch.equal(loc.data[et]["edge_index"], ref.data[et]["edge_index"]), et
+            for side in ("by_dst", "by_src"):
+                for k in ("ptr", "col", "eid"):
+                    assert torch.equal(loc._csr[et][side][k], ref._csr[et][side][k]), (et, side, k)
+        for k in mine:                                       # and the batches the rank trains on
+            a, b = loc.batch(local_batches[k]), part.batch(batches[k])
+            assert torch.equal(a["tx"]["pos"], b["tx"]["pos"]) and torch.equal(a[TX_TX].edge_index, b[TX_TX].edge_index)
+            assert info["units"][k] == (int(sum(part.edge_sizes[TX_BD][t] for t in batches[k])),
+                                        int(sum(part.edge_sizes[TX_TX][t] for t in batches[k])))
+        assert peak_local < 0.8 * peak_full, (peak_local, peak_full)
+        seen |= set(tiles)
+        del loc, ref
+    assert seen == {t for ids in batches for t in ids}
