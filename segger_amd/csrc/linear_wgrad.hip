@@ -24,6 +24,7 @@
 // a stage goes through a double-buffered LDS tile so that it leaves as full rows, one 8- or 16-byte store per lane,
 // issued one stage later (after the ring's barrier).  The stores share vmcnt with the LDS-DMA loads: the counted
 // waits below include them.
+#include <cstdlib>
 #include "common.h"
 
 namespace segger {
@@ -699,7 +700,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 constexpr int kNumCu = 256;
-constexpr int kMinStagesPerBlock = 32;     // 512 rows: below that a workgroup's partial [M*K] costs more than its GEMM
+// 512 rows: below that a workgroup's partial [M*K] costs more than its GEMM (SEGGER_WGRAD_MIN_STAGES overrides: tools)
+static const int kMinStagesPerBlock = [] {
+  const char* e = getenv("SEGGER_WGRAD_MIN_STAGES");
+  const int v = e ? atoi(e) : 0;
+  return v >= 4 && v <= 1024 ? v : 32;
+}();
 
 bool shape_ok(int m, int k) {
   return (m == 384 || m == 192 || m == 128 || m == 64) && (k == 256 || k == 128 || k == 64);
