@@ -32,8 +32,9 @@ JSON line:
   strong_value, strong_graphed_value   -- copies of strong.value / strong.graphed.value at the top level
   strong {scaling: "strong", workload, n_gpus, world_size, n_ranks_seen, census, batches, steps_per_rank,
           epoch_s, value, unit, mp_edges_per_s}
-      BASELINE config 4 as SURVEY.md 8(d) defines it: ONE fixed synthetic FOV (seed 0; every rank builds the same
-      one, no data-path collective) streamed as packed tile batches that `dp.rank_schedule` deals to the ranks by
+      BASELINE config 4 as SURVEY.md 8(d) defines it: ONE fixed synthetic FOV (seed 0; every rank derives the same
+      nodes, tiling, batch list and schedule -- no data-path collective -- and at N > 1 builds only the edges of its own
+      tiles: fov.build_fov_shard, `resident.generation`) streamed as packed tile batches that `dp.rank_schedule` deals to the ranks by
       balanced edge counts; one flat RCCL all-reduce per step; `epoch_s` = max over ranks between two barriers;
       `value` = 2 * Etb of the whole FOV / epoch_s.  Total work is independent of N: value(N) / value(1) is the
       strong-scaling speed-up.  `census` is an all-reduced one-hot of the ranks (all ones <=> RCCL saw N ranks).
