@@ -566,6 +566,9 @@ int segger_triplet_bwd(const segger_triplet_args* args, segger_stream_t stream);
  *   C in {32, 64, 128}.  Worth it below ~10^5 transcript rows (a captured 1M-edge step); at 10^6 rows the forward's chain
  *   atomics (4 returning atomics per triplet) make it slower than the kernel-by-kernel head (profiles/r04_loss_head_modes_c2.txt).
  */
+#define SEGGER_LOSS_HEAD_DEFER_FINISH 1   /* in reserved_: with grad_out given, the forward leaves its partial sums and the
+                                             backward launch (one extra workgroup) finishes the losses into `out`; both calls
+                                             get the same workspace, out and grad_out: a captured training step's form */
 typedef struct segger_loss_head_args {
   const void* z_tx; int64_t ld_ztx; int64_t n_tx;
   const void* z_bd; int64_t ld_zbd; int64_t n_bd;
@@ -659,6 +662,10 @@ typedef struct segger_linear_args {
 } segger_linear_args;
 int segger_linear_fwd_pair(const segger_linear_args* a, const segger_linear_args* b, int32_t k_in, int32_t dtype,
                            segger_stream_t stream);
+/* ... and with an input width per side (a first layer's two data gradients dX = dY W read 384 and 128 columns of dY): one
+ * launch for (k_a, k_b) = (384, 128) or equal widths, two otherwise. */
+int segger_linear_fwd_pair_k(const segger_linear_args* a, int32_t k_a, const segger_linear_args* b, int32_t k_b,
+                             int32_t dtype, segger_stream_t stream);
 
 /*
  * segger_linear_wgrad: the parameter gradients of the same projections,

@@ -215,6 +215,7 @@ EXPORTS = {
     "segger_linear_fwd_f32_split_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "segger_linear_fwd_f32_split": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp]),
     "segger_linear_fwd_pair": (C.c_int, [C.POINTER(LinearArgs), C.POINTER(LinearArgs), C.c_int32, C.c_int32, vp]),
+    "segger_linear_fwd_pair_k": (C.c_int, [C.POINTER(LinearArgs), C.c_int32, C.POINTER(LinearArgs), C.c_int32, C.c_int32, vp]),
     "segger_linear_wgrad_pair": (C.c_int, [C.POINTER(WgradArgs), C.POINTER(WgradArgs), C.c_int32, C.c_int32, vp]),
     "segger_linear_fwd_silu_grad": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                               C.c_int32, vp]),

@@ -53,15 +53,18 @@ struct LinearParams {
   const void* gate; int64_t ld_gate;
 };
 
+template <int K> constexpr int linear_lds_bytes() { return kChunk * (K * 2 + 16) + 4 * 32 * (kChunk * 2 + 16); }
+
+// `lds`: the workgroup's shared array of linear_lds_bytes<K>() bytes (declared by the kernel: two bodies of a pair launch
+// share one array instead of adding theirs up)
 template <typename T, int K, bool RB = false, bool SG = false>
-__device__ __forceinline__ void linear_fwd_body(const LinearParams p, const int64_t bid) {
+__device__ __forceinline__ void linear_fwd_body(const LinearParams p, const int64_t bid, unsigned char* lds) {
   constexpr int NK = K / 16;                       // k-steps
   constexpr int WSTRIDE = K * 2 + 16;              // bytes per LDS row of W
   constexpr int ESTRIDE = kChunk * 2 + 16;         // bytes per LDS row of the epilogue tile
   constexpr int PIECES = kChunk * K * 2 / 16;      // 16-byte pieces per W chunk
   constexpr int PPT = PIECES / 256;                // pieces per thread
   static_assert(PIECES % 256 == 0, "chunk must split evenly over the block");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[kChunk * WSTRIDE + 4 * 32 * ESTRIDE];
   unsigned char* lds_w = lds;
   unsigned char* lds_e = lds + kChunk * WSTRIDE;
 
@@ -213,16 +216,18 @@ __device__ __forceinline__ void linear_fwd_body(const LinearParams p, const int6
 
 template <typename T, int K, bool RB = false, bool SG = false>
 __global__ __launch_bounds__(256, 2) void linear_fwd_kernel(LinearParams p) {
-  linear_fwd_body<T, K, RB, SG>(p, blockIdx.x);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[linear_lds_bytes<K>()];
+  linear_fwd_body<T, K, RB, SG>(p, blockIdx.x, lds);
 }
 
 // Two projections with the same K in ONE launch: the blocks of `b` (a few: the boundary side of a hetero layer, ~500 rows)
 // are dispatched first and run beside the blocks of `a` instead of as a 7 us launch of their own (a captured 1M-edge
 // training step has six such pairs; same idea as gatv2_fwd_pair_kernel).
-template <typename T, int K>
+template <typename T, int KA, int KB = KA>
 __global__ __launch_bounds__(256, 2) void linear_fwd_pair_kernel(LinearParams a, LinearParams b, int nb_b) {
-  if ((int)blockIdx.x < nb_b) linear_fwd_body<T, K>(b, blockIdx.x);
-  else linear_fwd_body<T, K>(a, (int64_t)blockIdx.x - nb_b);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[linear_lds_bytes<(KA > KB ? KA : KB)>()];
+  if ((int)blockIdx.x < nb_b) linear_fwd_body<T, KB>(b, blockIdx.x, lds);
+  else linear_fwd_body<T, KA>(a, (int64_t)blockIdx.x - nb_b, lds);
 }
 
 // ---- resident-W form for large row counts ----------------------------------------------------------------------
@@ -386,11 +391,23 @@ int launch_linear(const LinearParams& p, int k_in, hipStream_t stream) {
 }
 
 template <typename T>
-int launch_linear_pair(const LinearParams& a, const LinearParams& b, int k_in, hipStream_t stream) {
+int launch_linear_pair(const LinearParams& a, const LinearParams& b, int k_in, hipStream_t stream, int k_b = 0) {
+  if (k_b == 0) k_b = k_in;
   bool done = false;
   int rc = launch_linear_res<T>(a, k_in, stream, &done);       // a large `a` goes its own (persistent) way
   if (rc != SEGGER_OK) return rc;
-  if (done) return launch_linear<T>(b, k_in, stream);
+  if (done) return launch_linear<T>(b, k_b, stream);
+  if (k_b != k_in) {
+    // different input widths (a first layer's two data gradients: 384 and 128 columns of dY): the pairs instantiated
+    const int64_t na = (a.n_rows + kRowsPerBlock - 1) / kRowsPerBlock, nb = (b.n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    if (k_in == 384 && k_b == 128 && na > 0 && nb > 0 && na + nb <= 0x7fffffffLL) {
+      hipLaunchKernelGGL((linear_fwd_pair_kernel<T, 384, 128>), dim3((unsigned)(na + nb)), dim3(256), 0, stream, a, b, (int)nb);
+      SEGGER_LAUNCH_CHECK("linear_fwd_pair_kernel");
+      return SEGGER_OK;
+    }
+    rc = launch_linear<T>(a, k_in, stream);
+    return rc != SEGGER_OK ? rc : launch_linear<T>(b, k_b, stream);
+  }
   const int64_t nb_a = (a.n_rows + kRowsPerBlock - 1) / kRowsPerBlock, nb_b = (b.n_rows + kRowsPerBlock - 1) / kRowsPerBlock;
   if (nb_a + nb_b > 0x7fffffffLL) { set_error("segger_linear_fwd_pair: too many rows"); return SEGGER_EUNSUPPORTED; }
   if (nb_a == 0) return launch_linear<T>(b, k_in, stream);
@@ -416,11 +433,18 @@ using namespace segger;
 
 extern "C" int segger_linear_fwd_pair(const segger_linear_args* a, const segger_linear_args* b, int32_t k_in, int32_t dtype,
                                       segger_stream_t stream) {
+  return segger_linear_fwd_pair_k(a, k_in, b, k_in, dtype, stream);
+}
+
+extern "C" int segger_linear_fwd_pair_k(const segger_linear_args* a, int32_t k_a, const segger_linear_args* b, int32_t k_b,
+                                        int32_t dtype, segger_stream_t stream) {
   SEGGER_REQUIRE(a && b, "segger_linear_fwd_pair: NULL args");
   const segger_linear_args* both[2] = {a, b};
+  const int32_t ks[2] = {k_a, k_b};
   if (dtype == SEGGER_F32) {      // fp32 storage: two launches of the exact-fp32 kernel
-    for (const segger_linear_args* q : both) {
-      const int rc = segger_linear_fwd(q->x, q->ldx, q->w, q->bias, q->y, q->ldy, q->n_rows, k_in, q->m_out, dtype, stream);
+    for (int i = 0; i < 2; ++i) {
+      const segger_linear_args* q = both[i];
+      const int rc = segger_linear_fwd(q->x, q->ldx, q->w, q->bias, q->y, q->ldy, q->n_rows, ks[i], q->m_out, dtype, stream);
       if (rc != SEGGER_OK) return rc;
     }
     return SEGGER_OK;
@@ -428,6 +452,7 @@ extern "C" int segger_linear_fwd_pair(const segger_linear_args* a, const segger_
   LinearParams p[2];
   for (int i = 0; i < 2; ++i) {
     const segger_linear_args* q = both[i];
+    const int32_t k_in = ks[i];
     SEGGER_REQUIRE(q->n_rows >= 0 && q->m_out > 0, "segger_linear_fwd_pair: bad sizes");
     if (!segger_linear_supported(k_in, q->m_out, dtype)) {
       set_error("segger_linear_fwd_pair: k_in=%d m_out=%d dtype=%d not supported", k_in, q->m_out, dtype);
@@ -439,8 +464,8 @@ extern "C" int segger_linear_fwd_pair(const segger_linear_args* a, const segger_
                    "segger_linear_fwd_pair: bad leading dimension");
     p[i] = LinearParams{q->x, q->ldx, q->w, q->bias, q->y, q->ldy, q->n_rows, q->m_out, nullptr, nullptr, 0, nullptr, 0};
   }
-  return dtype == SEGGER_BF16 ? launch_linear_pair<bf16_t>(p[0], p[1], k_in, (hipStream_t)stream)
-                              : launch_linear_pair<f16_t>(p[0], p[1], k_in, (hipStream_t)stream);
+  return dtype == SEGGER_BF16 ? launch_linear_pair<bf16_t>(p[0], p[1], k_a, (hipStream_t)stream, k_b)
+                              : launch_linear_pair<f16_t>(p[0], p[1], k_a, (hipStream_t)stream, k_b);
 }
 
 extern "C" int segger_linear_supported(int32_t k_in, int32_t m_out, int32_t dtype) {

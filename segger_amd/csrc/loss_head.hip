@@ -111,7 +111,15 @@ struct LossHeadParams {
   void* gtx; int64_t ld_gtx; float* gbd;
   float* partial; int32_t* ticket;
   int nb_tx, nb_bd, nb_sg;
+  int nb_sg_fin;             // loss_sg blocks of the FORWARD launch (the backward's nb_sg is one block per boundary)
+  int defer;                 // the forward left the finishing to the backward launch (segger_loss_head_args.reserved_ & 1)
 };
+
+// d loss / d (raw mean i): what segger_loss_combine_bwd computes; with `defer` from the hinted gradient directly (the
+// finishing launch that would have written graw did not run)
+__device__ __forceinline__ float graw_of(const LossHeadParams& p, int i) {
+  return p.defer ? (p.gout[3] * p.b[i] + p.gout[i]) * p.a[i] : p.graw[i];
+}
 
 // ---------------------------------------------------------------------------------------------------- forward ----
 template <typename T, int CPL>
@@ -258,14 +266,14 @@ __global__ __launch_bounds__(256) void loss_head_fwd_kernel(LossHeadParams p) {
 // of the forward do this, found by a ticket counter behind a __threadfence(): on this part a device-scope release writes
 // back the whole L2 of the XCD, once per block -- 0.76 of the forward's 0.90 ms at C2 (22k blocks), 30 of 44 us at 44k rows;
 // tools/bench_loss_head.py, profiles/r04_loss_head_modes_c2.txt.)
-__global__ __launch_bounds__(256) void loss_head_finish_kernel(LossHeadParams p) {
+__device__ __forceinline__ void loss_head_finish_body(const LossHeadParams& p) {
   __shared__ float wsum[4];
   __shared__ float raw[3];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int r = 0; r < 3; ++r) {      // (no arrays indexed by r: they would live in scratch memory)
     const int lo = r == 0 ? 0 : (r == 1 ? p.nb_tx : p.nb_tx + p.nb_bd);
-    const int hi = r == 0 ? p.nb_tx : (r == 1 ? p.nb_tx + p.nb_bd : p.nb_tx + p.nb_bd + p.nb_sg);
+    const int hi = r == 0 ? p.nb_tx : (r == 1 ? p.nb_tx + p.nb_bd : p.nb_tx + p.nb_bd + p.nb_sg_fin);
     const float scale = r == 0 ? (p.n_tx > 0 ? 1.0f / (float)p.n_tx : 0.f)
                       : r == 1 ? 1.0f
                                : (p.n_sg > 0 ? (p.sg_kind == SEGGER_LOSS_BCE ? 0.5f : 1.0f) / (float)p.n_sg : 0.f);
@@ -293,6 +301,8 @@ __global__ __launch_bounds__(256) void loss_head_finish_kernel(LossHeadParams p)
   }
 }
 
+__global__ __launch_bounds__(256) void loss_head_finish_kernel(LossHeadParams p) { loss_head_finish_body(p); }
+
 // --------------------------------------------------------------------------------------------------- backward ----
 template <typename T, int CPL>
 __global__ __launch_bounds__(256) void loss_head_bwd_kernel(LossHeadParams p) {
@@ -302,10 +312,14 @@ __global__ __launch_bounds__(256) void loss_head_bwd_kernel(LossHeadParams p) {
   const int blk = blockIdx.x;
   const T* ztx = static_cast<const T*>(p.ztx);
   const T* zbd = static_cast<const T*>(p.zbd);
+  if (p.defer && blk == p.nb_tx + p.nb_bd + p.nb_sg) {      // one extra workgroup: the forward's finishing launch, deferred
+    loss_head_finish_body(p);
+    return;
+  }
   if (blk < p.nb_tx) {
     // ---- one transcript row per 16-lane group: everything that lands on row r, summed in registers, stored once
-    const float sc_tx = p.n_tx > 0 ? p.graw[0] / (float)p.n_tx : 0.f;
-    const float sc_sg = p.n_sg > 0 ? p.graw[2] * (p.sg_kind == SEGGER_LOSS_BCE ? 0.5f : 1.0f) / (float)p.n_sg : 0.f;
+    const float sc_tx = p.n_tx > 0 ? graw_of(p, 0) / (float)p.n_tx : 0.f;
+    const float sc_sg = p.n_sg > 0 ? graw_of(p, 2) * (p.sg_kind == SEGGER_LOSS_BCE ? 0.5f : 1.0f) / (float)p.n_sg : 0.f;
     const int64_t base = (int64_t)blk * kItemsPerBlock;
     // the row's gradient through z = y / max(|y|, eps) when y is given (csrc/frontend.hip l2norm_kernel), then the store
     auto finish_row = [&](int64_t row, float (&g)[CPL]) {
@@ -433,7 +447,7 @@ __global__ __launch_bounds__(256) void loss_head_bwd_kernel(LossHeadParams p) {
     }
   } else if (blk < p.nb_tx + p.nb_bd) {
     // ---- loss_bd backward (csrc/heads.hip metric_kernel): own row, positive and negative rows by fp32 atomics
-    const float sc = p.graw[1];
+    const float sc = graw_of(p, 1);
     const int64_t base = (int64_t)(blk - p.nb_tx) * kItemsPerBlock;
 #pragma unroll 1
     for (int q = wave * 4 + grp; q < kItemsPerBlock; q += 16) {
@@ -478,7 +492,7 @@ __global__ __launch_bounds__(256) void loss_head_bwd_kernel(LossHeadParams p) {
     if (j >= p.n_bd || p.n_sg <= 0) return;
     const int64_t beg = p.sg_indptr[j] + 4 * wave, end = p.sg_indptr[j + 1];
     if (beg >= end) return;                                       // wave-uniform
-    const float sc = p.graw[2] * (p.sg_kind == SEGGER_LOSS_BCE ? 0.5f : 1.0f) / (float)p.n_sg;
+    const float sc = graw_of(p, 2) * (p.sg_kind == SEGGER_LOSS_BCE ? 0.5f : 1.0f) / (float)p.n_sg;
     float pj[KP][2], acc[KP][2];
 #pragma unroll
     for (int k = 0; k < KP; ++k) {
@@ -591,6 +605,9 @@ int fill_params(const segger_loss_head_args* a, bool bwd, LossHeadParams* out) {
   p.gtx = a->grad_tx; p.ld_gtx = a->ld_gtx; p.gbd = a->grad_bd;
   p.partial = static_cast<float*>(a->workspace); p.ticket = a->ticket;
   p.nb_tx = (int)nb_tx; p.nb_bd = (int)nb_bd; p.nb_sg = (int)nb_sg;
+  p.defer = (a->reserved_ & SEGGER_LOSS_HEAD_DEFER_FINISH) ? 1 : 0;
+  SEGGER_REQUIRE(!p.defer || a->grad_out, "segger_loss_head: DEFER_FINISH needs grad_out (the gradient the backward will receive)");
+  p.nb_sg_fin = (int)blocks_of(a->n_sg);
   if (!bwd) {
     SEGGER_REQUIRE(!a->tx_w == !a->tx_state && !a->tx_state == !a->tx_next && !a->tx_next == !a->tx_hot_id && !a->tx_hot_id == !a->tx_hot_acc,
                    "segger_loss_head_fwd: tx_w, tx_state, tx_next, tx_hot_id and tx_hot_acc go together");
@@ -615,7 +632,7 @@ int launch(const segger_loss_head_args* a, hipStream_t stream) {
   LossHeadParams p;
   const int rc = fill_params(a, BWD, &p);
   if (rc != SEGGER_OK) return rc;
-  const int64_t grid = (int64_t)p.nb_tx + p.nb_bd + p.nb_sg;
+  const int64_t grid = (int64_t)p.nb_tx + p.nb_bd + p.nb_sg + ((BWD && p.defer) ? 1 : 0);
   if (grid == 0) return SEGGER_OK;
 #define GO(T, CPL)                                                                                              \
   do {                                                                                                          \
@@ -636,7 +653,7 @@ int launch(const segger_loss_head_args* a, hipStream_t stream) {
 #undef BY_C
 #undef GO
   SEGGER_LAUNCH_CHECK("loss_head kernel");
-  if (!BWD) {
+  if (!BWD && !p.defer) {
     hipLaunchKernelGGL(loss_head_finish_kernel, dim3(1), dim3(256), 0, stream, p);
     SEGGER_LAUNCH_CHECK("loss_head_finish_kernel");
   }

@@ -764,6 +764,10 @@ class LossHeadSpec:
         # ``grad_out_hint`` float32 [4]: the gradient the backward will receive (a training step: e_3) -- the forward then
         # leaves the three scale factors behind and the backward skips their launch when it is handed that very tensor
         self.sg_of_tx, self.tx_state, self.grad_out_hint = sg_of_tx, tx_state, grad_out_hint
+        # one-launch head, with grad_out_hint: leave the finishing launch (the three means, the total) to the BACKWARD launch --
+        # the returned loss tensor is then only valid once the backward has run (a captured training step reads it after the
+        # replay); the caller promises that a backward with exactly the hinted gradient follows
+        self.defer_finish = False
 
 
 class _LossHead(torch.autograd.Function):
@@ -1011,7 +1015,9 @@ class _LossHeadFused(torch.autograd.Function):
                 if hint.dtype != torch.float32 or hint.numel() != 4 or not hint.is_contiguous() or hint.device != dev:
                     raise ValueError("loss_head: grad_out_hint must be a contiguous float32 [4] tensor on the embeddings' device")
                 g.grad_out = hint.data_ptr()
-            state = (tx_w, head, nxt, gbd, graw, hot_acc)
+                if getattr(spec, "defer_finish", False):
+                    g.reserved_ = 1                      # SEGGER_LOSS_HEAD_DEFER_FINISH
+            state = (tx_w, head, nxt, gbd, graw, hot_acc, out, ws, int(g.reserved_))
         with _lib.on_device(dev):
             rc = lib.segger_loss_head_fwd(C.byref(g), _lib.stream_ptr(dev))
         _lib.check(rc, "segger_loss_head_fwd")
@@ -1028,7 +1034,7 @@ class _LossHeadFused(torch.autograd.Function):
         bd = ctx.saved_tensors[8:13]
         spec = ctx.spec
         sg = ctx.saved_tensors[13:16] if spec.sg is not None else None
-        tx_w, head, nxt, gbd, graw, hot_acc = ctx.state
+        tx_w, head, nxt, gbd, graw, hot_acc, out_fwd, ws_fwd, deferred = ctx.state
         lib = _lib.load()
         dev, dt = z_tx.device, z_tx.dtype
         n_tx, c = int(z_tx.shape[0]), int(z_tx.shape[1])
@@ -1066,9 +1072,15 @@ class _LossHeadFused(torch.autograd.Function):
         g.a, g.b, g.grad_raw = a.data_ptr(), b.data_ptr(), graw.data_ptr()
         out_dummy = torch.empty(4, dtype=torch.float32, device=dev)
         g.out = out_dummy.data_ptr()
+        if deferred:
+            if ctx.hint is None or g_out.data_ptr() != ctx.hint.data_ptr():
+                raise RuntimeError("loss_head: defer_finish promised a backward with the hinted gradient")
+            # the forward left only its per-block partial sums: this launch finishes the losses (into the forward's output)
+            g.out, g.grad_out, g.reserved_ = out_fwd.data_ptr(), ctx.hint.data_ptr(), 1
         g.tx_w, g.tx_state, g.tx_next, g.grad_bd = tx_w.data_ptr(), head.data_ptr(), nxt.data_ptr(), gbd.data_ptr()
         g.tx_hot_id, g.tx_hot_acc = nxt[2 * n_tx:].data_ptr(), hot_acc.data_ptr()
-        ws = torch.empty(lib.segger_loss_head_workspace_bytes(n_tx, n_bd, int(g.n_sg)), dtype=torch.uint8, device=dev)
+        ws = ws_fwd if deferred else torch.empty(lib.segger_loss_head_workspace_bytes(n_tx, n_bd, int(g.n_sg)), dtype=torch.uint8,
+                                                 device=dev)
         g.workspace, g.workspace_bytes, g.ticket = ws.data_ptr(), ws.numel(), _ticket(dev).data_ptr()
         gtx = torch.empty((n_tx, c), dtype=dt, device=dev)
         g.grad_tx, g.ld_gtx = gtx.data_ptr(), c
@@ -1526,6 +1538,29 @@ def linear_wgrad_dx_launch(gy: Tensor, x: Tensor, wt: Tensor, want_bias: bool = 
     return gx, gw, gb
 
 
+def linear_fwd_pair_launch(xa: Tensor, wa: Tensor, xb: Tensor, wb: Tensor) -> Tuple[Tensor, Tensor]:
+    """``(xa @ wa.T, xb @ wb.T)`` for 16-bit activations whose widths may differ (``segger_linear_fwd_pair_k``: one launch
+    for widths (384, 128) or equal widths -- a first layer's two data gradients -- two otherwise)."""
+    _lib.require_cuda(xa, wa, xb, wb)
+    args, outs = [], []
+    for x, w in ((xa, wa), (xb, wb)):
+        n, k = x.shape
+        m = int(w.shape[0])
+        if w.dtype != x.dtype or not w.is_contiguous() or w.shape[1] != k:
+            raise ValueError("linear_fwd_pair: weights must be contiguous [M, K] in the activation dtype")
+        y = torch.empty((n, m), dtype=x.dtype, device=x.device)
+        a = _lib.LinearArgs()
+        a.x, a.ldx = _rows(x, k, "x")
+        a.w, a.y, a.ldy, a.n_rows, a.m_out = w.data_ptr(), y.data_ptr(), m, n, m
+        args.append(a)
+        outs.append(y)
+    with _lib.on_device(xa.device):
+        rc = _lib.load().segger_linear_fwd_pair_k(C.byref(args[0]), int(xa.shape[1]), C.byref(args[1]), int(xb.shape[1]),
+                                                  DTYPE_CODE[xa.dtype], _lib.stream_ptr(xa.device))
+    _lib.check(rc, "segger_linear_fwd_pair_k")
+    return outs[0], outs[1]
+
+
 def linear_wgrad_pair_launch(sides, dx: bool):
     """``sides`` = two (gy [n, M], x [n, K], wt [K, M] | None, want_bias) of one K and dtype -> [(gx | None, gw, gb | None)] * 2 from
     ONE launch (``segger_linear_wgrad_pair``; ``dx``: the one-pass form with the data gradients, else dW / db only)."""
@@ -1967,6 +2002,14 @@ class _LinearPair(torch.autograd.Function):
                 bias = [any(h and g for h, g in zip(st.has_bias, nn[len(st.rows):])) for st, nn in zip(sts, (na, nb))]
                 pre = linear_wgrad_pair_launch([(gya, xa, sts[0].wt_of.wt if dx else None, bias[0]),
                                                 (gyb, xb, sts[1].wt_of.wt if dx else None, bias[1])], dx)
+                if not dx and need[0] and need[1] and all(linear_supported(m, k, dt) for m in ms):
+                    # the two data gradients the one-pass kernel does not cover (a first layer reads K = 256): one launch
+                    for st in sts:
+                        if st.wt_of.key != st.w_key:
+                            raise RuntimeError("the projection weights changed between this forward and its backward "
+                                               "(optimizer step in between?): run backward before stepping")
+                    gxa, gxb = linear_fwd_pair_launch(gya, sts[0].wt_of.wt, gyb, sts[1].wt_of.wt)
+                    pre = [(gxa,) + tuple(pre[0][1:]), (gxb,) + tuple(pre[1][1:])]
         ra = _linear_backward(sts[0], xa, gya, need[0], na, pre[0])
         rb = _linear_backward(sts[1], xb, gyb, need[1], nb, pre[1])
         return (ra[0], rb[0], None, None) + ra[2:] + rb[2:]

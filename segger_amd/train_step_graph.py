@@ -65,6 +65,7 @@ def step_bucket(batch, granularity: float = 1.06, floor: int = 256) -> Dict[str,
 USE_ADAM_KERNEL = True       # (False: torch's fused Adam inside the captured step -- A/B switch)
 MERGED_DRAWS = True          # (False: dropout planes, both samplers and the negatives as launches of their own, the dropout
                              #  counter advanced at the head of the step, Adam's step counters by a launch of their own)
+DEFER_LOSS_FINISH = True     # (False: the one-launch loss head's finishing launch right behind its forward)
 STEP_INC = 256               # what a training forward advances the encoder's dropout counter by (ist_encoder.py)
 
 
@@ -104,7 +105,9 @@ class GraphedTrainStep:
         # launch of every step, so that the captured forward needs only the accumulating kernel (ops.segment_minmax)
         self.minmax = (z(2 * sizes["graphs"], 2), z(2 * sizes["graphs"], 2))
         self.nodes = {"tx": {"x": z(nt, dtype=i32), "pos": self.pos_all[:nt], "batch": self.batch_all[:nt]},
-                      "bd": {"x": z(nb, *template["bd"]["x"].shape[1:], dtype=template["bd"]["x"].dtype),
+                      # boundary features staged in the compute dtype (the cast of ist_encoder.py's `x_dict['bd'].to(dt)` is
+                      # made once per tile set and kept with it, not once per step)
+                      "bd": {"x": z(nb, *template["bd"]["x"].shape[1:], dtype=self._bd_dtype(lit_model, template)),
                              "pos": self.pos_all[nt:], "batch": z(nb, dtype=i64)}}
 
         def csr(n_rows, n_cols, n_edges):
@@ -155,6 +158,11 @@ class GraphedTrainStep:
         # autograd node READS a parameter gradient before the backward ends (a parameter used by two nodes has its two
         # gradients added on the spot): verified numerically during the warm-up of every capture, see _warm_up
         self.defer_sums = True
+
+    @staticmethod
+    def _bd_dtype(lit_model, template):
+        dt, src = lit_model.model.compute_dtype, template["bd"]["x"].dtype
+        return dt if (src.is_floating_point and dt in (torch.bfloat16, torch.float16)) else src
 
     def fits(self, batch) -> bool:
         s = self.sizes
@@ -213,6 +221,13 @@ class GraphedTrainStep:
         if of_tx is None:
             of_tx = keep["sg_of_tx"] = ops.anchor_index(ei[0], n_tx)
         w = lit._scheduled_weights(lit._w_start, lit._w_end)
+        bd_x, x_dt = bd["x"], self.nodes["bd"]["x"].dtype
+        if bd_x.dtype != x_dt:
+            key = ("bd_x", x_dt)
+            hit = keep.get(key)
+            if hit is None or hit.shape != bd_x.shape:
+                hit = keep[key] = bd_x.to(x_dt).contiguous()
+            bd_x = hit
         fb = ops.float_bits
         dummies = ("mod", n_tx, nt - n_tx)                    # dummy transcripts, round robin
         N = self.nodes
@@ -220,7 +235,7 @@ class GraphedTrainStep:
             # nodes: dummies are copies of node 0 (gene id: the last gene, whose rows-by-gene group they extend)
             (N["tx"]["x"], tx["x"], "const", self.n_genes - 1, 0, 0),
             (N["tx"]["pos"], tx["pos"], "tile", 2, 0, 0), (N["tx"]["batch"], tx["batch"], "tile", 1, 0, 0),
-            (N["bd"]["x"], bd["x"], "tile", max(int(bd["x"][0].numel()), 1), 0, 0),
+            (N["bd"]["x"], bd_x, "tile", max(int(bd_x[0].numel()), 1), 0, 0),
             (N["bd"]["pos"], bd["pos"], "tile", 2, 0, 0), (N["bd"]["batch"], bd["batch"], "tile", 1, 0, 0),
             (self.batch_all[nt:], bd["batch"], "tile", 1, 0, 0, s["graphs"]),
             (self.by_gene.indptr, by_gene.indptr[: self.n_genes], "const", nt, 0, 0),
@@ -315,6 +330,7 @@ class GraphedTrainStep:
                                 (self.sg_src, self.sg_pos, dst_neg, lit._sg_margin, 1e-6, self.g_tb.by_dst, True),
                                 sg_kind=lit._sg_loss_type, tx_anchors_are_rows=True, sg_of_tx=self.sg_of_tx,
                                 tx_state=self.tx_state, grad_out_hint=self._e_loss)
+        spec.defer_finish = DEFER_LOSS_FINISH      # the losses are read after the backward (self.out after the replay)
         out = ops.loss_head(z["tx"], z["bd"], self.head_a, self.scal[3:6], spec)
         if self.defer_sums:                                   # ~30 partial sums of the backward as one launch
             with ops.deferred_reductions(self.dev):

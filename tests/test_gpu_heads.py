@@ -649,3 +649,44 @@ def test_step_draws_equal_the_separate_launches(cuda):
     assert n2 is None and torch.equal(s2[0][0], ops.triplet_sample(ix_bd, seed=3, seed_dev=word)[0])
     p3, s3, _ = ops.step_draws(views[:1], 2, 0.5, [], None, word)
     assert s3 == [] and torch.equal(p3[0], ops.dropout_bits_many(views[:1], 2, 0.5, word)[0])
+
+
+@pytest.mark.parametrize("kind", ["triplet", "bce"])
+def test_one_launch_loss_head_deferred_finish(cuda, kind):
+    """``LossHeadSpec.defer_finish`` (a captured training step's form): the forward leaves its per-block partial sums, the
+    backward launch -- one extra workgroup -- finishes the three losses into the forward's output and takes its scale
+    factors from the hinted gradient directly: same losses (once the backward has run) and same gradients as the form with
+    the finishing launch."""
+    from segger_amd import ops
+    from segger_amd.graph import csr_from_coo
+    g = torch.Generator().manual_seed(3)
+    n, nb, e, C = 7001, 90, 2500, 64
+    y0 = torch.randn(n, C, generator=g).bfloat16()
+    yb0 = torch.randn(nb, C, generator=g).bfloat16()
+    pos, neg = torch.randint(0, n, (n,), generator=g), torch.randint(0, n, (n,), generator=g)
+    pos[::9] = -1
+    bpos, bneg = torch.randint(0, nb, (nb,), generator=g), torch.randint(0, nb, (nb,), generator=g)
+    dp, dn, w = torch.rand(nb, generator=g), torch.rand(nb, generator=g), torch.full((nb,), 1.0 / nb)
+    src = torch.randperm(n, generator=g)[:e]
+    dst = torch.randint(0, nb, (e,), generator=g)
+    dneg = (dst + torch.randint(1, nb, (e,), generator=g)) % nb
+    groups = csr_from_coo(dst.to(cuda), src.to(cuda), nb, n, validate=False)
+    a, b = torch.tensor([1.2, 1.0, 0.8], device=cuda), torch.tensor([0.5, 0.2, 0.3], device=cuda)
+    hint = torch.tensor([0.0, 0.0, 0.0, 1.0], device=cuda)
+    out = {}
+    for defer in (False, True):
+        y, yb = y0.to(cuda).requires_grad_(True), yb0.to(cuda).requires_grad_(True)
+        zs = ops.l2_normalize_many({"tx": y, "bd": yb})
+        spec = ops.LossHeadSpec((torch.arange(n, device=cuda), pos.to(cuda), neg.to(cuda), 0.3, 1e-6),
+                                (bpos.to(cuda), bneg.to(cuda), dp.to(cuda), dn.to(cuda), w.to(cuda), 1e-8),
+                                (src.to(cuda), dst.to(cuda), dneg.to(cuda), 0.4, 1e-6, groups, True), sg_kind=kind,
+                                tx_anchors_are_rows=True, grad_out_hint=hint)
+        spec.defer_finish = defer
+        res = ops.loss_head(zs["tx"], zs["bd"], a, b, spec)
+        res.backward(hint)
+        out[defer] = (res.detach().clone(), y.grad.float().clone(), yb.grad.float().clone())
+    assert torch.equal(out[True][0], out[False][0])                   # same partial sums, same fixed-order finish
+    assert out[False][0][3] > 0
+    for k in (1, 2):
+        scale = out[False][k].abs().max().item()
+        assert (out[True][k] - out[False][k]).abs().max().item() <= 2e-2 * scale
