@@ -339,11 +339,6 @@ def gatv2_bwd_pair_launch(first: tuple, first_kw: dict, second: tuple, second_kw
     return (gp_a[0], gp_a[1]), (gp_b[0], gp_b[1])
 
 
-import os as _os
-_EXP_INTERLEAVE = bool(int(_os.environ.get("SEGGER_EXP_INTERLEAVE", "0")))
-_EXP_INTERLEAVE_BUF: dict = {}
-
-
 def _gat_bwd_args(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optional[Tensor],
                   heads: int, channels: int, grad_out: Tensor, pre: Tensor, lse: Tensor,
                   grad_xl: Tensor, grad_xr: Tensor, *, apply_gelu: bool, negative_slope: float = 0.2,
@@ -386,16 +381,6 @@ def _gat_bwd_args(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optio
     a.pre, a.ld_pre = _rows(pre, hc, "pre")
     a.lse = lse.data_ptr()
     grad_pre = torch.empty((n_dst, hc), dtype=dt, device=dev)
-    if _EXP_INTERLEAVE and g.by_src is not None:
-        # bounding experiment (tools/bench_gat.py, VERDICT r3 task 7 i): x_r and grad_pre as the two halves of ONE [n_dst, 2 HC]
-        # row, so that the source pass's two gathers per edge hit adjacent 256-byte halves (the copy of x_r is made once
-        # per x_r buffer and kept: what the destination pass would write on its way)
-        hit = _EXP_INTERLEAVE_BUF.get(xr.data_ptr())
-        if hit is None or hit.shape != (n_dst, 2 * hc) or hit.dtype != dt:
-            hit = _EXP_INTERLEAVE_BUF[xr.data_ptr()] = torch.empty((n_dst, 2 * hc), dtype=dt, device=dev)
-            hit[:, :hc].copy_(xr)
-        xr, grad_pre = hit[:, :hc], hit[:, hc:]
-        a.x_r, a.ld_xr = _rows(xr, hc, "x_r")
     dsum = torch.empty((n_dst, heads, 2), dtype=torch.float32, device=dev)     # (lse, D) pairs for the source pass
     a.grad_pre, a.ld_gp = _rows(grad_pre, hc, "grad_pre")
     a.dsum = dsum.data_ptr()
