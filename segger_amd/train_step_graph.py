@@ -140,6 +140,7 @@ class GraphedTrainStep:
         self._grads: list = []
         self._training: Optional[bool] = None
         self._iota = torch.arange(nt, device=dev)
+        self._captured_hp = None
         self._late = (0, False)                               # (dropout-counter advance owed to the step's end, Adam's counters advanced)
         self._warming = False
         # The captured forward runs on ALIASES of the parameters (same storage, distinct autograd leaves).  A leaf's
@@ -403,10 +404,20 @@ class GraphedTrainStep:
                     old = state[id(p)].get(k)
                     v.zero_() if old is None else v.copy_(old)
 
+    def _hyper(self) -> tuple:
+        """The optimizer hyper-parameters a capture bakes into its kernel arguments (segger_adam_step takes lr / betas / eps by
+        value): a scheduler or a manual change of ``param_groups`` between steps must trigger a new capture, not be ignored."""
+        return tuple((g["lr"] if not isinstance(g["lr"], Tensor) else id(g["lr"]), tuple(g["betas"]), g["eps"],
+                      g.get("weight_decay", 0)) for g in self.opt.param_groups)
+
     def step(self, batch, capture: bool = True) -> Tensor:
-        """-> [loss_tx, loss_bd, loss_sg, loss] (a static device tensor, overwritten by the next step)."""
+        """-> [loss_tx, loss_bd, loss_sg, loss] (a static device tensor, overwritten by the next step).  Optimizer step
+        hooks (``register_step_pre_hook`` / ``_post_hook``) do not run inside a replay; a changed learning rate / betas / eps
+        re-captures the bucket."""
         lit = self.lit
         self.stage(batch)
+        if self.graph is not None and self._captured_hp != self._hyper():
+            self.graph = self.graph_opt = None                # (the old graphs' memory returns to the pool with them)
         if not capture:
             self._run()
         elif self.graph is None or self._training != lit.model.training:
@@ -442,6 +453,7 @@ class GraphedTrainStep:
             self._pack_refs = [(pk, pk.w, pk.b, pk._wt) for pk in ops.packs_of(aliases)]
             self._grads = [p.grad for p in self._params]
             self._training = lit.model.training
+            self._captured_hp = self._hyper()
             self._replay()                                    # (capturing runs nothing)
         else:
             self._replay()

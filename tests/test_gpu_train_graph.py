@@ -423,3 +423,29 @@ def test_merged_draws_step_equals_separate_draws_step(cuda, monkeypatch):
     assert a[1] == b[1] == 256 * 9 and a[2] == b[2] == 9.0
     assert torch.allclose(a[0], b[0], rtol=2e-3, atol=1e-5), (a[0] - b[0]).abs().max()
     assert (a[3] - b[3]).abs().max().item() <= 2e-3 * b[3].abs().max().item()
+
+
+def test_captured_step_follows_a_changed_learning_rate(cuda):
+    """segger_adam_step takes lr / betas / eps by value, so a captured graph has them baked in: changing the learning rate
+    between steps (an LR scheduler) must re-capture the bucket -- with lr = 0 the parameters stop moving."""
+    from segger_amd import tiles as T
+    from segger_amd.synthetic import SyntheticSpec
+    from segger_amd.train_step_graph import GraphedTrainer
+    spec = SyntheticSpec(n_tx=12000, n_bd=300, k_tx=6, seed=43)
+    m, bg = _model(spec, cuda, torch.float32)
+    opt = m.configure_optimizers(capturable=True)
+    trainer = GraphedTrainer(m, opt, granularity=1.5)
+    trainer.step(bg); trainer.step(bg)
+    assert trainer.n_captures == 1 and trainer.buckets[0].graph is not None
+    before = torch.cat([p.detach().reshape(-1).clone() for p in m.parameters()])
+    first_graph = trainer.buckets[0].graph
+    for g in opt.param_groups:
+        g["lr"] = 0.0
+    trainer.step(bg)
+    after = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    assert trainer.buckets[0].graph is not first_graph          # re-captured
+    assert torch.equal(before, after)                           # and the new rate was used
+    for g in opt.param_groups:
+        g["lr"] = 1e-3
+    trainer.step(bg)
+    assert not torch.equal(before, torch.cat([p.detach().reshape(-1) for p in m.parameters()]))

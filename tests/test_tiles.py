@@ -266,3 +266,38 @@ def test_single_tile_batches_are_read_only_views_and_the_checksum_sees_a_write(g
     t = next(t for t in range(len(part)) if part.tile(t)[("tx", "neighbors", "tx")].edge_index.numel())
     part.tile(t)[("tx", "neighbors", "tx")].edge_index.add_(1)           # what a consumer must NOT do
     assert part.checksum() != before
+
+
+def test_fov_graph_subset_is_the_induced_subgraph():
+    """``synthetic.fov_graph`` with node subsets (what a data-parallel rank assembles from its own tiles' nodes and edges,
+    ``fov.build_fov_shard``): node attributes are the selected rows, ``index`` keeps the GLOBAL ids, and edges given in
+    global ids come back in the subset's numbering -- the induced subgraph of the full graph."""
+    from segger_amd.hetero import TX_BD, TX_NB_BD, TX_TX
+    from segger_amd.synthetic import fov_graph
+    g = torch.Generator().manual_seed(4)
+    nt, nb, G = 200, 30, 16
+    nodes = dict(centres=torch.rand(nb, 2, generator=g), bd_type=torch.randint(0, 4, (nb,), generator=g),
+                 bd_x=torch.randn(nb, 8, generator=g), cell=torch.randint(0, nb, (nt,), generator=g),
+                 pos=torch.rand(nt, 2, generator=g), gene=torch.randint(0, G, (nt,), generator=g),
+                 gene_cluster=torch.randint(0, 4, (G,), generator=g), aux={})
+    tx_ids = torch.arange(nt)[torch.rand(nt, generator=g) < 0.4]
+    bd_ids = torch.arange(nb)[torch.rand(nb, generator=g) < 0.5]
+    keep_t, keep_b = torch.zeros(nt, dtype=torch.bool), torch.zeros(nb, dtype=torch.bool)
+    keep_t[tx_ids] = True; keep_b[bd_ids] = True
+    ett = torch.randint(0, nt, (2, 900), generator=g)
+    etb = torch.stack([torch.randint(0, nt, (300,), generator=g), torch.randint(0, nb, (300,), generator=g)])
+    ep = torch.stack([torch.randint(0, nt, (400,), generator=g), torch.randint(0, nb, (400,), generator=g)])
+    full = fov_graph(nodes, (ett, etb, ep))
+    sub_edges = (ett[:, keep_t[ett[0]] & keep_t[ett[1]]], etb[:, keep_t[etb[0]] & keep_b[etb[1]]], ep[:, keep_t[ep[0]] & keep_b[ep[1]]])
+    sub = fov_graph(nodes, sub_edges, tx_ids, bd_ids)
+    assert torch.equal(full["tx"]["index"], torch.arange(nt)) and torch.equal(sub["tx"]["index"], tx_ids)
+    assert torch.equal(sub["bd"]["index"].long(), bd_ids)
+    for a in ("x", "pos", "cluster", "cell"):
+        assert torch.equal(sub["tx"][a], full["tx"][a][tx_ids]), a
+    for a in ("x", "pos", "cluster"):
+        assert torch.equal(sub["bd"][a], full["bd"][a][bd_ids]), a
+    for et, e_glob, (ids_s, ids_d) in ((TX_TX, sub_edges[0], (tx_ids, tx_ids)), (TX_BD, sub_edges[1], (tx_ids, bd_ids)),
+                                      (TX_NB_BD, sub_edges[2], (tx_ids, bd_ids))):
+        loc = sub[et].edge_index
+        assert loc.shape == e_glob.shape
+        assert torch.equal(ids_s[loc[0]], e_glob[0]) and torch.equal(ids_d[loc[1]], e_glob[1])
