@@ -674,9 +674,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
                                                            float* __restrict__ grad_w, float* __restrict__ grad_b) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= width) return;
-  float t = 0.f;
-#pragma unroll 8
-  for (int g = 0; g < kRedGroups; ++g) t += part2[(int64_t)g * width + e];
+  // (the order of reduce_many_kernel over the same 32 groups, csrc/reduce.hip: a sum comes out bit-identical whether it
+  // was launched here or queued and flushed with others)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+  for (int g = 0; g < kRedGroups; g += 4) {
+    s0 += part2[(int64_t)g * width + e];       s1 += part2[(int64_t)(g + 1) * width + e];
+    s2 += part2[(int64_t)(g + 2) * width + e]; s3 += part2[(int64_t)(g + 3) * width + e];
+  }
+  const float t = (s0 + s1) + (s2 + s3);
   if (e < mk) grad_w[e] = t;
   else if (grad_b) grad_b[e - mk] = t;
 }
