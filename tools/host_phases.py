@@ -46,6 +46,25 @@ for name in ("adam_step", "_refresh_stale_packs", "stage", "triplet_sample", "sa
              "rows_by_id", "segment_minmax"):
     setattr(ops, name, timed(name, getattr(ops, name)))
 
+# PROFILE_FN=_HeteroGatLayer.backward : cProfile INSIDE that function (on whichever thread runs it), printed at the end
+prof = None
+if os.environ.get("PROFILE_FN"):
+    import cProfile, pstats, io
+    cname, mname = os.environ["PROFILE_FN"].split(".")
+    cls = getattr(ops, cname)
+    inner = getattr(cls, mname)
+    prof = cProfile.Profile()
+
+    def profiled(*a, **k):
+        if not on[0]:
+            return inner(*a, **k)
+        prof.enable()
+        try:
+            return inner(*a, **k)
+        finally:
+            prof.disable()
+    setattr(cls, mname, staticmethod(profiled))
+
 phases = collections.defaultdict(float)
 
 
@@ -79,3 +98,7 @@ for k, v in phases.items():
 print("per function (host, us / step; calls / step):")
 for k, (c, s) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
     print(f"  {k:40s} {s / n * 1e6:8.1f}   {c / n:5.1f}")
+if prof is not None:
+    st = io.StringIO()
+    pstats.Stats(prof, stream=st).sort_stats("tottime").print_stats(25)
+    print("\n".join(l[:140] for l in st.getvalue().splitlines()))
