@@ -279,3 +279,35 @@ def test_shard_residency_persistent_bucket_and_vote_world2():
     for r in res:
         assert r["flat_ptr_stable"] and r["grads_are_views"] and r["mean_ok"] and r["zero_ok"]
         assert r["entered_after_no_vote"] is False and r["agree_when_all_ok"] is True and r["alive"] == 2.0
+
+
+def _disagree_worker(rank, world, port, out):
+    """Ranks that hold DIFFERENT batch lists (a bug upstream) must fail loudly before the first step, not deadlock in a
+    mismatched collective half-way through the epoch."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from segger_amd.dp import strong_scaling_epoch
+    weights = [5.0, 4.0, 3.0, 2.0] if rank == 0 else [5.0, 4.0, 3.0, 2.0, 1.0, 1.0]      # 2 vs 3 steps per rank
+    steps = []
+    try:
+        strong_scaling_epoch(weights, lambda k, i: steps.append(k), units=None)
+        res = "no error"
+    except RuntimeError as e:
+        res = str(e)
+    out.put((rank, res, len(steps)))
+    dist.destroy_process_group()
+
+
+def test_strong_epoch_refuses_ranks_that_disagree_on_the_schedule():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_disagree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, res, n_steps in got:
+        assert "do not agree on the batch list" in res and n_steps == 0, (rank, res)
