@@ -74,6 +74,9 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+RESULT_OUT = sys.stdout        # main() swaps it for a duplicate of the real stdout and points fd 1 at stderr
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -296,20 +299,96 @@ def hip_edge_scores(model, batch, dtype):
     return sim.float()
 
 
-def _auroc_entry(scores_hip, scores_oracle, labels, a_oracle):
+ATOL_16 = 2e-2                  # bf16 / fp16 atol 2e-2 on cosine scores
+FRAC_OVER_BOUND_16 = 2e-3       # share of edges allowed beyond it (16-bit storage; see DESIGN.md 1 for where they come from)
+
+
+def _over_atol(d, ref, name):
+    """Per-edge miss of SURVEY.md 8(d)'s elementwise bar: fp32 rtol 1e-5 / atol 1e-6 (x10: 4 layers of fp32 sums in another
+    order), 16-bit atol 2e-2."""
+    return d > (1e-5 * ref.abs() + 1e-5 if name == "f32" else ATOL_16)
+
+
+def _auroc_entry(scores_hip, scores_oracle, labels, a_oracle, name="f32"):
     from segger_amd.metrics import auroc
     a = auroc(scores_hip, labels)
     d = (scores_hip - scores_oracle).abs()
+    frac = float(_over_atol(d, scores_oracle, name).float().mean())
+    bound = 0.0 if name == "f32" else FRAC_OVER_BOUND_16
     return {"hip": a, "oracle": a_oracle, "delta": abs(a - a_oracle), "max_abs_score_diff": float(d.max()),
-            "mean_abs_score_diff": float(d.mean())}
+            "mean_abs_score_diff": float(d.mean()), "frac_over_atol": frac, "frac_over_atol_bound": bound,
+            "atol": "1e-5*|ref|+1e-5" if name == "f32" else ATOL_16,
+            "met": bool(abs(a - a_oracle) <= 1e-3 and frac <= bound)}
+
+
+@torch.no_grad()
+def elementwise_diag(model, b, bc, sd, s_or, trace_or, dev, dtype=torch.bfloat16, top=10):
+    """Where the 16-bit per-edge score differences come from (weights = ``model``'s, tile = ``b``): the HIP path at
+    ``dtype`` against the fp32 oracle layer by layer, the same against the oracle's OWN arithmetic with 16-bit activation
+    storage (``storage_round``: no HIP kernel involved), and the ``top`` worst edges with the pre-normalisation norms of
+    their endpoints."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import segger_oracle as O
+    from segger_amd import TX_NB_BD
+    ei = bc[TX_NB_BD].edge_index
+    # (1) the oracle with its activations stored in `dtype`
+    trace16 = {}
+    z16 = O.ist_encoder_forward(sd, bc.x_dict, bc.edge_index_dict, bc.pos_dict, bc.batch_dict, n_heads=2, storage_round=dtype,
+                                trace=trace16)
+    s16 = O.edge_scores(z16["tx"], z16["bd"], ei).float().to(dev)
+    d16 = (s16 - s_or).abs()
+    # (2) the HIP path at `dtype`, activations captured after every layer and before the normalisation
+    enc = model.model
+    seen, hooks = {}, []
+    for li, layer in enumerate(enc.conv_layers):
+        hooks.append(layer.register_forward_hook(lambda m, a, out, li=li: seen.__setitem__(f"layer{li}", out)))
+    keep_dt, keep_n = enc.compute_dtype, enc.normalize_embeddings
+    enc.compute_dtype, enc.normalize_embeddings = dtype, False
+    try:
+        seen["pre_norm"] = model.forward(b)
+    finally:
+        enc.compute_dtype, enc.normalize_embeddings = keep_dt, keep_n
+        for h in hooks:
+            h.remove()
+    s_hip = hip_edge_scores(model, b, dtype)
+    s_f32 = hip_edge_scores(model, b, torch.float32)
+    per_layer = {}
+    for name, got in seen.items():
+        ref = trace_or[name]
+        per_layer[name] = {k: {"hip_16": float((got[k].float().cpu() - ref[k]).abs().max()),
+                               "oracle_16bit_storage": float((trace16[name][k] - ref[k]).abs().max()),
+                               "ref_max_abs": float(ref[k].abs().max())} for k in ("tx", "bd")}
+    n_tx_pre = trace_or["pre_norm"]["tx"].norm(dim=-1)
+    n_bd_pre = trace_or["pre_norm"]["bd"].norm(dim=-1)
+    d = (s_hip - s_or).abs()
+    worst = torch.topk(d, min(top, d.numel())).indices.cpu()
+    rows = []
+    for e in worst.tolist():
+        i, j = int(ei[0, e]), int(ei[1, e])
+        rows.append({"edge": e, "tx": i, "bd": j, "oracle": float(s_or[e]), "hip_f32": float(s_f32[e]), "hip_16": float(s_hip[e]),
+                     "oracle_16bit_storage": float(s16[e]), "pre_norm_tx": float(n_tx_pre[i]), "pre_norm_bd": float(n_bd_pre[j])})
+    over = _over_atol(d, s_or, "bf16")
+    over16 = _over_atol(d16, s_or, "bf16")
+    return {"dtype": str(dtype).replace("torch.", ""),
+            "oracle_with_16bit_storage_vs_oracle": {"max_abs_score_diff": float(d16.max()), "mean_abs_score_diff": float(d16.mean()),
+                                                    "frac_over_atol": float(over16.float().mean())},
+            "hip_16_vs_oracle_with_16bit_storage": {"max_abs_score_diff": float((s_hip - s16).abs().max()),
+                                                    "mean_abs_score_diff": float((s_hip - s16).abs().mean())},
+            "edges_over_atol_in_both": int((over & over16).sum()), "edges_over_atol_hip": int(over.sum()),
+            "edges_over_atol_oracle_16bit_storage": int(over16.sum()),
+            "pre_norm_row_norm_quantiles_tx": [float(q) for q in torch.quantile(n_tx_pre.float(), torch.tensor([0.0, 0.01, 0.5, 1.0]))],
+            "median_pre_norm_tx_of_edges_over_atol": float(n_tx_pre[ei[0][over.cpu()]].median()) if bool(over.any()) else None,
+            "per_layer_max_abs_diff_vs_oracle": per_layer, "worst_edges": rows[:5]}
 
 
 def auroc_vs_oracle(ctx, dev, trained=None):
     """The AUROC half of the headline metric (BASELINE.json: "AUROC vs ref"): the HIP encoder with the oracle's own
     seed-0 weights on the oracle's own C2/10 tile, candidate edges ranked by cosine score against label = "the
-    candidate is the transcript's true nucleus" (SURVEY.md 8(d)); bar |dAUROC| <= 1e-3.  The oracle's scores come from
-    the ``cpu_baseline`` leg (checker only).  ``trained``: the benchmark model after its timed steps -- the same tile
-    scored once more by both sides with THOSE weights (untrained weights rank at chance, AUROC 0.50)."""
+    candidate is the transcript's true nucleus" (SURVEY.md 8(d)); bars: |dAUROC| <= 1e-3 AND the share of edges whose score
+    misses SURVEY.md 8(d)'s elementwise tolerance (``frac_over_atol``) <= ``frac_over_atol_bound``.  The oracle's scores
+    come from the ``cpu_baseline`` leg (checker only).  ``trained``: the benchmark model after its timed steps -- the same
+    tile scored once more by both sides with THOSE weights (untrained weights rank at chance, AUROC 0.50), with
+    ``elementwise`` = :func:`elementwise_diag` of the bf16 leg."""
     from segger_amd import LitISTEncoder
     from segger_amd.metrics import auroc
     spec, b = ctx["spec"], ctx["batch"].to(dev)
@@ -321,28 +400,34 @@ def auroc_vs_oracle(ctx, dev, trained=None):
     s_or = ctx["oracle_scores"].to(dev)
     a_or = auroc(s_or, lab)
     out = {"what": "edge-AUROC of tx-neighbors-bd cosine scores, HIP path vs the CPU oracle (fp32), identical weights "
-                   "and inputs; bar: delta <= 1e-3", "tile": ctx["tile"], "n_edges": int(lab.numel()),
-           "positives": int(lab.sum()), "dtype": {}}
+                   "and inputs; bars: delta <= 1e-3 and frac_over_atol <= frac_over_atol_bound", "tile": ctx["tile"],
+           "n_edges": int(lab.numel()), "positives": int(lab.sum()), "dtype": {}}
     for name in ("f32", "bf16", "f16"):
-        out["dtype"][name] = _auroc_entry(hip_edge_scores(m, b, _DT[name]), s_or, lab, a_or)
-    out["met"] = all(v["delta"] <= 1e-3 for v in out["dtype"].values())
+        out["dtype"][name] = _auroc_entry(hip_edge_scores(m, b, _DT[name]), s_or, lab, a_or, name)
+    out["met"] = all(v["met"] for v in out["dtype"].values())
     if trained is not None:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import segger_oracle as O
         sd = {k: v.detach().float().cpu() for k, v in trained.state_dict().items()}
         bc = ctx["batch"]
         torch.set_num_threads(host_threads())
+        trace = {}
         with torch.no_grad():
-            z = O.ist_encoder_forward(sd, bc.x_dict, bc.edge_index_dict, bc.pos_dict, bc.batch_dict, n_heads=2)
+            z = O.ist_encoder_forward(sd, bc.x_dict, bc.edge_index_dict, bc.pos_dict, bc.batch_dict, n_heads=2, trace=trace)
             s_tr = O.edge_scores(z["tx"], z["bd"], bc[O.TX_NB_BD].edge_index).float().to(dev)
         a_tr = auroc(s_tr, lab)
         was_training = trained.training
         trained.eval()
         out["trained_weights"] = {"what": "same tile, weights of the benchmark model after its timed C2 steps and FOV epochs",
-                                  "dtype": {n: _auroc_entry(hip_edge_scores(trained, b, _DT[n]), s_tr, lab, a_tr)
+                                  "dtype": {n: _auroc_entry(hip_edge_scores(trained, b, _DT[n]), s_tr, lab, a_tr, n)
                                             for n in ("f32", "bf16", "f16")}}
+        try:
+            out["trained_weights"]["elementwise"] = elementwise_diag(trained, b, bc, sd, s_tr, trace, dev)
+        except Exception as e:  # noqa: BLE001  (diagnostic only)
+            out["trained_weights"]["elementwise"] = {"error": f"{type(e).__name__}: {e}"}
         trained.train(was_training)
-        out["met"] = out["met"] and all(v["delta"] <= 1e-3 for v in out["trained_weights"]["dtype"].values())
+        out["trained_weights"]["met"] = all(v["met"] for v in out["trained_weights"]["dtype"].values())
+        out["met"] = out["met"] and out["trained_weights"]["met"]
     return out
 
 
@@ -383,8 +468,8 @@ def fov_tiles_auroc(model, part, dev, n_tiles=8, seed=1):
     out = {"what": f"{len(sample)} seeded random tiles of the resident FOV, weights as the timed epochs left them",
            "tiles": sample, "n_edges": int(lab.numel()), "positives": int(lab.sum()), "oracle_seconds": t_or, "dtype": {}}
     for name in _DT:
-        out["dtype"][name] = _auroc_entry(cat[name], cat["oracle"], lab, a_or)
-    out["met"] = all(v["delta"] <= 1e-3 for v in out["dtype"].values())
+        out["dtype"][name] = _auroc_entry(cat[name], cat["oracle"], lab, a_or, name)
+    out["met"] = all(v["met"] for v in out["dtype"].values())
     return out
 
 
@@ -464,6 +549,125 @@ def c5_record(model, part, batches, data, tiling, bd_dim, dev, margin=10.0, spot
     return out
 
 
+def graphed_dp_world1(model, gopt, part, local_batches, weights_all, units_of, dev, backend, ms_graphed):
+    """The captured step in its data-parallel form on ONE rank: graph (forward + backward + pack into the persistent flat
+    buffer) | eager ``all_reduce`` on a one-rank RCCL communicator + divide | graph (Adam) -- the per-step cost N > 1 adds
+    before any xGMI time.  A process group is created for this phase only and destroyed after it."""
+    import socket
+    from segger_amd.dp import FlatGradBucket, strong_scaling_epoch
+    from segger_amd.train_step_graph import GraphedTrainer
+    made = False
+    if not dist.is_initialized():
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ["MASTER_PORT"] = str(port)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=0, world_size=1)
+        made = True
+    try:
+        bk = FlatGradBucket(model.parameters(), force_collective=True)
+        tr = GraphedTrainer(model, gopt, grad_bucket=bk)
+        rec = strong_scaling_epoch(weights_all, lambda k, i: tr.step(part.batch(local_batches[k]) if k is not None else None),
+                                   lambda k: units_of[k], sync=torch.cuda.synchronize, device=dev, warmup=-1)
+        # the collective alone, as the step issues it (same buffer, same stream)
+        ms_ar = time_kernel(lambda: bk.all_reduce_mean(packed=True), iters=200, warm=20)
+        etb_g, _ = rec["units_total"]
+        ms = rec["epoch_s"] / max(rec["steps_per_rank"], 1) * 1e3
+        kinds = sorted({(b.graph is not None, b.graph_opt is not None) for b in tr.buckets})
+        out = {"what": "the same second epoch through the N > 1 route at world size 1: two hipGraphs per step around one "
+                       f"forced {dist.get_backend()} all-reduce (+ divide) of the persistent flat fp32 gradient buffer "
+                       f"({bk.numel * 4} bytes); no xGMI hop in it",
+               "backend": dist.get_backend(), "world_size": dist.get_world_size(), "two_graphs": kinds == [(True, True)],
+               "value": 2.0 * etb_g / rec["epoch_s"], "unit": "edges/s", "epoch_s": rec["epoch_s"], "ms_per_step": ms,
+               "overhead_ms_per_step_vs_graphed": ms - ms_graphed, "allreduce_plus_divide_ms": ms_ar,
+               "shape_buckets": len(tr.buckets), "flat_bucket_bytes": bk.numel * 4}
+        del tr
+        return out
+    finally:
+        if made:
+            dist.destroy_process_group()
+
+
+def predicted_schedule(weights, strong, worlds=(2, 4, 8)):
+    """What ``dp.rank_schedule`` does with THIS batch list at N ranks.  ``imbalance`` = heaviest rank's edge count / the mean
+    (what bounds an epoch without per-step synchronisation); ``sync_imbalance`` = sum over steps of the heaviest batch of the
+    step / the mean rank load (every step ends in an all-reduce, so each step costs its slowest rank; time taken as
+    proportional to the packed edge count).  ``predicted_speedup`` = N / sync_imbalance x (captured step / captured
+    data-parallel step at world 1): an upper bound -- the all-reduce's xGMI time at N > 1 is not in it (unmeasured)."""
+    from segger_amd.dp import rank_schedule
+    out = {}
+    g, d = strong.get("graphed") or {}, strong.get("graphed_dp_world1") or {}
+    route = (g.get("ms_per_step") / d["ms_per_step"]) if g.get("ms_per_step") and d.get("ms_per_step") else None
+    for n in worlds:
+        sched = rank_schedule(weights, n)
+        loads = [sum(weights[k] for k in r if k is not None) for r in sched]
+        mean = sum(loads) / n
+        steps = len(sched[0])
+        sync = sum(max((weights[r[i]] if r[i] is not None else 0.0) for r in sched) for i in range(steps))
+        out[str(n)] = {"steps_per_rank": steps, "imbalance": max(loads) / mean, "sync_imbalance": sync / mean,
+                       "empty_steps": sum(1 for r in sched for k in r if k is None),
+                       "predicted_speedup": None if route is None else n / (sync / mean) * route}
+    out["note"] = ("from dp.rank_schedule on the real batch list; predicted_speedup is relative to strong.graphed at N = 1 and "
+                   "leaves out the xGMI time of the 1.6 MB all-reduce (latency-bound; unmeasured on hardware)")
+    return out
+
+
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` with no launcher environment: this process becomes the PARENT of the job.  It never
+    initialises a GPU (``torch.cuda.device_count()`` does not, ``is_available()`` would) -- it checks that N devices are
+    visible, starts ``python -m torch.distributed.run --nproc-per-node N bench.py <the same arguments>`` as a CHILD process
+    (never an exec), lets rank 0's JSON line through on the inherited stdout and returns the children's exit code."""
+    import socket
+    import subprocess
+    n = args.gpus
+    need_gpu = not (args.dry_launch and args.backend != "nccl")
+    if need_gpu:
+        seen = torch.cuda.device_count()
+        if seen < n and not (args.allow_shared_gpu and seen >= 1 and args.backend != "nccl"):
+            log(f"[bench] --gpus {n} but only {seen} GPU(s) visible: refusing to run (a line with n_gpus < {n} would be "
+                f"mistaken for the {n}-GPU result)")
+            return 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_threads() // n)))
+    log(f"[bench] self-launch: {n} ranks on 127.0.0.1:{port}")
+    # the children's stdout is filtered: JSON lines (rank 0's result) pass to stdout, anything else a library prints
+    # there (gloo's connection banner does) goes to stderr -- stdout stays ONE JSON line
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:
+        if line.lstrip().startswith("{") and line.rstrip().endswith("}"):
+            sys.stdout.write(line); sys.stdout.flush()
+        else:
+            sys.stderr.write(line); sys.stderr.flush()
+    return proc.wait()
+
+
+def dry_launch(args, rank, local_rank, world) -> int:
+    """The launch path without the workload: join the group, all-reduce the rank census, rank 0 prints one JSON line."""
+    from segger_amd.dp import rank_census
+    dev = None
+    if args.backend == "nccl":
+        dev = torch.device("cuda", local_rank % max(torch.cuda.device_count(), 1))
+        torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend, **({"device_id": dev} if dev is not None else {}))
+    rec = rank_census(dev)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "backend": args.backend, "census": rec["census"],
+                          "n_ranks_seen": rec["n_ranks_seen"], "launched_by": os.environ.get("TORCHELASTIC_RUN_ID") and "torch.distributed.run"}),
+              file=RESULT_OUT, flush=True)
+    return 0 if rec["n_ranks_seen"] == world else 3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -482,20 +686,39 @@ def main():
     ap.add_argument("--strong-edges-per-batch", type=int, default=1_000_000,
                     help="segger's edges_per_batch default (data_module.py:158)")
     ap.add_argument("--no-c5", action="store_true", help="skip the config-5 record (fp16 hipGraph predict sweeps over the FOV)")
+    ap.add_argument("--no-c5-100m", action="store_true", help="skip the config-5 record at BASELINE's own size (100M tx)")
+    ap.add_argument("--c5-n-tx", type=int, default=100_000_000, help="transcripts of the inference-only FOV (BASELINE C5)")
+    ap.add_argument("--c5-edges-per-batch", type=int, default=16_000_000)
     ap.add_argument("--no-default-dropin", action="store_true", help="skip the fp32 + eager + 1M-edge-batch record")
     ap.add_argument("--auroc-tiles", type=int, default=8, help="FOV tiles scored by the oracle for auroc.fov_tiles")
     ap.add_argument("--no-dropout", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for dry runs)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch check only: every rank joins the process group, the census is all-reduced, rank 0 prints "
+                         "{n_gpus, census, ...}; no model, and with --backend gloo no GPU")
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="let several ranks share a GPU when fewer than --gpus are visible (gloo rehearsals on a one-GPU box)")
     args = ap.parse_args()
     if os.environ.get("SEGGER_BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack each N seconds
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["SEGGER_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))                 # parent: starts the N ranks, never touches a GPU itself
+    # stdout carries ONE JSON line: anything a native library prints there (RCCL's version banner at communicator creation
+    # does) is sent to stderr -- fd 1 becomes fd 2, the real stdout is kept for the result
+    global RESULT_OUT
+    sys.stdout.flush()
+    RESULT_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; start it as "
+                         f"`python bench.py --gpus N` (it launches its own ranks) or with --nproc-per-node equal to --gpus")
+    if args.dry_launch:
+        raise SystemExit(dry_launch(args, rank, local_rank, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU fallback")
     dev_id = local_rank % torch.cuda.device_count()      # == local_rank on a real N-GPU launch
@@ -720,7 +943,7 @@ def main():
 
     # ---- strong scaling: ONE fixed FOV streamed as packed tile batches over all ranks (BASELINE config 4) ----
     strong = None
-    auroc_fov = c5 = default_dropin = None
+    auroc_fov = c5 = c5_100m = default_dropin = None
     if not args.no_strong:
         from segger_amd.dp import seed_rank, strong_scaling_epoch
         from segger_amd.fov import batch_weights, build_fov_batches
@@ -858,7 +1081,17 @@ def main():
         else:
             strong["graphed"] = {"value": None, "error": err or "another rank failed its pre-flight"}
         del trainer
+        # ---- what ONE GPU can measure of N > 1: the data-parallel route's per-step overhead (two graphs + one RCCL
+        # all-reduce + divide between them, here on a one-rank communicator) and the schedule's predicted imbalance ----
+        if rank == 0 and world == 1 and strong["graphed"].get("value"):
+            try:
+                strong["graphed_dp_world1"] = graphed_dp_world1(model, gopt, part, local_batches, weights_all, units_of, dev,
+                                                                args.backend, strong["graphed"]["ms_per_step"])
+                log(f"[bench] strong.graphed_dp_world1: {strong['graphed_dp_world1']}")
+            except Exception as e:  # noqa: BLE001  (single process: nobody waits in a collective)
+                strong["graphed_dp_world1"] = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
+            strong["predicted"] = predicted_schedule(weights_all, strong)
             log(f"[bench] strong: {strong}")
         # ---- AUROC vs the oracle on tiles of this FOV, and config 5 on it (single process only) -----------------------
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -876,6 +1109,32 @@ def main():
             except Exception as e:  # noqa: BLE001
                 c5 = {"error": f"{type(e).__name__}: {e}"}
         del part, batches, fov_data
+        # ---- config 5 at the size BASELINE.json names: 100M transcripts, fp16, hipGraph-captured batched predict -----------
+        if rank == 0 and world == 1 and not args.no_c5 and not args.no_c5_100m:
+            try:
+                local_batches = units_of = weights_all = None
+                torch.cuda.empty_cache()
+                torch.cuda.reset_peak_memory_stats()
+                t = time.perf_counter()
+                spec100 = SyntheticSpec(n_tx=args.c5_n_tx, n_bd=args.c5_n_tx // 100, k_tx=args.k, seed=0)
+                part100, batches100, _aux100, tiling100 = build_fov_batches(spec100, dev, edges_per_batch=args.c5_edges_per_batch)
+                torch.cuda.synchronize()
+                t_build = time.perf_counter() - t
+                c5_100m = c5_record(model, part100, batches100, None, tiling100, spec100.bd_dim, dev)
+                p100 = c5_100m.pop("packed_batches")
+                c5_100m.update({
+                    "workload": f"C5: {args.c5_n_tx} tx / {args.c5_n_tx // 100} nuclei, k={args.k}, {len(tiling100)} tiles packed into "
+                                f"{len(batches100)} batches of <= {args.c5_edges_per_batch} edges; inference only, fp16, one hipGraph "
+                                f"per shape bucket (first sweep captures, second is timed), weights as the training phases left them",
+                    "fov_build_s": t_build, "batches": p100["batches"], "capture_sweep_s": p100["capture_sweep_s"],
+                    "edges_scored": p100["edges_scored"], "transcripts_out": p100["transcripts_out"],
+                    "ms_per_batch": p100["ms_per_batch"], "spot_check": p100["spot_check"],
+                    "resident_bytes": part100.resident_bytes(), "peak_hbm_gib": torch.cuda.max_memory_allocated() / 2 ** 30})
+                log(f"[bench] c5_100m: {c5_100m}")
+                del part100, batches100, _aux100, tiling100
+            except Exception as e:  # noqa: BLE001
+                c5_100m = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
 
     cpu = None
     auroc = None
@@ -916,7 +1175,7 @@ def main():
             "roofline": roof, "roofline_other": extra, "cpu_baseline": cpu, "predict": predict,
             "f32": f32, "strong": strong,
             "auroc": None if auroc is None else dict(auroc, fov_tiles=auroc_fov),
-            "c5": c5, "default_dropin": default_dropin,
+            "c5": c5, "c5_100m": c5_100m, "default_dropin": default_dropin,
             "strong_value": None if not strong else strong.get("value"),
             "strong_graphed_value": None if not strong or not strong.get("graphed") else strong["graphed"].get("value"),
         }
@@ -925,7 +1184,7 @@ def main():
                                  + gat_fwd_algorithmic_bytes(etb, args.n_bd, 128, 2) + gat_bwd_algorithmic_bytes(etb, args.n_bd, args.n_tx, 128, 2, 2))
             res["step_algorithmic_frac"] = b_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS   # per GPU (weak scaling)
             res["step_algorithmic_bytes"] = b_step
-        print(json.dumps(res), flush=True)
+        print(json.dumps(res), file=RESULT_OUT, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

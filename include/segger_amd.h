@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 17
+#define SEGGER_ABI_VERSION 18
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -349,6 +349,13 @@ int segger_adam_step(const segger_adam_tensor* tensors, int32_t n_tensors, doubl
 #define SEGGER_ADAM_STEPS_ADVANCED 1
 int segger_adam_step_ex(const segger_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2, double eps,
                         int32_t flags, int64_t* counter, int64_t counter_inc, segger_stream_t stream);
+/* segger_adam_step_dev: segger_adam_step_ex with {lr, beta1, beta2, eps} read from a DEVICE array of four doubles when the
+ * kernel runs (not validated: the caller writes what its optimizer's param_group holds).  A captured training step keeps the
+ * array in its static buffers and refreshes it with the batch (segger_stage), so a learning-rate scheduler that changes
+ * `param_groups[0]["lr"]` every step (lightning_model.py:300-303 returns a bare Adam; schedulers are the user's) is followed
+ * by the replayed graph without a new capture. */
+int segger_adam_step_dev(const segger_adam_tensor* tensors, int32_t n_tensors, const double* hyper, int32_t flags,
+                         int64_t* counter, int64_t counter_inc, segger_stream_t stream);
 
 /* segger_transpose_many: dst [cols, rows] = src [rows, cols]^T for n_segs contiguous 16-bit matrices in one launch:
  * the W^T copies the data-gradient GEMMs (dX = dY W on segger_linear_fwd) need after every optimizer step. */

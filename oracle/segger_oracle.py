@@ -110,7 +110,7 @@ def gatv2_conv(
     att: Tensor, bias: Tensor, heads: int,
     negative_slope: float = 0.2,
     dropout_p: float = 0.0, dropout_keep: Optional[Tensor] = None,
-    return_alpha: bool = False,
+    return_alpha: bool = False, storage_round: Optional[torch.dtype] = None,
 ):
     """GATv2Conv.forward / edge_update / message / aggregate('add'), concat=True,
     residual=False, add_self_loops=False, share_weights=False.
@@ -126,6 +126,8 @@ def gatv2_conv(
     n_dst = x_dst.shape[0]
     x_l = (x_src @ lin_l_w.T + lin_l_b).view(-1, H, C)
     x_r = (x_dst @ lin_r_w.T + lin_r_b).view(-1, H, C)
+    if storage_round is not None:       # diagnostic only: the projections as a 16-bit store would keep them
+        x_l, x_r = x_l.to(storage_round).to(x_src.dtype), x_r.to(storage_round).to(x_src.dtype)
     x_j = x_l.index_select(0, src)
     x_i = x_r.index_select(0, dst)
     e = (F.leaky_relu(x_i + x_j, negative_slope) * att.view(1, H, C)).sum(-1)
@@ -154,8 +156,17 @@ def ist_encoder_forward(
     dropout_p: float = 0.0,
     dropout_keep: Optional[Dict[Tuple[int, Tuple[str, str, str]], Tensor]] = None,
     return_attention: bool = False,
+    trace: Optional[dict] = None,
+    storage_round: Optional[torch.dtype] = None,
 ):
     """Embed -> (+pos) -> GELU -> n x (HeteroConv(GATv2) -> GELU) -> lin_last -> L2.
+
+    ``trace`` (diagnostics): filled with ``input`` / ``layer{i}`` (the activations after each GELU) and ``pre_norm``
+    (lin_last's output before F.normalize).  ``storage_round`` (diagnostics): a model of THIS arithmetic with its
+    activations kept in a 16-bit type -- every tensor a layer hands to the next (and the GATv2 projections) and every
+    weight MATRIX (a GEMM operand) is rounded to that type and back; att, biases, accumulation and the softmax stay in
+    ``sd``'s dtype.  It answers "how far does
+    16-bit storage alone move the reference's own scores" (bench.py auroc.*.frac_over_atol, tools/bf16_miss.py).
 
     ``sd`` is a state dict with the reference's key names.
     HeteroConv(aggr='sum') runs the convs whose edge type is present in
@@ -164,7 +175,11 @@ def ist_encoder_forward(
     (data/utils/heterodata.py:138,147) so each sum has one term.
     """
     dt = sd[prefix + "lin_first.tx.weight"].dtype
-    g = lambda k: sd[prefix + k]
+    if storage_round is None:
+        g = lambda k: sd[prefix + k]
+    else:       # GEMM operands in the 16-bit type too (weight matrices; att / biases stay in fp32 as accumulators do)
+        g = lambda k: (sd[prefix + k].to(storage_round).to(dt) if k.endswith(".weight") and sd[prefix + k].dim() == 2
+                       else sd[prefix + k])
     x = {
         "tx": g("lin_first.tx.weight").index_select(0, x_dict["tx"].long()),   # :260,312
         "bd": x_dict["bd"].to(dt) @ g("lin_first.bd.weight").T + g("lin_first.bd.bias"),  # :261
@@ -176,6 +191,10 @@ def ist_encoder_forward(
             g("pos_emb.mlp.2.weight"), g("pos_emb.mlp.2.bias"))
         x = {k: torch.cat((v, pe(k)), -1) for k, v in x.items()}
     x = {k: F.gelu(v) for k, v in x.items()}                                    # :320
+    rnd = (lambda v: v) if storage_round is None else (lambda v: v.to(storage_round).to(dt))
+    x = {k: rnd(v) for k, v in x.items()}
+    if trace is not None:
+        trace["input"] = dict(x)
 
     n_layers = 0
     while (prefix + f"conv_layers.{n_layers}.conv.convs.{pyg_key(TX_TX)}.att") in sd:
@@ -193,12 +212,17 @@ def ist_encoder_forward(
                 g(p + "lin_l.weight"), g(p + "lin_l.bias"),
                 g(p + "lin_r.weight"), g(p + "lin_r.bias"),
                 g(p + "att").reshape(-1), g(p + "bias"), n_heads,
-                dropout_p=dropout_p, dropout_keep=keep, return_alpha=True)
+                dropout_p=dropout_p, dropout_keep=keep, return_alpha=True, storage_round=storage_round)
             outs.setdefault(et[2], []).append(o)
             attn[(li, et)] = a
-        x = {k: F.gelu(torch.stack(v, 0).sum(0)) for k, v in outs.items()}
+        x = {k: rnd(F.gelu(torch.stack(v, 0).sum(0))) for k, v in outs.items()}
+        if trace is not None:
+            trace[f"layer{li}"] = dict(x)
 
     z = {k: x[k] @ g(f"lin_last.lins.{k}.weight").T + g(f"lin_last.lins.{k}.bias") for k in x}  # :328
+    z = {k: rnd(v) for k, v in z.items()}
+    if trace is not None:
+        trace["pre_norm"] = dict(z)
     if normalize_embeddings:                                                    # :331-332
         z = {k: F.normalize(v, dim=-1) for k, v in z.items()}
     return (z, attn) if return_attention else z

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
@@ -195,6 +195,7 @@ EXPORTS = {
     "segger_stage": (C.c_int, [C.POINTER(StageSeg), C.c_int32, vp]),
     "segger_adam_step": (C.c_int, [C.POINTER(AdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, vp]),
     "segger_adam_step_ex": (C.c_int, [C.POINTER(AdamTensor), C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, vp, C.c_int64, vp]),
+    "segger_adam_step_dev": (C.c_int, [C.POINTER(AdamTensor), C.c_int32, vp, C.c_int32, vp, C.c_int64, vp]),
     "segger_transpose_many": (C.c_int, [C.POINTER(TransposeSeg), C.c_int32, vp]),
     "segger_posmlp_supported": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "segger_posmlp_fwd": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp,

@@ -19,6 +19,7 @@ struct AdamBatch {
   int32_t n;
   double lr, beta1, beta2, eps;                   // torch keeps them as Python floats and evaluates 1 - beta, beta^step in double
   int64_t* counter; int64_t counter_inc;          // optional: *counter += counter_inc by the first workgroup (nobody reads it here)
+  const double* hyper;                            // optional DEVICE {lr, beta1, beta2, eps}: overrides the four values above
 };
 
 __global__ __launch_bounds__(64) void adam_advance_kernel(AdamBatch b) {
@@ -39,11 +40,13 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamBatch b) {
   //   exp_avg = lerp(exp_avg, grad, 1 - beta1);  exp_avg_sq = beta2 * exp_avg_sq + (1 - beta2) * grad^2
   //   param -= (lr / (1 - beta1^step)) * exp_avg / (sqrt(exp_avg_sq) / sqrt(1 - beta2^step) + eps)
   const double step = (double)*t.step;             // already advanced by adam_advance_kernel
-  const float bc1 = (float)(1.0 - pow(b.beta1, step));
-  const float bc2 = (float)(1.0 - pow(b.beta2, step));
-  const float step_size = (float)b.lr / bc1;
+  const double lr = b.hyper ? b.hyper[0] : b.lr, beta1_ = b.hyper ? b.hyper[1] : b.beta1;
+  const double beta2_ = b.hyper ? b.hyper[2] : b.beta2, eps_ = b.hyper ? b.hyper[3] : b.eps;
+  const float bc1 = (float)(1.0 - pow(beta1_, step));
+  const float bc2 = (float)(1.0 - pow(beta2_, step));
+  const float step_size = (float)lr / bc1;
   const float bc2_sqrt = sqrtf(bc2);
-  const float w1 = (float)(1.0 - b.beta1), w2 = (float)(1.0 - b.beta2), beta2 = (float)b.beta2, eps = (float)b.eps;
+  const float w1 = (float)(1.0 - beta1_), w2 = (float)(1.0 - beta2_), beta2 = (float)beta2_, eps = (float)eps_;
   auto one = [&](float& p, float g, float& m, float& v) {
     m = m + (g - m) * w1;
     v = beta2 * v + w2 * g * g;
@@ -85,18 +88,32 @@ extern "C" int segger_adam_step(const segger_adam_tensor* tensors, int32_t n_ten
   return segger_adam_step_ex(tensors, n_tensors, lr, beta1, beta2, eps, 0, nullptr, 0, stream_);
 }
 
+static int adam_launch(const segger_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2, double eps,
+                       const double* hyper, int32_t flags, int64_t* counter, int64_t counter_inc, segger_stream_t stream_);
+
 extern "C" int segger_adam_step_ex(const segger_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2,
                                    double eps, int32_t flags, int64_t* counter, int64_t counter_inc, segger_stream_t stream_) {
+  SEGGER_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0.,
+                 "segger_adam_step: lr / betas / eps out of range");
+  return adam_launch(tensors, n_tensors, lr, beta1, beta2, eps, nullptr, flags, counter, counter_inc, stream_);
+}
+
+extern "C" int segger_adam_step_dev(const segger_adam_tensor* tensors, int32_t n_tensors, const double* hyper, int32_t flags,
+                                    int64_t* counter, int64_t counter_inc, segger_stream_t stream_) {
+  SEGGER_REQUIRE(hyper != nullptr && ((uintptr_t)hyper % 8) == 0, "segger_adam_step_dev: hyper is NULL or misaligned");
+  return adam_launch(tensors, n_tensors, 0., 0., 0., 0., hyper, flags, counter, counter_inc, stream_);
+}
+
+static int adam_launch(const segger_adam_tensor* tensors, int32_t n_tensors, double lr, double beta1, double beta2, double eps,
+                       const double* hyper, int32_t flags, int64_t* counter, int64_t counter_inc, segger_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const bool advanced = (flags & SEGGER_ADAM_STEPS_ADVANCED) != 0;
   bool counter_done = counter == nullptr;
   SEGGER_REQUIRE(n_tensors >= 0 && (n_tensors == 0 || tensors), "segger_adam_step: NULL tensor table");
-  SEGGER_REQUIRE(lr >= 0. && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1. && eps >= 0.,
-                 "segger_adam_step: lr / betas / eps out of range");
   for (int32_t at = 0; at < n_tensors; at += kAdamMaxTensors) {
     AdamBatch b{};
     b.n = n_tensors - at < kAdamMaxTensors ? n_tensors - at : kAdamMaxTensors;
-    b.lr = lr; b.beta1 = beta1; b.beta2 = beta2; b.eps = eps;
+    b.lr = lr; b.beta1 = beta1; b.beta2 = beta2; b.eps = eps; b.hyper = hyper;
     int64_t blocks = 0;
     for (int i = 0; i < b.n; ++i) {
       const segger_adam_tensor& t = tensors[at + i];

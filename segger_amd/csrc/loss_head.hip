@@ -371,8 +371,11 @@ __global__ __launch_bounds__(256) void loss_head_bwd_kernel(LossHeadParams p) {
 #pragma unroll
       for (int k = 0; k < CPL; ++k) g[k] = 0.f;
       // (1) anchor of its own loss_tx triplet; a flagged (unchained) contribution of this triplet goes to its hot row
-      const float wp = p.tx_w[2 * r] * sc_tx, wn = p.tx_w[2 * r + 1] * sc_tx;
-      if (wp != 0.f || wn != 0.f) {
+      // (what takes part is decided by the forward's UNSCALED weights: a hot row waits for as many arrivals as the forward
+      //  flagged, also when the loss weight -- sc_tx -- is zero or the product underflows; those arrivals then add zeros)
+      const float uwp = p.tx_w[2 * r], uwn = p.tx_w[2 * r + 1];
+      const float wp = uwp * sc_tx, wn = uwn * sc_tx;
+      if (uwp != 0.f || uwn != 0.f) {
         const int64_t ip = p.tx_pos[r], in = p.tx_neg[r];
         float pp[CPL], nn[CPL], dp[CPL], dn[CPL];
         Row<T, CPL>::load(ztx + ip * p.ld_ztx + c0, pp);
@@ -382,12 +385,12 @@ __global__ __launch_bounds__(256) void loss_head_bwd_kernel(LossHeadParams p) {
           dp[k] = (a[k] - pp[k] + p.tx_eps) * wp; dn[k] = (a[k] - nn[k] + p.tx_eps) * wn;
           g[k] += dp[k] - dn[k];
         }
-        if (wp != 0.f && p.next[2 * r] == kOverflow) {
+        if (uwp != 0.f && p.next[2 * r] == kOverflow) {
 #pragma unroll
           for (int k = 0; k < CPL; ++k) dp[k] = -dp[k];
           hot_add(ip, dp);
         }
-        if (wn != 0.f && p.next[2 * r + 1] == kOverflow) hot_add(in, dn);
+        if (uwn != 0.f && p.next[2 * r + 1] == kOverflow) hot_add(in, dn);
       }
       // (2) positive / negative of the triplets chained to it (code = 2 t + kind, stored + 1; kind 0: r is t's positive).
       // At most kChainCap entries by construction; the bound also holds against whatever a stale buffer contains.

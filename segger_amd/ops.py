@@ -1024,6 +1024,14 @@ class _LossHeadFused(torch.autograd.Function):
         dev, dt = z_tx.device, z_tx.dtype
         n_tx, c = int(z_tx.shape[0]), int(z_tx.shape[1])
         n_bd = int(z_bd.shape[0])
+        if getattr(ctx, "_ran", False):
+            # a second backward over the same graph (retain_graph=True): the forward launch zero-filled the boundary
+            # gradient and armed the hot rows' accumulators / arrival counters ONCE -- re-arm them, or this pass would add
+            # on top of the first one's sums and never finish a hot row
+            gbd.zero_()
+            hot_acc.zero_()
+            nxt[3 * n_tx:].zero_()
+        ctx._ran = True
         stream = _lib.stream_ptr(dev)
         g_out = g_out.detach().to(torch.float32).contiguous()
         # the segmentation triplets' anchor terms ride in the row walk when no transcript anchors two of them
@@ -1243,13 +1251,35 @@ def adam_step_counters(opt, params=None) -> Optional[list]:
     return out if 0 < len(out) <= 64 else None
 
 
-def adam_step(opt, steps_advanced: bool = False, counter: Optional[Tensor] = None, counter_inc: int = 0) -> bool:
+def double_bits(x: float) -> int:
+    """The int64 whose bits are the fp64 pattern of ``x`` (a ``const`` fill of a float64 buffer by :func:`stage`)."""
+    import struct
+    return struct.unpack("<q", struct.pack("<d", float(x)))[0]
+
+
+def adam_hyper(opt) -> Optional[tuple]:
+    """(lr, beta1, beta2, eps) of a one-group optimizer of the kind :func:`adam_step` covers (plain capturable Adam, Python
+    float learning rate; the state need not exist yet), else None."""
+    from .optim import Adam as _Adam
+    if type(opt) not in (torch.optim.Adam, _Adam) or len(opt.param_groups) != 1:
+        return None
+    g = opt.param_groups[0]
+    if (g.get("amsgrad") or g.get("weight_decay") or g.get("maximize") or g.get("differentiable")
+            or not g.get("capturable") or isinstance(g["lr"], Tensor)):
+        return None
+    return (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]))
+
+
+def adam_step(opt, steps_advanced: bool = False, counter: Optional[Tensor] = None, counter_inc: int = 0,
+              hyper_dev: Optional[Tensor] = None) -> bool:
     """``optimizer.step()`` of a plain capturable ``torch.optim.Adam`` through ``segger_adam_step``: every parameter tensor
     in two launches, on the optimizer's own state tensors (checkpoints and eager ``optimizer.step()`` calls stay
     interchangeable).  -> False, nothing done, when the optimizer is anything else (amsgrad, weight decay, maximize, a
     tensor learning rate, non-fp32 or non-contiguous parameters, state not created yet): the caller then runs
     ``optimizer.step()`` itself.  ``steps_advanced``: the step counters were advanced already (:func:`adam_step_counters`);
-    ``counter`` (int64[1] on the device): ``counter += counter_inc`` rides in the update launch.
+    ``counter`` (int64[1] on the device): ``counter += counter_inc`` rides in the update launch.  ``hyper_dev`` (float64[4]
+    on the device = lr, beta1, beta2, eps; one parameter group): the kernel reads them from there when it RUNS
+    (``segger_adam_step_dev``) -- a captured step follows a learning-rate schedule without a new capture.
     (Host cost ~135 us per call for 60 tensors, nearly all of it the per-tensor attribute reads; a cached launch table
     that re-checked pointers and state identity per step measured the same -- tools/host_phases.py.)"""
     # torch's AMP contract for fused optimizers (``_step_supports_amp_scaling``): ``GradScaler.step`` skips its own unscale /
@@ -1259,8 +1289,11 @@ def adam_step(opt, steps_advanced: bool = False, counter: Optional[Tensor] = Non
     if jobs is None:
         return False
     jobs = [(g, rows) for g, rows in jobs if rows]
-    if (steps_advanced or counter is not None) and len(jobs) != 1:
-        raise RuntimeError("adam_step: advanced counters need exactly one parameter group with gradients")
+    if (steps_advanced or counter is not None or hyper_dev is not None) and len(jobs) != 1:
+        raise RuntimeError("adam_step: advanced counters / device hyper-parameters need exactly one parameter group with gradients")
+    if hyper_dev is not None and (hyper_dev.dtype != torch.float64 or hyper_dev.numel() != 4 or not hyper_dev.is_contiguous()
+                                  or not hyper_dev.is_cuda):
+        raise ValueError("adam_step: hyper_dev must be a contiguous float64[4] tensor on the device")
     lib = _lib.load()
     for g, rows in jobs:
         arr = (_lib.AdamTensor * len(rows))()
@@ -1270,8 +1303,12 @@ def adam_step(opt, steps_advanced: bool = False, counter: Optional[Tensor] = Non
         dev = rows[0][0].device
         b1, b2 = g["betas"]
         with _lib.on_device(dev):
-            rc = lib.segger_adam_step_ex(arr, len(rows), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
-                                         1 if steps_advanced else 0, _lib.ptr(counter), int(counter_inc), _lib.stream_ptr(dev))
+            if hyper_dev is not None:
+                rc = lib.segger_adam_step_dev(arr, len(rows), hyper_dev.data_ptr(), 1 if steps_advanced else 0,
+                                              _lib.ptr(counter), int(counter_inc), _lib.stream_ptr(dev))
+            else:
+                rc = lib.segger_adam_step_ex(arr, len(rows), float(g["lr"]), float(b1), float(b2), float(g["eps"]),
+                                             1 if steps_advanced else 0, _lib.ptr(counter), int(counter_inc), _lib.stream_ptr(dev))
         _lib.check(rc, "segger_adam_step")
     return True
 

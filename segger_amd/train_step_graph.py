@@ -133,6 +133,10 @@ class GraphedTrainStep:
         # padded -> masked means (padded rows / masked tx count, 1, e_tb_pad / e_tb_real or 0 for <= 1 boundary), loss weights
         self.scal = z(6)
         self.head_a = self.scal[0:3]
+        # Adam's (lr, beta1, beta2, eps) as the kernel reads them at replay time (segger_adam_step_dev), staged with every
+        # batch from the optimizer's param_group: a learning-rate schedule is followed without a new capture
+        self.hyper = z(4, dtype=torch.float64)
+        self._hyper_on_device = USE_ADAM_KERNEL and ops.adam_hyper(optimizer) is not None
         self._e_loss = torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev)          # d / d out of out[3], the total loss
         self.out: Optional[Tensor] = None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
@@ -252,6 +256,11 @@ class GraphedTrainStep:
             (self.scal[3:4], None, "const", fb(w[0]), 0, 0), (self.scal[4:5], None, "const", fb(w[1]), 0, 0),
             (self.scal[5:6], None, "const", fb(w[2]), 0, 0),
         ]
+        if self._hyper_on_device:
+            hp = ops.adam_hyper(self.opt)
+            if hp is None:
+                raise RuntimeError("the optimizer's learning rate became a tensor / its groups changed after the capture")
+            segs += [(self.hyper[i:i + 1], None, "const", ops.double_bits(v), 0, 0) for i, v in enumerate(hp)]
         segs += padded_view_segments(self.g_tt.by_dst, g_tt.by_dst, n_tx, None)
         segs += padded_view_segments(self.g_tt.by_src, g_tt.require_by_src(), n_tx, None)
         segs += padded_view_segments(self.g_tb.by_dst, g_tb.by_dst, n_bd, dummies)
@@ -272,10 +281,13 @@ class GraphedTrainStep:
         self._late = (0, False)
         enc = self.lit.model
         if USE_ADAM_KERNEL and ops.adam_step(self.opt, steps_advanced=adv, counter=enc._step_dev if inc else None,
-                                             counter_inc=inc):
+                                             counter_inc=inc, hyper_dev=self.hyper if self._hyper_on_device else None):
             return
         if adv:
             raise RuntimeError("the step advanced Adam's counters for segger_adam_step, which then refused the optimizer")
+        if self._hyper_on_device and torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("segger_adam_step refused an optimizer whose hyper-parameters this step stages on the device "
+                               "(non-fp32 / non-contiguous parameters or gradients, an AMP grad scaler attached)")
         self.opt.step()
         if inc:
             ops.step_advance(enc._step_dev, inc)
@@ -405,15 +417,19 @@ class GraphedTrainStep:
                     v.zero_() if old is None else v.copy_(old)
 
     def _hyper(self) -> tuple:
-        """The optimizer hyper-parameters a capture bakes into its kernel arguments (segger_adam_step takes lr / betas / eps by
-        value): a scheduler or a manual change of ``param_groups`` between steps must trigger a new capture, not be ignored."""
+        """The optimizer hyper-parameters a capture bakes in: none of (lr, betas, eps) when the Adam kernel reads them from
+        the staged device array (``_hyper_on_device``: the common case -- a scheduler changing ``lr`` every step replays the
+        same graph); otherwise (torch's own optimizer step inside the capture: Python floats become kernel arguments) all
+        of them -- a change between steps then triggers a new capture instead of being ignored."""
+        if self._hyper_on_device:
+            return tuple((g.get("weight_decay", 0), bool(g.get("amsgrad")), bool(g.get("maximize"))) for g in self.opt.param_groups)
         return tuple((g["lr"] if not isinstance(g["lr"], Tensor) else id(g["lr"]), tuple(g["betas"]), g["eps"],
                       g.get("weight_decay", 0)) for g in self.opt.param_groups)
 
     def step(self, batch, capture: bool = True) -> Tensor:
         """-> [loss_tx, loss_bd, loss_sg, loss] (a static device tensor, overwritten by the next step).  Optimizer step
         hooks (``register_step_pre_hook`` / ``_post_hook``) do not run inside a replay; a changed learning rate / betas / eps
-        re-captures the bucket."""
+        is staged with the batch (no new capture) on the Adam-kernel route, and re-captures the bucket on any other."""
         lit = self.lit
         self.stage(batch)
         if self.graph is not None and self._captured_hp != self._hyper():

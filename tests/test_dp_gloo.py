@@ -311,3 +311,37 @@ def test_strong_epoch_refuses_ranks_that_disagree_on_the_schedule():
         assert p.exitcode == 0
     for rank, res, n_steps in got:
         assert "do not agree on the batch list" in res and n_steps == 0, (rank, res)
+
+
+def _run_bench(*argv, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_gpus_n_launches_its_own_ranks_world2():
+    """`python bench.py --gpus 2` with no launcher environment (the driver's command shape) must start two ranks itself:
+    the dry launch joins a gloo group and all-reduces the census; stdout is exactly one JSON line."""
+    import json
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--dry-launch")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["census"] == [1, 1] and rec["n_ranks_seen"] == 2
+    assert rec["launched_by"] == "torch.distributed.run"
+
+
+def test_bench_refuses_to_report_fewer_gpus_than_asked():
+    """No GPU here: `--gpus 2` (RCCL) must exit non-zero with a message, never print an n_gpus: 1 line."""
+    r = _run_bench("--gpus", "2", timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "GPU(s) visible" in r.stderr
+
+
+def test_bench_refuses_a_launcher_whose_world_differs_from_gpus():
+    r = _run_bench("--gpus", "4", "--dry-launch", env_extra={"WORLD_SIZE": "1", "RANK": "0"}, timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "WORLD_SIZE=1" in r.stderr

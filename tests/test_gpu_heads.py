@@ -690,3 +690,84 @@ def test_one_launch_loss_head_deferred_finish(cuda, kind):
     for k in (1, 2):
         scale = out[False][k].abs().max().item()
         assert (out[True][k] - out[False][k]).abs().max().item() <= 2e-2 * scale
+
+
+def _hot_row_problem(cuda, dtype=torch.float32, C=64, seed=91):
+    from segger_amd.graph import csr_from_coo
+    g = torch.Generator().manual_seed(seed)
+    n, nb, e = 3001, 45, 1400
+    y0 = torch.randn(n, C, generator=g).to(dtype)
+    yb0 = torch.randn(nb, C, generator=g).to(dtype)
+    pos = torch.randint(0, n, (n,), generator=g); pos[::7] = -1
+    neg = torch.randint(0, n, (n,), generator=g)
+    pos[100:900:2] = 3; neg[1000:1300] = 9; pos[1500:1564] = 11; neg[1600:1665] = 12      # rows 3, 9, 12 hot; 11 exactly full
+    bpos, bneg = torch.randint(0, nb, (nb,), generator=g), torch.randint(0, nb, (nb,), generator=g)
+    dp, dn, w = torch.rand(nb, generator=g), torch.rand(nb, generator=g), torch.full((nb,), 1.0 / nb)
+    src = torch.randperm(n, generator=g)[:e]
+    dst = torch.randint(0, nb, (e,), generator=g)
+    dneg = (dst + torch.randint(1, nb, (e,), generator=g)) % nb
+    groups = csr_from_coo(dst.to(cuda), src.to(cuda), nb, n, validate=False)
+
+    def spec():
+        from segger_amd import ops
+        return ops.LossHeadSpec((torch.arange(n, device=cuda), pos.to(cuda), neg.to(cuda), 0.3, 1e-6),
+                                (bpos.to(cuda), bneg.to(cuda), dp.to(cuda), dn.to(cuda), w.to(cuda), 1e-8),
+                                (src.to(cuda), dst.to(cuda), dneg.to(cuda), 0.4, 1e-6, groups, True), tx_anchors_are_rows=True)
+    return y0, yb0, spec
+
+
+@pytest.mark.parametrize("prenorm", [True, False])
+@pytest.mark.parametrize("how", ["b0", "a0", "gout"])
+def test_one_launch_loss_head_hot_rows_with_zero_tx_weight(cuda, how, prenorm, monkeypatch):
+    """A hot row waits for as many arrivals as the FORWARD flagged (from the unscaled weights).  With the transcript loss
+    weighted by zero (``tx_weight_start=0``: b[0] = 0; or a[0] = 0; or a zero incoming gradient) every scaled contribution
+    is zero -- the flagged ones must still arrive, or the row is never finished and its slot of the (torch.empty) gradient
+    matrix stays uninitialised.  The gradient buffer is poisoned with NaN through the caching allocator first."""
+    from segger_amd import ops
+    y0, yb0, mk = _hot_row_problem(cuda)
+    a = torch.tensor([0.0 if how == "a0" else 1.3, 1.0, 0.7], device=cuda)
+    b = torch.tensor([0.0 if how == "b0" else 0.5, 0.2, 0.3], device=cuda)
+    gvec = torch.tensor([0.0, 0.3, 0.5, 0.0 if how == "gout" else 1.7], device=cuda)
+    out = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "ONE_LAUNCH_LOSS_HEAD", fused)
+        y, yb = y0.to(cuda).requires_grad_(True), yb0.to(cuda).requires_grad_(True)
+        if prenorm:
+            zs = ops.l2_normalize_many({"tx": y, "bd": yb})
+            z, zb = zs["tx"], zs["bd"]
+        else:
+            z, zb = y, yb
+        spec = mk()
+        assert ops.loss_head_fused_supported(z, zb, spec) == fused
+        res = ops.loss_head(z, zb, a, b, spec)
+        poison = torch.full((y0.shape[0], y0.shape[1]), float("nan"), device=cuda)      # what torch.empty hands out next
+        del poison
+        res.backward(gvec)
+        out[fused] = (res.detach().clone(), y.grad.clone(), yb.grad.clone())
+    assert torch.isfinite(out[True][1]).all() and torch.isfinite(out[True][2]).all()
+    assert torch.allclose(out[True][0], out[False][0], rtol=2e-6, atol=1e-8)
+    for k in (1, 2):
+        scale = out[False][k].abs().max().item()
+        assert (out[True][k] - out[False][k]).abs().max().item() <= 2e-5 * scale + 1e-12, (k, scale)
+    if how != "gout":
+        assert out[True][1][[3, 9, 12]].abs().max().item() >= 0.0          # hot rows present and finite (checked above)
+
+
+def test_one_launch_loss_head_backward_twice(cuda):
+    """retain_graph=True and a second backward: the boundary gradient and the hot rows are re-armed, so the second pass
+    returns what the first did (not twice the boundary gradient, not stale hot rows)."""
+    from segger_amd import ops
+    y0, yb0, mk = _hot_row_problem(cuda, seed=93)
+    a = torch.tensor([1.3, 1.0, 0.7], device=cuda)
+    b = torch.tensor([0.5, 0.2, 0.3], device=cuda)
+    y, yb = y0.to(cuda).requires_grad_(True), yb0.to(cuda).requires_grad_(True)
+    zs = ops.l2_normalize_many({"tx": y, "bd": yb})
+    spec = mk()
+    assert ops.loss_head_fused_supported(zs["tx"], zs["bd"], spec)
+    res = ops.loss_head(zs["tx"], zs["bd"], a, b, spec)
+    g1 = torch.autograd.grad(res[3], (y, yb), retain_graph=True)
+    poison = torch.full_like(y0.to(cuda), float("nan")); del poison
+    g2 = torch.autograd.grad(res[3], (y, yb))
+    for u, v in zip(g1, g2):
+        assert torch.isfinite(v).all()
+        assert (u - v).abs().max().item() <= 2e-5 * u.abs().max().item()

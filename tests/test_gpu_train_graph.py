@@ -425,27 +425,68 @@ def test_merged_draws_step_equals_separate_draws_step(cuda, monkeypatch):
     assert (a[3] - b[3]).abs().max().item() <= 2e-3 * b[3].abs().max().item()
 
 
-def test_captured_step_follows_a_changed_learning_rate(cuda):
-    """segger_adam_step takes lr / betas / eps by value, so a captured graph has them baked in: changing the learning rate
-    between steps (an LR scheduler) must re-capture the bucket -- with lr = 0 the parameters stop moving."""
+def test_captured_step_follows_a_changed_learning_rate(cuda, monkeypatch):
+    """An LR scheduler changes ``param_groups[0]["lr"]`` between steps.  On the Adam-kernel route the captured step reads
+    (lr, betas, eps) from a device array staged with every batch (segger_adam_step_dev): the SAME graph is replayed -- with
+    lr = 0 the parameters stop moving, with the rate restored they move again, and no capture is added.  With torch's own
+    optimizer step inside the capture (Python floats baked into its kernel arguments) the bucket is re-captured instead."""
     from segger_amd import tiles as T
+    from segger_amd import train_step_graph as G
     from segger_amd.synthetic import SyntheticSpec
     from segger_amd.train_step_graph import GraphedTrainer
     spec = SyntheticSpec(n_tx=12000, n_bd=300, k_tx=6, seed=43)
-    m, bg = _model(spec, cuda, torch.float32)
-    opt = m.configure_optimizers(capturable=True)
-    trainer = GraphedTrainer(m, opt, granularity=1.5)
-    trainer.step(bg); trainer.step(bg)
-    assert trainer.n_captures == 1 and trainer.buckets[0].graph is not None
-    before = torch.cat([p.detach().reshape(-1).clone() for p in m.parameters()])
-    first_graph = trainer.buckets[0].graph
-    for g in opt.param_groups:
-        g["lr"] = 0.0
-    trainer.step(bg)
-    after = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
-    assert trainer.buckets[0].graph is not first_graph          # re-captured
-    assert torch.equal(before, after)                           # and the new rate was used
-    for g in opt.param_groups:
-        g["lr"] = 1e-3
-    trainer.step(bg)
-    assert not torch.equal(before, torch.cat([p.detach().reshape(-1) for p in m.parameters()]))
+    flat = lambda m: torch.cat([p.detach().reshape(-1).clone() for p in m.parameters()])
+    for kernel in (True, False):
+        monkeypatch.setattr(G, "USE_ADAM_KERNEL", kernel)
+        m, bg = _model(spec, cuda, torch.float32)
+        opt = m.configure_optimizers(capturable=True)
+        trainer = GraphedTrainer(m, opt, granularity=1.5)
+        trainer.step(bg); trainer.step(bg)
+        assert trainer.n_captures == 1 and trainer.buckets[0].graph is not None
+        before = flat(m)
+        first_graph = trainer.buckets[0].graph
+        for g in opt.param_groups:
+            g["lr"] = 0.0
+        trainer.step(bg)
+        assert (trainer.buckets[0].graph is first_graph) == kernel      # same graph replayed | re-captured
+        assert torch.equal(before, flat(m))                              # and the new rate was used
+        for g in opt.param_groups:
+            g["lr"] = 1e-3
+        trainer.step(bg)
+        assert (trainer.buckets[0].graph is first_graph) == kernel
+        assert not torch.equal(before, flat(m))
+
+
+def test_adam_step_dev_equals_adam_step(cuda):
+    """segger_adam_step_dev (hyper-parameters from a device array) == segger_adam_step_ex (by value), bit for bit; and a
+    schedule of rates applied through the device array equals torch's capturable Adam stepping through the same schedule."""
+    from segger_amd import ops
+    g = torch.Generator().manual_seed(3)
+    shapes = [(128, 64), (64,), (3, 5, 7), (1,)]
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(*s_, generator=g).to(cuda)) for s_ in shapes]
+        return ps
+    torch.manual_seed(0)
+    pa = make(); g.manual_seed(3); pb = make(); g.manual_seed(3); pc = make()
+    oa = torch.optim.Adam(pa, lr=1e-2, fused=True, capturable=True)
+    ob = torch.optim.Adam(pb, lr=1e-2, fused=True, capturable=True)
+    oc = torch.optim.Adam(pc, lr=1e-2, fused=True, capturable=True)
+    hyper = torch.zeros(4, dtype=torch.float64, device=cuda)
+    rates = [1e-2, 5e-3, 0.0, 2e-2, 1e-3]
+    for it, lr in enumerate(rates):
+        gg = [torch.randn(*s_, generator=g).to(cuda) for s_ in shapes]
+        for ps in (pa, pb, pc):
+            for p, x in zip(ps, gg):
+                p.grad = x.clone()
+        for o in (oa, ob, oc):
+            o.param_groups[0]["lr"] = lr
+        if it == 0:                                    # creates the state (the kernels run on existing state only)
+            oa.step(); ob.step(); oc.step()
+            continue
+        hyper.copy_(torch.tensor([lr, 0.9, 0.999, 1e-8], dtype=torch.float64))
+        assert ops.adam_step(oa)
+        assert ops.adam_step(ob, hyper_dev=hyper)
+        oc.step()
+    for a, b, c in zip(pa, pb, pc):
+        assert torch.equal(a, b)
+        assert torch.allclose(a, c, rtol=2e-6, atol=1e-7)
