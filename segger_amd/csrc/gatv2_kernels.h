@@ -23,6 +23,9 @@ namespace segger {
 #ifndef SEGGER_FWD_UNROLL
 #define SEGGER_FWD_UNROLL 4
 #endif
+#ifndef SEGGER_FWD_UNROLL_WPR
+#define SEGGER_FWD_UNROLL_WPR 2
+#endif
 #ifndef SEGGER_DST_UNROLL
 #define SEGGER_DST_UNROLL 4
 #endif
@@ -124,6 +127,15 @@ constexpr int kDppRowRor0 = 0x120;   // row_ror:n
 // is wave-uniform and a group may be handed a batch with valid[0] == false.
 // per-edge side information handed to the body next to the neighbour id
 constexpr int kMetaNone = 0, kMetaEid = 1, kMetaBits = 2;
+// The lane id recomputed where it is used (two VALU instructions per 64-edge chunk).  In wave-per-row mode the chunk loop
+// reads `lane` once per chunk for its coalesced id load; kept live across the edge loops it is the value the register
+// allocator picks to SPILL at 4 waves per SIMD (as a zero-extended 64-bit pair, reloaded behind an s_waitcnt vmcnt(0) at
+// every chunk head: tools/kernel_resources.py).  `volatile`: LLVM may not hoist it back out of the loop.
+__device__ __forceinline__ int lane_id_fresh() {
+  int x;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+  return x;
+}
 template <int GS, bool WPR, int META, int U, typename Body>
 __device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const void* __restrict__ meta,
                                          int64_t beg, int64_t end, int lane, int grp, int gl, Body&& body) {
@@ -135,7 +147,7 @@ __device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const 
   constexpr bool kDpp = !WPR && GS == 16;
   static_assert(GS % U == 0, "group size must be a multiple of the edge unroll");
   for (int64_t e0 = beg; e0 < end; e0 += CHUNK) {
-    const int me = WPR ? lane : gl;
+    const int me = WPR ? lane_id_fresh() : gl;
     // slots of this chunk that hold an edge (32-bit: the per-slot validity tests are one v_cmp_lt_i32 each instead of a
     // 64-bit add + compare)
     const int rem = (int)(end - e0 < (int64_t)CHUNK ? end - e0 : (int64_t)CHUNK);
@@ -198,7 +210,7 @@ __device__ __forceinline__ void walk_row_prefetch(const int32_t* __restrict__ co
   using B0 = std::integral_constant<int, 0>;
   using B1 = std::integral_constant<int, 1>;
   for (int64_t e0 = beg; e0 < end; e0 += CHUNK) {
-    const int me = WPR ? lane : gl;
+    const int me = WPR ? lane_id_fresh() : gl;
     const int rem = (int)(end - e0 < (int64_t)CHUNK ? end - e0 : (int64_t)CHUNK);
     int myc = 0, myeid = 0;
     if (me < rem) {
@@ -362,10 +374,13 @@ __device__ __forceinline__ float sign_mul(float nde, float nt) {     // de * sgn
 }
 
 // position -> row through the optional degree-balanced order (include/segger_amd.h: segger_csr_row_order)
+// -> the row as a 32-bit id (node ids are int32 throughout: `col`): one register instead of two across the edge walk --
+// the 64-bit row was what the allocator spilled at 4 waves per SIMD -- and in wave-per-row mode, where every lane of the
+// wave works on the same row, a SCALAR register (readfirstlane).  Addresses are formed as (int64_t)row * ld where used.
 template <bool WPR>
-__device__ __forceinline__ int64_t visit_row(const int32_t* __restrict__ order, int64_t pos, bool ok) {
-  if constexpr (WPR) return pos;
-  return (order != nullptr && ok) ? (int64_t)order[pos] : pos;
+__device__ __forceinline__ int visit_row(const int32_t* __restrict__ order, int64_t pos, bool ok) {
+  if constexpr (WPR) return __builtin_amdgcn_readfirstlane((int)pos);
+  return (order != nullptr && ok) ? order[pos] : (int)pos;
 }
 
 struct LaneGeo {
@@ -399,7 +414,11 @@ __device__ __forceinline__ void load_att(const float* att, int ch0, float slope,
 template <typename T, int H, int LPH, bool WPR>
 __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid) {
   using G = Geo<H, LPH>;
-  constexpr int GS = G::GS, NG = G::NG, U = SEGGER_FWD_UNROLL < GS ? SEGGER_FWD_UNROLL : GS;
+  // wave-per-row: 2 rows in flight per group (NG groups: 2 NG edges per wave batch) -- the merge of the groups' states and
+  // the wave-wide id hand-off need the registers the second pair of row buffers would take (4 in flight spills at 4 waves
+  // per SIMD; these rows are the few-thousand-block tx-belongs-bd side, latency-bound beside the tx-neighbors-tx blocks)
+  constexpr int UF = WPR ? SEGGER_FWD_UNROLL_WPR : SEGGER_FWD_UNROLL;
+  constexpr int GS = G::GS, NG = G::NG, U = UF < GS ? UF : GS;
   const int64_t blk = xcd_remap(bid, p.nblocks_padded, p.nblocks);
   if (blk < 0) return;
   const LaneGeo L = lane_geo<G>();
@@ -407,7 +426,7 @@ __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid)
   const bool head_leader = L.lane_on && (L.gl % LPH) == 0;
   const int64_t pos = WPR ? (blk * 4 + L.wave) : ((blk * 4 + L.wave) * NG + L.grp);
   const bool row_ok = pos < p.n_rows;
-  const int64_t row = visit_row<WPR>(p.order, pos, row_ok);
+  const int row = visit_row<WPR>(p.order, pos, row_ok);
   const char* __restrict__ xl = static_cast<const char*>(p.xl) + (size_t)ch0 * sizeof(T);
   const uint32_t ld_xl = (uint32_t)(p.ld_xl * sizeof(T));
   const bool dropout = p.drop_thr != 0;
@@ -529,7 +548,7 @@ __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid)
       for (int i = 0; i < 4; ++i) o[i] = f32x2{gelu_erf(o[i].x), gelu_erf(o[i].y)};
     }
     store_pairs(static_cast<T*>(p.out) + row * p.ld_out + ch0, o);
-    if (p.lse && head_leader) p.lse[row * H + h] = lse;
+    if (p.lse && head_leader) p.lse[(int64_t)row * H + h] = lse;
 #ifdef EXP_EXTRA_STORES      // bounding build: the bytes a fused next-layer projection would write from here
     if (p.gxl) {
       T* q = static_cast<T*>(p.gxl) + row * p.ld_gxl + ch0;
@@ -621,7 +640,13 @@ __device__ __forceinline__ void gatv2_bwd_dst_body(SEGGER_BODY_PARAM p, int64_t 
     if (rbase >= p.n_rows) break;              // wave-uniform
     const int64_t pos = rbase + (WPR ? 0 : L.grp);
     const bool row_ok = pos < p.n_rows;
-    const int64_t row = visit_row<WPR>(p.order, pos, row_ok);
+    const int row = visit_row<WPR>(p.order, pos, row_ok);
+    // the per-row loads / stores below address `matrix + row * ld + ch0`; with ch0 loop-invariant the compiler hoists one
+    // 64-bit `matrix + ch0` pointer PER MATRIX out of this loop (9 VGPR pairs) and spills some of them.  An opaque copy of
+    // ch0 per iteration keeps those sums inside it: scalar row base + 32-bit lane offset, no registers held across rows.
+    int ch0r = L.ch0;
+    asm volatile("" : "+v"(ch0r));
+#define ch0 ch0r
 
     f32x2 nxr[4], g[4], Sg[4];
     float D = 0.f, lse = 0.f, Sde = 0.f;
@@ -645,7 +670,7 @@ __device__ __forceinline__ void gatv2_bwd_dst_body(SEGGER_BODY_PARAM p, int64_t 
         d2 = pk_fma(g[i], pr[i] - b, d2);
       }
       D = d2.x + d2.y;
-      lse = p.lse[row * H + h];
+      lse = p.lse[(int64_t)row * H + h];
     }
     D = lane_block_sum<LPH>(D);
     const bool writer = row_ok && L.lane_on && (!WPR || L.grp == 0);
@@ -658,7 +683,7 @@ __device__ __forceinline__ void gatv2_bwd_dst_body(SEGGER_BODY_PARAM p, int64_t 
       }
       store_pairs(static_cast<T*>(p.gpre) + row * p.ld_gp + ch0, g);
       if (head_leader)      // (lse, D) side by side: the source pass fetches both with one 8-byte load per (edge, head)
-        *reinterpret_cast<float2*>(p.dsum + (row * H + h) * 2) = float2{lse, D};
+        *reinterpret_cast<float2*>(p.dsum + ((int64_t)row * H + h) * 2) = float2{lse, D};
 #pragma unroll
       for (int i = 0; i < 4; ++i) dbias[i] = dbias[i] + g[i];
     }
@@ -732,6 +757,7 @@ __device__ __forceinline__ void gatv2_bwd_dst_body(SEGGER_BODY_PARAM p, int64_t 
       for (int i = 0; i < 4; ++i) dxr[i] = (a1[i] * Sde + a2[i] * Sg[i]) * kLn2;
       store_pairs(static_cast<T*>(p.gxr) + row * p.ld_gxr + ch0, dxr);
     }
+#undef ch0
   }
 
   // grad_att = c1 * Pt + c2 * Qt ; block partials of grad_att / grad_bias -> slab[blk]
@@ -780,7 +806,7 @@ __device__ __forceinline__ void gatv2_bwd_src_body(SEGGER_BODY_PARAM p, int64_t 
   const int h = L.h, ch0 = L.ch0;
   const int64_t pos = WPR ? (blk * 4 + L.wave) : ((blk * 4 + L.wave) * NG + L.grp);
   const bool row_ok = pos < p.n_rows;
-  const int64_t row = visit_row<WPR>(p.order, pos, row_ok);
+  const int row = visit_row<WPR>(p.order, pos, row_ok);
   const char* __restrict__ xr_base = static_cast<const char*>(p.xr) + (size_t)ch0 * sizeof(T);
   const char* __restrict__ g_base = static_cast<const char*>(p.gpre) + (size_t)ch0 * sizeof(T);
   const uint32_t ld_xr = (uint32_t)(p.ld_xr * sizeof(T)), ld_gp = (uint32_t)(p.ld_gp * sizeof(T));

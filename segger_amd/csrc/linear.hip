@@ -287,7 +287,9 @@ __global__ __launch_bounds__(kResWaves * 64, 1) void linear_res_kernel(LinearPar
     for (int s = 0; s < NK; ++s) xb[s] = xn[s];
     if (t + stride < n_tiles) x_load(xn, t + stride);             // under this tile's MFMAs
     const int64_t row0 = t * 32;
-#pragma unroll
+    // NCH == 2 (M = 128): fully unrolled the two chunks' MFMA chains and epilogues are interleaved by the scheduler and the
+    // tile loop spills 136 bytes per lane (7 reloads inside it); kept as a loop the kernel needs no scratch
+#pragma unroll NCH == 2 ? 1 : NCH
     for (int c = 0; c < NCH; ++c) {
       const int c0 = c * kChunk;
       f32x16 acc[2];

@@ -187,6 +187,17 @@ def rank_census(device=None, group=None) -> dict:
     return {"world_size": world, "n_ranks_seen": sum(1 for c in census if c == 1), "census": census}
 
 
+def schedule_fingerprint(batch_weights: Sequence[float]) -> int:
+    """A 62-bit hash of the batch list's weights (order included), the same on every platform and process (Python's own
+    ``hash`` of floats is, but not salted strings'; this one is explicit FNV-1a over the IEEE-754 bytes)."""
+    import struct
+    h = 0xcbf29ce484222325
+    for w in batch_weights:
+        for b in struct.pack("<d", float(w)):
+            h = ((h ^ b) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return h >> 2
+
+
 def strong_scaling_epoch(batch_weights: Sequence[float], step, units=None, *, sync=None, device=None,
                          warmup: int = 0, group=None) -> dict:
     """One data-parallel epoch over a FIXED list of packed batches (BASELINE config 4: total work does not grow
@@ -201,12 +212,20 @@ def strong_scaling_epoch(batch_weights: Sequence[float], step, units=None, *, sy
     world = dist.get_world_size(group) if on else 1
     rank = dist.get_rank(group) if on else 0
     sched = rank_schedule(batch_weights, world)[rank]
-    if on:      # every rank must take the same number of steps: each one is a collective (a mismatch would deadlock, not fail)
-        n = torch.tensor([len(sched), -len(sched)], dtype=torch.int64, device=device)
+    if on:
+        # every rank must take the same number of steps (each one is a collective: a mismatch would deadlock, not fail) over
+        # the SAME batch list: ranks that derive the weights themselves (rank-local FOV generation) could agree on the count
+        # and still train overlapping or missing batches -- one MAX all-reduce of (x, -x) pairs compares the step count and
+        # a 62-bit fingerprint of the weights
+        fp = schedule_fingerprint(batch_weights)
+        n = torch.tensor([len(sched), -len(sched), fp, -fp], dtype=torch.int64, device=device)
         dist.all_reduce(n, op=dist.ReduceOp.MAX, group=group)
         if int(n[0]) != len(sched) or int(-n[1]) != len(sched):
             raise RuntimeError(f"strong_scaling_epoch: rank {rank} has {len(sched)} steps, others between {int(-n[1])} and "
                                f"{int(n[0])}: the ranks do not agree on the batch list")
+        if int(n[2]) != fp or int(-n[3]) != fp:
+            raise RuntimeError(f"strong_scaling_epoch: rank {rank}'s batch weights have fingerprint {fp:016x}, another rank's "
+                               f"differ: the ranks do not agree on the batch list")
     sync = sync or (lambda: None)
     for k in (sched if warmup < 0 else sched[:warmup]):     # warmup < 0: one whole untimed epoch first
         step(k, 0)

@@ -44,16 +44,20 @@ class EdgeCSR:
         return int(self.col.shape[0])
 
     def c_struct(self) -> _lib.Csr:
-        # built once per view and kept while the arrays stay the same objects (4 layers x 3 passes ask for it every step)
-        key = (id(self.indptr), id(self.col), id(self.eid), id(self.order), self.n_rows, self.n_cols)
+        # built once per view (4 layers x 3 passes ask for it every step) and kept while the arrays are the SAME tensor
+        # objects at the SAME addresses: the entry holds the tensors themselves (an id() of a freed tensor can be reused by
+        # a new one) and their data pointers (resize_ / set_ / `.data =` keep the object and move the storage)
         hit = self.__dict__.get("_c_struct")
-        if hit is not None and hit[0] == key:
-            return hit[1]
-        c = _lib.Csr(self.indptr.data_ptr(),
-                     self.col.data_ptr() if self.n_edges else None,
-                     self.eid.data_ptr() if self.n_edges else None,
-                     self.n_rows, self.n_cols, self.n_edges, _lib.ptr(self.order))
-        self.__dict__["_c_struct"] = (key, c)
+        if hit is not None:
+            ts, ptrs, dims, c = hit
+            if (ts[0] is self.indptr and ts[1] is self.col and ts[2] is self.eid and ts[3] is self.order
+                    and dims == (self.n_rows, self.n_cols)
+                    and ptrs == (self.indptr.data_ptr(), self.col.data_ptr(), self.eid.data_ptr(), _lib.ptr(self.order))):
+                return c
+        ptrs = (self.indptr.data_ptr(), self.col.data_ptr(), self.eid.data_ptr(), _lib.ptr(self.order))
+        c = _lib.Csr(ptrs[0], ptrs[1] if self.n_edges else None, ptrs[2] if self.n_edges else None,
+                     self.n_rows, self.n_cols, self.n_edges, ptrs[3])
+        self.__dict__["_c_struct"] = ((self.indptr, self.col, self.eid, self.order), ptrs, (self.n_rows, self.n_cols), c)
         return c
 
     def balanced_order(self, window: int = ROW_ORDER_WINDOW) -> "EdgeCSR":

@@ -3,6 +3,8 @@
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -281,13 +283,15 @@ def test_shard_residency_persistent_bucket_and_vote_world2():
         assert r["entered_after_no_vote"] is False and r["agree_when_all_ok"] is True and r["alive"] == 2.0
 
 
-def _disagree_worker(rank, world, port, out):
+def _disagree_worker(rank, world, port, out, same_count=False):
     """Ranks that hold DIFFERENT batch lists (a bug upstream) must fail loudly before the first step, not deadlock in a
     mismatched collective half-way through the epoch."""
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from segger_amd.dp import strong_scaling_epoch
     weights = [5.0, 4.0, 3.0, 2.0] if rank == 0 else [5.0, 4.0, 3.0, 2.0, 1.0, 1.0]      # 2 vs 3 steps per rank
+    if same_count:      # same number of batches and steps, different weights (rank-local tile counts that disagree)
+        weights = [5.0, 4.0, 3.0, 2.0] if rank == 0 else [5.0, 4.0, 2.0, 3.0]
     steps = []
     try:
         strong_scaling_epoch(weights, lambda k, i: steps.append(k), units=None)
@@ -298,11 +302,12 @@ def _disagree_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_strong_epoch_refuses_ranks_that_disagree_on_the_schedule():
+@pytest.mark.parametrize("same_count", [False, True])
+def test_strong_epoch_refuses_ranks_that_disagree_on_the_schedule(same_count):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_disagree_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_disagree_worker, args=(r, 2, port, q, same_count)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=180) for _ in range(2)]

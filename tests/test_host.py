@@ -316,3 +316,23 @@ def test_step_bucket_sizes_leave_a_dummy_of_every_kind():
     assert s["tx"] > 50_000 and s["bd"] > 512 and s["e_tt"] >= 730_000 and s["e_tb"] >= 19_000 and s["graphs"] >= 3
     assert s["tx"] <= 50_000 * 1.07 and s["e_tt"] <= 730_000 * 1.07          # one granule at most on the transcript side
     assert step_bucket(b, granularity=1.06) == s
+
+
+def test_edge_csr_struct_cache_follows_the_storage_not_the_object_id():
+    """EdgeCSR.c_struct() caches the ctypes struct per view; the cache must notice a tensor whose storage moved
+    (``set_`` keeps the Python object) and a replaced field (a freed tensor's id() can be reused)."""
+    from segger_amd.graph import EdgeCSR
+    indptr = torch.tensor([0, 1, 2], dtype=torch.int64)
+    col = torch.tensor([1, 0], dtype=torch.int32)
+    eid = torch.tensor([0, 1], dtype=torch.int32)
+    g = EdgeCSR(indptr, col, eid, 2, 2)
+    c0 = g.c_struct()
+    assert g.c_struct() is c0                               # cached
+    assert c0.col == col.data_ptr()
+    other = torch.tensor([0, 1], dtype=torch.int32)
+    col.set_(other)                                         # same object, new storage
+    c1 = g.c_struct()
+    assert c1 is not c0 and c1.col == other.data_ptr()
+    g.eid = torch.tensor([1, 0], dtype=torch.int32)         # replaced field
+    c2 = g.c_struct()
+    assert c2 is not c1 and c2.eid == g.eid.data_ptr()

@@ -1,0 +1,86 @@
+"""Register audit of the shipped kernels (no GPU): `make asm` emits the gfx950 assembly of every translation unit and
+tools/kernel_resources.py reads each kernel's descriptor.  Every kernel the C2 training step and the captured 1M-edge step
+launch (the committed launch sequences under profiles/) must run without scratch memory -- a spill inside a hot loop is a
+scratch round trip behind an s_waitcnt vmcnt(0)."""
+import glob
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def _norm(name: str) -> str:
+    """'void segger::k<a, b>(segger::P)' / 'segger::(anonymous namespace)::k<a, b>(P)' -> 'k<a,b>'"""
+    name = name.strip()
+    name = re.sub(r"^void ", "", name)
+    name = name.replace("(anonymous namespace)::", "").replace("segger::", "")
+    depth, out = 0, []
+    for ch in name:                       # cut the argument list: the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out).replace(" ", "")
+
+
+@pytest.fixture(scope="module")
+def table():
+    if shutil.which("make") is None or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc: the assembly cannot be produced here")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "segger_amd", "csrc"), "asm", "-j8"], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    import kernel_resources
+    rows = kernel_resources.kernels()
+    assert len(rows) > 300
+    return {_norm(r["name"]): r for r in rows}
+
+
+def _launched(pattern):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    assert files, pattern
+    names = set()
+    for ln in open(files[-1]):            # the newest round's sequence
+        m = re.search(r"grid=\d+\s+(.*)$", ln)
+        if m and "segger::" in m.group(1):
+            names.add(_norm(m.group(1)))
+    return files[-1], names
+
+
+@pytest.mark.parametrize("pattern", ["r0*_c2_step_sequence.txt", "r0*_small_batch_step_sequence.txt"])
+def test_kernels_of_the_timed_steps_use_no_scratch(table, pattern):
+    path, names = _launched(pattern)
+    assert len(names) >= 15, (path, names)
+    missing = sorted(n for n in names if n not in table)
+    # (the profiler truncates very long names: match those by prefix)
+    for n in list(missing):
+        hits = [k for k in table if k.startswith(n.rstrip(".")[:60])]
+        if hits:
+            missing.remove(n)
+            names.discard(n)
+            names.update(hits[:1])
+    assert not missing, f"{path}: kernels not found in build/asm: {missing}"
+    spilled = {n: table[n]["scratch"] for n in names if table[n]["scratch"]}
+    assert not spilled, f"{path}: kernels with scratch memory (bytes per lane): {spilled}"
+
+
+def test_flagship_aggregation_and_projection_kernels_use_no_scratch(table):
+    """H = 2, C = 64 (segger's CLI defaults) at every storage type the encoder runs 16-bit; the persistent projection at
+    every shipped (K, M)."""
+    want = []
+    for t in ("bf16_t", "f16_t"):
+        want += [f"gatv2_fwd_kernel<{t},2,8,false>", f"gatv2_fwd_kernel<{t},2,8,true>", f"gatv2_fwd_pair_kernel<{t},2,8>",
+                 f"gatv2_bwd_dst_kernel<{t},2,8,false,false>", f"gatv2_bwd_dst_kernel<{t},2,8,true,true>",
+                 f"gatv2_bwd_src_kernel<{t},2,8,false>", f"gatv2_bwd_src_dst_pair_kernel<{t},2,8>"]
+        want += [f"linear_res_kernel<{t},{k},{n}>" for k in (128, 64) for n in (6, 2, 1)]
+    for n in want:
+        assert n in table, n
+        assert table[n]["scratch"] == 0, (n, table[n])
