@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 18
+#define SEGGER_ABI_VERSION 19
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -800,6 +800,25 @@ int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float* table, con
                           int64_t n, int32_t n_rows_table, int32_t D, void* gpe, int64_t ld_gpe, float* gtable,
                           const int64_t* gene_ptr, const int32_t* gene_rows, void* workspace, size_t workspace_bytes,
                           int32_t dtype, segger_stream_t stream);
+/* segger_front_join_fwd/bwd: the encoder's layer-0 input of BOTH node types, one launch each way
+ * (ist_encoder.py:312-320: x = {k: gelu(cat(lin_first[k](x[k]), pos_emb(pos[k])))}):
+ *   out_tx[r] = gelu(cat(table[ids[r]], pe[r]))  r < n_tx;   out_bd[r] = gelu(cat(xb[r], pe[n_tx + r]))  r < n_bd
+ * with `pe` the positional embeddings of the two types back to back ([n_tx + n_bd, D]: one embedder call) and xb =
+ * lin_first['bd'](x_bd).  bwd: g_pe [n_tx + n_bd, D] = g[:, D:] * gelu'(pe) written as ONE matrix, g_xb = g_bd[:, :D] *
+ * gelu'(xb), g_table (optional) as segger_embed_gelu_bwd (gene_ptr / gene_rows / workspace of
+ * segger_embed_gelu_bwd_workspace_bytes(n_tx, n_rows_table, D)).  It replaces torch's cat + GELU (+ their backward, and
+ * the full-size cat that joins the two slices' gradients) on the boundary side of a small batch. */
+typedef struct segger_front_join_args {
+  const float* table; const int32_t* ids; int32_t n_rows_table; int32_t D; int32_t dtype; int32_t reserved_;
+  const void* pe; int64_t ld_pe; int64_t n_tx, n_bd;
+  const void* xb; int64_t ld_xb;
+  void* out_tx; int64_t ld_out_tx; void* out_bd; int64_t ld_out_bd;                      /* forward outputs [n, 2D] */
+  const void* g_tx; int64_t ld_g_tx; const void* g_bd; int64_t ld_g_bd;                  /* backward inputs [n, 2D] */
+  void* g_pe; int64_t ld_g_pe; void* g_xb; int64_t ld_g_xb;                              /* backward outputs */
+  float* g_table; const int64_t* gene_ptr; const int32_t* gene_rows; void* workspace; size_t workspace_bytes;
+} segger_front_join_args;
+int segger_front_join_fwd(const segger_front_join_args* args, segger_stream_t stream);
+int segger_front_join_bwd(const segger_front_join_args* args, segger_stream_t stream);
 int segger_l2norm_fwd(const void* y, int64_t ld_y, int64_t n, int32_t channels, float eps, void* z, int64_t ld_z,
                       int32_t dtype, segger_stream_t stream);
 int segger_l2norm_bwd(const void* y, int64_t ld_y, const void* gz, int64_t ld_gz, int64_t n, int32_t channels,

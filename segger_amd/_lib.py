@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
@@ -150,6 +150,18 @@ class L2NormSeg(C.Structure):
                 ("gz", vp), ("ld_gz", C.c_int64), ("gz_f32", C.c_int32), ("reserved_", C.c_int32)]
 
 
+class FrontJoinArgs(C.Structure):
+    _fields_ = [
+        ("table", vp), ("ids", vp), ("n_rows_table", C.c_int32), ("D", C.c_int32), ("dtype", C.c_int32), ("reserved_", C.c_int32),
+        ("pe", vp), ("ld_pe", C.c_int64), ("n_tx", C.c_int64), ("n_bd", C.c_int64),
+        ("xb", vp), ("ld_xb", C.c_int64),
+        ("out_tx", vp), ("ld_out_tx", C.c_int64), ("out_bd", vp), ("ld_out_bd", C.c_int64),
+        ("g_tx", vp), ("ld_g_tx", C.c_int64), ("g_bd", vp), ("ld_g_bd", C.c_int64),
+        ("g_pe", vp), ("ld_g_pe", C.c_int64), ("g_xb", vp), ("ld_g_xb", C.c_int64),
+        ("g_table", vp), ("gene_ptr", vp), ("gene_rows", vp), ("workspace", vp), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 class LossHeadArgs(C.Structure):
     _fields_ = [
         ("z_tx", vp), ("ld_ztx", C.c_int64), ("n_tx", C.c_int64),
@@ -251,6 +263,8 @@ EXPORTS = {
                                          vp, C.c_int64, vp, C.c_int64, vp, C.c_size_t, vp]),
     "segger_posfreq": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_float, C.c_float, vp, C.c_int32, vp]),
     "segger_embed_gelu_fwd": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, C.c_int32, vp]),
+    "segger_front_join_fwd": (C.c_int, [C.POINTER(FrontJoinArgs), vp]),
+    "segger_front_join_bwd": (C.c_int, [C.POINTER(FrontJoinArgs), vp]),
     "segger_embed_gelu_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),
     "segger_embed_gelu_bwd": (C.c_int, [vp, C.c_int64, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64,
                                         vp, vp, vp, vp, C.c_size_t, C.c_int32, vp]),

@@ -90,6 +90,69 @@ __global__ __launch_bounds__(256) void embed_gelu_bwd_pe_kernel(const T* __restr
   Vec8<T>::store(gpe + row * ld_gpe + c0, g);
 }
 
+// ---------------------------------------------------------------------------------------------
+// front join: the encoder's input of BOTH node types in one launch each way (ist_encoder.py:312-320)
+//   x_tx[r] = gelu(cat(table[ids[r]], pe[r]))            r < n_tx
+//   x_bd[r] = gelu(cat(xb[r], pe[n_tx + r]))             r < n_bd     (xb = lin_first['bd'] output)
+// `pe` holds the positional embeddings of both types back to back (one embedder call); the backward writes its
+// gradient as ONE [n_tx + n_bd, D] matrix (autograd would zero-fill and copy a full-size matrix to join two slices).
+// ---------------------------------------------------------------------------------------------
+struct FrontJoin {
+  const float* table; const int32_t* ids; int D;
+  const void* pe; int64_t ld_pe; int64_t n_tx, n_bd;
+  const void* xb; int64_t ld_xb;
+  void* out_tx; int64_t ld_out_tx; void* out_bd; int64_t ld_out_bd;
+  const void* g_tx; int64_t ld_g_tx; const void* g_bd; int64_t ld_g_bd;
+  void* g_pe; int64_t ld_g_pe; void* g_xb; int64_t ld_g_xb;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void front_join_fwd_kernel(FrontJoin p) {
+  const int D = p.D, per_row = (2 * D) / 8;
+  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = item / per_row;
+  if (row >= p.n_tx + p.n_bd) return;
+  const int c0 = (int)(item % per_row) * 8;
+  const bool is_bd = row >= p.n_tx;
+  const int64_t r = is_bd ? row - p.n_tx : row;
+  float v[8];
+  if (c0 >= D) Vec8<T>::load(static_cast<const T*>(p.pe) + row * p.ld_pe + (c0 - D), v);
+  else if (is_bd) Vec8<T>::load(static_cast<const T*>(p.xb) + r * p.ld_xb + c0, v);
+  else Vec8<float>::load(p.table + (int64_t)p.ids[r] * D + c0, v);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = gelu_erf(v[k]);
+  T* o = is_bd ? static_cast<T*>(p.out_bd) + r * p.ld_out_bd : static_cast<T*>(p.out_tx) + r * p.ld_out_tx;
+  Vec8<T>::store(o + c0, v);
+}
+
+// items: [ (n_tx + n_bd) positional halves | n_bd dense halves ], D/8 threads each
+template <typename T>
+__global__ __launch_bounds__(256) void front_join_bwd_kernel(FrontJoin p) {
+  const int D = p.D, per_row = D / 8;
+  const int64_t item = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t row = item / per_row;
+  const int c0 = (int)(item % per_row) * 8;
+  const int64_t n_all = p.n_tx + p.n_bd;
+  if (row >= n_all + p.n_bd) return;
+  float g[8], x[8];
+  if (row < n_all) {                                   // positional half of either type
+    const bool is_bd = row >= p.n_tx;
+    const T* gsrc = is_bd ? static_cast<const T*>(p.g_bd) + (row - p.n_tx) * p.ld_g_bd : static_cast<const T*>(p.g_tx) + row * p.ld_g_tx;
+    Vec8<T>::load(gsrc + D + c0, g);
+    Vec8<T>::load(static_cast<const T*>(p.pe) + row * p.ld_pe + c0, x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] *= gelu_erf_grad(x[k]);
+    Vec8<T>::store(static_cast<T*>(p.g_pe) + row * p.ld_g_pe + c0, g);
+  } else {                                             // dense half of a boundary row
+    row -= n_all;
+    Vec8<T>::load(static_cast<const T*>(p.g_bd) + row * p.ld_g_bd + c0, g);
+    Vec8<T>::load(static_cast<const T*>(p.xb) + row * p.ld_xb + c0, x);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k] *= gelu_erf_grad(x[k]);
+    Vec8<T>::store(static_cast<T*>(p.g_xb) + row * p.ld_g_xb + c0, g);
+  }
+}
+
 // backward, embedding table: gtable[g, c] = gelu'(table[g, c]) * sum_{n: ids[n] = g} gx0[n, c].
 // LDS float atomics (ds_add_f32) retire about one lane every three clocks per CU on gfx950 -- a per-block LDS
 // table took 0.66 ms for 1 M rows whatever the id distribution -- so the sum runs over the rows GROUPED BY GENE
@@ -442,6 +505,31 @@ extern "C" size_t segger_embed_gelu_bwd_workspace_bytes(int64_t n, int32_t n_row
   return (size_t)emb_max_chunks(n, n_rows_table) * (size_t)D * sizeof(float) + ((size_t)n_rows_table + 1) * sizeof(int) + 32;
 }
 
+// gtable = gelu'(table) * (rows of gx0[:, :D] summed per id): plan + gather + finish (see emb_gather_kernel)
+static int embed_table_grad(const void* gx0, int64_t ld_g, const float* table, int64_t n, int32_t n_rows_table, int32_t D,
+                            float* gtable, const int64_t* gene_ptr, const int32_t* gene_rows, void* workspace,
+                            size_t workspace_bytes, int32_t dtype, hipStream_t stream) {
+  SEGGER_REQUIRE(table && gene_ptr && gene_rows, "embedding-table gradient: table / gene_ptr / gene_rows required");
+  const size_t need = segger_embed_gelu_bwd_workspace_bytes(n, n_rows_table, D);
+  if (!workspace || workspace_bytes < need) {
+    set_error("embedding-table gradient: workspace %zu < %zu bytes", workspace_bytes, need);
+    return SEGGER_EWORKSPACE;
+  }
+  const int64_t gd = (int64_t)n_rows_table * D;
+  const int64_t max_chunks = emb_max_chunks(n, n_rows_table);
+  SEGGER_REQUIRE(max_chunks < 0x7fffffffLL, "embedding-table gradient: too many rows");
+  float* partial = static_cast<float*>(workspace);
+  int* chunk_ptr = reinterpret_cast<int*>(static_cast<char*>(workspace) + (((size_t)max_chunks * D * sizeof(float) + 15) & ~(size_t)15));
+  hipLaunchKernelGGL(emb_plan_kernel, dim3(1), dim3(256), 0, stream, gene_ptr, (int)n_rows_table, chunk_ptr);
+  const int P = D / 8, R = 256 / P > 0 ? 256 / P : 1;
+  const size_t lds = (size_t)R * D * sizeof(float);
+#define GO(T) hipLaunchKernelGGL((emb_gather_kernel<T>), dim3((unsigned)max_chunks), dim3((unsigned)(P * R)), lds, stream, (const T*)gx0, ld_g, gene_ptr, gene_rows, chunk_ptr, (int)n_rows_table, D, partial)
+  DISPATCH_DTYPE(dtype, GO(float), GO(bf16_t), GO(f16_t))
+#undef GO
+  hipLaunchKernelGGL(emb_finish_kernel, dim3((unsigned)((gd + 255) / 256)), dim3(256), 0, stream, partial, chunk_ptr, table, (int)n_rows_table, D, gtable);
+  return SEGGER_OK;
+}
+
 extern "C" int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float* table, const void* pe, int64_t ld_pe,
                                      int64_t n, int32_t n_rows_table, int32_t D, void* gpe, int64_t ld_gpe, float* gtable,
                                      const int64_t* gene_ptr, const int32_t* gene_rows, void* workspace,
@@ -466,25 +554,85 @@ extern "C" int segger_embed_gelu_bwd(const void* gx0, int64_t ld_g, const float*
 #undef GO
   }
   if (gtable) {
-    SEGGER_REQUIRE(table && gene_ptr && gene_rows, "segger_embed_gelu_bwd: table / gene_ptr / gene_rows required for the table gradient");
-    const size_t need = segger_embed_gelu_bwd_workspace_bytes(n, n_rows_table, D);
-    if (!workspace || workspace_bytes < need) {
-      set_error("segger_embed_gelu_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
-      return SEGGER_EWORKSPACE;
-    }
-    const int64_t max_chunks = emb_max_chunks(n, n_rows_table);
-    SEGGER_REQUIRE(max_chunks < 0x7fffffffLL, "segger_embed_gelu_bwd: too many rows");
-    float* partial = static_cast<float*>(workspace);
-    int* chunk_ptr = reinterpret_cast<int*>(static_cast<char*>(workspace) + (((size_t)max_chunks * D * sizeof(float) + 15) & ~(size_t)15));
-    hipLaunchKernelGGL(emb_plan_kernel, dim3(1), dim3(256), 0, stream, gene_ptr, (int)n_rows_table, chunk_ptr);
-    const int P = D / 8, R = 256 / P > 0 ? 256 / P : 1;
-    const size_t lds = (size_t)R * D * sizeof(float);
-#define GO(T) hipLaunchKernelGGL((emb_gather_kernel<T>), dim3((unsigned)max_chunks), dim3((unsigned)(P * R)), lds, stream, (const T*)gx0, ld_g, gene_ptr, gene_rows, chunk_ptr, (int)n_rows_table, D, partial)
-    DISPATCH_DTYPE(dtype, GO(float), GO(bf16_t), GO(f16_t))
-#undef GO
-    hipLaunchKernelGGL(emb_finish_kernel, dim3((unsigned)((gd + 255) / 256)), dim3(256), 0, stream, partial, chunk_ptr, table, (int)n_rows_table, D, gtable);
+    const int rc = embed_table_grad(gx0, ld_g, table, n, n_rows_table, D, gtable, gene_ptr, gene_rows, workspace, workspace_bytes,
+                                    dtype, stream);
+    if (rc != SEGGER_OK) return rc;
   }
   SEGGER_LAUNCH_CHECK("embed_gelu_bwd kernels");
+  return SEGGER_OK;
+}
+
+static int front_join_fill(const segger_front_join_args* a, bool bwd, FrontJoin* out) {
+  SEGGER_REQUIRE(a != nullptr, "segger_front_join: args is NULL");
+  SEGGER_REQUIRE(a->n_tx >= 0 && a->n_bd >= 0 && a->D > 0 && a->D % 8 == 0 && a->D <= 2048 && a->n_rows_table > 0,
+                 "segger_front_join: sizes (D a multiple of 8, <= 2048)");
+  SEGGER_REQUIRE(a->dtype == SEGGER_F32 || a->dtype == SEGGER_BF16 || a->dtype == SEGGER_F16, "segger_front_join: unknown dtype %d", a->dtype);
+  const size_t es = esize(a->dtype);
+  const int D = a->D;
+  auto ok = [&](const void* p, int64_t ld, int width) { return p && aligned16(p) && ld >= width && ((size_t)ld * es) % 16 == 0; };
+  const int64_t n_all = a->n_tx + a->n_bd;
+  SEGGER_REQUIRE(n_all == 0 || ok(a->pe, a->ld_pe, D), "segger_front_join: pe NULL, misaligned or ld < D");
+  SEGGER_REQUIRE(a->n_tx == 0 || (a->table && a->ids && aligned16(a->table)), "segger_front_join: table / ids");
+  SEGGER_REQUIRE(a->n_bd == 0 || ok(a->xb, a->ld_xb, D), "segger_front_join: xb NULL, misaligned or ld < D");
+  if (!bwd) {
+    SEGGER_REQUIRE(a->n_tx == 0 || ok(a->out_tx, a->ld_out_tx, 2 * D), "segger_front_join_fwd: out_tx");
+    SEGGER_REQUIRE(a->n_bd == 0 || ok(a->out_bd, a->ld_out_bd, 2 * D), "segger_front_join_fwd: out_bd");
+  } else {
+    SEGGER_REQUIRE(a->n_tx == 0 || ok(a->g_tx, a->ld_g_tx, 2 * D), "segger_front_join_bwd: g_tx");
+    SEGGER_REQUIRE(a->n_bd == 0 || (ok(a->g_bd, a->ld_g_bd, 2 * D) && ok(a->g_xb, a->ld_g_xb, D)), "segger_front_join_bwd: g_bd / g_xb");
+    SEGGER_REQUIRE(n_all == 0 || ok(a->g_pe, a->ld_g_pe, D), "segger_front_join_bwd: g_pe");
+  }
+  FrontJoin p{};
+  p.table = a->table; p.ids = a->ids; p.D = D;
+  p.pe = a->pe; p.ld_pe = a->ld_pe; p.n_tx = a->n_tx; p.n_bd = a->n_bd;
+  p.xb = a->xb; p.ld_xb = a->ld_xb;
+  p.out_tx = a->out_tx; p.ld_out_tx = a->ld_out_tx; p.out_bd = a->out_bd; p.ld_out_bd = a->ld_out_bd;
+  p.g_tx = a->g_tx; p.ld_g_tx = a->ld_g_tx; p.g_bd = a->g_bd; p.ld_g_bd = a->ld_g_bd;
+  p.g_pe = a->g_pe; p.ld_g_pe = a->ld_g_pe; p.g_xb = a->g_xb; p.ld_g_xb = a->ld_g_xb;
+  *out = p;
+  return SEGGER_OK;
+}
+
+extern "C" int segger_front_join_fwd(const segger_front_join_args* a, segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  FrontJoin p;
+  const int rc = front_join_fill(a, false, &p);
+  if (rc != SEGGER_OK) return rc;
+  const int64_t items = (p.n_tx + p.n_bd) * (2 * p.D / 8);
+  if (items == 0) return SEGGER_OK;
+  const int64_t nb = (items + 255) / 256;
+  SEGGER_REQUIRE(nb < 0x7fffffffLL, "segger_front_join_fwd: too many rows");
+#define GO(T) hipLaunchKernelGGL((front_join_fwd_kernel<T>), dim3((unsigned)nb), dim3(256), 0, stream, p)
+  DISPATCH_DTYPE(a->dtype, GO(float), GO(bf16_t), GO(f16_t))
+#undef GO
+  SEGGER_LAUNCH_CHECK("front_join_fwd_kernel");
+  return SEGGER_OK;
+}
+
+extern "C" int segger_front_join_bwd(const segger_front_join_args* a, segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  FrontJoin p;
+  const int rc = front_join_fill(a, true, &p);
+  if (rc != SEGGER_OK) return rc;
+  const int64_t items = (p.n_tx + 2 * p.n_bd) * (p.D / 8);
+  if (items > 0) {
+    const int64_t nb = (items + 255) / 256;
+    SEGGER_REQUIRE(nb < 0x7fffffffLL, "segger_front_join_bwd: too many rows");
+#define GO(T) hipLaunchKernelGGL((front_join_bwd_kernel<T>), dim3((unsigned)nb), dim3(256), 0, stream, p)
+    DISPATCH_DTYPE(a->dtype, GO(float), GO(bf16_t), GO(f16_t))
+#undef GO
+    SEGGER_LAUNCH_CHECK("front_join_bwd_kernel");
+  }
+  if (a->g_table) {
+    if (a->n_tx == 0) {
+      SEGGER_HIP(hipMemsetAsync(a->g_table, 0, (size_t)a->n_rows_table * a->D * sizeof(float), stream));
+      return SEGGER_OK;
+    }
+    const int rc2 = embed_table_grad(a->g_tx, a->ld_g_tx, a->table, a->n_tx, a->n_rows_table, a->D, a->g_table, a->gene_ptr,
+                                     a->gene_rows, a->workspace, a->workspace_bytes, a->dtype, stream);
+    if (rc2 != SEGGER_OK) return rc2;
+    SEGGER_LAUNCH_CHECK("front_join table gradient");
+  }
   return SEGGER_OK;
 }
 

@@ -146,6 +146,7 @@ class _SplitRows(torch.autograd.Function):
 
 
 MERGED_POS_EMBED = True     # one embedder call for both node types (tools flip it for A/B runs)
+FRONT_JOIN = True           # ... and one gather / concat / GELU launch for both (ops.front_join); False: per type, torch on 'bd'
 
 
 class GATv2Conv(Module):
@@ -363,9 +364,11 @@ class ISTEncoder(Module):
         p = self.conv_layers[0].conv[TX_TX].dropout
         return self.planes_of(views, ops.dropout_bits_many([(c, sd) for _, _, c, sd in views], self.n_heads, p, step))
 
-    def _pos_embed_pair(self, pos_dict, batch_dict, num_graphs, dt, gelu: bool, graphs):
-        """(pe_tx, pe_bd): ``pos_emb`` of both node types, in one call where the batch vectors allow it.  With ``gelu``
-        pe_tx is the pair ``(gelu(h), h or None)`` of ``Positional2dEmbedder.forward(return_pre=True)``."""
+    def _pos_embed_pair(self, pos_dict, batch_dict, num_graphs, dt, gelu: bool, graphs, joint: bool = False):
+        """(pe_tx, pe_bd, None): ``pos_emb`` of both node types, in one call where the batch vectors allow it.  With ``gelu``
+        pe_tx is the pair ``(gelu(h), h or None)`` of ``Positional2dEmbedder.forward(return_pre=True)``.  ``joint``: when
+        the two types were embedded by one call (and ``gelu`` is off), return ``(None, None, pe)`` instead, ``pe`` the
+        un-split [n_tx + n_bd, D] matrix (for :func:`ops.front_join`)."""
         b_tx, b_bd = batch_dict.get("tx"), batch_dict.get("bd")
         staged = graphs.get("pos_all") if graphs is not None else None
         # (large batches -- the `split` route -- keep one call per type: there the launches do not matter, and joining
@@ -373,7 +376,7 @@ class ISTEncoder(Module):
         if staged is None and (not MERGED_POS_EMBED or gelu or b_tx is None or b_bd is None or num_graphs is None):
             one = lambda k, **kw: self.pos_emb(pos_dict[k], batch_dict.get(k), num_graphs=num_graphs, dtype=dt, gelu=gelu,
                                                **kw)
-            return (one("tx", return_pre=True) if gelu else one("tx")), one("bd")
+            return (one("tx", return_pre=True) if gelu else one("tx")), one("bd"), None
         if staged is not None:                               # a captured step stages the concatenation itself
             pos_all, batch_all = staged
         else:
@@ -381,8 +384,10 @@ class ISTEncoder(Module):
             batch_all = torch.cat((b_tx.long(), b_bd.long() + int(num_graphs)), 0)
         pe = self.pos_emb(pos_all, batch_all, num_graphs=2 * int(num_graphs), dtype=dt, gelu=gelu,
                           minmax=graphs.get("minmax") if graphs is not None else None)
+        if joint and not gelu:
+            return None, None, pe
         pe_tx, pe_bd = _SplitRows.apply(pe, int(pos_dict["tx"].shape[0]))
-        return ((pe_tx, None) if gelu else pe_tx), pe_bd
+        return ((pe_tx, None) if gelu else pe_tx), pe_bd, None
 
     def _materialize_bd(self, d_in: int, device) -> None:
         if "bd" not in self.lin_first:
@@ -413,11 +418,13 @@ class ISTEncoder(Module):
             # of the front end, and the embedder's parameters receive ONE gradient each (what lets a captured step
             # postpone its partial sums, ops.deferred_reductions).  `split`: the GELU of ist_encoder.py:320 comes
             # applied (gelu(cat(a, b)) = cat(gelu(a), gelu(b))).
-            pe_tx, pe_bd = self._pos_embed_pair(pos_dict, batch_dict, num_graphs, dt, split, graphs)
+            pe_tx, pe_bd, pe_all = self._pos_embed_pair(pos_dict, batch_dict, num_graphs, dt, split, graphs,
+                                                        joint=fused_tx and FRONT_JOIN)
             pre_tx = None
             if split:
                 pe_tx, pre_tx = pe_tx
-            x_bd = torch.cat((F.gelu(x_bd), pe_bd), -1) if split else F.gelu(torch.cat((x_bd, pe_bd), -1))
+            if pe_all is None:
+                x_bd = torch.cat((F.gelu(x_bd), pe_bd), -1) if split else F.gelu(torch.cat((x_bd, pe_bd), -1))
             if fused_tx:
                 # gather + concat + GELU in one kernel; its table gradient sums over rows grouped by gene id: one
                 # sort per batch (not needed without grad), cached with the batch or supplied with `graphs`
@@ -438,7 +445,11 @@ class ISTEncoder(Module):
                             by_gene = ops.rows_by_id(ids, emb.weight.shape[0])
                             if cache is not None:
                                 cache[key] = by_gene
-                if split:
+                if pe_all is not None:
+                    # both node types: gather / concat / GELU in one launch, and back in one (the boundary side's torch cat +
+                    # GELU + their backward, and the full-size cat joining the two slices' gradients of the embedder's output)
+                    x_tx, x_bd = ops.front_join(emb.weight, ids, x_bd, pe_all, by_gene)
+                elif split:
                     # keep gelu(cat(E[g], pe)) as its parts: the first layer projects it as T[g] + W_pe gelu(pe)
                     x_tx = ops.EmbedInput(emb.weight, ids.to(torch.int32).contiguous(), pe_tx, by_gene, pre_tx)
                 else:

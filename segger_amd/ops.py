@@ -2385,6 +2385,88 @@ class _EmbedGelu(torch.autograd.Function):
         return gtable, None, gpe, None
 
 
+class _FrontJoin(torch.autograd.Function):
+    """(gelu(cat(table[ids], pe[:n_tx])), gelu(cat(xb, pe[n_tx:]))): the encoder's layer-0 input of both node types in one
+    launch each way (``segger_front_join_fwd`` / ``_bwd``); ``pe`` = the positional embeddings of the two types back to
+    back.  The backward returns the gradient of ``pe`` as one matrix."""
+
+    @staticmethod
+    def forward(ctx, table, ids, xb, pe, by_gene):
+        _lib.require_cuda(table, ids, xb, pe)
+        lib = _lib.load()
+        n_tx, n_bd, d = int(ids.shape[0]), int(xb.shape[0]), int(pe.shape[1])
+        dev, dt = pe.device, pe.dtype
+        out_tx = torch.empty((n_tx, 2 * d), dtype=dt, device=dev)
+        out_bd = torch.empty((n_bd, 2 * d), dtype=dt, device=dev)
+        a = _lib.FrontJoinArgs()
+        a.table, a.ids, a.n_rows_table, a.D, a.dtype = table.data_ptr(), _lib.ptr(ids) if n_tx else None, int(table.shape[0]), d, DTYPE_CODE[dt]
+        a.pe, a.ld_pe = _rows(pe, d, "pe")
+        a.n_tx, a.n_bd = n_tx, n_bd
+        a.xb, a.ld_xb = _rows(xb, d, "xb")
+        a.out_tx, a.ld_out_tx, a.out_bd, a.ld_out_bd = out_tx.data_ptr(), 2 * d, out_bd.data_ptr(), 2 * d
+        with _lib.on_device(dev):
+            rc = lib.segger_front_join_fwd(C.byref(a), _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_front_join_fwd")
+        ctx.save_for_backward(table, ids, xb, pe)
+        ctx.by_gene = by_gene
+        return out_tx, out_bd
+
+    @staticmethod
+    def backward(ctx, g_tx, g_bd):
+        table, ids, xb, pe = ctx.saved_tensors
+        lib = _lib.load()
+        n_tx, n_bd, d = int(ids.shape[0]), int(xb.shape[0]), int(pe.shape[1])
+        dev, dt = pe.device, pe.dtype
+
+        def rows2(g, n):
+            if g is None:
+                g = torch.zeros((n, 2 * d), dtype=dt, device=dev)
+            if g.dtype != dt:
+                g = g.to(dt)
+            if g.stride(-1) != 1:
+                g = g.contiguous()
+            return g
+        g_tx, g_bd = rows2(g_tx, n_tx), rows2(g_bd, n_bd)
+        g_pe = torch.empty((n_tx + n_bd, d), dtype=dt, device=dev)
+        g_xb = torch.empty((n_bd, d), dtype=dt, device=dev)
+        want_table = ctx.needs_input_grad[0]
+        g_table = torch.empty_like(table) if want_table else None
+        g = int(table.shape[0])
+        ws_bytes = lib.segger_embed_gelu_bwd_workspace_bytes(n_tx, g, d) if want_table else 0
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        by_gene = ctx.by_gene
+        if want_table and by_gene is None and n_tx:
+            by_gene = rows_by_id(ids, g)
+        a = _lib.FrontJoinArgs()
+        a.table, a.ids, a.n_rows_table, a.D, a.dtype = table.data_ptr(), _lib.ptr(ids) if n_tx else None, g, d, DTYPE_CODE[dt]
+        a.pe, a.ld_pe = _rows(pe, d, "pe")
+        a.n_tx, a.n_bd = n_tx, n_bd
+        a.xb, a.ld_xb = _rows(xb, d, "xb")
+        a.g_tx, a.ld_g_tx = _rows(g_tx, 2 * d, "g_tx")
+        a.g_bd, a.ld_g_bd = _rows(g_bd, 2 * d, "g_bd")
+        a.g_pe, a.ld_g_pe, a.g_xb, a.ld_g_xb = g_pe.data_ptr(), d, g_xb.data_ptr(), d
+        if want_table:
+            a.g_table = g_table.data_ptr()
+            if n_tx:
+                a.gene_ptr, a.gene_rows = by_gene.indptr.data_ptr(), by_gene.col.data_ptr()
+            a.workspace, a.workspace_bytes = ws.data_ptr(), ws_bytes
+        with _lib.on_device(dev):
+            rc = lib.segger_front_join_bwd(C.byref(a), _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_front_join_bwd")
+        return g_table, None, g_xb, g_pe, None
+
+
+def front_join(table: Tensor, ids: Tensor, xb: Tensor, pe: Tensor, by_gene: Optional[EdgeCSR] = None):
+    """-> (x_tx [n_tx, 2D], x_bd [n_bd, 2D]) = (gelu(cat(table[ids], pe[:n_tx])), gelu(cat(xb, pe[n_tx:]))), reference
+    ist_encoder.py:312-320 for both node types.  ``pe``: [n_tx + n_bd, D]; ``by_gene`` as :func:`embed_gelu`."""
+    if table.dtype != torch.float32 or not table.is_contiguous():
+        raise TypeError("front_join: the embedding table must be contiguous fp32")
+    d = int(table.shape[1])
+    if pe.shape[1] != d or xb.shape[1] != d or d % 8 or pe.shape[0] != ids.shape[0] + xb.shape[0] or xb.dtype != pe.dtype:
+        raise ValueError("front_join: pe [n_tx + n_bd, D] and xb [n_bd, D] must match the table width and each other's dtype")
+    return _FrontJoin.apply(table, ids.to(torch.int32).contiguous(), xb, pe, by_gene)
+
+
 def rows_by_id(ids: Tensor, n_ids: int) -> EdgeCSR:
     """Rows grouped by id (``indptr`` over ids, ``col`` = row numbers, ascending inside an id): what the
     embedding-table gradient sums over.  One radix sort; cache it per batch (``ISTEncoder`` does)."""

@@ -771,3 +771,65 @@ def test_one_launch_loss_head_backward_twice(cuda):
     for u, v in zip(g1, g2):
         assert torch.isfinite(v).all()
         assert (u - v).abs().max().item() <= 2e-5 * u.abs().max().item()
+
+
+@pytest.mark.parametrize("n_bd", [0, 1, 411])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_front_join_autograd(cuda, dtype, n_bd):
+    """segger_front_join_fwd / _bwd: (gelu(cat(E[g], pe[:n_tx])), gelu(cat(x_bd, pe[n_tx:]))) of both node types in one
+    launch each way (reference ist_encoder.py:312-320 per type) against torch in float64: outputs, the gradient of the
+    un-split positional matrix, of the boundary features and of the embedding table (genes that never occur: zero rows).
+    Inputs with a row stride (views into wider matrices) included."""
+    from segger_amd import ops
+    g = torch.Generator().manual_seed(40 + n_bd)
+    n, G, D = 3000, 37, 128
+    table = torch.randn(G, D, generator=g)
+    ids = torch.randint(0, G - 2, (n,), generator=g)
+    pe = torch.randn(n + n_bd, D, generator=g).to(dtype)
+    xb_wide = torch.randn(n_bd, D + 64, generator=g).to(dtype)                 # boundary features as a strided view
+    g_tx = torch.randn(n, 2 * D, generator=g).to(dtype)
+    g_bd = torch.randn(n_bd, 2 * D, generator=g).to(dtype)
+    t_d, pe_d = table.to(cuda).requires_grad_(True), pe.to(cuda).requires_grad_(True)
+    xbw_d = xb_wide.to(cuda).requires_grad_(True)
+    by_gene = ops.rows_by_id(ids.to(cuda).to(torch.int32), G)
+    x_tx, x_bd = ops.front_join(t_d, ids.to(cuda), xbw_d[:, :D], pe_d, by_gene)
+    assert x_tx.shape == (n, 2 * D) and x_bd.shape == (n_bd, 2 * D)
+    torch.autograd.backward((x_tx, x_bd), (g_tx.to(cuda), g_bd.to(cuda)))
+    t_r, pe_r, xb_r = table.double().requires_grad_(True), pe.double().requires_grad_(True), xb_wide.double().requires_grad_(True)
+    r_tx = torch.nn.functional.gelu(torch.cat((t_r[ids], pe_r[:n]), -1))
+    r_bd = torch.nn.functional.gelu(torch.cat((xb_r[:, :D], pe_r[n:]), -1))
+    torch.autograd.backward((r_tx, r_bd), (g_tx.double(), g_bd.double()))
+    rt = 1e-5 if dtype == torch.float32 else (1e-2 if dtype == torch.bfloat16 else 2e-3)
+    assert torch.allclose(x_tx.double().cpu(), r_tx, rtol=rt, atol=rt)
+    assert torch.allclose(x_bd.double().cpu(), r_bd, rtol=rt, atol=rt)
+    assert torch.allclose(pe_d.grad.double().cpu(), pe_r.grad, rtol=rt, atol=rt)
+    assert torch.allclose(xbw_d.grad.double().cpu(), xb_r.grad, rtol=rt, atol=rt)
+    assert torch.allclose(t_d.grad.double().cpu(), t_r.grad, rtol=1e-4, atol=1e-3 if dtype == torch.float32 else 8e-2)
+    assert (t_d.grad[G - 2:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_encoder_front_join_equals_the_per_type_route(cuda, dtype, monkeypatch):
+    """ISTEncoder with ops.front_join (default) against the per-type route (embed_gelu on 'tx', torch cat + GELU on 'bd'):
+    same embeddings and parameter gradients up to the rounding of one GELU implementation against the other."""
+    from segger_amd import ist_encoder as IE
+    from segger_amd.synthetic import SyntheticSpec
+    from tests.test_gpu_model import build
+    spec = SyntheticSpec(n_tx=9000, n_bd=260, k_tx=6, seed=5)
+    out = {}
+    for on in (True, False):
+        monkeypatch.setattr(IE, "FRONT_JOIN", on)
+        m, _, bcpu, _ = build(spec, cuda, dtype=dtype)
+        m.eval()
+        bg = bcpu.to(cuda)
+        z = m(bg)
+        (z["tx"].float().square().sum() * 0.5 + z["bd"].float()[:, ::2].sum()).backward()
+        out[on] = (z["tx"].float().detach(), z["bd"].float().detach(),
+                   {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    tol = 2e-6 if dtype == torch.float32 else 2e-2
+    assert (out[True][0] - out[False][0]).abs().max().item() <= tol
+    assert (out[True][1] - out[False][1]).abs().max().item() <= tol
+    assert out[True][2].keys() == out[False][2].keys()
+    for k, g1 in out[True][2].items():
+        g0 = out[False][2][k]
+        assert (g1 - g0).abs().max().item() <= (1e-4 if dtype == torch.float32 else 6e-2) * max(g0.abs().max().item(), 1e-3), k
