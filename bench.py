@@ -184,18 +184,43 @@ def other_kernel_classes(dev, n, etb, hc, elem, gen, ops, batch):
     dneg = (dstp + torch.randint(1, nbd, (etb,), device=dev, generator=gen)) % nbd
     groups = csr_from_coo(dstp, src, nbd, n, validate=False)
 
-    def trip_sg(unique):
-        z.grad = None; zb.grad = None
-        ops.triplet_edge_loss(z, zb, src, dstp, dneg, 0.4, pos_groups=groups, anchors_unique=unique).backward()
-    with torch.no_grad():
-        ms_f = time_kernel(lambda: ops.triplet_edge_loss(z, zb, src, dstp, dneg, 0.4), iters=10, warm=2)
+    # (the step runs these behind ONE zero fill shared with loss_tx's atomics -- ops._LossHead: timed here as launched there,
+    #  the kernels alone on zero-filled buffers; the fill is its own entry)
+    import ctypes as C
+    from segger_amd import _lib
+    lib = _lib.load()
+    stream = torch.cuda.current_stream().cuda_stream
+    i64 = lambda t: t.to(torch.int64).contiguous()
+    sg = (i64(src), i64(dstp), i64(dneg))
+    ga = torch.zeros(n, 64, dtype=dt, device=dev)
+    gb = torch.zeros(nbd, 64, dtype=torch.float32, device=dev)
+    one = torch.ones(1, device=dev)
+
+    def sg_args(unique):
+        sa = ops._triplet_args(*sg, z.detach(), zb.detach(), 0.4, 1e-6)
+        sa.grad_a, sa.grad_a_packed, sa.grad_b, sa.grad_b_packed = ga.data_ptr(), 1, gb.data_ptr(), 0
+        sa.pos_indptr, sa.pos_eid = groups.indptr.data_ptr(), groups.eid.data_ptr()
+        sa.anchor_unique = int(unique)
+        sa.grad_scale, sa.grad_scale_dev = 1.0, one.data_ptr()
+        return sa
     nb = etb * 3 * 64 * elem + etb * 64 * (elem + 4)
     for name, uq in (("triplet_bwd_loss_sg_grouped", True), ("triplet_bwd_loss_sg_two_kernels", False)):
-        ms = max(time_kernel(lambda: trip_sg(uq), iters=10, warm=2) - ms_f, 1e-6)
+        sa = sg_args(uq)
+
+        def run(sa=sa):
+            _lib.check(lib.segger_triplet_bwd(C.byref(sa), stream), "segger_triplet_bwd")
+        ms = time_kernel(run, iters=10, warm=2)
         out[name] = {"achieved": nb / (ms * 1e-3) / 1e9, "frac": nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s",
                      "algorithmic_bytes_per_launch": nb, "ms_per_launch": ms,
-                     "note": f"backward of loss_sg ({etb} triplets; zero fills + kernel(s); forward subtracted): 3 row reads, "
-                             "one anchor row stored, one negative row of fp32 atomics per active triplet"}
+                     "note": f"backward of loss_sg ({etb} triplets), the kernel(s) as the step launches them (the zero fill is "
+                             "shared with loss_tx: `loss_grad_zero_fill`): 3 row reads, one anchor row stored, one negative row "
+                             "of fp32 atomics per active triplet; the PMC traffic above the algorithmic bytes is those atomics "
+                             "(memory-side: counted ~8 B per 4-B add)"}
+    zfill = torch.empty(n * 64 * elem + nbd * 64 * 4, dtype=torch.uint8, device=dev)
+    ms = time_kernel(lambda: zfill.zero_(), iters=10, warm=2)
+    out["loss_grad_zero_fill"] = {"achieved": zfill.numel() / (ms * 1e-3) / 1e9, "frac": zfill.numel() / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                  "unit": "GB/s", "algorithmic_bytes_per_launch": zfill.numel(), "ms_per_launch": ms,
+                                  "note": "the one fill both loss backward kernels accumulate into ([n_tx, 64] bf16 + [n_bd, 64] fp32)"}
     return out
 
 

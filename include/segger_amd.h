@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 19
+#define SEGGER_ABI_VERSION 20
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -646,6 +646,25 @@ int segger_linear_fwd_silu_grad(const void* x, int64_t ldx, const void* w, const
 int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void* w, const float* bias, const void* rowbias,
                               int64_t ld_rb, const int32_t* rowidx, void* y, int64_t ldy, int64_t n_rows, int32_t k_in,
                               int32_t m_out, int32_t dtype, segger_stream_t stream);
+
+/* segger_gene_table_fwd/bwd: the per-gene table of segger_linear_fwd_rowbias and everything that flows back through it,
+ * one launch each way (csrc/gene_table.hip) -- torch formed it with ~25 small launches per step (gelu, cat, vendor GEMMs,
+ * slice gradients).  The first hetero layer projects gelu(cat(E[gene], pe)) with n_w (<= 4) stacked nn.Linear maps
+ * w[i] [m[i], ld_w[i] >= 2 D] fp32 (GATv2Conv.lin_l / lin_r, ist_encoder.py:111-124), bias b[i] [m[i]] or NULL; M = sum m[i].
+ *   fwd: tab [n_genes, ld_tab >= M] = gelu(E) Wa^T + b, Wa = w[:, 0:D], in `dtype`; wc [M, D] = w[:, D:2D] and wc_t [D, M]
+ *        its transpose, both in `dtype` (either may be NULL).
+ *   bwd: from g_tab [n_genes, M] fp32 (rows of dY summed by gene) and g_wc [M, D] fp32 (dWc of the positional GEMM; NULL:
+ *        right halves left untouched): g_table [n_genes, D] = gelu'(E) * (g_tab Wa) (NULL to skip); g_w[i] [m[i], 2 D]
+ *        contiguous fp32 = [g_tab^T gelu(E) | g_wc] rows of weight i; g_b[i] [m[i]] = column sums of g_tab (NULL to skip). */
+typedef struct segger_gene_table_args {
+  const float* table; int32_t n_genes; int32_t D; int32_t n_w; int32_t dtype;
+  const float* w[4]; int64_t ld_w[4]; int32_t m[4]; const float* b[4];
+  void* tab; int64_t ld_tab; void* wc; void* wc_t;                    /* forward outputs */
+  const float* g_tab; const float* g_wc;                              /* backward inputs */
+  float* g_table; float* g_w[4]; float* g_b[4];                       /* backward outputs */
+} segger_gene_table_args;
+int segger_gene_table_fwd(const segger_gene_table_args* args, segger_stream_t stream);
+int segger_gene_table_bwd(const segger_gene_table_args* args, segger_stream_t stream);
 
 /* segger_linear_fwd_f32_split: the fp32-storage projection on the bf16 matrix pipe -- every fp32 operand as the sum of three
  * bf16 numbers, the product as its six leading partial products, each exact in the MFMA's fp32 accumulator

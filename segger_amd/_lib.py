@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
@@ -150,6 +150,16 @@ class L2NormSeg(C.Structure):
                 ("gz", vp), ("ld_gz", C.c_int64), ("gz_f32", C.c_int32), ("reserved_", C.c_int32)]
 
 
+class GeneTableArgs(C.Structure):
+    _fields_ = [
+        ("table", vp), ("n_genes", C.c_int32), ("D", C.c_int32), ("n_w", C.c_int32), ("dtype", C.c_int32),
+        ("w", vp * 4), ("ld_w", C.c_int64 * 4), ("m", C.c_int32 * 4), ("b", vp * 4),
+        ("tab", vp), ("ld_tab", C.c_int64), ("wc", vp), ("wc_t", vp),
+        ("g_tab", vp), ("g_wc", vp),
+        ("g_table", vp), ("g_w", vp * 4), ("g_b", vp * 4),
+    ]
+
+
 class FrontJoinArgs(C.Structure):
     _fields_ = [
         ("table", vp), ("ids", vp), ("n_rows_table", C.c_int32), ("D", C.c_int32), ("dtype", C.c_int32), ("reserved_", C.c_int32),
@@ -263,6 +273,8 @@ EXPORTS = {
                                          vp, C.c_int64, vp, C.c_int64, vp, C.c_size_t, vp]),
     "segger_posfreq": (C.c_int, [vp, vp, vp, vp, C.c_int64, C.c_int32, C.c_float, C.c_float, vp, C.c_int32, vp]),
     "segger_embed_gelu_fwd": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, C.c_int64, C.c_int32, vp]),
+    "segger_gene_table_fwd": (C.c_int, [C.POINTER(GeneTableArgs), vp]),
+    "segger_gene_table_bwd": (C.c_int, [C.POINTER(GeneTableArgs), vp]),
     "segger_front_join_fwd": (C.c_int, [C.POINTER(FrontJoinArgs), vp]),
     "segger_front_join_bwd": (C.c_int, [C.POINTER(FrontJoinArgs), vp]),
     "segger_embed_gelu_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32, C.c_int32]),

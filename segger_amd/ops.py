@@ -2321,6 +2321,110 @@ def embed_linear_supported(x: "EmbedInput", m_out: int) -> bool:
             and linear_supported(m_out, k, x.dtype) and linear_wgrad_supported(m_out, k, x.dtype))
 
 
+EMBED_LINEAR_ONE_NODE = True     # tools flip it: False = the table and its gradients through torch ops around _RowBiasLinear
+
+
+def _gene_table_args(table, weights, biases, dt):
+    a = _lib.GeneTableArgs()
+    d = int(table.shape[1])
+    a.table, a.n_genes, a.D, a.n_w, a.dtype = table.data_ptr(), int(table.shape[0]), d, len(weights), DTYPE_CODE[dt]
+    for i, (w, b) in enumerate(zip(weights, biases)):
+        if w.dtype != torch.float32 or w.dim() != 2 or w.shape[1] != 2 * d or w.stride(1) != 1:
+            raise ValueError("embed_linear: weights must be fp32 [m, 2 D] with a dense last dimension")
+        a.w[i], a.ld_w[i], a.m[i] = w.data_ptr(), int(w.stride(0)) if w.shape[0] > 1 else 2 * d, int(w.shape[0])
+        if b is not None:
+            if b.dtype != torch.float32 or not b.is_contiguous() or b.numel() != w.shape[0]:
+                raise ValueError("embed_linear: biases must be contiguous fp32 [m]")
+            a.b[i] = b.data_ptr()
+    return a
+
+
+class _EmbedLinear(torch.autograd.Function):
+    """``linear(gelu(cat(table[ids], pe)), cat(weights), cat(biases))`` as ONE autograd node on hand-written kernels only:
+    forward = ``segger_gene_table_fwd`` (the per-gene table T = gelu(E) Wa^T + b, and the positional half Wc / Wc^T of the
+    weights in the compute dtype) + ``segger_linear_fwd_rowbias``; backward = the one-pass MFMA kernel (dc, dWc from one
+    read of dY) + the by-gene row sum of dY + ``segger_gene_table_bwd`` (dE, both halves of every weight's gradient, the
+    bias gradients).  Arguments: c = gelu(pre) [n, D] (compute dtype), pre (or None), table, ids, by_gene, n_w, then the n_w
+    weights and the n_w biases (None allowed)."""
+
+    @staticmethod
+    def forward(ctx, c, pre, table, ids, by_gene, n_w, *wb):
+        weights, biases = wb[:n_w], wb[n_w:]
+        lib = _lib.load()
+        dev, dt = c.device, c.dtype
+        n, d = c.shape
+        g = int(table.shape[0])
+        m = sum(int(w.shape[0]) for w in weights)
+        a = _gene_table_args(table, weights, biases, dt)
+        tab = torch.empty((g, m), dtype=dt, device=dev)
+        wc = torch.empty((m, d), dtype=dt, device=dev)
+        wc_t = torch.empty((d, m), dtype=dt, device=dev)
+        a.tab, a.ld_tab, a.wc, a.wc_t = tab.data_ptr(), m, wc.data_ptr(), wc_t.data_ptr()
+        y = torch.empty((n, m), dtype=dt, device=dev)
+        cp, ldc = _rows(c, d, "c")
+        with _lib.on_device(dev):
+            _lib.check(lib.segger_gene_table_fwd(C.byref(a), _lib.stream_ptr(dev)), "segger_gene_table_fwd")
+            rc = lib.segger_linear_fwd_rowbias(cp, ldc, wc.data_ptr(), None, tab.data_ptr(), m, ids.data_ptr(),
+                                               y.data_ptr(), m, n, d, m, DTYPE_CODE[dt], _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_linear_fwd_rowbias")
+        ctx.save_for_backward(c, pre, table, ids, wc, wc_t, *weights)
+        ctx.by_gene, ctx.n_w, ctx.has_bias = by_gene, n_w, tuple(b is not None for b in biases)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        c, pre, table, ids, wc, wc_t = ctx.saved_tensors[:6]
+        weights = ctx.saved_tensors[6:]
+        n_w = ctx.n_w
+        lib = _lib.load()
+        dev, dt = c.device, c.dtype
+        d = int(c.shape[1])
+        m = int(wc.shape[0])
+        gy = gy.to(dt)
+        if gy.shape[0] > 1 and gy.stride(1) != 1:
+            gy = gy.contiguous()
+        need = ctx.needs_input_grad
+        want_c = need[0] or (pre is not None and need[1])
+        want_w = any(need[6:6 + n_w])
+        gc = gw = None
+        gated = False
+        if FUSED_WGRAD_DX and want_c and want_w and c.shape[0] > 0 and linear_wgrad_dx_supported(m, d, dt):
+            gated = pre is not None and FUSED_GELU_GATE and linear_wgrad_dx_gate_supported(m, d, dt)
+            gc, gw, _ = linear_wgrad_dx_launch(gy, c, wc_t, want_bias=False, gate=pre if gated else None)
+        else:
+            if want_c:
+                gc = linear_fwd_launch(gy, wc_t, None)
+            if want_w:
+                gw, _ = linear_wgrad_launch(gy, c, want_bias=False)
+        by_gene = ctx.by_gene if ctx.by_gene is not None else rows_by_id(ids, int(table.shape[0]))
+        gt = segment_rowsum(gy, by_gene)
+        if gw is not None and lib.segger_reductions_pending() >= 0:
+            # inside ops.deferred_reductions the weight gradient above is a placeholder until the flush: run what is queued
+            # now (one launch) and go on deferring -- the launch below READS dWc
+            with _lib.on_device(dev):
+                _lib.check(lib.segger_reductions_flush(_lib.stream_ptr(dev)), "segger_reductions_flush")
+                _lib.check(lib.segger_reductions_defer_begin(), "segger_reductions_defer_begin")
+        biases = [None] * n_w
+        a = _gene_table_args(table, weights, biases, dt)
+        a.g_tab, a.g_wc = gt.data_ptr(), _lib.ptr(gw)
+        g_table = torch.empty_like(table) if need[2] else None
+        a.g_table = _lib.ptr(g_table)
+        g_w, g_b = [], []
+        for i, w in enumerate(weights):
+            gwi = torch.empty((int(w.shape[0]), 2 * d), dtype=torch.float32, device=dev) if need[6 + i] else None
+            gbi = (torch.empty(int(w.shape[0]), dtype=torch.float32, device=dev)
+                   if ctx.has_bias[i] and need[6 + n_w + i] else None)
+            a.g_w[i], a.g_b[i] = _lib.ptr(gwi), _lib.ptr(gbi)
+            g_w.append(gwi); g_b.append(gbi)
+        with _lib.on_device(dev):
+            _lib.check(lib.segger_gene_table_bwd(C.byref(a), _lib.stream_ptr(dev)), "segger_gene_table_bwd")
+        if pre is not None:
+            if gc is not None and not gated:
+                gc = torch.ops.aten.gelu_backward(gc, pre)
+            return (None, gc, g_table, None, None, None, *g_w, *g_b)
+        return (gc, None, g_table, None, None, None, *g_w, *g_b)
+
+
 def embed_linear(x: "EmbedInput", weight, bias) -> Tensor:
     """``linear(gelu(cat(table[ids], pe)), W, b)`` for the stacked first-layer projections without the concatenated
     [n, 2D] input: the embedding half depends on a row only through its gene, so it is a per-gene table
@@ -2329,6 +2433,10 @@ def embed_linear(x: "EmbedInput", weight, bias) -> Tensor:
     weights = tuple(weight) if isinstance(weight, (list, tuple)) else (weight,)
     biases = tuple(bias) if isinstance(bias, (list, tuple)) else (bias,)
     d = int(x.table.shape[1])
+    if (EMBED_LINEAR_ONE_NODE and len(weights) <= 4 and x.act_pe.shape[1] == d
+            and all(w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == 2 * d and w.stride(1) == 1 for w in weights)
+            and all(b is None or (b.dtype == torch.float32 and b.is_contiguous()) for b in biases)):
+        return _EmbedLinear.apply(x.act_pe, x.pre_pe, x.table, x.ids, x.by_gene, len(weights), *weights, *biases)
     w = weights[0] if len(weights) == 1 else torch.cat(weights, 0)                # [M, 2D] fp32 master weights
     tab = torch.nn.functional.gelu(x.table) @ w[:, :d].t()                         # [G, M]
     if any(b is not None for b in biases):

@@ -509,3 +509,40 @@ def test_16bit_scores_with_trained_weights_track_the_references_own_16bit_roundi
     f_h, f_o = ((hbf - s0).abs() > 2e-2).float().mean().item(), ((s_bf - s0).abs() > 2e-2).float().mean().item()
     assert f_h <= 2.0 * f_o + 2e-3, (f_h, f_o)
     assert m_f16 < m_h / 4, (m_f16, m_h)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_first_layer_table_route_one_node_equals_the_torch_composed_route(cuda, dtype, monkeypatch):
+    """Large batches project the first layer as per-gene table + positional GEMM (ops.embed_linear).  The table, the cast of
+    the positional half of the weights and every gradient that flows back through them (embedding table, both halves of the
+    three stacked weights, their biases) now come from segger_gene_table_fwd / _bwd inside ONE autograd node; round 4 formed
+    them with torch ops (gelu, cat, vendor GEMMs, slice gradients).  Same embeddings, same parameter gradients."""
+    from segger_amd import ops
+    from segger_amd.synthetic import SyntheticSpec
+    spec = SyntheticSpec(n_tx=7000, n_bd=150, k_tx=6, seed=9)
+    out, used = {}, {}
+    for one in (True, False):
+        monkeypatch.setattr(ops, "EMBED_LINEAR_ONE_NODE", one)
+        calls = []
+        real = ops._EmbedLinear.apply
+        monkeypatch.setattr(ops._EmbedLinear, "apply", staticmethod(lambda *a, **k: (calls.append(1), real(*a, **k))[1]))
+        m, _, bcpu, _ = build(spec, cuda, dtype=dtype)
+        m.model.split_first_layer_min_rows = 0            # take the large-batch route on this small tile
+        m.eval()
+        bg = bcpu.to(cuda)
+        z = m(bg)
+        (z["tx"].float().square().sum() * 0.5 + z["bd"].float()[:, ::2].sum() + z["tx"].float()[:, 1::3].sum()).backward()
+        out[one] = (z["tx"].float().detach(), z["bd"].float().detach(),
+                    {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+        used[one] = len(calls)
+        monkeypatch.undo()
+    if dtype != torch.float32:
+        assert used[True] == 1 and used[False] == 0          # (fp32 storage keeps the whole-row first layer)
+    tol = 2e-6 if dtype == torch.float32 else 2e-2
+    assert (out[True][0] - out[False][0]).abs().max().item() <= tol
+    assert (out[True][1] - out[False][1]).abs().max().item() <= tol
+    assert out[True][2].keys() == out[False][2].keys()
+    for k, g1 in out[True][2].items():
+        g0 = out[False][2][k]
+        assert torch.isfinite(g1).all(), k
+        assert (g1 - g0).abs().max().item() <= (1e-4 if dtype == torch.float32 else 6e-2) * max(g0.abs().max().item(), 1e-3), k
