@@ -177,10 +177,14 @@ def other_kernel_classes(dev, n, etb, hc, elem, gen, ops, batch):
                                           "~1.3 TB/s of added bytes on this part (MI355X_MICROARCH.md)"}
     # loss_sg backward: tx-belongs-bd triplets with unique anchors, grouped by positive row
     from segger_amd.graph import csr_from_coo
-    nbd = max(n // 100, 2)
+    # (the tile's own tx-belongs-bd edges: anchors and positives with the locality the step sees; negatives sampled as
+    #  lightning_model.py:178-181)
+    from segger_amd import TX_BD
+    ei_tb = batch[TX_BD].edge_index
+    nbd = int(batch["bd"].num_nodes)
+    etb = int(ei_tb.shape[1])
     zb = torch.nn.functional.normalize(torch.randn(nbd, 64, device=dev, generator=gen), dim=-1).to(dt).requires_grad_(True)
-    src = torch.randperm(n, device=dev, generator=gen)[:etb]
-    dstp = torch.randint(0, nbd, (etb,), device=dev, generator=gen)
+    src, dstp = ei_tb[0].long(), ei_tb[1].long()
     dneg = (dstp + torch.randint(1, nbd, (etb,), device=dev, generator=gen)) % nbd
     groups = csr_from_coo(dstp, src, nbd, n, validate=False)
 

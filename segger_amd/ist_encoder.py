@@ -364,19 +364,21 @@ class ISTEncoder(Module):
         p = self.conv_layers[0].conv[TX_TX].dropout
         return self.planes_of(views, ops.dropout_bits_many([(c, sd) for _, _, c, sd in views], self.n_heads, p, step))
 
-    def _pos_embed_pair(self, pos_dict, batch_dict, num_graphs, dt, gelu: bool, graphs, joint: bool = False):
-        """(pe_tx, pe_bd, None): ``pos_emb`` of both node types, in one call where the batch vectors allow it.  With ``gelu``
+    def _pos_embed_pair(self, pos_dict, batch_dict, num_graphs, dt, gelu: bool, graphs, joint: bool = False,
+                        bd_plain: bool = False):
+        """(pe_tx, pe_bd, None, plain): ``pos_emb`` of both node types (``plain``: pe_bd comes without the GELU), in one call where the batch vectors allow it.  With ``gelu``
         pe_tx is the pair ``(gelu(h), h or None)`` of ``Positional2dEmbedder.forward(return_pre=True)``.  ``joint``: when
         the two types were embedded by one call (and ``gelu`` is off), return ``(None, None, pe)`` instead, ``pe`` the
-        un-split [n_tx + n_bd, D] matrix (for :func:`ops.front_join`)."""
+        un-split [n_tx + n_bd, D] matrix (for :func:`ops.front_join`).  ``bd_plain``: with one call per type, the
+        boundaries' embedding comes WITHOUT the GELU whatever ``gelu`` says (``ops.front_join`` applies it)."""
         b_tx, b_bd = batch_dict.get("tx"), batch_dict.get("bd")
         staged = graphs.get("pos_all") if graphs is not None else None
         # (large batches -- the `split` route -- keep one call per type: there the launches do not matter, and joining
         # the two gradients of the embedder's output would copy a [n_tx, D] matrix)
         if staged is None and (not MERGED_POS_EMBED or gelu or b_tx is None or b_bd is None or num_graphs is None):
-            one = lambda k, **kw: self.pos_emb(pos_dict[k], batch_dict.get(k), num_graphs=num_graphs, dtype=dt, gelu=gelu,
-                                               **kw)
-            return (one("tx", return_pre=True) if gelu else one("tx")), one("bd"), None
+            one = lambda k, g=gelu, **kw: self.pos_emb(pos_dict[k], batch_dict.get(k), num_graphs=num_graphs, dtype=dt,
+                                                       gelu=g, **kw)
+            return (one("tx", return_pre=True) if gelu else one("tx")), one("bd", gelu and not bd_plain), None, bd_plain or not gelu
         if staged is not None:                               # a captured step stages the concatenation itself
             pos_all, batch_all = staged
         else:
@@ -385,9 +387,9 @@ class ISTEncoder(Module):
         pe = self.pos_emb(pos_all, batch_all, num_graphs=2 * int(num_graphs), dtype=dt, gelu=gelu,
                           minmax=graphs.get("minmax") if graphs is not None else None)
         if joint and not gelu:
-            return None, None, pe
+            return None, None, pe, True
         pe_tx, pe_bd = _SplitRows.apply(pe, int(pos_dict["tx"].shape[0]))
-        return ((pe_tx, None) if gelu else pe_tx), pe_bd, None
+        return ((pe_tx, None) if gelu else pe_tx), pe_bd, None, not gelu
 
     def _materialize_bd(self, d_in: int, device) -> None:
         if "bd" not in self.lin_first:
@@ -418,12 +420,16 @@ class ISTEncoder(Module):
             # of the front end, and the embedder's parameters receive ONE gradient each (what lets a captured step
             # postpone its partial sums, ops.deferred_reductions).  `split`: the GELU of ist_encoder.py:320 comes
             # applied (gelu(cat(a, b)) = cat(gelu(a), gelu(b))).
-            pe_tx, pe_bd, pe_all = self._pos_embed_pair(pos_dict, batch_dict, num_graphs, dt, split, graphs,
-                                                        joint=fused_tx and FRONT_JOIN)
+            join = fused_tx and FRONT_JOIN
+            pe_tx, pe_bd, pe_all, bd_plain = self._pos_embed_pair(pos_dict, batch_dict, num_graphs, dt, split, graphs,
+                                                                  joint=join, bd_plain=join)
             pre_tx = None
             if split:
                 pe_tx, pre_tx = pe_tx
-            if pe_all is None:
+            if pe_all is None and join and bd_plain and pe_bd.dtype == x_bd.dtype:
+                # one embedder call per type: the boundary side alone through the join (no transcript rows, no table gradient)
+                _, x_bd = ops.front_join(emb.weight.detach(), x_dict["tx"][:0], x_bd, pe_bd, None)
+            elif pe_all is None:
                 x_bd = torch.cat((F.gelu(x_bd), pe_bd), -1) if split else F.gelu(torch.cat((x_bd, pe_bd), -1))
             if fused_tx:
                 # gather + concat + GELU in one kernel; its table gradient sums over rows grouped by gene id: one
