@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 20
+#define SEGGER_ABI_VERSION 21
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -646,6 +646,15 @@ int segger_linear_fwd_silu_grad(const void* x, int64_t ldx, const void* w, const
 int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void* w, const float* bias, const void* rowbias,
                               int64_t ld_rb, const int32_t* rowidx, void* y, int64_t ldy, int64_t n_rows, int32_t k_in,
                               int32_t m_out, int32_t dtype, segger_stream_t stream);
+
+/* segger_linear_wgrad_f32_split: segger_linear_wgrad for fp32 storage on the bf16 matrix pipe (both operands split three ways,
+ * six partial products; csrc/linear_f32_split.hip) -- the weight gradient autograd forms as `grad.t() @ x` for the nn.Linear
+ * maps of ist_encoder.py:111-124,282-286.  Same arguments, workspace (segger_linear_wgrad_workspace_bytes) and deterministic
+ * slab-order sums as segger_linear_wgrad; error within the exact-fp32 kernel's own, not bit-identical to it. */
+int segger_linear_wgrad_f32_split_supported(int32_t m_out, int32_t k_in);
+int segger_linear_wgrad_f32_split(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t n_rows, int32_t m_out,
+                                  int32_t k_in, float* grad_w, float* grad_b, void* workspace, size_t workspace_bytes,
+                                  segger_stream_t stream);
 
 /* segger_gene_table_fwd/bwd: the per-gene table of segger_linear_fwd_rowbias and everything that flows back through it,
  * one launch each way (csrc/gene_table.hip) -- torch formed it with ~25 small launches per step (gelu, cat, vendor GEMMs,

@@ -52,6 +52,11 @@ int linear_f32_launch(const void* x, int64_t ldx, const void* w, const float* bi
                       int k_in, int m_out, hipStream_t stream, const float* rowbias = nullptr, const int32_t* rowidx = nullptr,
                       int64_t ld_rb = 0);
 size_t wgrad_f32_workspace_bytes(int64_t n_rows, int m_out, int k_in);
+// csrc/linear_f32_split.hip: the same weight gradient as six bf16 partial products (same partial-sum layout)
+bool wgrad_f32_split_shape_ok(int m, int k);
+int64_t wgrad_f32_split_grid(int64_t n_rows, int m, int k);
+int wgrad_f32_split_launch(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t n_rows, int m_out, int k_in,
+                           float* partial, int64_t* n_slabs, hipStream_t stream);
 int wgrad_f32_launch(const void* dy, int64_t ld_dy, const void* x, int64_t ld_x, int64_t n_rows, int m_out, int k_in,
                      float* partial, int64_t* n_slabs, hipStream_t stream);
 

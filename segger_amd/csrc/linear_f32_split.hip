@@ -156,10 +156,218 @@ __global__ __launch_bounds__(256, 2) void linear_f32_split_kernel(SplitParams p)
   }
 }
 
+// ------------------------------------------------------------------------------------------------ weight gradient
+// dW[M, K] = dY[n, M]^T X[n, K], db = sum_n dY for fp32 operands on the bf16 matrix pipe: both operands split three ways
+// as above, the product as its six leading partial products.  The exact-fp32 kernel (csrc/linear_f32.hip,
+// v_mfma_f32_32x32x2_f32) is MFMA-bound at 0.94 ms for 1M x (384, 128); the six bf16 products are 0.375 of that matrix time.
+// Structure (as csrc/linear_wgrad.hip, without its LDS-DMA -- the fp32 rows have to pass through the VALU to be split):
+// a persistent workgroup owns a slab of rows and keeps the whole [M, K] accumulator in its waves' registers; 16 rows per
+// stage: every thread loads its 16-byte pieces of the stage's dY / X rows (the NEXT stage's loads are in flight under
+// this stage's MFMAs), splits them and writes three bf16 planes per matrix into one of two LDS buffers (row stride
+// width * 2 + 64 bytes: the transposing reads are conflict-free); the MFMA operands -- the row index is the k dimension
+// of both -- come out of LDS transposed by ds_read_b64_tr_b16.  One barrier per stage.  Partial sums per workgroup in the
+// layout of the other weight-gradient kernels (summed in slab order by reduce_partials: deterministic).
+typedef short s16x4s __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x2s lds_read_tr_s(const unsigned char* p) {
+  const s16x4s v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4s*)(const_cast<unsigned char*>(p)));
+  return __builtin_bit_cast(u32x2s, v);
+}
+
+struct WgSplitParams {
+  const float* dy; int64_t ld_dy;
+  const float* x; int64_t ld_x;
+  int64_t n_rows, n_stages, stages_per_block;
+  float* partial;            // [gridDim.x][M * K + M]
+};
+
+// 4 consecutive floats -> 4 bf16 of each plane
+__device__ __forceinline__ void split4(const f32x4 v, u32x2s& hi, u32x2s& mid, u32x2s& lo) {
+  const uint32_t h0 = Vec8<bf16_t>::pack(v.x, v.y), h1 = Vec8<bf16_t>::pack(v.z, v.w);
+  float a, b, c, d;
+  Vec8<bf16_t>::unpack2(h0, a, b); Vec8<bf16_t>::unpack2(h1, c, d);
+  const float r0 = v.x - a, r1 = v.y - b, r2 = v.z - c, r3 = v.w - d;
+  const uint32_t m0 = Vec8<bf16_t>::pack(r0, r1), m1 = Vec8<bf16_t>::pack(r2, r3);
+  Vec8<bf16_t>::unpack2(m0, a, b); Vec8<bf16_t>::unpack2(m1, c, d);
+  hi = u32x2s{h0, h1}; mid = u32x2s{m0, m1};
+  lo = u32x2s{Vec8<bf16_t>::pack(r0 - a, r1 - b), Vec8<bf16_t>::pack(r2 - c, r3 - d)};
+}
+
+constexpr int kWgRows = 16;                    // rows per stage = one 32x32x16 k-step
+
+template <int M, int K, int NW>
+__global__ __launch_bounds__(NW * 64) void wgrad_f32_split_kernel(WgSplitParams p) {
+  constexpr int NT = NW * 64;
+  constexpr int WM = NW == 8 ? 4 : 2, WK = 2;
+  constexpr int TM = M / 32, TK = K / 32;
+  static_assert(TM % WM == 0 && TK % WK == 0, "tile grid does not split over the waves");
+  constexpr int MT = TM / WM, KT = TK / WK;
+  constexpr int SY = M * 2 + 64, SX = K * 2 + 64;                 // bytes per row of a plane
+  constexpr int PY = kWgRows * SY, PX = kWgRows * SX;             // one plane of a stage
+  constexpr int BUF = 3 * PY + 3 * PX;
+  constexpr int PPR = (M + K) / 4;                                // 16-byte pieces per stage row (dY then X)
+  static_assert((kWgRows * PPR) % NT == 0, "pieces do not split evenly over the workgroup");
+  constexpr int PIECES = kWgRows * PPR / NT;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave % WM, wk = wave / WM;
+
+  const int64_t s_beg = (int64_t)blockIdx.x * p.stages_per_block;
+  int64_t s_end = s_beg + p.stages_per_block;
+  if (s_end > p.n_stages) s_end = p.n_stages;
+
+  // this thread's pieces of a stage: fixed (row, column) for the whole kernel
+  int prow[PIECES], pcol[PIECES], pdst[PIECES];
+  bool pis_y[PIECES];
+#pragma unroll
+  for (int j = 0; j < PIECES; ++j) {
+    const int q = tid + j * NT, row = q / PPR, c = q % PPR;
+    prow[j] = row;
+    pis_y[j] = c < M / 4;
+    pcol[j] = pis_y[j] ? 4 * c : 4 * (c - M / 4);
+    pdst[j] = pis_y[j] ? row * SY + pcol[j] * 2 : 3 * PY + row * SX + pcol[j] * 2;
+  }
+  f32x4 nxt[PIECES], dbp[PIECES];
+#pragma unroll
+  for (int j = 0; j < PIECES; ++j) dbp[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](int64_t s) {
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      int64_t row = s * kWgRows + prow[j];
+      const bool ok = row < p.n_rows;
+      if (!ok) row = p.n_rows - 1;                                // clamp: loaded, zeroed below
+      const float* src = pis_y[j] ? p.dy + row * p.ld_dy + pcol[j] : p.x + row * p.ld_x + pcol[j];
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+      nxt[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+
+  // transposing-read addresses (csrc/linear_wgrad.hip): lane (g, i16) reads 4 rows x 16 columns blocks
+  const int g = lane >> 4, i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
+  const int row_a = 8 * (g >> 1) + tq, col_a = 16 * (g & 1) + 4 * tp;
+  const int off_y = row_a * SY + col_a * 2 + wm * MT * 64;
+  const int off_x = 3 * PY + row_a * SX + col_a * 2 + wk * KT * 64;
+
+  f32x16 acc[MT][KT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < KT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  if (s_beg < s_end) fetch(s_beg);
+  for (int64_t s = s_beg; s < s_end; ++s) {
+    unsigned char* buf = lds + ((s - s_beg) & 1) * BUF;
+#pragma unroll
+    for (int j = 0; j < PIECES; ++j) {
+      u32x2s h, m, l;
+      split4(nxt[j], h, m, l);
+      const int plane = pis_y[j] ? PY : PX;
+      *reinterpret_cast<u32x2s*>(buf + pdst[j]) = h;
+      *reinterpret_cast<u32x2s*>(buf + pdst[j] + plane) = m;
+      *reinterpret_cast<u32x2s*>(buf + pdst[j] + 2 * plane) = l;
+      if (pis_y[j]) dbp[j] = dbp[j] + nxt[j];
+    }
+    if (s + 1 < s_end) fetch(s + 1);                             // in flight under this stage's MFMAs
+    __syncthreads();                                             // (also: every wave has left the reads of stage s - 2)
+    u32x4 fa[3][MT], fb[3][KT];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        const u32x2s lo = lds_read_tr_s(buf + q * PY + off_y + a * 64);
+        const u32x2s hi = lds_read_tr_s(buf + q * PY + off_y + a * 64 + 4 * SY);
+        fa[q][a] = u32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+#pragma unroll
+      for (int b = 0; b < KT; ++b) {
+        const u32x2s lo = lds_read_tr_s(buf + q * PX + off_x + b * 64);
+        const u32x2s hi = lds_read_tr_s(buf + q * PX + off_x + b * 64 + 4 * SX);
+        fb[q][b] = u32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int b = 0; b < KT; ++b) {
+        f32x16 c = acc[a][b];
+        c = mfma_bf16(fa[2][a], fb[0][b], c);                    // smallest terms first
+        c = mfma_bf16(fa[0][a], fb[2][b], c);
+        c = mfma_bf16(fa[1][a], fb[1][b], c);
+        c = mfma_bf16(fa[1][a], fb[0][b], c);
+        c = mfma_bf16(fa[0][a], fb[1][b], c);
+        c = mfma_bf16(fa[0][a], fb[0][b], c);
+        acc[a][b] = c;
+      }
+  }
+
+  // acc tile (a, b) element e of lane l is dW[m][k]: m = 32 (wm MT + a) + (e & 3) + 8 (e >> 2) + 4 (l >> 5), k = 32 (wk KT + b) + (l & 31)
+  float* out = p.partial + (int64_t)blockIdx.x * ((int64_t)M * K + M);
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < KT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = 32 * (wm * MT + a) + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        out[m * K + 32 * (wk * KT + b) + r] = acc[a][b][e];
+      }
+  // db: every thread holds the sums of its dY pieces' columns over its row of every stage; the 16 rows meet in LDS
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(lds);                    // [16][M]
+#pragma unroll
+  for (int j = 0; j < PIECES; ++j)
+    if (pis_y[j]) *reinterpret_cast<f32x4*>(red + prow[j] * M + pcol[j]) = dbp[j];
+  __syncthreads();
+  for (int m = tid; m < M; m += NT) {
+    float sum = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < kWgRows; ++rr) sum += red[rr * M + m];
+    out[M * K + m] = sum;
+  }
+}
+
+constexpr int split_waves(int m, int k) { return (m / 32) * (k / 32) >= 32 ? 8 : 4; }
+constexpr int64_t kSplitMinStages = 32;        // 512 rows per workgroup at least
+
 }  // namespace
+
+bool wgrad_f32_split_shape_ok(int m, int k) {
+  return (m == 384 && k == 128) || (m == 128 && (k == 128 || k == 256)) || (m == 64 && (k == 64 || k == 128 || k == 256));
+}
+
+int64_t wgrad_f32_split_grid(int64_t n_rows, int m, int k) {
+  const int64_t stages = (n_rows + kWgRows - 1) / kWgRows;
+  const int64_t want = (stages + kSplitMinStages - 1) / kSplitMinStages;
+  const int64_t cap = split_waves(m, k) == 8 ? device_cu_count() : 2 * (int64_t)device_cu_count();
+  const int64_t c = cap > 0 ? cap : 256;
+  return want < c ? (want < 1 ? 1 : want) : c;
+}
+
+int wgrad_f32_split_launch(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t n_rows, int m_out, int k_in,
+                           float* partial, int64_t* n_slabs, hipStream_t stream) {
+  const int64_t grid = wgrad_f32_split_grid(n_rows, m_out, k_in);
+  WgSplitParams p{dy, ld_dy, x, ld_x, n_rows, (n_rows + kWgRows - 1) / kWgRows, 0, partial};
+  p.stages_per_block = (p.n_stages + grid - 1) / grid;
+  *n_slabs = grid;
+#define CASE(MM, KK) if (m_out == MM && k_in == KK) { \
+    hipLaunchKernelGGL((wgrad_f32_split_kernel<MM, KK, split_waves(MM, KK)>), dim3((unsigned)grid), dim3(split_waves(MM, KK) * 64), 0, stream, p); \
+    SEGGER_LAUNCH_CHECK("wgrad_f32_split_kernel"); return SEGGER_OK; }
+  CASE(384, 128) CASE(128, 128) CASE(128, 256) CASE(64, 64) CASE(64, 128) CASE(64, 256)
+#undef CASE
+  set_error("segger_linear_wgrad_f32_split: m_out=%d k_in=%d not supported", m_out, k_in);
+  return SEGGER_EUNSUPPORTED;
+}
+
 }  // namespace segger
 
 using namespace segger;
+
+extern "C" int segger_linear_wgrad_f32_split_supported(int32_t m_out, int32_t k_in) { return wgrad_f32_split_shape_ok(m_out, k_in); }
 
 extern "C" int segger_linear_fwd_f32_split_supported(int32_t k_in, int32_t m_out) {
   return (k_in == 128 && m_out > 0 && m_out % kCH == 0) || (k_in == 384 && m_out == 128);

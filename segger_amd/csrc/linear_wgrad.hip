@@ -796,7 +796,11 @@ extern "C" int segger_linear_wgrad_supported(int32_t m_out, int32_t k_in, int32_
 extern "C" size_t segger_linear_wgrad_workspace_bytes(int64_t n_rows, int32_t m_out, int32_t k_in) {
   if (n_rows <= 0 || !shape_ok(m_out, k_in)) return 16;
   const size_t b16 = (size_t)(grid_for(n_rows, m_out, k_in) + kRedGroups) * ((size_t)m_out * k_in + m_out) * sizeof(float);
-  const size_t b32 = wgrad_f32_workspace_bytes(n_rows, m_out, k_in);       // (the fp32 kernel's slab count)
+  size_t b32 = wgrad_f32_workspace_bytes(n_rows, m_out, k_in);             // (the fp32 kernels' slab counts)
+  if (wgrad_f32_split_shape_ok(m_out, k_in)) {
+    const size_t bs = (size_t)(wgrad_f32_split_grid(n_rows, m_out, k_in) + kRedGroups) * ((size_t)m_out * k_in + m_out) * sizeof(float);
+    b32 = bs > b32 ? bs : b32;
+  }
   return b16 > b32 ? b16 : b32;
 }
 
@@ -928,6 +932,33 @@ bool launch_wgrad_pair(const WgradParams& a, int ma, int64_t grid_a, const Wgrad
 }
 }  // namespace
 }  // namespace segger
+
+extern "C" int segger_linear_wgrad_f32_split(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t n_rows,
+                                             int32_t m_out, int32_t k_in, float* grad_w, float* grad_b, void* workspace,
+                                             size_t workspace_bytes, segger_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  SEGGER_REQUIRE(n_rows >= 0 && grad_w != nullptr, "segger_linear_wgrad_f32_split: bad sizes or NULL grad_w");
+  if (!wgrad_f32_split_shape_ok(m_out, k_in)) {
+    set_error("segger_linear_wgrad_f32_split: m_out=%d k_in=%d not supported", m_out, k_in);
+    return SEGGER_EUNSUPPORTED;
+  }
+  if (n_rows == 0) {
+    SEGGER_HIP(hipMemsetAsync(grad_w, 0, (size_t)m_out * k_in * sizeof(float), stream));
+    if (grad_b) SEGGER_HIP(hipMemsetAsync(grad_b, 0, (size_t)m_out * sizeof(float), stream));
+    return SEGGER_OK;
+  }
+  SEGGER_REQUIRE(dy && x && aligned16(dy) && aligned16(x) && ld_dy >= m_out && ld_x >= k_in && ld_dy % 4 == 0 && ld_x % 4 == 0,
+                 "segger_linear_wgrad_f32_split: rows must be 16-byte aligned");
+  const size_t need = segger_linear_wgrad_workspace_bytes(n_rows, m_out, k_in);
+  if (workspace == nullptr || workspace_bytes < need) {
+    set_error("segger_linear_wgrad_f32_split: workspace %zu < %zu bytes", workspace_bytes, need);
+    return SEGGER_EWORKSPACE;
+  }
+  int64_t slabs = 0;
+  const int rc = wgrad_f32_split_launch(dy, ld_dy, x, ld_x, n_rows, m_out, k_in, static_cast<float*>(workspace), &slabs, stream);
+  if (rc != SEGGER_OK) return rc;
+  return reduce_partials(static_cast<float*>(workspace), slabs, m_out, k_in, grad_w, grad_b, stream);
+}
 
 extern "C" int segger_linear_wgrad_pair(const segger_wgrad_args* a, const segger_wgrad_args* b, int32_t k_in, int32_t dtype,
                                         segger_stream_t stream_) {

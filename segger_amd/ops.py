@@ -1506,9 +1506,15 @@ def linear_wgrad_launch(gy: Tensor, x: Tensor, want_bias: bool = True) -> Tuple[
     gb = torch.empty(m, dtype=torch.float32, device=x.device) if want_bias else None
     ws_bytes = _wgrad_ws_bytes(n, m, k)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    split = (F32_SPLIT and F32_SPLIT_WGRAD and x.dtype == torch.float32 and ldg % 4 == 0 and ldx % 4 == 0
+             and bool(lib.segger_linear_wgrad_f32_split_supported(m, k)))
     with _lib.on_device(x.device):
-        rc = lib.segger_linear_wgrad(gp, ldg, xp, ldx, n, m, k, DTYPE_CODE[x.dtype], gw.data_ptr(), _lib.ptr(gb),
-                                     ws.data_ptr(), ws_bytes, _lib.stream_ptr(x.device))
+        if split:        # fp32 storage: six bf16 partial products instead of the exact-fp32 MFMA (see F32_SPLIT)
+            rc = lib.segger_linear_wgrad_f32_split(gp, ldg, xp, ldx, n, m, k, gw.data_ptr(), _lib.ptr(gb), ws.data_ptr(),
+                                                   ws_bytes, _lib.stream_ptr(x.device))
+        else:
+            rc = lib.segger_linear_wgrad(gp, ldg, xp, ldx, n, m, k, DTYPE_CODE[x.dtype], gw.data_ptr(), _lib.ptr(gb),
+                                         ws.data_ptr(), ws_bytes, _lib.stream_ptr(x.device))
     _lib.check(rc, "segger_linear_wgrad")
     _defer_keep(ws, gw, gb)
     return gw, gb
@@ -2044,6 +2050,7 @@ class _LinearPair(torch.autograd.Function):
 # profiles/r04_f32_split.txt -- fp32 accumulation dominates both) and every fp32 parity test holds with it.  It is not
 # bit-identical to a chain of fp32 FMAs: SEGGER_AMD_F32_EXACT=1 (or ops.F32_SPLIT = False) selects the exact kernels.
 F32_SPLIT = os.environ.get("SEGGER_AMD_F32_EXACT", "0") in ("", "0")
+F32_SPLIT_WGRAD = True       # (with F32_SPLIT) the weight gradients on the split as well (segger_linear_wgrad_f32_split)
 LINEAR_PAIR = True           # tools flip it: False = one launch per projection
 WGRAD_PAIR = True            # ... and per projection backward
 

@@ -469,3 +469,29 @@ def test_linear_fp32_split_autograd_switch(cuda, monkeypatch):
     for a, r in zip(out[True], out[False]):
         assert (a - r).abs().max().item() <= 2e-5 * r.abs().max().item()
     assert not torch.equal(out[True][0], out[False][0])       # (it did take the other kernel)
+
+
+@pytest.mark.parametrize("m,k,n", [(384, 128, 40037), (384, 128, 17), (128, 128, 5000), (64, 256, 8191), (64, 64, 3), (64, 128, 1024),
+                                   (128, 256, 2049)])
+def test_wgrad_fp32_split_within_the_exact_kernels_error(cuda, m, k, n, monkeypatch):
+    """segger_linear_wgrad_f32_split (dW = dY^T X, db = sum dY; both fp32 operands as three bf16 parts, six partial products
+    on the bf16 MFMA, fp32 accumulation) against fp64: the error relative to sum |dY||X| stays within twice the exact-fp32
+    kernel's own; partial last stage, a single row, row strides (views into wider matrices), wide dynamic range."""
+    from segger_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(m + k + n)
+    gy_w = torch.randn(n, m + 64, device=cuda, generator=g) * torch.rand(n, 1, device=cuda, generator=g).mul(5).exp()
+    x_w = torch.randn(n, k + 32, device=cuda, generator=g)
+    gy, x = gy_w[:, :m], x_w[:, 16:16 + k][:, :k] if False else x_w[:, :k]
+    out = {}
+    for split in (True, False):
+        monkeypatch.setattr(ops, "F32_SPLIT", split)
+        out[split] = ops.linear_wgrad_launch(gy, x)
+    ref_w = gy.double().t() @ x.double()
+    ref_b = gy.double().sum(0)
+    bound = gy.double().abs().t() @ x.double().abs()
+    e = {s_: ((out[s_][0].double() - ref_w).abs() / bound).max().item() for s_ in out}
+    assert e[True] <= max(2 * e[False], 2.0 ** -22), e
+    eb = {s_: ((out[s_][1].double() - ref_b).abs() / gy.double().abs().sum(0)).max().item() for s_ in out}
+    assert eb[True] <= max(2 * eb[False], 2.0 ** -21), eb
+    if n > 16:
+        assert not torch.equal(out[True][0], out[False][0])       # (it did take the other kernel)
