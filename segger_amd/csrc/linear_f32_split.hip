@@ -194,6 +194,13 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2s& hi, u32x2s& mid, u
 }
 
 constexpr int kWgRows = 16;                    // rows per stage = one 32x32x16 k-step
+template <int N, typename F>
+__device__ __forceinline__ void static_for_wgs(F&& f) {
+  if constexpr (N > 0) {
+    static_for_wgs<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
 
 template <int M, int K, int NW>
 __global__ __launch_bounds__(NW * 64) void wgrad_f32_split_kernel(WgSplitParams p) {
@@ -229,18 +236,25 @@ __global__ __launch_bounds__(NW * 64) void wgrad_f32_split_kernel(WgSplitParams 
     pcol[j] = pis_y[j] ? 4 * c : 4 * (c - M / 4);
     pdst[j] = pis_y[j] ? row * SY + pcol[j] * 2 : 3 * PY + row * SX + pcol[j] * 2;
   }
-  f32x4 nxt[PIECES], dbp[PIECES];
+#ifndef SEGGER_WGS_AHEAD
+#define SEGGER_WGS_AHEAD 1                     // stages of global loads in flight (register slots): 1M x (384, 128) on one
+                                               // MI355X: 1 -> 0.64 ms, 2 -> 0.99, 3 -> 0.76 (exact fp32: 1.19; one MFMA and no
+                                               // split: 0.41 = the 2 GB of fp32 operands at the achievable HBM rate)
+#endif
+  constexpr int AH = SEGGER_WGS_AHEAD;
+  f32x4 ring[AH][PIECES], dbp[PIECES];
 #pragma unroll
   for (int j = 0; j < PIECES; ++j) dbp[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  auto fetch = [&](int64_t s) {
+  auto fetch = [&](auto slot_c, int64_t s) {
+    constexpr int SL = decltype(slot_c)::value;
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) {
       int64_t row = s * kWgRows + prow[j];
-      const bool ok = row < p.n_rows;
+      const bool ok = row < p.n_rows && s < s_end;
       if (!ok) row = p.n_rows - 1;                                // clamp: loaded, zeroed below
       const float* src = pis_y[j] ? p.dy + row * p.ld_dy + pcol[j] : p.x + row * p.ld_x + pcol[j];
       const f32x4 v = *reinterpret_cast<const f32x4*>(src);
-      nxt[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      ring[SL][j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
 
@@ -258,20 +272,27 @@ __global__ __launch_bounds__(NW * 64) void wgrad_f32_split_kernel(WgSplitParams 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-  if (s_beg < s_end) fetch(s_beg);
-  for (int64_t s = s_beg; s < s_end; ++s) {
+  // one stage: split the ring slot's rows into the LDS buffer, refill the slot with the stage AH ahead (in flight under
+  // this and the next stages' MFMAs), barrier, MFMAs
+  auto stage = [&](auto slot_c, int64_t s) {
+    constexpr int SL = decltype(slot_c)::value;
     unsigned char* buf = lds + ((s - s_beg) & 1) * BUF;
 #pragma unroll
     for (int j = 0; j < PIECES; ++j) {
       u32x2s h, m, l;
-      split4(nxt[j], h, m, l);
+#ifdef EXP_WGS_NOSPLIT      // bounding build: no VALU split (planes = raw words)
+      h = u32x2s{__float_as_uint(ring[SL][j].x), __float_as_uint(ring[SL][j].y)};
+      m = u32x2s{__float_as_uint(ring[SL][j].z), __float_as_uint(ring[SL][j].w)}; l = h;
+#else
+      split4(ring[SL][j], h, m, l);
+#endif
       const int plane = pis_y[j] ? PY : PX;
       *reinterpret_cast<u32x2s*>(buf + pdst[j]) = h;
       *reinterpret_cast<u32x2s*>(buf + pdst[j] + plane) = m;
       *reinterpret_cast<u32x2s*>(buf + pdst[j] + 2 * plane) = l;
-      if (pis_y[j]) dbp[j] = dbp[j] + nxt[j];
+      if (pis_y[j]) dbp[j] = dbp[j] + ring[SL][j];
     }
-    if (s + 1 < s_end) fetch(s + 1);                             // in flight under this stage's MFMAs
+    fetch(slot_c, s + AH);
     __syncthreads();                                             // (also: every wave has left the reads of stage s - 2)
     u32x4 fa[3][MT], fb[3][KT];
 #pragma unroll
@@ -294,15 +315,25 @@ __global__ __launch_bounds__(NW * 64) void wgrad_f32_split_kernel(WgSplitParams 
 #pragma unroll
       for (int b = 0; b < KT; ++b) {
         f32x16 c = acc[a][b];
+#ifdef EXP_WGS_ONEMFMA      // bounding build: one product instead of six
+        c = mfma_bf16(fa[0][a] ^ fa[1][a] ^ fa[2][a], fb[0][b] ^ fb[1][b] ^ fb[2][b], c);
+#else
         c = mfma_bf16(fa[2][a], fb[0][b], c);                    // smallest terms first
         c = mfma_bf16(fa[0][a], fb[2][b], c);
         c = mfma_bf16(fa[1][a], fb[1][b], c);
         c = mfma_bf16(fa[1][a], fb[0][b], c);
         c = mfma_bf16(fa[0][a], fb[1][b], c);
         c = mfma_bf16(fa[0][a], fb[0][b], c);
+#endif
         acc[a][b] = c;
       }
-  }
+  };
+  static_for_wgs<AH>([&](auto d) { fetch(d, s_beg + decltype(d)::value); });
+  int64_t s = s_beg;
+#pragma unroll 1
+  for (; s + AH <= s_end; s += AH)
+    static_for_wgs<AH>([&](auto d) { stage(d, s + decltype(d)::value); });
+  static_for_wgs<AH>([&](auto d) { if (s + decltype(d)::value < s_end) stage(d, s + decltype(d)::value); });
 
   // acc tile (a, b) element e of lane l is dW[m][k]: m = 32 (wm MT + a) + (e & 3) + 8 (e >> 2) + 4 (l >> 5), k = 32 (wk KT + b) + (l & 31)
   float* out = p.partial + (int64_t)blockIdx.x * ((int64_t)M * K + M);
@@ -337,7 +368,9 @@ constexpr int64_t kSplitMinStages = 32;        // 512 rows per workgroup at leas
 }  // namespace
 
 bool wgrad_f32_split_shape_ok(int m, int k) {
-  return (m == 384 && k == 128) || (m == 128 && (k == 128 || k == 256)) || (m == 64 && (k == 64 || k == 128 || k == 256));
+  // (instantiated for (64, 64) and (64, 128) as well, where the exact kernel is faster -- 0.14 / 0.23 vs 0.20 / 0.26 ms: few
+  //  MFMAs per staged row)
+  return (m == 384 && k == 128) || (m == 128 && (k == 128 || k == 256)) || (m == 64 && k == 256);
 }
 
 int64_t wgrad_f32_split_grid(int64_t n_rows, int m, int k) {
