@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 21
+#define SEGGER_ABI_VERSION 22
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -651,6 +651,10 @@ int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void* w, const f
  * six partial products; csrc/linear_f32_split.hip) -- the weight gradient autograd forms as `grad.t() @ x` for the nn.Linear
  * maps of ist_encoder.py:111-124,282-286.  Same arguments, workspace (segger_linear_wgrad_workspace_bytes) and deterministic
  * slab-order sums as segger_linear_wgrad; error within the exact-fp32 kernel's own, not bit-identical to it. */
+/* segger_f32_split_planes: planes [3][rows * cols] bf16 (hi, mid, lo: they add up to the fp32 number exactly) of w [rows, cols]
+ * fp32 row-major, laid out as w or, transpose != 0, as w^T [cols, rows]: the weight operand of segger_linear_fwd_f32_split,
+ * refreshed after every optimizer step. */
+int segger_f32_split_planes(const float* w, int32_t rows, int32_t cols, int32_t transpose, void* planes, segger_stream_t stream);
 int segger_linear_wgrad_f32_split_supported(int32_t m_out, int32_t k_in);
 int segger_linear_wgrad_f32_split(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t n_rows, int32_t m_out,
                                   int32_t k_in, float* grad_w, float* grad_b, void* workspace, size_t workspace_bytes,

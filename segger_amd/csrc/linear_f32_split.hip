@@ -400,6 +400,37 @@ int wgrad_f32_split_launch(const float* dy, int64_t ld_dy, const float* x, int64
 
 using namespace segger;
 
+namespace segger { namespace {
+// planes[q][o] (q = hi, mid, lo) of w [rows, cols] fp32, o running over the matrix in its own order or, `transpose`, over w^T
+__global__ __launch_bounds__(256) void f32_split_planes_kernel(const float* __restrict__ w, int rows, int cols, int transpose,
+                                                              bf16_t* __restrict__ out) {
+  const int64_t n = (int64_t)rows * cols, o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= n) return;
+  const float v = transpose ? w[(o % rows) * cols + o / rows] : w[o];
+  const uint32_t h = Vec8<bf16_t>::pack(v, 0.f);
+  float hf, mf, z;
+  Vec8<bf16_t>::unpack2(h, hf, z);
+  const float r = v - hf;
+  const uint32_t m = Vec8<bf16_t>::pack(r, 0.f);
+  Vec8<bf16_t>::unpack2(m, mf, z);
+  const uint32_t l = Vec8<bf16_t>::pack(r - mf, 0.f);
+  out[o].v = (uint16_t)(h & 0xffffu); out[n + o].v = (uint16_t)(m & 0xffffu); out[2 * n + o].v = (uint16_t)(l & 0xffffu);
+}
+} }  // namespace segger::(anonymous)
+
+extern "C" int segger_f32_split_planes(const float* w, int32_t rows, int32_t cols, int32_t transpose, void* planes,
+                                       segger_stream_t stream) {
+  SEGGER_REQUIRE(rows >= 0 && cols >= 0, "segger_f32_split_planes: negative size");
+  const int64_t n = (int64_t)rows * cols;
+  if (n == 0) return SEGGER_OK;
+  SEGGER_REQUIRE(w && planes, "segger_f32_split_planes: NULL pointer");
+  SEGGER_REQUIRE(n < (int64_t)0x7fffffff * 256, "segger_f32_split_planes: matrix too large");
+  hipLaunchKernelGGL(f32_split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, rows, cols,
+                     transpose, static_cast<bf16_t*>(planes));
+  SEGGER_LAUNCH_CHECK("f32_split_planes_kernel");
+  return SEGGER_OK;
+}
+
 extern "C" int segger_linear_wgrad_f32_split_supported(int32_t m_out, int32_t k_in) { return wgrad_f32_split_shape_ok(m_out, k_in); }
 
 extern "C" int segger_linear_fwd_f32_split_supported(int32_t k_in, int32_t m_out) {

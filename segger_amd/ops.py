@@ -1418,15 +1418,24 @@ def linear_fwd_launch(x: Tensor, w: Tensor, bias: Optional[Tensor], out: Optiona
     return y
 
 
-def f32_split_planes(w: Tensor) -> Tensor:
+def f32_split_planes(w: Tensor, transposed: bool = False) -> Tensor:
     """bf16 [3, M, K]: hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid) of an fp32 matrix (the weight operand of
-    :func:`linear_f32_split_launch`)."""
-    w = w.detach().float()
-    hi = w.bfloat16()
-    r = w - hi.float()
-    mid = r.bfloat16()
-    lo = (r - mid.float()).bfloat16()
-    return torch.stack((hi, mid, lo)).contiguous()
+    :func:`linear_f32_split_launch`); ``transposed``: the planes of w^T, [3, K, M].  One launch (``segger_f32_split_planes``)."""
+    w = w.detach()
+    if not w.is_cuda:                     # (host tensors: plain torch, for tests of the split's algebra)
+        w = w.float().t().contiguous() if transposed else w.float()
+        hi = w.bfloat16()
+        r = w - hi.float()
+        mid = r.bfloat16()
+        return torch.stack((hi, mid, (r - mid.float()).bfloat16())).contiguous()
+    if w.dtype != torch.float32 or w.dim() != 2 or not w.is_contiguous():
+        w = w.float().contiguous()
+    m, k = int(w.shape[0]), int(w.shape[1])
+    out = torch.empty((3, k, m) if transposed else (3, m, k), dtype=torch.bfloat16, device=w.device)
+    with _lib.on_device(w.device):
+        rc = _lib.load().segger_f32_split_planes(w.data_ptr(), m, k, int(transposed), out.data_ptr(), _lib.stream_ptr(w.device))
+    _lib.check(rc, "segger_f32_split_planes")
+    return out
 
 
 def linear_f32_split_supported(k_in: int, m_out: int) -> bool:
@@ -1762,7 +1771,7 @@ class _Pack:
         hit = self.__dict__.get(slot)
         if hit is None or hit[0] != self.key:
             with torch.no_grad():
-                hit = (self.key, f32_split_planes(self.w.t().contiguous() if transposed else self.w))
+                hit = (self.key, f32_split_planes(self.w, transposed=transposed))
             self.__dict__[slot] = hit
         return hit[1]
 

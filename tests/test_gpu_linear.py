@@ -437,6 +437,8 @@ def test_linear_fp32_split_within_the_exact_kernels_error(cuda, k, m, n):
     assert ops.linear_f32_split_supported(k, m)
     w3 = ops.f32_split_planes(w)
     assert torch.equal(w3.float().sum(0), w)                  # the three parts add up to the fp32 number exactly
+    assert torch.equal(w3.cpu(), ops.f32_split_planes(w.cpu()))                                   # kernel == the torch formulas
+    assert torch.equal(ops.f32_split_planes(w, transposed=True), ops.f32_split_planes(w.t().contiguous()))
     y_split = ops.linear_f32_split_launch(x, w3, b)
     y_exact = ops.linear_fwd_launch(x, w, b)
     ref = x.double() @ w.double().t() + b.double()
