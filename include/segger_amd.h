@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 22
+#define SEGGER_ABI_VERSION 23
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -689,6 +689,11 @@ int segger_gene_table_bwd(const segger_gene_table_args* args, segger_stream_t st
 int segger_linear_fwd_f32_split_supported(int32_t k_in, int32_t m_out);
 int segger_linear_fwd_f32_split(const float* x, int64_t ldx, const void* w3, const float* bias, float* y, int64_t ldy,
                                 int64_t n_rows, int32_t k_in, int32_t m_out, segger_stream_t stream);
+/* ... with y[row, :] += rowbias[rowidx[row], :] in the epilogue (fp32 table [n_ids, ld_rb >= m_out]; no bias): the fp32 form
+ * of segger_linear_fwd_rowbias on the split kernel. */
+int segger_linear_fwd_f32_split_rowbias(const float* x, int64_t ldx, const void* w3, const float* rowbias, int64_t ld_rb,
+                                        const int32_t* rowidx, float* y, int64_t ldy, int64_t n_rows, int32_t k_in,
+                                        int32_t m_out, segger_stream_t stream);
 
 /* segger_linear_fwd_pair: two such projections with the same k_in and dtype as ONE launch -- a hetero layer projects its
  * transcripts ([lin_l | lin_r | lin_l], ist_encoder.py:109-134 through HeteroConv) and its ~10^2-10^3 boundaries (lin_r)

@@ -30,6 +30,7 @@ struct SplitParams {
   float* y; int64_t ldy;
   int64_t n_rows;
   int m_out;
+  const float* rowbias; const int32_t* rowidx; int64_t ld_rb;     // optional: y[row, :] += rowbias[rowidx[row], :] (fp32 table)
 };
 
 // 8 consecutive floats -> their hi / mid / lo bf16 parts (round to nearest each time: the remainders are exact in fp32)
@@ -110,11 +111,13 @@ __global__ __launch_bounds__(256, 2) void linear_f32_split_kernel(SplitParams p)
   auto store_tile = [&](const f32x16& acc, int c0, int ct) {
     if (!row_ok) return;
     float* yr = p.y + row * p.ldy + c0;
+    const float* tr = p.rowbias ? p.rowbias + (int64_t)p.rowidx[row] * p.ld_rb + c0 : nullptr;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int col = ct * 32 + 8 * g + 4 * h;
       f32x4 v = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
       if (p.bias) v = v + *reinterpret_cast<const f32x4*>(p.bias + c0 + col);
+      if (tr) v = v + *reinterpret_cast<const f32x4*>(tr + col);
       *reinterpret_cast<f32x4*>(yr + col) = v;
     }
   };
@@ -437,8 +440,26 @@ extern "C" int segger_linear_fwd_f32_split_supported(int32_t k_in, int32_t m_out
   return (k_in == 128 && m_out > 0 && m_out % kCH == 0) || (k_in == 384 && m_out == 128);
 }
 
+static int split_fwd_launch(const float* x, int64_t ldx, const void* w3, const float* bias, const float* rowbias, int64_t ld_rb,
+                            const int32_t* rowidx, float* y, int64_t ldy, int64_t n_rows, int32_t k_in, int32_t m_out,
+                            segger_stream_t stream);
+
 extern "C" int segger_linear_fwd_f32_split(const float* x, int64_t ldx, const void* w3, const float* bias, float* y, int64_t ldy,
                                            int64_t n_rows, int32_t k_in, int32_t m_out, segger_stream_t stream) {
+  return split_fwd_launch(x, ldx, w3, bias, nullptr, 0, nullptr, y, ldy, n_rows, k_in, m_out, stream);
+}
+
+extern "C" int segger_linear_fwd_f32_split_rowbias(const float* x, int64_t ldx, const void* w3, const float* rowbias, int64_t ld_rb,
+                                                   const int32_t* rowidx, float* y, int64_t ldy, int64_t n_rows, int32_t k_in,
+                                                   int32_t m_out, segger_stream_t stream) {
+  SEGGER_REQUIRE(n_rows == 0 || (rowbias && rowidx && aligned16(rowbias) && ld_rb >= m_out && ld_rb % 4 == 0),
+                 "segger_linear_fwd_f32_split_rowbias: table NULL, misaligned or ld < m_out");
+  return split_fwd_launch(x, ldx, w3, nullptr, rowbias, ld_rb, rowidx, y, ldy, n_rows, k_in, m_out, stream);
+}
+
+static int split_fwd_launch(const float* x, int64_t ldx, const void* w3, const float* bias, const float* rowbias, int64_t ld_rb,
+                            const int32_t* rowidx, float* y, int64_t ldy, int64_t n_rows, int32_t k_in, int32_t m_out,
+                            segger_stream_t stream) {
   SEGGER_REQUIRE(n_rows >= 0, "segger_linear_fwd_f32_split: negative size");
   if (!segger_linear_fwd_f32_split_supported(k_in, m_out)) {
     set_error("segger_linear_fwd_f32_split: k_in=%d m_out=%d not supported (128 -> multiple of 64, 384 -> 128)", k_in, m_out);
@@ -450,7 +471,7 @@ extern "C" int segger_linear_fwd_f32_split(const float* x, int64_t ldx, const vo
                      ldx % 4 == 0 && ldy % 4 == 0, "segger_linear_fwd_f32_split: rows (and the bias) must be 16-byte aligned");
   const int64_t nb = (n_rows + 127) / 128;
   SEGGER_REQUIRE(nb <= 0x7fffffffLL, "segger_linear_fwd_f32_split: too many rows");
-  SplitParams p{x, ldx, static_cast<const bf16_t*>(w3), bias, y, ldy, n_rows, m_out};
+  SplitParams p{x, ldx, static_cast<const bf16_t*>(w3), bias, y, ldy, n_rows, m_out, rowbias, rowidx, ld_rb};
   if (k_in == 128) hipLaunchKernelGGL((linear_f32_split_kernel<128>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((linear_f32_split_kernel<384>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
   SEGGER_LAUNCH_CHECK("linear_f32_split_kernel");

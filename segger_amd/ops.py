@@ -2381,10 +2381,16 @@ class _EmbedLinear(torch.autograd.Function):
         a.tab, a.ld_tab, a.wc, a.wc_t = tab.data_ptr(), m, wc.data_ptr(), wc_t.data_ptr()
         y = torch.empty((n, m), dtype=dt, device=dev)
         cp, ldc = _rows(c, d, "c")
+        split = (F32_SPLIT and dt == torch.float32 and ldc % 4 == 0 and linear_f32_split_supported(d, m))
         with _lib.on_device(dev):
             _lib.check(lib.segger_gene_table_fwd(C.byref(a), _lib.stream_ptr(dev)), "segger_gene_table_fwd")
-            rc = lib.segger_linear_fwd_rowbias(cp, ldc, wc.data_ptr(), None, tab.data_ptr(), m, ids.data_ptr(),
-                                               y.data_ptr(), m, n, d, m, DTYPE_CODE[dt], _lib.stream_ptr(dev))
+            if split:      # fp32 storage: the positional GEMM on the bf16x3 split, the table row added in its epilogue
+                w3 = f32_split_planes(wc)
+                rc = lib.segger_linear_fwd_f32_split_rowbias(cp, ldc, w3.data_ptr(), tab.data_ptr(), m, ids.data_ptr(),
+                                                             y.data_ptr(), m, n, d, m, _lib.stream_ptr(dev))
+            else:
+                rc = lib.segger_linear_fwd_rowbias(cp, ldc, wc.data_ptr(), None, tab.data_ptr(), m, ids.data_ptr(),
+                                                   y.data_ptr(), m, n, d, m, DTYPE_CODE[dt], _lib.stream_ptr(dev))
         _lib.check(rc, "segger_linear_fwd_rowbias")
         ctx.save_for_backward(c, pre, table, ids, wc, wc_t, *weights)
         ctx.by_gene, ctx.n_w, ctx.has_bias = by_gene, n_w, tuple(b is not None for b in biases)
@@ -2412,7 +2418,10 @@ class _EmbedLinear(torch.autograd.Function):
             gc, gw, _ = linear_wgrad_dx_launch(gy, c, wc_t, want_bias=False, gate=pre if gated else None)
         else:
             if want_c:
-                gc = linear_fwd_launch(gy, wc_t, None)
+                if F32_SPLIT and dt == torch.float32 and gy.stride(0) % 4 == 0 and linear_f32_split_supported(m, d):
+                    gc = linear_f32_split_launch(gy, f32_split_planes(wc, transposed=True), None)
+                else:
+                    gc = linear_fwd_launch(gy, wc_t, None)
             if want_w:
                 gw, _ = linear_wgrad_launch(gy, c, want_bias=False)
         by_gene = ctx.by_gene if ctx.by_gene is not None else rows_by_id(ids, int(table.shape[0]))
