@@ -3,8 +3,10 @@
 on the BASELINE.json C2 tile (1M transcripts, 10k nuclei, k=15), bf16 storage.
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N ...           (no launcher environment: this process starts its own N ranks -- self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 2 --backend gloo --dry-launch     (the launch path alone: census of the ranks, no GPU)
 
 One step = one pass of the hot path over one synthetic tile per rank (weak
 scaling: every rank owns a tile of the same size, different seed): encoder
@@ -18,7 +20,9 @@ JSON line:
   roofline {bound, kernel, achieved, peak, unit, frac, traffic, algorithmic_bytes_per_launch, ms_per_launch}
   roofline_other {gatv2_bwd_tx_tx, gatv2_fwd_tx_tx_eval,                            -- the other kernel classes of the step,
                   projection_fwd, projection_bwd_one_pass, projection_bwd_two_kernels,  each {achieved GB/s, frac of 8 TB/s,
-                  first_layer_rowbias_fwd, positional_embedder_fwd, triplet_bwd_loss_tx} algorithmic_bytes_per_launch, ms_per_launch}
+                  first_layer_rowbias_fwd, positional_embedder_fwd, triplet_bwd_loss_tx, algorithmic_bytes_per_launch, ms_per_launch}
+                  triplet_bwd_loss_sg_grouped / _two_kernels (the kernels alone, on the tile's own tx-belongs-bd edges),
+                  loss_grad_zero_fill (the one fill both loss backward kernels accumulate into)}
       algorithmic bytes (s = element size, n = rows):  projection fwd  n (K + M) s ;  its whole backward (dX, dW, db)
       n (M + 2 K) s -- dY and X read once, dX written once ;  first layer (row-bias form)  n (K + M) s + 4 n ids ;
       positional embedder (training forward)  n (8 + D s) + stored activations 2 n (2 Dh s + 4) ;  triplet backward
@@ -39,21 +43,35 @@ JSON line:
       `value` = 2 * Etb of the whole FOV / epoch_s.  Total work is independent of N: value(N) / value(1) is the
       strong-scaling speed-up.  `census` is an all-reduced one-hot of the ranks (all ones <=> RCCL saw N ranks).
       At N = 1, `strong.graphed` {value, ms_per_step, epoch_s, shape_buckets} repeats the epoch with every training
-      step replayed as one hipGraph (segger_amd.train_step_graph).
+      step replayed as one hipGraph (segger_amd.train_step_graph);
+      `strong.graphed_dp_world1` {ms_per_step, overhead_ms_per_step_vs_graphed, allreduce_plus_divide_ms, backend, ...}
+      (N = 1) repeats it through the N > 1 route on a one-rank RCCL communicator: two hipGraphs per step around one forced
+      all-reduce + divide of the persistent flat gradient buffer -- the per-step cost data parallelism adds before any xGMI
+      time; `strong.predicted` {"2" | "4" | "8": {imbalance, sync_imbalance, steps_per_rank, empty_steps, predicted_speedup}}:
+      what dp.rank_schedule does with this batch list at N ranks (predicted_speedup: an upper bound, see predicted_schedule)
   untimed_setup {csr_build_ms, uncached_step_ms, first_step_ms}, csr_build_ms
       what the timed region leaves out: it replays ONE resident batch whose sorted edge views (both CSR views of the 15M
       tx-neighbors-tx edges + tx-belongs-bd by destination), sampler indices and masks are cached on the batch
-  auroc {what, tile, n_edges, positives, dtype {f32, bf16, f16: {hip, oracle, delta, max_abs_score_diff, ...}}, met,
+  auroc {what, tile, n_edges, positives, dtype {f32, bf16, f16: {hip, oracle, delta, max_abs_score_diff, mean_abs_score_diff,
+         frac_over_atol, frac_over_atol_bound, atol, met}}, met, trained_weights {dtype {...}, elementwise {...}, met},
          fov_tiles {tiles, n_edges, oracle_seconds, dtype {...}, met}}
       (N = 1)  the "AUROC vs ref" half of the metric: tx-neighbors-bd candidate edges ranked by cosine score
       (lightning_model.py:275-279), HIP path vs the CPU oracle with identical weights: the cpu_baseline leg's C2/10 tile
       with its seed-0 weights, and `--auroc-tiles` (8) seeded random tiles of the 50M-tx FOV with the weights the timed
-      epochs left behind.  Bar: delta <= 1e-3 in every dtype.
+      epochs left behind.  Bars, in every dtype: delta <= 1e-3 AND frac_over_atol (share of edges whose score misses
+      SURVEY.md 8(d)'s elementwise tolerance: fp32 rtol 1e-5 + atol 1e-5, 16-bit atol 2e-2) <= frac_over_atol_bound (0 /
+      2e-3).  `trained_weights.elementwise`: where the 16-bit per-edge differences come from -- the HIP path layer by layer
+      against the fp32 oracle and against the oracle's own arithmetic with 16-bit activation / GEMM-operand storage
+      (oracle `storage_round`), the worst edges with their endpoints' pre-normalisation norms.
   c5 {dtype "f16", edges_per_s, ms, buckets, packed_batches {...}, predict_tiles {...}}
       (N = 1)  BASELINE config 5 on the resident 50M-tx FOV: GraphedPredictorPool sweeps (first sweep captures, second is
       timed) over the partition's packed batches and over the reference's overlapping prediction tiles
       (tile_dataset.py:218-246); `spot_check` compares assignments with the eager predict_step on 4 tiles.
-      (The 100M-tx run of the same code: tools/fov_stream.py, profiles/r0N_fov_100m_e16M.json.)
+  c5_100m {dtype "f16", edges_per_s, ms, buckets, batches, fov_build_s, capture_sweep_s, edges_scored, transcripts_out,
+           spot_check, resident_bytes, peak_hbm_gib}
+      (N = 1)  BASELINE config 5 at the size it names: after the 50M phases have freed their partition a 100M-transcript FOV
+      is generated on the device (16M-edge packed batches), GraphedPredictorPool captures one graph per shape bucket in a
+      first sweep and the second sweep is timed; 4 batches are compared with the eager predict_step.
   default_dropin {ms_per_step, value, batches, dtype "f32"}
       (N = 1)  what INTEGRATION.md's import swap alone gives: fp32 storage, eager steps, 1M-edge batches (100 of the FOV's)
 """
