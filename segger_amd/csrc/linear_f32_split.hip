@@ -23,6 +23,16 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// A workgroup barrier that orders LDS traffic only: this wave's LDS operations have completed (lgkmcnt(0)), then s_barrier.
+// __syncthreads() is a release fence as well -- s_waitcnt vmcnt(0): every global load in flight (the prefetch these kernels
+// live on) and every output store would have to drain at each barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("" ::: "memory");                         // (compiler: no memory access moves across)
+  __builtin_amdgcn_s_waitcnt(0xC07F);                    // lgkmcnt(0)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 struct SplitParams {
   const float* x; int64_t ldx;
   const bf16_t* w3;          // [3][m_out][K]
@@ -58,8 +68,11 @@ constexpr int kWS = kKS * 2 + 16;              // LDS row stride of a staged pla
 // A workgroup (4 waves) owns 128 rows; a wave keeps the split fragments of its 32 rows x 128 k in registers (96 VGPRs).
 //   K == 128: chunks of 64 output columns stream through LDS (three planes: 52 KB), one accumulator pair per chunk;
 //   K == 384 (M == 128): k slices outermost, the whole [32, 128] output of a wave stays in accumulators.
+#ifndef SEGGER_FS_K384_WAVES
+#define SEGGER_FS_K384_WAVES 1            // K = 384: one wave per SIMD (512 registers): next slice's rows AND next W chunk in flight
+#endif
 template <int K>
-__global__ __launch_bounds__(256, 2) void linear_f32_split_kernel(SplitParams p) {
+__global__ __launch_bounds__(256, K == 128 ? 2 : SEGGER_FS_K384_WAVES) void linear_f32_split_kernel(SplitParams p) {
   constexpr int NS = K / kKS;                  // k slices
   constexpr int NACC = NS == 1 ? 2 : 4;        // 32-column accumulator tiles alive
   __shared__ __attribute__((aligned(16))) unsigned char lds[3 * kCH * kWS];
@@ -90,6 +103,26 @@ __global__ __launch_bounds__(256, 2) void linear_f32_split_kernel(SplitParams p)
       *reinterpret_cast<u32x4*>(lds + (plane * kCH + wrow) * kWS + wcol * 16) = v;
     }
   };
+  // the same in two halves: global -> registers (in flight under the previous chunk's MFMAs AND output stores: vmcnt is
+  // in order, so a chunk staged only after the stores were issued waits for them to drain -- 6 store drains per block),
+  // registers -> LDS behind the barrier
+  u32x4 wreg[12];
+  auto w_fetch = [&](int c0, int slice) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int piece = tid + 256 * i;
+      const int plane = piece >> 10, wrow = (piece >> 4) & 63, wcol = piece & 15;
+      wreg[i] = *reinterpret_cast<const u32x4*>(p.w3 + ((int64_t)plane * M + c0 + wrow) * K + slice * kKS + wcol * 8);
+    }
+  };
+  auto w_commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      const int piece = tid + 256 * i;
+      const int plane = piece >> 10, wrow = (piece >> 4) & 63, wcol = piece & 15;
+      *reinterpret_cast<u32x4*>(lds + (plane * kCH + wrow) * kWS + wcol * 16) = wreg[i];
+    }
+  };
   // both 32-column tiles of the staged chunk, their (dependent) MFMA chains interleaved
   auto chunk_mma = [&](f32x16& acc0, f32x16& acc1) {
 #pragma unroll
@@ -100,15 +133,22 @@ __global__ __launch_bounds__(256, 2) void linear_f32_split_kernel(SplitParams p)
       const u32x4 wm1 = *reinterpret_cast<const u32x4*>(lds + kCH * kWS + off + 32 * kWS);
       const u32x4 wl0 = *reinterpret_cast<const u32x4*>(lds + 2 * kCH * kWS + off);
       const u32x4 wl1 = *reinterpret_cast<const u32x4*>(lds + 2 * kCH * kWS + off + 32 * kWS);
+#ifdef EXP_FS_ONEMFMA       // bounding build: one product instead of six
+      acc0 = mfma_bf16(wh0 ^ wm0 ^ wl0, xh[s] ^ xm[s] ^ xl[s], acc0); acc1 = mfma_bf16(wh1 ^ wm1 ^ wl1, xh[s] ^ xm[s] ^ xl[s], acc1);
+#else
       acc0 = mfma_bf16(wl0, xh[s], acc0); acc1 = mfma_bf16(wl1, xh[s], acc1);        // smallest terms first
       acc0 = mfma_bf16(wh0, xl[s], acc0); acc1 = mfma_bf16(wh1, xl[s], acc1);
       acc0 = mfma_bf16(wm0, xm[s], acc0); acc1 = mfma_bf16(wm1, xm[s], acc1);
       acc0 = mfma_bf16(wm0, xh[s], acc0); acc1 = mfma_bf16(wm1, xh[s], acc1);
       acc0 = mfma_bf16(wh0, xm[s], acc0); acc1 = mfma_bf16(wh1, xm[s], acc1);
       acc0 = mfma_bf16(wh0, xh[s], acc0); acc1 = mfma_bf16(wh1, xh[s], acc1);
+#endif
     }
   };
   auto store_tile = [&](const f32x16& acc, int c0, int ct) {
+#ifdef EXP_FS_NOSTORE       // bounding build: no output traffic (one lane's store keeps the arithmetic alive)
+    if (lane != 63 || blockIdx.x != 0) return;
+#endif
     if (!row_ok) return;
     float* yr = p.y + row * p.ldy + c0;
     const float* tr = p.rowbias ? p.rowbias + (int64_t)p.rowidx[row] * p.ld_rb + c0 : nullptr;
@@ -124,12 +164,14 @@ __global__ __launch_bounds__(256, 2) void linear_f32_split_kernel(SplitParams p)
 
   f32x16 acc[NACC];
   if constexpr (NS == 1) {
+    w_fetch(0, 0);
     load_x(0);
     const int n_chunks = M / kCH;
     for (int c = 0; c < n_chunks; ++c) {
-      __syncthreads();                                       // every wave has left the previous chunk's reads
-      stage_w(c * kCH, 0);
-      __syncthreads();
+      lds_barrier();                                       // every wave has left the previous chunk's reads
+      w_commit();
+      lds_barrier();
+      if (c + 1 < n_chunks) w_fetch((c + 1) * kCH, 0);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -143,17 +185,49 @@ __global__ __launch_bounds__(256, 2) void linear_f32_split_kernel(SplitParams p)
     for (int a = 0; a < NACC; ++a)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][e] = 0.f;
+    // software pipeline over the (slice, chunk) stages: the NEXT slice's fp32 rows and the NEXT stage's W planes are in
+    // flight (registers) under this stage's MFMAs -- the slice-by-slice form exposed one load latency per slice and one W
+    // staging per stage: 0.68 of its 0.90 ms remained with one MFMA and no stores (tools/build_variant_file.sh fs_*)
+#if SEGGER_FS_K384_WAVES == 1
+    f32x4 xraw[16];
+    auto fetch_x = [&](int slice) {
+      const float* xr = p.x + row * p.ldx + slice * kKS + 8 * h;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        xraw[2 * s] = *reinterpret_cast<const f32x4*>(xr + 16 * s);
+        xraw[2 * s + 1] = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4);
+      }
+    };
+    fetch_x(0);
+    w_fetch(0, 0);
+#pragma unroll 1
+    for (int slice = 0; slice < NS; ++slice) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) split8(xraw[2 * s], xraw[2 * s + 1], xh[s], xm[s], xl[s]);
+      if (slice + 1 < NS) fetch_x(slice + 1);
+#pragma unroll
+      for (int c = 0; c < NACC / 2; ++c) {
+        lds_barrier();
+        w_commit();
+        lds_barrier();
+        if (c + 1 < NACC / 2) w_fetch((c + 1) * kCH, slice);
+        else if (slice + 1 < NS) w_fetch(0, slice + 1);
+        chunk_mma(acc[2 * c], acc[2 * c + 1]);
+      }
+    }
+#else
 #pragma unroll 1
     for (int slice = 0; slice < NS; ++slice) {
       load_x(slice);
 #pragma unroll
       for (int c = 0; c < NACC / 2; ++c) {
-        __syncthreads();
+        lds_barrier();
         stage_w(c * kCH, slice);
-        __syncthreads();
+        lds_barrier();
         chunk_mma(acc[2 * c], acc[2 * c + 1]);
       }
     }
+#endif
 #pragma unroll
     for (int a = 0; a < NACC; ++a) store_tile(acc[a], (a / 2) * kCH, a & 1);
   }
@@ -296,7 +370,7 @@ __global__ __launch_bounds__(NW * 64) void wgrad_f32_split_kernel(WgSplitParams 
       if (pis_y[j]) dbp[j] = dbp[j] + ring[SL][j];
     }
     fetch(slot_c, s + AH);
-    __syncthreads();                                             // (also: every wave has left the reads of stage s - 2)
+    lds_barrier();                                             // (also: every wave has left the reads of stage s - 2)
     u32x4 fa[3][MT], fb[3][KT];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
