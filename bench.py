@@ -60,7 +60,7 @@ JSON line:
       with its seed-0 weights, and `--auroc-tiles` (8) seeded random tiles of the 50M-tx FOV with the weights the timed
       epochs left behind.  Bars, in every dtype: delta <= 1e-3 AND frac_over_atol (share of edges whose score misses
       SURVEY.md 8(d)'s elementwise tolerance: fp32 rtol 1e-5 + atol 1e-5, 16-bit atol 2e-2) <= frac_over_atol_bound (fp32 0,
-      bf16 5e-3, f16 5e-4).  `trained_weights.elementwise`: where the 16-bit per-edge differences come from -- the HIP path layer by layer
+      bf16 5e-3, f16 1e-3).  `trained_weights.elementwise`: where the 16-bit per-edge differences come from -- the HIP path layer by layer
       against the fp32 oracle and against the oracle's own arithmetic with 16-bit activation / GEMM-operand storage
       (oracle `storage_round`), the worst edges with their endpoints' pre-normalisation norms.
   c5 {dtype "f16", edges_per_s, ms, buckets, packed_batches {...}, predict_tiles {...}}
@@ -351,8 +351,8 @@ def hip_edge_scores(model, batch, dtype):
 ATOL_16 = 2e-2                  # bf16 / fp16 atol 2e-2 on cosine scores
 # share of edges allowed beyond it (DESIGN.md 1 for where they come from).  bf16: the REFERENCE's own arithmetic with bf16
 # activation / GEMM-operand storage (oracle storage_round: no HIP kernel) leaves 1.0-1.5e-3 of the edges beyond atol with
-# trained weights, the HIP path 1.6-2.3e-3 over the runs seen (0 with seed-0 weights and on the FOV tiles); f16: <= 2.5e-5.
-FRAC_OVER_BOUND = {"f32": 0.0, "bf16": 5e-3, "f16": 5e-4}
+# trained weights, the HIP path 1.6-2.3e-3 over the runs seen (0 with seed-0 weights and on the FOV tiles); f16: 4e-6 - 2.5e-4.
+FRAC_OVER_BOUND = {"f32": 0.0, "bf16": 5e-3, "f16": 1e-3}
 
 
 def _over_atol(d, ref, name):
