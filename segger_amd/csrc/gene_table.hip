@@ -19,7 +19,10 @@
 namespace segger {
 namespace {
 
-constexpr int kTI = 32, kTJ = 64, kTK = 16;        // a 256-thread workgroup owns a 32 x 64 tile of the product
+// a 256-thread workgroup owns a 32 x 64 tile of the product; 64 k per staged step: the products are latency-bound (16-24
+// workgroups, each a chain of load -> barrier -> FMA steps), so few long steps with 24 loads in flight per thread beat many
+// short ones (16 k per step: 79 us for the backward at G = 256, M = 384, D = 128)
+constexpr int kTI = 32, kTJ = 64, kTK = 64;
 
 struct GeneTable {
   const float* table; int G, D, n_w, M;
@@ -48,15 +51,26 @@ __device__ __forceinline__ void tile_gemm(int K, int i0, int j0, FA a, FB b, FE 
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;          // rows 2 ti, 2 ti + 1; columns tj + 16 c
   float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   for (int k0 = 0; k0 < K; k0 += kTK) {
+    float av[kTI * kTK / 256], bv[kTK * kTJ / 256];                    // all of the step's loads first, then the LDS writes
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {                                      // 32 x 16 elements of A
-      const int e = tid + 256 * q, r = e / kTK, kk = e % kTK;
-      As[r][kk] = a(i0 + r, k0 + kk);
+    for (int q = 0; q < kTI * kTK / 256; ++q) {
+      const int e = tid + 256 * q;
+      av[q] = a(i0 + e / kTK, k0 + e % kTK);
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {                                      // 16 x 64 elements of B
-      const int e = tid + 256 * q, kk = e / kTJ, c = e % kTJ;
-      Bs[kk][c] = b(k0 + kk, j0 + c);
+    for (int q = 0; q < kTK * kTJ / 256; ++q) {
+      const int e = tid + 256 * q;
+      bv[q] = b(k0 + e / kTJ, j0 + e % kTJ);
+    }
+#pragma unroll
+    for (int q = 0; q < kTI * kTK / 256; ++q) {
+      const int e = tid + 256 * q;
+      As[e / kTK][e % kTK] = av[q];
+    }
+#pragma unroll
+    for (int q = 0; q < kTK * kTJ / 256; ++q) {
+      const int e = tid + 256 * q;
+      Bs[e / kTJ][e % kTJ] = bv[q];
     }
     __syncthreads();
 #pragma unroll
