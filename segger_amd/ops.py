@@ -2341,6 +2341,7 @@ def embed_linear_supported(x: "EmbedInput", m_out: int) -> bool:
 
 
 EMBED_LINEAR_ONE_NODE = True     # tools flip it: False = the table and its gradients through torch ops around _RowBiasLinear
+EMBED_LINEAR_MAX_GENES = 1024
 
 
 def _gene_table_args(table, weights, biases, dt):
@@ -2461,7 +2462,9 @@ def embed_linear(x: "EmbedInput", weight, bias) -> Tensor:
     weights = tuple(weight) if isinstance(weight, (list, tuple)) else (weight,)
     biases = tuple(bias) if isinstance(bias, (list, tuple)) else (bias,)
     d = int(x.table.shape[1])
-    if (EMBED_LINEAR_ONE_NODE and len(weights) <= 4 and x.act_pe.shape[1] == d
+    # (the table kernels are latency-sized: a few hundred genes.  A 5k-gene panel's dW reduction would take 0.6 ms on their
+    #  24 workgroups -- the torch-composed route with its vendor GEMMs below serves those)
+    if (EMBED_LINEAR_ONE_NODE and len(weights) <= 4 and x.act_pe.shape[1] == d and x.table.shape[0] <= EMBED_LINEAR_MAX_GENES
             and all(w.dtype == torch.float32 and w.dim() == 2 and w.shape[1] == 2 * d and w.stride(1) == 1 for w in weights)
             and all(b is None or (b.dtype == torch.float32 and b.is_contiguous()) for b in biases)):
         return _EmbedLinear.apply(x.act_pe, x.pre_pe, x.table, x.ids, x.by_gene, len(weights), *weights, *biases)
