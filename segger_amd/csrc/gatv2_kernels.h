@@ -646,7 +646,7 @@ __device__ __forceinline__ void gatv2_bwd_dst_body(SEGGER_BODY_PARAM p, int64_t 
     // ch0 per iteration keeps those sums inside it: scalar row base + 32-bit lane offset, no registers held across rows.
     int ch0r = L.ch0;
     asm volatile("" : "+v"(ch0r));
-#define ch0 ch0r
+    const int ch0 = ch0r;                      // (shadows the function-scope ch0 for the rest of this iteration)
 
     f32x2 nxr[4], g[4], Sg[4];
     float D = 0.f, lse = 0.f, Sde = 0.f;
@@ -757,7 +757,6 @@ __device__ __forceinline__ void gatv2_bwd_dst_body(SEGGER_BODY_PARAM p, int64_t 
       for (int i = 0; i < 4; ++i) dxr[i] = (a1[i] * Sde + a2[i] * Sg[i]) * kLn2;
       store_pairs(static_cast<T*>(p.gxr) + row * p.ld_gxr + ch0, dxr);
     }
-#undef ch0
   }
 
   // grad_att = c1 * Pt + c2 * Qt ; block partials of grad_att / grad_bias -> slab[blk]
