@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 23
+#define SEGGER_ABI_VERSION 24
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -651,6 +651,14 @@ int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void* w, const f
  * six partial products; csrc/linear_f32_split.hip) -- the weight gradient autograd forms as `grad.t() @ x` for the nn.Linear
  * maps of ist_encoder.py:111-124,282-286.  Same arguments, workspace (segger_linear_wgrad_workspace_bytes) and deterministic
  * slab-order sums as segger_linear_wgrad; error within the exact-fp32 kernel's own, not bit-identical to it. */
+/* segger_linear_fwd_f32_gate: y = (x @ W^T) * act'(gate) at fp32 storage -- the data gradient through GELU (gate_kind 1) or
+ * SiLU (2) with torch's separate gelu_backward / silu_backward pass folded into the GEMM epilogue (ist_encoder.py:47,320:
+ * the positional MLP's SiLU, the GELU on the first layer's input).  w_is_planes != 0: W as the three bf16 planes of
+ * segger_f32_split_planes (shapes of segger_linear_fwd_f32_split_supported); else W [m_out, k_in] fp32 on the exact-fp32
+ * kernel (k_in 64 / 128 / 256).  gate [n_rows, ld_gate >= m_out] fp32. */
+int segger_linear_fwd_f32_gate(const float* x, int64_t ldx, const void* w, int32_t w_is_planes, const float* gate,
+                               int64_t ld_gate, int32_t gate_kind, float* y, int64_t ldy, int64_t n_rows, int32_t k_in,
+                               int32_t m_out, segger_stream_t stream);
 /* segger_f32_split_planes: planes [3][rows * cols] bf16 (hi, mid, lo: they add up to the fp32 number exactly) of w [rows, cols]
  * fp32 row-major, laid out as w or, transpose != 0, as w^T [cols, rows]: the weight operand of segger_linear_fwd_f32_split,
  * refreshed after every optimizer step. */

@@ -33,6 +33,9 @@ struct LinF32Params {
   // optional per-row additive term: y[row, :] += rowbias[rowidx[row], :] (fp32 table, row stride ld_rb): the per-gene
   // table form of the first layer (ops.embed_linear), as in linear.hip
   const float* rowbias; const int32_t* rowidx; int64_t ld_rb;
+  // optional: y[row, c] *= act'(gate[row, c]) (gate_kind 1 = GELU, 2 = SiLU): the data gradient through an activation,
+  // torch's separate gelu_backward / silu_backward pass folded into the epilogue (as segger_linear_fwd_silu_grad at 16 bit)
+  const float* gate; int64_t ld_gate; int gate_kind;
 };
 
 // A workgroup (4 waves) owns 128 rows and produces all M columns: X is read once.  A wave keeps its 32 rows as B-operand
@@ -117,6 +120,11 @@ __global__ __launch_bounds__(256, K <= 256 ? 2 : 1) void linear_f32_kernel(LinF3
             v = v + b;
           }
           if (tr) v = v + *reinterpret_cast<const f32x4*>(tr + col);
+          if (p.gate) {
+            const f32x4 gq = *reinterpret_cast<const f32x4*>(p.gate + row * p.ld_gate + c0 + col);
+            v = f32x4{v.x * gate_grad(gq.x, p.gate_kind), v.y * gate_grad(gq.y, p.gate_kind),
+                      v.z * gate_grad(gq.z, p.gate_kind), v.w * gate_grad(gq.w, p.gate_kind)};
+          }
           *reinterpret_cast<f32x4*>(yr + col) = v;
         }
       }
@@ -340,9 +348,11 @@ void launch_wgrad_f32(const WgF32Params& p, int64_t grid, hipStream_t stream) {
 
 // (declared in common.h for csrc/linear.hip and csrc/linear_wgrad.hip, which dispatch on the dtype)
 int linear_f32_launch(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t n_rows,
-                      int k_in, int m_out, hipStream_t stream, const float* rowbias, const int32_t* rowidx, int64_t ld_rb) {
+                      int k_in, int m_out, hipStream_t stream, const float* rowbias, const int32_t* rowidx, int64_t ld_rb,
+                      const float* gate, int64_t ld_gate, int gate_kind) {
   LinF32Params p{static_cast<const float*>(x), ldx, static_cast<const float*>(w), bias, static_cast<float*>(y), ldy,
-                 n_rows, m_out, rowbias, rowidx, ld_rb};
+                 n_rows, m_out, rowbias, rowidx, ld_rb, gate, ld_gate, gate_kind};
+  if (gate && k_in == 384) { set_error("segger_linear_fwd_f32_gate: k_in 64, 128 or 256 on the exact kernel"); return SEGGER_EUNSUPPORTED; }
   if (rowbias && k_in == 384) { set_error("segger_linear_fwd_rowbias (fp32): k_in 64, 128 or 256"); return SEGGER_EUNSUPPORTED; }
   const int64_t nb = (n_rows + 127) / 128;
   if (nb > 0x7fffffffLL) { set_error("segger_linear_fwd: too many rows"); return SEGGER_EUNSUPPORTED; }

@@ -41,6 +41,7 @@ struct SplitParams {
   int64_t n_rows;
   int m_out;
   const float* rowbias; const int32_t* rowidx; int64_t ld_rb;     // optional: y[row, :] += rowbias[rowidx[row], :] (fp32 table)
+  const float* gate; int64_t ld_gate; int gate_kind;              // optional: y *= act'(gate) (1 = GELU, 2 = SiLU)
 };
 
 // 8 consecutive floats -> their hi / mid / lo bf16 parts (round to nearest each time: the remainders are exact in fp32)
@@ -158,6 +159,11 @@ __global__ __launch_bounds__(256, K == 128 ? 2 : SEGGER_FS_K384_WAVES) void line
       f32x4 v = f32x4{acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
       if (p.bias) v = v + *reinterpret_cast<const f32x4*>(p.bias + c0 + col);
       if (tr) v = v + *reinterpret_cast<const f32x4*>(tr + col);
+      if (p.gate) {
+        const f32x4 gq = *reinterpret_cast<const f32x4*>(p.gate + row * p.ld_gate + c0 + col);
+        v = f32x4{v.x * gate_grad(gq.x, p.gate_kind), v.y * gate_grad(gq.y, p.gate_kind),
+                  v.z * gate_grad(gq.z, p.gate_kind), v.w * gate_grad(gq.w, p.gate_kind)};
+      }
       *reinterpret_cast<f32x4*>(yr + col) = v;
     }
   };
@@ -516,7 +522,7 @@ extern "C" int segger_linear_fwd_f32_split_supported(int32_t k_in, int32_t m_out
 
 static int split_fwd_launch(const float* x, int64_t ldx, const void* w3, const float* bias, const float* rowbias, int64_t ld_rb,
                             const int32_t* rowidx, float* y, int64_t ldy, int64_t n_rows, int32_t k_in, int32_t m_out,
-                            segger_stream_t stream);
+                            segger_stream_t stream, const float* gate = nullptr, int64_t ld_gate = 0, int gate_kind = 0);
 
 extern "C" int segger_linear_fwd_f32_split(const float* x, int64_t ldx, const void* w3, const float* bias, float* y, int64_t ldy,
                                            int64_t n_rows, int32_t k_in, int32_t m_out, segger_stream_t stream) {
@@ -531,9 +537,26 @@ extern "C" int segger_linear_fwd_f32_split_rowbias(const float* x, int64_t ldx, 
   return split_fwd_launch(x, ldx, w3, nullptr, rowbias, ld_rb, rowidx, y, ldy, n_rows, k_in, m_out, stream);
 }
 
+extern "C" int segger_linear_fwd_f32_gate(const float* x, int64_t ldx, const void* w, int32_t w_is_planes, const float* gate,
+                                          int64_t ld_gate, int32_t gate_kind, float* y, int64_t ldy, int64_t n_rows, int32_t k_in,
+                                          int32_t m_out, segger_stream_t stream) {
+  SEGGER_REQUIRE(n_rows >= 0 && (gate_kind == 1 || gate_kind == 2), "segger_linear_fwd_f32_gate: gate_kind 1 (GELU) or 2 (SiLU)");
+  if (n_rows == 0) return SEGGER_OK;
+  SEGGER_REQUIRE(x && w && y && gate && aligned16(x) && aligned16(w) && aligned16(y) && aligned16(gate) && ldx >= k_in &&
+                     ldy >= m_out && ld_gate >= m_out && ldx % 4 == 0 && ldy % 4 == 0 && ld_gate % 4 == 0,
+                 "segger_linear_fwd_f32_gate: NULL pointer or rows not 16-byte aligned");
+  if (w_is_planes) return split_fwd_launch(x, ldx, w, nullptr, nullptr, 0, nullptr, y, ldy, n_rows, k_in, m_out, stream, gate, ld_gate, gate_kind);
+  if (!((k_in == 64 || k_in == 128 || k_in == 256) && m_out > 0 && m_out % 64 == 0)) {
+    set_error("segger_linear_fwd_f32_gate: k_in=%d m_out=%d not supported (k_in 64 / 128 / 256, m_out %% 64 == 0)", k_in, m_out);
+    return SEGGER_EUNSUPPORTED;
+  }
+  return linear_f32_launch(x, ldx, w, nullptr, y, ldy, n_rows, k_in, m_out, (hipStream_t)stream, nullptr, nullptr, 0, gate, ld_gate,
+                           gate_kind);
+}
+
 static int split_fwd_launch(const float* x, int64_t ldx, const void* w3, const float* bias, const float* rowbias, int64_t ld_rb,
                             const int32_t* rowidx, float* y, int64_t ldy, int64_t n_rows, int32_t k_in, int32_t m_out,
-                            segger_stream_t stream) {
+                            segger_stream_t stream, const float* gate, int64_t ld_gate, int gate_kind) {
   SEGGER_REQUIRE(n_rows >= 0, "segger_linear_fwd_f32_split: negative size");
   if (!segger_linear_fwd_f32_split_supported(k_in, m_out)) {
     set_error("segger_linear_fwd_f32_split: k_in=%d m_out=%d not supported (128 -> multiple of 64, 384 -> 128)", k_in, m_out);
@@ -545,7 +568,7 @@ static int split_fwd_launch(const float* x, int64_t ldx, const void* w3, const f
                      ldx % 4 == 0 && ldy % 4 == 0, "segger_linear_fwd_f32_split: rows (and the bias) must be 16-byte aligned");
   const int64_t nb = (n_rows + 127) / 128;
   SEGGER_REQUIRE(nb <= 0x7fffffffLL, "segger_linear_fwd_f32_split: too many rows");
-  SplitParams p{x, ldx, static_cast<const bf16_t*>(w3), bias, y, ldy, n_rows, m_out, rowbias, rowidx, ld_rb};
+  SplitParams p{x, ldx, static_cast<const bf16_t*>(w3), bias, y, ldy, n_rows, m_out, rowbias, rowidx, ld_rb, gate, ld_gate, gate_kind};
   if (k_in == 128) hipLaunchKernelGGL((linear_f32_split_kernel<128>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((linear_f32_split_kernel<384>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
   SEGGER_LAUNCH_CHECK("linear_f32_split_kernel");

@@ -117,8 +117,14 @@ class Positional2dEmbedder(Module):
             pos = self.normalize(pos, batch, num_graphs)
             freq = sinusoidal_embedding(pos.flatten(), fd, max_period=10000).reshape(n, 2, fd).to(dtype)
         l0, l2 = self.mlp[0], self.mlp[2]
-        h = F.silu(ops.linear(freq, l0.weight, l0.bias))
-        h = ops.linear(h, l2.weight, l2.bias).flatten(-2)
+        flat = freq.reshape(-1, fd)
+        if (dtype == torch.float32 and ops.F32_GATE_EPILOGUE and l0.bias is not None and l2.bias is not None
+                and ops.mlp_silu_f32_supported(flat, l0.weight, l2.weight)):
+            # fp32 storage: the MLP as one autograd node (SiLU's derivative in the data-gradient GEMM's epilogue)
+            h = ops.mlp_silu_f32(flat, l0.weight, l0.bias, l2.weight, l2.bias).reshape(n, -1)
+        else:
+            h = F.silu(ops.linear(freq, l0.weight, l0.bias))
+            h = ops.linear(h, l2.weight, l2.bias).flatten(-2)
         if gelu and return_pre:
             return F.gelu(h), None
         return F.gelu(h) if gelu else h

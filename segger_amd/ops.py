@@ -918,11 +918,13 @@ def anchor_index(src: Tensor, n_rows: int) -> Tensor:
 
 
 ONE_LAUNCH_LOSS_HEAD = True      # tools flip it: False = the round-3 loss head (three kernels + combination each way)
-# the one-launch head up to this many transcript rows (a captured 1M-edge step: ~50k): its forward threads loss_tx's
-# contributions into per-row chains with 4 returning atomics per triplet -- 250 us at 10^6 rows against 150 us for the whole
-# kernel-by-kernel forward, and its gathered backward gains only 70 us there (tools/bench_loss_head.py,
-# profiles/r04_loss_head_modes_c2.txt; a variant with the contributions radix-sorted by target row instead: sort 270 us)
-LOSS_HEAD_ONE_LAUNCH_MAX_ROWS = 131072
+# The one-launch head for batches up to this many transcript rows.  Round 4 kept large batches on the kernel-by-kernel head: at
+# 10^6 rows its forward (chains threaded with 4 returning atomics per triplet: 250 us against 150 us) and its gathered backward
+# (-70..130 us) tied in bf16 (tools/bench_loss_head.py, profiles/r04_loss_head_modes_c2.txt).  Round 5 measured the whole C2
+# step (tools/bench_step.py, alternating variants in one process): bf16 12.93-13.08 -> 12.88-12.93 ms, and at fp32 storage --
+# where the kernel-by-kernel backward adds 128 M fp32 atomics -- 27.4-27.6 -> 26.5 ms: the one-launch head at every size the
+# kernel's 30-bit row ids allow.
+LOSS_HEAD_ONE_LAUNCH_MAX_ROWS = (1 << 30) - 2
 
 
 def loss_head_fused_supported(z_tx: Tensor, z_bd: Tensor, spec: "LossHeadSpec") -> bool:
@@ -1436,6 +1438,66 @@ def f32_split_planes(w: Tensor, transposed: bool = False) -> Tensor:
         rc = _lib.load().segger_f32_split_planes(w.data_ptr(), m, k, int(transposed), out.data_ptr(), _lib.stream_ptr(w.device))
     _lib.check(rc, "segger_f32_split_planes")
     return out
+
+
+def linear_f32_gate_launch(x: Tensor, w: Tensor, gate: Tensor, kind: str) -> Tensor:
+    """``(x @ w.T) * act'(gate)`` at fp32 storage, ``kind`` in ("gelu", "silu") (``segger_linear_fwd_f32_gate``): the data
+    gradient through an activation in one kernel; on the bf16x3 split when :data:`F32_SPLIT` covers the shape."""
+    _lib.require_cuda(x, w, gate)
+    n, k = x.shape
+    m = int(w.shape[0])
+    if x.dtype != torch.float32 or gate.dtype != torch.float32 or tuple(gate.shape) != (n, m) or w.shape[1] != k:
+        raise ValueError("linear_f32_gate: x fp32 [n, K], w [M, K], gate fp32 [n, M]")
+    xp, ldx = _rows(x, k, "x")
+    gp, ldg = _rows(gate, m, "gate")
+    y = torch.empty((n, m), dtype=torch.float32, device=x.device)
+    split = F32_SPLIT and ldx % 4 == 0 and linear_f32_split_supported(k, m)
+    wq = f32_split_planes(w) if split else w.detach().float().contiguous()
+    with _lib.on_device(x.device):
+        rc = _lib.load().segger_linear_fwd_f32_gate(xp, ldx, wq.data_ptr(), int(split), gp, ldg, {"gelu": 1, "silu": 2}[kind],
+                                                    y.data_ptr(), m, n, k, m, _lib.stream_ptr(x.device))
+    _lib.check(rc, "segger_linear_fwd_f32_gate")
+    return y
+
+
+def linear_f32_gate_supported(k_in: int, m_out: int) -> bool:
+    return (m_out % 64 == 0 and k_in in (64, 128, 256)) or (F32_SPLIT and linear_f32_split_supported(k_in, m_out))
+
+
+class _MlpSiluF32(torch.autograd.Function):
+    """``linear(silu(linear(x, w0, b0)), w2, b2)`` at fp32 storage as ONE autograd node (the positional embedder's shared MLP,
+    ist_encoder.py:43-49, on its un-fused route): the backward's SiLU derivative rides in the epilogue of the data-gradient
+    GEMM (``segger_linear_fwd_f32_gate``) instead of torch's silu_backward pass.  ``x`` receives no gradient (the sinusoid
+    features are constants)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w2, b2):
+        z1 = linear_fwd_launch(x, w0.detach(), b0.detach())
+        h1 = torch.nn.functional.silu(z1)
+        y = linear_fwd_launch(h1, w2.detach(), b2.detach())
+        ctx.save_for_backward(x, z1, h1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, z1, h1, w2 = ctx.saved_tensors
+        gy = gy.contiguous()
+        gw2, gb2 = linear_wgrad_launch(gy, h1)
+        dz1 = linear_f32_gate_launch(gy, w2.detach().t().contiguous(), z1, "silu")
+        gw0, gb0 = linear_wgrad_launch(dz1, x)
+        return None, gw0, gb0, gw2, gb2
+
+
+def mlp_silu_f32_supported(x: Tensor, w0: Tensor, w2: Tensor) -> bool:
+    d_in, d_h, d_out = int(w0.shape[1]), int(w0.shape[0]), int(w2.shape[0])
+    return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] > 0 and not x.requires_grad
+            and linear_supported(d_in, d_h, torch.float32) and linear_supported(d_h, d_out, torch.float32)
+            and linear_wgrad_supported(d_h, d_in, torch.float32) and linear_wgrad_supported(d_out, d_h, torch.float32)
+            and linear_f32_gate_supported(d_out, d_h))
+
+
+def mlp_silu_f32(x: Tensor, w0, b0, w2, b2) -> Tensor:
+    return _MlpSiluF32.apply(x, w0, b0, w2, b2)
 
 
 def linear_f32_split_supported(k_in: int, m_out: int) -> bool:
@@ -2059,6 +2121,7 @@ class _LinearPair(torch.autograd.Function):
 # profiles/r04_f32_split.txt -- fp32 accumulation dominates both) and every fp32 parity test holds with it.  It is not
 # bit-identical to a chain of fp32 FMAs: SEGGER_AMD_F32_EXACT=1 (or ops.F32_SPLIT = False) selects the exact kernels.
 F32_SPLIT = os.environ.get("SEGGER_AMD_F32_EXACT", "0") in ("", "0")
+F32_GATE_EPILOGUE = True     # fp32 storage: gelu' / silu' of a data gradient in the GEMM's epilogue (segger_linear_fwd_f32_gate)
 F32_SPLIT_WGRAD = True       # (with F32_SPLIT) the weight gradients on the split as well (segger_linear_wgrad_f32_split)
 LINEAR_PAIR = True           # tools flip it: False = one launch per projection
 WGRAD_PAIR = True            # ... and per projection backward
@@ -2419,7 +2482,11 @@ class _EmbedLinear(torch.autograd.Function):
             gc, gw, _ = linear_wgrad_dx_launch(gy, c, wc_t, want_bias=False, gate=pre if gated else None)
         else:
             if want_c:
-                if F32_SPLIT and dt == torch.float32 and gy.stride(0) % 4 == 0 and linear_f32_split_supported(m, d):
+                if (dt == torch.float32 and pre is not None and need[1] and gy.stride(0) % 4 == 0 and F32_GATE_EPILOGUE
+                        and linear_f32_gate_supported(m, d)):
+                    gc = linear_f32_gate_launch(gy, wc_t, pre, "gelu")      # dX * gelu'(pre) in one kernel
+                    gated = True
+                elif F32_SPLIT and dt == torch.float32 and gy.stride(0) % 4 == 0 and linear_f32_split_supported(m, d):
                     gc = linear_f32_split_launch(gy, f32_split_planes(wc, transposed=True), None)
                 else:
                     gc = linear_fwd_launch(gy, wc_t, None)

@@ -499,3 +499,27 @@ def test_wgrad_fp32_split_within_the_exact_kernels_error(cuda, m, k, n, monkeypa
     took_split = bool(_lib.load().segger_linear_wgrad_f32_split_supported(m, k))     # ((64, 64) / (64, 128): the exact kernel is faster)
     if n > 16:
         assert torch.equal(out[True][0], out[False][0]) != took_split      # (it did take the other kernel)
+
+
+@pytest.mark.parametrize("kind", ["gelu", "silu"])
+@pytest.mark.parametrize("k,m,n,split", [(384, 128, 3001, True), (384, 128, 3001, False), (64, 64, 4097, False), (128, 128, 130, True),
+                                         (256, 64, 77, False)])
+def test_linear_f32_gate_epilogue(cuda, k, m, n, split, kind, monkeypatch):
+    """segger_linear_fwd_f32_gate: (x @ W^T) * act'(gate) in one kernel (exact-fp32 MFMA or the bf16x3 split) against torch's
+    matmul + gelu_backward / silu_backward in float64; gate and x as views with a row stride."""
+    from segger_amd import ops
+    monkeypatch.setattr(ops, "F32_SPLIT", split)
+    if not split and k == 384:
+        pytest.skip("the exact kernel's gate form covers k_in 64 / 128 / 256 (the split serves 384)")
+    g = torch.Generator(device=cuda).manual_seed(k + m + n)
+    xw = torch.randn(n, k + 16, device=cuda, generator=g)
+    gw = torch.randn(n, m + 8, device=cuda, generator=g) * 2
+    x, gate = xw[:, :k], gw[:, :m]
+    w = torch.randn(m, k, device=cuda, generator=g) / k ** 0.5
+    y = ops.linear_f32_gate_launch(x, w, gate, kind)
+    gd = gate.double().requires_grad_(True)
+    act = torch.nn.functional.gelu(gd) if kind == "gelu" else torch.nn.functional.silu(gd)
+    (dact,) = torch.autograd.grad(act.sum(), gd)
+    ref = (x.double() @ w.double().t()) * dact
+    bound = (x.double().abs() @ w.double().abs().t()) * dact.abs() + 1e-30
+    assert ((y.double() - ref).abs() / (bound + 1e-6)).max().item() < 2e-5
