@@ -126,6 +126,10 @@ class Positional2dEmbedder(Module):
             h = F.silu(ops.linear(freq, l0.weight, l0.bias))
             h = ops.linear(h, l2.weight, l2.bias).flatten(-2)
         if gelu and return_pre:
+            if dtype == torch.float32 and h.is_cuda and ops.F32_GATE_EPILOGUE:
+                # as ops.posmlp documents it: gelu(h) is a constant for autograd and the gradient arrives for h -- the consumer
+                # (ops.embed_linear) applies gelu'(h) in the epilogue of its data-gradient GEMM instead of a gelu_backward pass
+                return F.gelu(h).detach(), h
             return F.gelu(h), None
         return F.gelu(h) if gelu else h
 
