@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 24
+#define SEGGER_ABI_VERSION 25
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -651,6 +651,12 @@ int segger_linear_fwd_rowbias(const void* x, int64_t ldx, const void* w, const f
  * six partial products; csrc/linear_f32_split.hip) -- the weight gradient autograd forms as `grad.t() @ x` for the nn.Linear
  * maps of ist_encoder.py:111-124,282-286.  Same arguments, workspace (segger_linear_wgrad_workspace_bytes) and deterministic
  * slab-order sums as segger_linear_wgrad; error within the exact-fp32 kernel's own, not bit-identical to it. */
+/* segger_linear_fwd_f32_act: y = x @ W^T + b AND y_act = act(y) (act_kind 1 = GELU, 2 = SiLU) from one kernel at fp32 storage:
+ * the pre-activation the backward keeps and the activation the next layer reads (the positional MLP's Linear -> SiLU and its
+ * output's GELU, ist_encoder.py:43-49,320) without torch's separate elementwise pass.  Exact-fp32 kernel, k_in 64 / 128 / 256. */
+int segger_linear_fwd_f32_act(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
+                              float* y_act, int64_t ld_yact, int32_t act_kind, int64_t n_rows, int32_t k_in, int32_t m_out,
+                              segger_stream_t stream);
 /* segger_linear_fwd_f32_gate: y = (x @ W^T) * act'(gate) at fp32 storage -- the data gradient through GELU (gate_kind 1) or
  * SiLU (2) with torch's separate gelu_backward / silu_backward pass folded into the GEMM epilogue (ist_encoder.py:47,320:
  * the positional MLP's SiLU, the GELU on the first layer's input).  w_is_planes != 0: W as the three bf16 planes of

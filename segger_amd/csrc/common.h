@@ -50,7 +50,8 @@ inline int device_cu_count() {
 // ------------------------------------------------- fp32 projections (csrc/linear_f32.hip) ---
 int linear_f32_launch(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t n_rows,
                       int k_in, int m_out, hipStream_t stream, const float* rowbias = nullptr, const int32_t* rowidx = nullptr,
-                      int64_t ld_rb = 0, const float* gate = nullptr, int64_t ld_gate = 0, int gate_kind = 0);
+                      int64_t ld_rb = 0, const float* gate = nullptr, int64_t ld_gate = 0, int gate_kind = 0,
+                      float* y_act = nullptr, int64_t ld_yact = 0, int act_kind = 0);
 size_t wgrad_f32_workspace_bytes(int64_t n_rows, int m_out, int k_in);
 // csrc/linear_f32_split.hip: the same weight gradient as six bf16 partial products (same partial-sum layout)
 bool wgrad_f32_split_shape_ok(int m, int k);
@@ -238,6 +239,9 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
 __device__ __forceinline__ float silu_grad(float z) {             // d/dz z sigmoid(z)
   const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
   return sg * (1.0f + z * (1.0f - sg));
+}
+__device__ __forceinline__ float act_apply(float z, int kind) {   // kind 1 = GELU (erf form), 2 = SiLU
+  return kind == 1 ? gelu_erf(z) : z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
 }
 // y *= d act / d gate in a GEMM epilogue: kind 1 = GELU (erf form), 2 = SiLU
 __device__ __forceinline__ float gate_grad(float g, int kind) { return kind == 1 ? gelu_erf_grad(g) : silu_grad(g); }

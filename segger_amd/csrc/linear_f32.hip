@@ -36,6 +36,9 @@ struct LinF32Params {
   // optional: y[row, c] *= act'(gate[row, c]) (gate_kind 1 = GELU, 2 = SiLU): the data gradient through an activation,
   // torch's separate gelu_backward / silu_backward pass folded into the epilogue (as segger_linear_fwd_silu_grad at 16 bit)
   const float* gate; int64_t ld_gate; int gate_kind;
+  // optional second output: y_act[row, c] = act(y[row, c]) (act_kind 1 = GELU, 2 = SiLU) from the same epilogue -- the
+  // pre-activation (kept for the backward) and the activation (the next layer's input) from one kernel
+  float* y_act; int64_t ld_yact; int act_kind;
 };
 
 // A workgroup (4 waves) owns 128 rows and produces all M columns: X is read once.  A wave keeps its 32 rows as B-operand
@@ -126,6 +129,9 @@ __global__ __launch_bounds__(256, K <= 256 ? 2 : 1) void linear_f32_kernel(LinF3
                       v.z * gate_grad(gq.z, p.gate_kind), v.w * gate_grad(gq.w, p.gate_kind)};
           }
           *reinterpret_cast<f32x4*>(yr + col) = v;
+          if (p.y_act)
+            *reinterpret_cast<f32x4*>(p.y_act + row * p.ld_yact + c0 + col) =
+                f32x4{act_apply(v.x, p.act_kind), act_apply(v.y, p.act_kind), act_apply(v.z, p.act_kind), act_apply(v.w, p.act_kind)};
         }
       }
     }
@@ -349,9 +355,10 @@ void launch_wgrad_f32(const WgF32Params& p, int64_t grid, hipStream_t stream) {
 // (declared in common.h for csrc/linear.hip and csrc/linear_wgrad.hip, which dispatch on the dtype)
 int linear_f32_launch(const void* x, int64_t ldx, const void* w, const float* bias, void* y, int64_t ldy, int64_t n_rows,
                       int k_in, int m_out, hipStream_t stream, const float* rowbias, const int32_t* rowidx, int64_t ld_rb,
-                      const float* gate, int64_t ld_gate, int gate_kind) {
+                      const float* gate, int64_t ld_gate, int gate_kind, float* y_act, int64_t ld_yact, int act_kind) {
   LinF32Params p{static_cast<const float*>(x), ldx, static_cast<const float*>(w), bias, static_cast<float*>(y), ldy,
-                 n_rows, m_out, rowbias, rowidx, ld_rb, gate, ld_gate, gate_kind};
+                 n_rows, m_out, rowbias, rowidx, ld_rb, gate, ld_gate, gate_kind, y_act, ld_yact, act_kind};
+  if (y_act && k_in == 384) { set_error("segger_linear_fwd_f32_act: k_in 64, 128 or 256"); return SEGGER_EUNSUPPORTED; }
   if (gate && k_in == 384) { set_error("segger_linear_fwd_f32_gate: k_in 64, 128 or 256 on the exact kernel"); return SEGGER_EUNSUPPORTED; }
   if (rowbias && k_in == 384) { set_error("segger_linear_fwd_rowbias (fp32): k_in 64, 128 or 256"); return SEGGER_EUNSUPPORTED; }
   const int64_t nb = (n_rows + 127) / 128;

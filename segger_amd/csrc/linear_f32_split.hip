@@ -537,6 +537,22 @@ extern "C" int segger_linear_fwd_f32_split_rowbias(const float* x, int64_t ldx, 
   return split_fwd_launch(x, ldx, w3, nullptr, rowbias, ld_rb, rowidx, y, ldy, n_rows, k_in, m_out, stream);
 }
 
+extern "C" int segger_linear_fwd_f32_act(const float* x, int64_t ldx, const float* w, const float* bias, float* y, int64_t ldy,
+                                         float* y_act, int64_t ld_yact, int32_t act_kind, int64_t n_rows, int32_t k_in,
+                                         int32_t m_out, segger_stream_t stream) {
+  SEGGER_REQUIRE(n_rows >= 0 && (act_kind == 1 || act_kind == 2), "segger_linear_fwd_f32_act: act_kind 1 (GELU) or 2 (SiLU)");
+  if (n_rows == 0) return SEGGER_OK;
+  SEGGER_REQUIRE(x && w && y && y_act && aligned16(x) && aligned16(w) && aligned16(y) && aligned16(y_act) && (!bias || aligned16(bias)) &&
+                     ldx >= k_in && ldy >= m_out && ld_yact >= m_out && ldx % 4 == 0 && ldy % 4 == 0 && ld_yact % 4 == 0,
+                 "segger_linear_fwd_f32_act: NULL pointer or rows not 16-byte aligned");
+  if (!((k_in == 64 || k_in == 128 || k_in == 256) && m_out > 0 && m_out % 64 == 0)) {
+    set_error("segger_linear_fwd_f32_act: k_in=%d m_out=%d not supported (k_in 64 / 128 / 256, m_out %% 64 == 0)", k_in, m_out);
+    return SEGGER_EUNSUPPORTED;
+  }
+  return linear_f32_launch(x, ldx, w, bias, y, ldy, n_rows, k_in, m_out, (hipStream_t)stream, nullptr, nullptr, 0, nullptr, 0, 0,
+                           y_act, ld_yact, act_kind);
+}
+
 extern "C" int segger_linear_fwd_f32_gate(const float* x, int64_t ldx, const void* w, int32_t w_is_planes, const float* gate,
                                           int64_t ld_gate, int32_t gate_kind, float* y, int64_t ldy, int64_t n_rows, int32_t k_in,
                                           int32_t m_out, segger_stream_t stream) {

@@ -120,7 +120,11 @@ class Positional2dEmbedder(Module):
         flat = freq.reshape(-1, fd)
         if (dtype == torch.float32 and ops.F32_GATE_EPILOGUE and l0.bias is not None and l2.bias is not None
                 and ops.mlp_silu_f32_supported(flat, l0.weight, l2.weight)):
-            # fp32 storage: the MLP as one autograd node (SiLU's derivative in the data-gradient GEMM's epilogue)
+            # fp32 storage: the MLP as one autograd node (SiLU, and the GELU that follows, in the GEMMs' epilogues; SiLU's
+            # derivative in the data-gradient GEMM's epilogue)
+            if gelu and return_pre:
+                h, gh = ops.mlp_silu_f32(flat, l0.weight, l0.bias, l2.weight, l2.bias, gelu_out=True)
+                return gh.reshape(n, -1), h.reshape(n, -1)
             h = ops.mlp_silu_f32(flat, l0.weight, l0.bias, l2.weight, l2.bias).reshape(n, -1)
         else:
             h = F.silu(ops.linear(freq, l0.weight, l0.bias))

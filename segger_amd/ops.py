@@ -1460,6 +1460,25 @@ def linear_f32_gate_launch(x: Tensor, w: Tensor, gate: Tensor, kind: str) -> Ten
     return y
 
 
+def linear_f32_act_launch(x: Tensor, w: Tensor, bias: Optional[Tensor], kind: str) -> Tuple[Tensor, Tensor]:
+    """``(y, act(y))`` with ``y = x @ w.T + bias`` at fp32 storage from ONE kernel (``segger_linear_fwd_f32_act``; exact-fp32
+    MFMA, K in 64 / 128 / 256), ``kind`` in ("gelu", "silu")."""
+    _lib.require_cuda(x, w)
+    n, k = x.shape
+    m = int(w.shape[0])
+    if x.dtype != torch.float32 or w.dtype != torch.float32 or w.shape[1] != k or not w.is_contiguous():
+        raise ValueError("linear_f32_act: x fp32 [n, K], w contiguous fp32 [M, K]")
+    xp, ldx = _rows(x, k, "x")
+    y = torch.empty((n, m), dtype=torch.float32, device=x.device)
+    ya = torch.empty((n, m), dtype=torch.float32, device=x.device)
+    b = None if bias is None else bias.detach().float().contiguous()
+    with _lib.on_device(x.device):
+        rc = _lib.load().segger_linear_fwd_f32_act(xp, ldx, w.data_ptr(), _lib.ptr(b), y.data_ptr(), m, ya.data_ptr(), m,
+                                                   {"gelu": 1, "silu": 2}[kind], n, k, m, _lib.stream_ptr(x.device))
+    _lib.check(rc, "segger_linear_fwd_f32_act")
+    return y, ya
+
+
 def linear_f32_gate_supported(k_in: int, m_out: int) -> bool:
     return (m_out % 64 == 0 and k_in in (64, 128, 256)) or (F32_SPLIT and linear_f32_split_supported(k_in, m_out))
 
@@ -1471,21 +1490,24 @@ class _MlpSiluF32(torch.autograd.Function):
     features are constants)."""
 
     @staticmethod
-    def forward(ctx, x, w0, b0, w2, b2):
-        z1 = linear_fwd_launch(x, w0.detach(), b0.detach())
-        h1 = torch.nn.functional.silu(z1)
-        y = linear_fwd_launch(h1, w2.detach(), b2.detach())
+    def forward(ctx, x, w0, b0, w2, b2, gelu_out=False):
+        w0d, w2d = w0.detach().contiguous(), w2.detach().contiguous()
+        z1, h1 = linear_f32_act_launch(x, w0d, b0, "silu")           # pre-activation and SiLU from one kernel
         ctx.save_for_backward(x, z1, h1, w2)
-        return y
+        if gelu_out:                                                  # (y, gelu(y)): the second a constant for autograd
+            y, gy_ = linear_f32_act_launch(h1, w2d, b2, "gelu")
+            ctx.mark_non_differentiable(gy_)
+            return y, gy_
+        return linear_fwd_launch(h1, w2d, b2.detach())
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _unused=None):
         x, z1, h1, w2 = ctx.saved_tensors
         gy = gy.contiguous()
         gw2, gb2 = linear_wgrad_launch(gy, h1)
         dz1 = linear_f32_gate_launch(gy, w2.detach().t().contiguous(), z1, "silu")
         gw0, gb0 = linear_wgrad_launch(dz1, x)
-        return None, gw0, gb0, gw2, gb2
+        return None, gw0, gb0, gw2, gb2, None
 
 
 def mlp_silu_f32_supported(x: Tensor, w0: Tensor, w2: Tensor) -> bool:
@@ -1493,11 +1515,14 @@ def mlp_silu_f32_supported(x: Tensor, w0: Tensor, w2: Tensor) -> bool:
     return (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] > 0 and not x.requires_grad
             and linear_supported(d_in, d_h, torch.float32) and linear_supported(d_h, d_out, torch.float32)
             and linear_wgrad_supported(d_h, d_in, torch.float32) and linear_wgrad_supported(d_out, d_h, torch.float32)
-            and linear_f32_gate_supported(d_out, d_h))
+            and linear_f32_gate_supported(d_out, d_h) and d_in in (64, 128, 256) and d_h in (64, 128, 256)
+            and d_h % 64 == 0 and d_out % 64 == 0)
 
 
-def mlp_silu_f32(x: Tensor, w0, b0, w2, b2) -> Tensor:
-    return _MlpSiluF32.apply(x, w0, b0, w2, b2)
+def mlp_silu_f32(x: Tensor, w0, b0, w2, b2, gelu_out: bool = False):
+    """``linear(silu(linear(x)))``; ``gelu_out``: ``(y, gelu(y))`` with the GELU a constant for autograd (the gradient is
+    expected for ``y``: the consumer applies gelu')."""
+    return _MlpSiluF32.apply(x, w0, b0, w2, b2, gelu_out)
 
 
 def linear_f32_split_supported(k_in: int, m_out: int) -> bool:
