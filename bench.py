@@ -22,7 +22,9 @@ JSON line:
                   projection_fwd, projection_bwd_one_pass, projection_bwd_two_kernels,  each {achieved GB/s, frac of 8 TB/s,
                   first_layer_rowbias_fwd, positional_embedder_fwd, triplet_bwd_loss_tx, algorithmic_bytes_per_launch, ms_per_launch}
                   triplet_bwd_loss_sg_grouped / _two_kernels (the kernels alone, on the tile's own tx-belongs-bd edges),
-                  loss_grad_zero_fill (the one fill both loss backward kernels accumulate into)}
+                  loss_grad_zero_fill (the one fill both loss backward kernels accumulate into),
+                  loss_head_one_launch_fwd / _bwd (the step's default loss head since round 5; the triplet_* entries above are the
+                  kernel-by-kernel head it replaced)}
       algorithmic bytes (s = element size, n = rows):  projection fwd  n (K + M) s ;  its whole backward (dX, dW, db)
       n (M + 2 K) s -- dY and X read once, dX written once ;  first layer (row-bias form)  n (K + M) s + 4 n ids ;
       positional embedder (training forward)  n (8 + D s) + stored activations 2 n (2 Dh s + 4) ;  triplet backward
@@ -240,6 +242,41 @@ def other_kernel_classes(dev, n, etb, hc, elem, gen, ops, batch):
                              "(memory-side: counted ~8 B per 4-B add).  Random unit embeddings: every triplet violates the "
                              "margin (all stores and atomics happen); inside the training step the same kernel takes ~77 us "
                              "(profiles/r05_c2_step_breakdown.txt)"}
+    # the one-launch loss head (the step's default at every size since round 5): the three losses, their weighted sum and the
+    # whole backward down to the un-normalised embeddings as segger_loss_head_fwd / _bwd (+ the boundary side's l2norm backward)
+    try:
+        y_tx = torch.randn(n, 64, device=dev, generator=gen).to(dt).requires_grad_(True)
+        y_bd = torch.randn(nbd, 64, device=dev, generator=gen).to(dt).requires_grad_(True)
+        bpos = torch.randint(0, nbd, (nbd,), device=dev, generator=gen); bneg = torch.randint(0, nbd, (nbd,), device=dev, generator=gen)
+        bdp, bdn = torch.rand(nbd, device=dev, generator=gen), torch.rand(nbd, device=dev, generator=gen)
+        bw_ = torch.full((nbd,), 1.0 / nbd, device=dev)
+        ha, hb = torch.ones(3, device=dev), torch.tensor([0.5, 0.2, 0.3], device=dev)
+        hint = torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev)
+        tf = tb = 0.0
+        reps = 8
+        for i in range(reps + 2):
+            y_tx.grad = y_bd.grad = None
+            zs = ops.l2_normalize_many({"tx": y_tx, "bd": y_bd})
+            spec = ops.LossHeadSpec((anchors, p_, q_, 0.3, 1e-6), (bpos, bneg, bdp, bdn, bw_, 1e-8),
+                                    (src, dstp, dneg, 0.4, 1e-6, groups, True), tx_anchors_are_rows=True, grad_out_hint=hint)
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            e0.record(); res_ = ops.loss_head(zs["tx"], zs["bd"], ha, hb, spec); e1.record(); res_.backward(hint); e2.record()
+            torch.cuda.synchronize()
+            if i >= 2:
+                tf += e0.elapsed_time(e1) / reps; tb += e1.elapsed_time(e2) / reps
+        nb_f = (3 * n + 3 * etb) * 64 * elem + 16 * n                       # rows read + chain words
+        nb_b = (3 * n + 2 * n + 3 * etb) * 64 * elem + n * 64 * elem          # rows gathered per row (anchor, pos, neg, ~2 chained) + the row stored
+        out["loss_head_one_launch_fwd"] = {"achieved": nb_f / (tf * 1e-3) / 1e9, "frac": nb_f / (tf * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "unit": "GB/s", "algorithmic_bytes_per_launch": nb_f, "ms_per_launch": tf,
+                                           "note": "segger_loss_head_fwd + the finishing launch: loss_tx | loss_bd | loss_sg block ranges, "
+                                                   "contribution chains threaded by atomicExch (random triplets: worst-case locality)"}
+        out["loss_head_one_launch_bwd"] = {"achieved": nb_b / (tb * 1e-3) / 1e9, "frac": nb_b / (tb * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "unit": "GB/s", "algorithmic_bytes_per_launch": nb_b, "ms_per_launch": tb,
+                                           "note": "segger_loss_head_bwd (rows gathered over their chains, summed in registers, pushed "
+                                                   "through the normalisation backward, stored once; no float atomic on the transcript "
+                                                   "matrix) + the boundary side's l2norm backward"}
+    except Exception as e:  # noqa: BLE001  (auxiliary entry)
+        out["loss_head_one_launch_error"] = f"{type(e).__name__}: {e}"
     zfill = torch.empty(n * 64 * elem + nbd * 64 * 4, dtype=torch.uint8, device=dev)
     ms = time_kernel(lambda: zfill.zero_(), iters=10, warm=2)
     out["loss_grad_zero_fill"] = {"achieved": zfill.numel() / (ms * 1e-3) / 1e9, "frac": zfill.numel() / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
