@@ -20,6 +20,26 @@ template <> __device__ __forceinline__ float ld1<f16_t>(const f16_t* p) { return
 // posfreq: out[(n*2 + c), :] = [cos(p * f_j) | sin(p * f_j)],  p = (pos[n,c] - lo) / (hi - lo + eps)
 // one thread = 8 consecutive j of one (n, c): a 16-byte (32-byte for fp32) store into each half
 // ---------------------------------------------------------------------------------------------
+// sin / cos of the embedder's angles.  p is a min-max normalised coordinate in [0, 1] and the frequencies decay from 1, so every
+// angle lies in [0, 1]: no range reduction is needed and the Taylor series to x^11 / x^12 (remainders 3e-8 / 3e-9 at |x| = 1.5,
+// below fp32 rounding) replace libm's sincosf, whose ~70 instructions per angle made this kernel VALU-bound (0.43 ms for the
+// 2 GB it writes at C2: 4.7 TB/s).  Outside [-1.5, 1.5] (never reached by normalised coordinates) the libm call stays.
+__device__ __forceinline__ void sincos_unit(float x, float* s, float* c) {
+  if (__builtin_expect(fabsf(x) > 1.5f, 0)) { sincosf(x, s, c); return; }
+  const float t = x * x;
+  float ps = fmaf(t, -2.5052108385e-08f, 2.7557319224e-06f);
+  ps = fmaf(ps, t, -1.9841269841e-04f);
+  ps = fmaf(ps, t, 8.3333333333e-03f);
+  ps = fmaf(ps, t, -1.6666666667e-01f);
+  *s = fmaf(ps * t, x, x);
+  float pc = fmaf(t, 2.0876756988e-09f, -2.7557319224e-07f);
+  pc = fmaf(pc, t, 2.4801587302e-05f);
+  pc = fmaf(pc, t, -1.3888888889e-03f);
+  pc = fmaf(pc, t, 4.1666666667e-02f);
+  pc = fmaf(pc, t, -0.5f);
+  *c = fmaf(pc, t, 1.0f);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void posfreq_kernel(const float* __restrict__ pos, const int64_t* __restrict__ batch,
                                                      const float* __restrict__ mins, const float* __restrict__ maxs,
@@ -41,7 +61,7 @@ __global__ __launch_bounds__(256) void posfreq_kernel(const float* __restrict__ 
   const float p = (pos[2 * node + c] - lo) / (hi - lo + eps);
   float cs[8], sn[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) sincosf(p * freqs[j0 + k], &sn[k], &cs[k]);
+  for (int k = 0; k < 8; ++k) sincos_unit(p * freqs[j0 + k], &sn[k], &cs[k]);
   T* o = out + rc * freq_dim;
   Vec8<T>::store(o + j0, cs);
   Vec8<T>::store(o + half + j0, sn);
