@@ -25,6 +25,9 @@ template <> __device__ __forceinline__ float ld1<f16_t>(const f16_t* p) { return
 // below fp32 rounding) replace libm's sincosf, whose ~70 instructions per angle made this kernel VALU-bound (0.43 ms for the
 // 2 GB it writes at C2: 4.7 TB/s).  Outside [-1.5, 1.5] (never reached by normalised coordinates) the libm call stays.
 __device__ __forceinline__ void sincos_unit(float x, float* s, float* c) {
+#ifdef EXP_POSFREQ_LIBM      // A/B build: libm for every angle
+  sincosf(x, s, c); return;
+#endif
   if (__builtin_expect(fabsf(x) > 1.5f, 0)) { sincosf(x, s, c); return; }
   const float t = x * x;
   float ps = fmaf(t, -2.5052108385e-08f, 2.7557319224e-06f);
