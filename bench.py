@@ -935,17 +935,15 @@ def main():
         kb = None
         if drop > 0:
             kb = (ops.dropout_bits(g_tt.by_dst, H, drop, [11])[0], ops.dropout_bits(g_tt.by_src, H, drop, [11])[0])
-        # ... and the logits it keeps for the backward's destination pass (round 5), as the training step launches it
-        elog = ops.logits_buffer(g_tt, H, C, dev)
         fwd = lambda: ops.gatv2_fwd_launch(g_tt.by_dst, xp[:, :hc], xp[:, hc:2 * hc], att, bias, H, C, out,
                                            pre=pre, lse=lse, apply_gelu=True, dropout_p=drop, seed=11,
-                                           keep_bits=None if kb is None else kb[0], logits=elog)
+                                           keep_bits=None if kb is None else kb[0])
         ms_fwd = time_kernel(fwd)
         gy = torch.randn(n_tx, hc, device=dev, generator=gen).to(dtype)
         gxp = torch.empty_like(xp)
         bwd = lambda: ops.gatv2_bwd_launch(g_tt, xp[:, :hc], xp[:, hc:2 * hc], att, bias, H, C, gy, pre, lse,
                                            gxp[:, :hc], gxp[:, hc:2 * hc], apply_gelu=True, dropout_p=drop, seed=11,
-                                           keep_bits=kb, logits=elog)
+                                           keep_bits=kb)
         ms_bwd = time_kernel(bwd)
         b_fwd = gat_fwd_algorithmic_bytes(ett, n_tx, hc, elem)
         b_bwd = gat_bwd_algorithmic_bytes(ett, n_tx, n_tx, hc, H, elem)
@@ -1040,7 +1038,7 @@ def main():
         from segger_amd.fov import batch_weights, build_fov_batches
         del batch, batch_cpu
         if rank == 0:
-            del xp, out, pre, lse, gy, gxp, g_tt, fwd, bwd, kb, elog
+            del xp, out, pre, lse, gy, gxp, g_tt, fwd, bwd, kb
         opt.zero_grad(set_to_none=True)
         torch.cuda.empty_cache()
         t = time.perf_counter()

@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 26
+#define SEGGER_ABI_VERSION 25
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -160,11 +160,6 @@ typedef struct segger_gatv2_fwd_args {
                                above, precomputed by segger_dropout_bits for this layer's seed.  The kernels then test
                                a bit instead of hashing per (edge, head); results are identical.  Ignored when alpha
                                is requested or the geometry runs on the generic kernels. */
-  float* logits;          /* optional output for the backward: the attention logits e_ij * log2(e) (the kernels' base-2
-                             units) as [heads][ld_logits] planes in by_dst SLOT order; written only by the group-per-row
-                             kernels of a specialised geometry (low average degree: tx-neighbors-tx), else left untouched --
-                             hand the same pointer to segger_gatv2_bwd either way.  NULL = skip. */
-  int64_t ld_logits;      /* plane stride, >= n_edges + 4 (the backward reads 16 bytes at the last slots) */
 } segger_gatv2_fwd_args;
 
 int segger_gatv2_fwd(const segger_gatv2_fwd_args* args, segger_stream_t stream);
@@ -228,10 +223,6 @@ typedef struct segger_gatv2_bwd_args {
                              fills the tx-belongs-bd window of the stacked projection gradient) */
   int64_t ld_zero;
   int32_t grad_xl_zeroed; /* one-pass form (src_unique): grad_xl already holds zeros (see zero_rows_out): skip the fill */
-  const float* logits;    /* optional: the forward's `logits` planes (same graph, same x_l / x_r / att).  The destination
-                             pass of a group-per-row, two-pass backward then reads the logits instead of recomputing them
-                             (14 FMAs + 3 cross-lane adds per edge and lane); ignored elsewhere.  NULL = recompute. */
-  int64_t ld_logits;
 } segger_gatv2_bwd_args;
 
 size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads, int32_t channels);

@@ -143,10 +143,6 @@ static int fwd_params(const segger_gatv2_fwd_args* a, GatParams& p, bool* empty)
   p.out = a->out; p.ld_out = a->ld_out; p.pre = a->pre; p.ld_pre = a->ld_pre;
   p.lse = a->lse; p.alpha = a->alpha;
   p.bits = a->alpha ? nullptr : a->keep_bits;
-  if (a->logits && g_need_align && !use_wave_per_row(a->by_dst)) {
-    SEGGER_REQUIRE(a->ld_logits >= a->by_dst.n_edges + 4 && ((uintptr_t)a->logits % 4) == 0, "segger_gatv2_fwd: ld_logits < n_edges + 4");
-    p.elog = a->logits; p.ld_elog = a->ld_logits;
-  }
   p.slope = a->negative_slope; p.apply_gelu = a->apply_gelu; p.rows_per_wave_iter = 1;
   set_dropout(p, a->dropout_p, a->seed, a->seed_dev);
   return SEGGER_OK;
@@ -265,10 +261,6 @@ void bwd_dst_params(const segger_gatv2_bwd_args* a, BwdState& s) {
   p.bits = a->keep_bits_dst;
   p.direct_gxl = s.direct ? 1 : 0;
   p.zero_rows = nullptr; p.ld_zero = 0;
-  p.elog = nullptr; p.ld_elog = 0;
-  if (a->logits && s.specialised && !s.direct && !use_wave_per_row(a->by_dst) && a->ld_logits >= s.n_edges + 4) {
-    p.elog = const_cast<float*>(a->logits); p.ld_elog = a->ld_logits;
-  }
 }
 
 // parameters of the source-side pass (rows = sources)
@@ -279,7 +271,6 @@ void bwd_src_params(const segger_gatv2_bwd_args* a, BwdState& s) {
   p.bits = a->keep_bits_src;
   p.n_rows = s.n_src; p.rows_per_wave_iter = 1;
   p.zero_rows = a->zero_rows_out; p.ld_zero = a->ld_zero;
-  p.elog = nullptr; p.ld_elog = 0;                      // (slot order of the by-destination view: of no use here)
 }
 
 // the one-pass form's own zero fill: sources without an out-edge keep a zero gradient, the others are stored by the

@@ -75,8 +75,6 @@ struct GatParams {
   void* out; int64_t ld_out;
   void* pre; int64_t ld_pre;     // fwd: output (nullable); bwd: input
   float* lse;                    // fwd: output (nullable); bwd: input
-  float* elog; int64_t ld_elog;  // group-per-row only, nullable: base-2 logits [H][ld_elog] in by-dst SLOT order -- fwd: output;
-                                 // dst pass: input (replaces the recomputation of the logits: -20 of ~67 VALU per edge)
   float* alpha;
   // backward
   const void* gout; int64_t ld_go;
@@ -179,7 +177,7 @@ __device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const 
           ed[u] = NEED_EID ? __builtin_amdgcn_ds_bpermute(slot << 2, myeid) : 0;
         }
       });
-      body(std::integral_constant<int, META>{}, valid, nbr, ed, e0 + t);       // (e0 + t: slot of the batch's first edge, group-per-row)
+      body(std::integral_constant<int, META>{}, valid, nbr, ed);
       if constexpr (kDpp) {
         myc = dpp_i<kDppRowRor0 + 16 - U>(myc);   // lane i <- lane i+U
         if constexpr (NEED_EID) myeid = dpp_i<kDppRowRor0 + 16 - U>(myeid);
@@ -249,7 +247,7 @@ __device__ __forceinline__ void walk_row_prefetch(const int32_t* __restrict__ co
           ed[u] = NEED_EID ? __builtin_amdgcn_ds_bpermute(slot << 2, myeid) : 0;
         }
       });
-      compute(buf_c, std::integral_constant<int, META>{}, valid, ed, e0 + t);
+      compute(buf_c, std::integral_constant<int, META>{}, valid, ed);
       if constexpr (kDpp) {
         myc = dpp_i<kDppRowRor0 + 16 - U>(myc);           // lane i <- lane i+U
         if constexpr (NEED_EID) myeid = dpp_i<kDppRowRor0 + 16 - U>(myeid);
@@ -293,8 +291,6 @@ __device__ __forceinline__ void walk_row_prefetch(const int32_t* __restrict__ co
 //    sum_e de*att*lrelu'(t) = att*(c1*sum_e de + c2*sum_e de*sgn(t)): only the
 //    sign sum is per channel; likewise grad_att = c1*sum de*t + c2*sum de*|t|.
 // ----------------------------------------------------------------------------
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));     // four floats at a 4-byte aligned address
-
 template <typename T> struct Raw8 {
   u32x4 r;
   __device__ __forceinline__ void load(const void* p) { r = *reinterpret_cast<const u32x4*>(p); }
@@ -461,7 +457,7 @@ __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid)
 #pragma unroll
     for (int u = 0; u < U; ++u) rawbuf[B][u].load(row_ptr(xl, nbr[u], ld_xl));   // invalid slots read row 0 / a row of the chunk
   };
-  auto body = [&](auto buf_c, auto meta_c, const bool (&valid)[U], const int (&ed)[U], int64_t slot0) {
+  auto body = [&](auto buf_c, auto meta_c, const bool (&valid)[U], const int (&ed)[U]) {
     constexpr int META = decltype(meta_c)::value;
     constexpr int B = decltype(buf_c)::value;
     if (!valid[0]) return;                            // wave-per-row tail (group-uniform)
@@ -477,21 +473,6 @@ __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid)
       const float pl = lane_block_sum<LPH>(logit_partial(t, a1, a2));
       e[u] = valid[u] ? pl : -INFINITY;
       mx = fmaxf(mx, e[u]);
-    }
-    if constexpr (!WPR && U == 4) {
-      // the batch's logits for the destination pass of the backward: one 16-byte store per head (plane h, the batch's
-      // four consecutive slots; a partial batch at the row's end stores its valid slots one by one -- the next slots
-      // belong to the next row)
-      if (p.elog != nullptr && head_leader) {
-        float* q = p.elog + (int64_t)h * p.ld_elog + slot0;
-        if (valid[3]) {
-          *reinterpret_cast<f32x4u*>(q) = f32x4u{e[0], e[1], e[2], e[3]};
-        } else {
-          q[0] = e[0];
-          if (valid[1]) q[1] = e[1];
-          if (valid[2]) q[2] = e[2];
-        }
-      }
     }
     const float sc = fast_exp2(m - mx);               // m = -inf -> 0 ; mx finite because valid[0]
     s *= sc;
@@ -519,9 +500,9 @@ __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid)
   };
   // 16-bit storage: the next batch's rows are requested before this batch's arithmetic.  fp32 rows take twice the
   // registers (the second buffer spills 20-65 of them at 4 waves per SIMD): plain walk, one buffer.
-  auto plain = [&](auto meta_c, const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U], int64_t slot0) {
+  auto plain = [&](auto meta_c, const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
     issue(std::integral_constant<int, 0>{}, nbr);
-    body(std::integral_constant<int, 0>{}, meta_c, valid, ed, slot0);
+    body(std::integral_constant<int, 0>{}, meta_c, valid, ed);
   };
   auto walk = [&](auto meta_c, const void* meta) {
     constexpr int META = decltype(meta_c)::value;
@@ -708,22 +689,12 @@ __device__ __forceinline__ void gatv2_bwd_dst_body(SEGGER_BODY_PARAM p, int64_t 
     }
 
     const int hbit = 1 << h;
-    // SAVED (compile time; group-per-row, two-pass form): the logits come from the forward (p.elog, plane h, the batch's four
-    // consecutive slots; every lane of a head reads the same 16 bytes; slots past the row's end belong to the next row or to
-    // the plane's padding: read, never used) instead of being recomputed -- 14 FMAs + 3 DPP adds per edge and lane
-    constexpr bool kCanSave = !WPR && !DIRECT && U == 4;
-    auto body_impl = [&](auto saved_c, auto meta_c, const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U], int64_t slot0) {
+    auto body = [&](auto meta_c, const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
       constexpr int META = decltype(meta_c)::value;
-      constexpr bool SAVED = decltype(saved_c)::value;
       if (!valid[0]) return;
       Raw8<T> raw[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) raw[u].load(row_ptr(xl, nbr[u], ld_xl));
-      float el[4] = {0.f, 0.f, 0.f, 0.f};
-      if constexpr (SAVED) {
-        const f32x4u q = *reinterpret_cast<const f32x4u*>(p.elog + (int64_t)h * p.ld_elog + slot0);
-        el[0] = q.x; el[1] = q.y; el[2] = q.z; el[3] = q.w;
-      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         f32x2 v[4], nt[4];
@@ -731,9 +702,7 @@ __device__ __forceinline__ void gatv2_bwd_dst_body(SEGGER_BODY_PARAM p, int64_t 
         f32x2 da2 = splat(0.f);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { nt[i] = nxr[i] - v[i]; da2 = pk_fma(g[i], v[i], da2); }
-        float pl;
-        if constexpr (SAVED) pl = el[u & 3];
-        else pl = lane_block_sum<LPH>(logit_partial(nt, na1, a2));
+        const float pl = lane_block_sum<LPH>(logit_partial(nt, na1, a2));
         float da = lane_block_sum<LPH>(da2.x + da2.y);
         const float a = valid[u] ? fast_exp2(pl - lse) : 0.f;
         float a_eff = a;
@@ -763,23 +732,12 @@ __device__ __forceinline__ void gatv2_bwd_dst_body(SEGGER_BODY_PARAM p, int64_t 
         }
       }
     };
-    auto run = [&](auto saved_c) {
-      auto body = [&](auto meta_c, const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U], int64_t slot0) {
-        body_impl(saved_c, meta_c, valid, nbr, ed, slot0);
-      };
-      if (dropout && p.bits)
-        walk_row<GS, WPR, kMetaBits, U>(p.col, p.bits, beg, end, L.lane, L.grp, L.gl, body);
-      else if (dropout)
-        walk_row<GS, WPR, kMetaEid, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
-      else
-        walk_row<GS, WPR, kMetaNone, U>(p.col, nullptr, beg, end, L.lane, L.grp, L.gl, body);
-    };
-    if constexpr (kCanSave) {
-      if (p.elog != nullptr) run(std::true_type{});                    // (uniform over the launch)
-      else run(std::false_type{});
-    } else {
-      run(std::false_type{});
-    }
+    if (dropout && p.bits)
+      walk_row<GS, WPR, kMetaBits, U>(p.col, p.bits, beg, end, L.lane, L.grp, L.gl, body);
+    else if (dropout)
+      walk_row<GS, WPR, kMetaEid, U>(p.col, p.eid, beg, end, L.lane, L.grp, L.gl, body);
+    else
+      walk_row<GS, WPR, kMetaNone, U>(p.col, nullptr, beg, end, L.lane, L.grp, L.gl, body);
 
     if constexpr (WPR) {
 #pragma unroll
@@ -883,7 +841,7 @@ __device__ __forceinline__ void gatv2_bwd_src_body(SEGGER_BODY_PARAM p, int64_t 
   }
 
   const int hbit = 1 << h;
-  auto body = [&](auto meta_c, const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U], int64_t) {
+  auto body = [&](auto meta_c, const bool (&valid)[U], const int (&nbr)[U], const int (&ed)[U]) {
     constexpr int META = decltype(meta_c)::value;
     if (!valid[0]) return;
     Raw8<T> rxr[U], rg[U];

@@ -14,7 +14,7 @@ from torch import Tensor
 
 from . import _lib
 from ._lib import DTYPE_CODE
-from .graph import EdgeCSR, EdgeGraph, WAVE_PER_ROW_DEGREE
+from .graph import EdgeCSR, EdgeGraph
 
 
 # --------------------------------------------------------------------------
@@ -246,11 +246,10 @@ def gatv2_fwd_launch(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias:
                      heads: int, channels: int, out: Tensor, *, pre: Optional[Tensor] = None,
                      lse: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
                      apply_gelu: bool = False, negative_slope: float = 0.2,
-                     dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tensor] = None,
-                     logits: Optional[Tensor] = None) -> None:
+                     dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tensor] = None) -> None:
     a, keep = _gat_fwd_args(by_dst, xl, xr, att, bias, heads, channels, out, pre=pre, lse=lse, alpha=alpha,
                             apply_gelu=apply_gelu, negative_slope=negative_slope, dropout_p=dropout_p, seed=seed,
-                            keep_bits=keep_bits, logits=logits)
+                            keep_bits=keep_bits)
     with _lib.on_device(xl.device):
         rc = _lib.load().segger_gatv2_fwd(C.byref(a), _lib.stream_ptr(xl.device))
     _lib.check(rc, "segger_gatv2_fwd")
@@ -279,8 +278,7 @@ def _gat_fwd_args(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
                   heads: int, channels: int, out: Tensor, *, pre: Optional[Tensor] = None,
                   lse: Optional[Tensor] = None, alpha: Optional[Tensor] = None,
                   apply_gelu: bool = False, negative_slope: float = 0.2,
-                  dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tensor] = None,
-                  logits: Optional[Tensor] = None):
+                  dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tensor] = None):
     _lib.require_cuda(xl, xr, att, out)
     hc = heads * channels
     if not (xl.dtype == xr.dtype == out.dtype) or xl.dtype not in DTYPE_CODE:
@@ -302,29 +300,7 @@ def _gat_fwd_args(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
     a.lse, a.alpha = _lib.ptr(lse), _lib.ptr(alpha)
     if keep_bits is not None and dropout_p > 0.0:
         a.keep_bits = _bits_ptr(keep_bits, by_dst.n_edges)
-    if logits is not None:
-        a.logits, a.ld_logits = _logits_ptr(logits, heads, by_dst.n_edges)
     return a, vecs                                       # (vecs: the fp32 copies the struct points at)
-
-
-SAVE_LOGITS = True          # the forward keeps its attention logits for the destination pass of the backward (tools: A/B)
-
-
-def logits_buffer(graph: "EdgeGraph", heads: int, channels: int, device) -> Optional[Tensor]:
-    """fp32 [heads, n_edges + 4] for ``segger_gatv2_fwd_args.logits`` when this edge type's kernels write / read it (a
-    specialised geometry walked one lane group per destination row, two-pass backward), else None."""
-    by_dst = graph.by_dst
-    if (not SAVE_LOGITS or by_dst.n_edges == 0 or not _has_specialised(heads, channels)
-            or by_dst.n_edges >= WAVE_PER_ROW_DEGREE * max(by_dst.n_rows, 1)
-            or (graph.by_src is None and graph.src_unique())):
-        return None
-    return torch.empty((heads, by_dst.n_edges + 4), dtype=torch.float32, device=device)
-
-
-def _logits_ptr(t: Tensor, heads: int, n_edges: int):
-    if t.dtype != torch.float32 or t.dim() != 2 or t.shape[0] != heads or t.shape[1] < n_edges + 4 or t.stride(1) != 1:
-        raise ValueError("gatv2: logits must be fp32 [heads, >= n_edges + 4]")
-    return t.data_ptr(), int(t.stride(0))
 
 
 def gatv2_bwd_launch(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optional[Tensor],
@@ -368,8 +344,7 @@ def _gat_bwd_args(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optio
                   heads: int, channels: int, grad_out: Tensor, pre: Tensor, lse: Tensor,
                   grad_xl: Tensor, grad_xr: Tensor, *, apply_gelu: bool, negative_slope: float = 0.2,
                   dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tuple] = None,
-                  zero_rows_out: Optional[Tensor] = None, grad_xl_zeroed: bool = False,
-                  logits: Optional[Tensor] = None):
+                  zero_rows_out: Optional[Tensor] = None, grad_xl_zeroed: bool = False):
     """-> (segger_gatv2_bwd_args, gparams [2, HC] fp32, the tensors the struct points at)."""
     _lib.require_cuda(xl, xr, grad_out)
     lib = _lib.load()
@@ -406,8 +381,6 @@ def _gat_bwd_args(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optio
     a.grad_out, a.ld_go = _rows(grad_out, hc, "grad_out")
     a.pre, a.ld_pre = _rows(pre, hc, "pre")
     a.lse = lse.data_ptr()
-    if logits is not None:
-        a.logits, a.ld_logits = _logits_ptr(logits, heads, g.n_edges)
     grad_pre = torch.empty((n_dst, hc), dtype=dt, device=dev)
     dsum = torch.empty((n_dst, heads, 2), dtype=torch.float32, device=dev)     # (lse, D) pairs for the source pass
     a.grad_pre, a.ld_gp = _rows(grad_pre, hc, "grad_pre")
@@ -437,12 +410,10 @@ class _GatV2Aggregate(torch.autograd.Function):
         pre = torch.empty((n_dst, hc), dtype=dt, device=dev) if (need_grad and apply_gelu) else None
         lse = torch.empty((n_dst, heads), dtype=torch.float32, device=dev) if need_grad else None
         alpha = torch.empty((graph.n_edges, heads), dtype=torch.float32, device=dev) if want_alpha else None
-        elog = logits_buffer(graph, heads, channels, dev) if (need_grad and not want_alpha) else None
         gatv2_fwd_launch(graph.by_dst, xl, xr, att, bias, heads, channels, out, pre=pre, lse=lse, alpha=alpha,
                          apply_gelu=apply_gelu, negative_slope=negative_slope, dropout_p=dropout_p, seed=seed,
-                         keep_bits=None if keep_bits is None else keep_bits[0], logits=elog)
+                         keep_bits=None if keep_bits is None else keep_bits[0])
         if need_grad:
-            ctx.elog = elog
             ctx.save_for_backward(xl, xr, att, bias, pre if apply_gelu else out, lse)
             ctx.graph, ctx.cfg = graph, (heads, channels, apply_gelu, negative_slope, dropout_p, seed)
             ctx.keep_bits = keep_bits
@@ -461,7 +432,7 @@ class _GatV2Aggregate(torch.autograd.Function):
         gxr = torch.empty((g.n_dst, hc), dtype=xl.dtype, device=xl.device)
         gatt, gbias = gatv2_bwd_launch(g, xl, xr, att, bias, heads, channels, grad_out, pre, lse, gxl, gxr,
                                        apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed,
-                                       keep_bits=ctx.keep_bits, logits=ctx.elog)
+                                       keep_bits=ctx.keep_bits)
         gatt = gatt.reshape(att.shape).to(att.dtype)
         gbias = gbias.reshape(bias.shape).to(bias.dtype) if bias is not None else None
         return gxl, gxr, gatt, gbias, None, None, None, None, None, None, None, None, None
@@ -500,13 +471,12 @@ class _HeteroGatLayer(torch.autograd.Function):
         lse_tx = torch.empty((nt, heads), dtype=torch.float32, device=dev) if need_grad else None
         lse_bd = torch.empty((nb, heads), dtype=torch.float32, device=dev) if need_grad else None
         alpha = torch.empty((g_tt.n_edges, heads), dtype=torch.float32, device=dev) if want_alpha else None
-        elog = logits_buffer(g_tt, heads, channels, dev) if (need_grad and not want_alpha) else None
         # both edge types in ONE launch (segger_gatv2_fwd_pair): at segger's default batch size the tx-belongs-bd blocks
         # disappear inside the tx-neighbors-tx launch (46 -> 40 us per layer); at C2 it measures neutral
         gatv2_fwd_pair_launch(
             dict(by_dst=g_tt.by_dst, xl=xl_tt, xr=xr_tt, att=att_tt, bias=bias_tt, heads=heads, channels=channels, out=y_tx,
                  pre=pre_tx, lse=lse_tx, alpha=alpha, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p,
-                 seed=seed_tt, keep_bits=None if bits_tt is None else bits_tt[0], logits=elog),
+                 seed=seed_tt, keep_bits=None if bits_tt is None else bits_tt[0]),
             dict(by_dst=g_tb.by_dst, xl=xl_tb, xr=xp_bd, att=att_tb, bias=bias_tb, heads=heads, channels=channels, out=y_bd,
                  pre=pre_bd, lse=lse_bd, apply_gelu=apply_gelu, negative_slope=slope, dropout_p=dropout_p, seed=seed_tb,
                  keep_bits=None if bits_tb is None else bits_tb[0]))
@@ -514,7 +484,6 @@ class _HeteroGatLayer(torch.autograd.Function):
             ctx.save_for_backward(xp_tx, xp_bd, att_tt, bias_tt, att_tb, bias_tb,
                                   pre_tx if apply_gelu else y_tx, pre_bd if apply_gelu else y_bd, lse_tx, lse_bd)
             ctx.graphs = (g_tt, g_tb)
-            ctx.elog = elog
             ctx.cfg = (heads, channels, apply_gelu, slope, dropout_p, seed_tt, seed_tb)
             ctx.bits = (bits_tt, bits_tb)
         if want_alpha:
@@ -543,7 +512,7 @@ class _HeteroGatLayer(torch.autograd.Function):
             (g_tt, xp_tx[:, :hc], xp_tx[:, hc:2 * hc], att_tt, bias_tt, heads, channels, gy_tx, pre_tx, lse_tx,
              gxp_tx[:, :hc], gxp_tx[:, hc:2 * hc]),
             dict(apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tt, keep_bits=ctx.bits[0],
-                 zero_rows_out=gxp_tx[:, 2 * hc:], logits=ctx.elog),
+                 zero_rows_out=gxp_tx[:, 2 * hc:]),
             (g_tb, xp_tx[:, 2 * hc:], xp_bd, att_tb, bias_tb, heads, channels, gy_bd, pre_bd, lse_bd,
              gxp_tx[:, 2 * hc:], gxp_bd),
             dict(apply_gelu=apply_gelu, negative_slope=slope, dropout_p=p, seed=seed_tb, keep_bits=ctx.bits[1]))

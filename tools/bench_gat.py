@@ -31,12 +31,11 @@ p = float(os.environ.get('DROP', 0.0))
 bits = None
 if os.environ.get('BITS', '0') == '1' and p > 0:    # dropout mask as precomputed bit planes (ops.dropout_bits)
     bits = (ops.dropout_bits(g.by_dst, H, p, [5])[0], ops.dropout_bits(g.by_src, H, p, [5])[0])
-elog = ops.logits_buffer(g, H, C, dev) if os.environ.get('LOGITS', '1') == '1' else None    # LOGITS=0: the backward recomputes them
-fwd = lambda: ops.gatv2_fwd_launch(g.by_dst, xp[:, :hc], xp[:, hc:2*hc], att, bias, H, C, out, pre=pre, lse=lse, apply_gelu=True, dropout_p=p, seed=5, keep_bits=None if bits is None else bits[0], logits=elog)
-bwd = lambda: ops.gatv2_bwd_launch(g, xp[:, :hc], xp[:, hc:2*hc], att, bias, H, C, gy, pre, lse, gxp[:, :hc], gxp[:, hc:2*hc], apply_gelu=True, dropout_p=p, seed=5, keep_bits=bits, logits=elog)
+fwd = lambda: ops.gatv2_fwd_launch(g.by_dst, xp[:, :hc], xp[:, hc:2*hc], att, bias, H, C, out, pre=pre, lse=lse, apply_gelu=True, dropout_p=p, seed=5, keep_bits=None if bits is None else bits[0])
+bwd = lambda: ops.gatv2_bwd_launch(g, xp[:, :hc], xp[:, hc:2*hc], att, bias, H, C, gy, pre, lse, gxp[:, :hc], gxp[:, hc:2*hc], apply_gelu=True, dropout_p=p, seed=5, keep_bits=bits)
 def t(fn, it=20):
     for _ in range(3): fn()
     torch.cuda.synchronize(); a = torch.cuda.Event(True); e = torch.cuda.Event(True); a.record()
     for _ in range(it): fn()
     e.record(); torch.cuda.synchronize(); return a.elapsed_time(e) / it
-print('logits', 'saved' if elog is not None else 'recomputed', os.environ.get('DTYPE', 'bf16'), mode, os.path.basename(os.environ.get('SEGGER_AMD_LIB', 'default')), 'bits', os.environ.get('BITS', '0'), 'drop', p, 'fwd %.3f ms  bwd(dst+src) %.3f ms' % (t(fwd), t(bwd)), flush=True)
+print(os.environ.get('DTYPE', 'bf16'), mode, os.path.basename(os.environ.get('SEGGER_AMD_LIB', 'default')), 'bits', os.environ.get('BITS', '0'), 'drop', p, 'fwd %.3f ms  bwd(dst+src) %.3f ms' % (t(fwd), t(bwd)), flush=True)
