@@ -18,6 +18,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float pk2 __attribute__((ext_vector_type(2)));          // a register pair for v_pk_mul / v_pk_add / v_pk_fma_f32
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -46,6 +47,10 @@ struct SplitParams {
 
 // 8 consecutive floats -> their hi / mid / lo bf16 parts (round to nearest each time: the remainders are exact in fp32)
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, u32x4& hi, u32x4& mid, u32x4& lo) {
+#ifdef EXP_FS_NOSPLIT        // bounding build: no VALU split (planes = raw words)
+  hi = __builtin_bit_cast(u32x4, a); mid = __builtin_bit_cast(u32x4, b); lo = hi ^ mid;
+  return;
+#endif
   const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   uint32_t h[4], m[4], l[4];
 #pragma unroll
@@ -213,11 +218,15 @@ __global__ __launch_bounds__(256, K == 128 ? 2 : SEGGER_FS_K384_WAVES) void line
       if (slice + 1 < NS) fetch_x(slice + 1);
 #pragma unroll
       for (int c = 0; c < NACC / 2; ++c) {
+#ifdef EXP_FS_NOWSTAGE       // bounding build: W staged once, never again (no W loads, LDS writes or barriers in the loop)
+        if (slice == 0 && c == 0) { lds_barrier(); w_commit(); lds_barrier(); }
+#else
         lds_barrier();
         w_commit();
         lds_barrier();
         if (c + 1 < NACC / 2) w_fetch((c + 1) * kCH, slice);
         else if (slice + 1 < NS) w_fetch(0, slice + 1);
+#endif
         chunk_mma(acc[2 * c], acc[2 * c + 1]);
       }
     }
@@ -266,6 +275,11 @@ struct WgSplitParams {
 
 // 4 consecutive floats -> 4 bf16 of each plane
 __device__ __forceinline__ void split4(const f32x4 v, u32x2s& hi, u32x2s& mid, u32x2s& lo) {
+#ifdef EXP_FS_NOSPLIT
+  hi = u32x2s{__float_as_uint(v.x), __float_as_uint(v.y)}; mid = u32x2s{__float_as_uint(v.z), __float_as_uint(v.w)};
+  lo = u32x2s{__float_as_uint(v.x) + 1u, __float_as_uint(v.w)};
+  return;
+#endif
   const uint32_t h0 = Vec8<bf16_t>::pack(v.x, v.y), h1 = Vec8<bf16_t>::pack(v.z, v.w);
   float a, b, c, d;
   Vec8<bf16_t>::unpack2(h0, a, b); Vec8<bf16_t>::unpack2(h1, c, d);
@@ -499,6 +513,293 @@ __global__ __launch_bounds__(256) void f32_split_planes_kernel(const float* __re
   const uint32_t l = Vec8<bf16_t>::pack(r - mf, 0.f);
   out[o].v = (uint16_t)(h & 0xffffu); out[n + o].v = (uint16_t)(m & 0xffffu); out[2 * n + o].v = (uint16_t)(l & 0xffffu);
 }
+
+// ------------------------------------------------------------------------------- W resident in registers (K * M = 49152)
+// The two big shapes -- 128 -> 384 (stacked lin_l | lin_r | lin_l) and its data gradient 384 -> 128 -- spent their time in
+// SERIES: the bounding builds of linear_f32_split_kernel<384> (tools/ab_fs384.sh; 0.872 ms at 1M rows) give back 0.19 ms
+// without five of the six products, 0.14 without the output stores, 0.12 without the W staging, 0.065 without the split --
+// with one wave per SIMD nothing runs under anything else.  Here the roles are swapped.  A persistent workgroup (one per CU,
+// 4 waves) keeps ALL of W in registers for the whole launch: wave w owns M / 4 output columns, 3 planes x M/4 x K bf16 =
+// 288 registers per lane as MFMA A-fragments.  The ROWS stream through LDS: a tile of 32 rows is loaded as fp32 by all
+// 256 threads (coalesced 16-byte pieces, one tile AHEAD in registers), split into its three bf16 planes and written to one
+// of two LDS buffers; every wave reads the tile's B-fragments from there (conflict-free ds_read_b128, row stride 2 K + 16).
+// One LDS-only barrier per tile and no W traffic in the loop.
+// The memory stream is what decides the speed of a kernel with ONE wave per SIMD -- nothing else runs while it waits, and
+// vmcnt counts loads and stores in one in-order queue.  So: per tile the loop issues, in this order, the row loads of tile
+// t + 2 (piece by piece, each right after its register was split into the planes of tile t + 1: 48 KB per CU in flight all
+// the time, not just between a block of loads and its use), the output stores of tile t - 1 (kept in 16 registers per column tile; its gate values were loaded a tile earlier)
+// and the gate loads of tile t; the wait before the split of tile t + 1's rows is then vmcnt(stores + gate loads issued
+// after them): the loads have had a whole tile to arrive and no store is ever waited for.  All of it branch-free (buffer
+// loads / stores: rows past the end are out of range, dropped by the memory unit) so the counter arithmetic stays exact.
+template <int K, int M, int GATE>                     // GATE: 0 none, 1 GELU, 2 SiLU (p.gate_kind at compile time: no branch in the loop)
+__global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitParams p, int n_tiles) {
+  static_assert(K * M == 384 * 128 && K % 128 == 0 && M % 128 == 0, "W must fill 288 registers per lane");
+  constexpr int NKS = K / 16;                  // k-steps of a tile: 24 / 8
+  constexpr int NCT = M / 128;                 // 32-column tiles per wave: 1 / 3
+  constexpr int NPAR = NCT == 1 ? 2 : 1;       // independent accumulator chains per column tile (NCT * NPAR >= 2)
+  constexpr int XS = K * 2 + 16;               // LDS row stride of a plane (bytes)
+  constexpr int PLANE = 32 * XS, BUF = 3 * PLANE;
+  constexpr int CPL = K / 128;                 // 16-byte pieces per lane and row (32 lanes per row): 3 / 1
+  constexpr int NP = 4 * CPL;                  // pieces per thread and tile (rows rg, rg + 8, rg + 16, rg + 24): 12 / 4
+  constexpr int HEAD = NKS / 3;                // k-steps before the split starts
+  static_assert(HEAD + NP <= NKS, "the split must fit behind the head");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int l32 = tid & 31, rg = tid >> 5;
+  const int G = gridDim.x;
+  int t = blockIdx.x;
+  if (t >= n_tiles) return;
+
+  u32x4 wf[3][NCT][NKS];
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int s = 0; s < NKS; ++s)
+        wf[q][ct][s] = *reinterpret_cast<const u32x4*>(p.w3 + ((int64_t)q * M + (wave * NCT + ct) * 32 + r) * K + 16 * s + 8 * h);
+#ifndef EXP_FS_WF_VGPR
+  // two of the three planes pinned to accumulation registers (the MFMA reads its A operand from either file): no
+  // v_accvgpr_read copies in front of the MFMAs
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) asm volatile("" : "+a"(wf[q][ct][s]));
+#endif
+
+  // x, y, gate as raw buffers (the host checked that they are below 2 GB): 32-bit offsets, out-of-range lanes dropped --
+  // kNoRow + any column offset stays out of range
+  constexpr uint32_t kNoRow = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t xb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)(uint32_t)(p.n_rows * p.ldx * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t yb = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)(uint32_t)(p.n_rows * p.ldy * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t gb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gate), 0, GATE ? (int)(uint32_t)(p.n_rows * p.ld_gate * 4) : 0, 0x00020000);
+  const uint32_t ldx4 = (uint32_t)p.ldx * 4u, ldy4 = (uint32_t)p.ldy * 4u, ldg4 = (uint32_t)p.ld_gate * 4u;
+  const uint32_t n_rows = (uint32_t)p.n_rows;
+
+  f32x4 raw[NP];
+  auto fetch_piece = [&](int tile, int j) {    // (rows past the end: zeros)
+    const uint32_t row = (uint32_t)tile * 32u + rg + 8 * (j / CPL);
+    const uint32_t off = row < n_rows ? row * ldx4 + l32 * 16u : kNoRow;
+    raw[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xb, off + (j % CPL) * 512, 0, 0));
+  };
+  auto fetch = [&](int tile) {                  // in piece order, pinned: the loop's counted waits (vmcnt(NP - 1 + later
+#pragma unroll                                  // stores / gate loads) before piece 0's split, ...) are derived from the
+    for (int j = 0; j < NP; ++j) {               // order of issue on BOTH ways into the loop -- a prologue that loads piece 0
+      fetch_piece(tile, j);                      // last (the scheduler did) turns every one of them into vmcnt(0)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  unsigned char* const cbase = lds + rg * XS + l32 * 8;
+  auto commit_piece = [&](int buf_off, int j) {
+    u32x2s hi, mid, lo;
+    split4(raw[j], hi, mid, lo);
+    unsigned char* d = cbase + buf_off + (j / CPL) * 8 * XS + (j % CPL) * 256;
+    *reinterpret_cast<u32x2s*>(d) = hi;
+    *reinterpret_cast<u32x2s*>(d + PLANE) = mid;
+    *reinterpret_cast<u32x2s*>(d + 2 * PLANE) = lo;
+  };
+  // the finished tile waiting for its store: accumulators, byte offsets of this lane's row in y / gate (~0: no row), gate
+  f32x16 pend[NCT];
+  uint32_t pend_y = kNoRow, pend_g = kNoRow;
+  f32x4 gq[GATE ? NCT * 4 : 1];
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) pend[ct][e] = 0.f;
+  if constexpr (GATE) {
+#pragma unroll
+    for (int g = 0; g < NCT * 4; ++g) gq[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const uint32_t col0 = (uint32_t)(wave * NCT * 32 + 4 * h) * 4u;       // byte offset of this lane's first column
+  auto gate_apply = [&](int e) {                // pend *= act'(gate), one value (the last tile; the loop does it in stages)
+    if constexpr (GATE != 0) {
+      static_assert(NCT == 1 && 2 * HEAD == 16, "gate: the 384 -> 128 shape, two values per HEAD k-step");
+      pend[0][e] *= gate_grad(gq[e / 4][e % 4], GATE);
+    }
+  };
+  auto store_pend = [&]() {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 v = f32x4{pend[ct][4 * g], pend[ct][4 * g + 1], pend[ct][4 * g + 2], pend[ct][4 * g + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yb, pend_y + (ct * 32 + 8 * g) * 4, 0, 0);
+      }
+  };
+  auto load_gate = [&](uint32_t off) {
+    if constexpr (GATE) {
+#pragma unroll
+      for (int g = 0; g < NCT * 4; ++g)
+        gq[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(gb, off + ((g / 4) * 32 + 8 * (g % 4)) * 4, 0, 0));
+    }
+  };
+
+  fetch(t);
+#pragma unroll
+  for (int j = 0; j < NP; ++j) commit_piece(0, j);
+  load_gate(kNoRow);         // (no row: zeros / dropped) -- the queue as every later iteration leaves it: gate loads, row
+  fetch(t + G);              // loads, stores; the compiler's counts at the loop head are then the steady-state ones
+  store_pend();
+  int b = 0;
+#ifdef EXP_FS_STAMPS
+  long long st_bar = 0, st_head = 0, st_commit = 0, st_tail = 0, st_n = 0, st_t0 = clock64();
+#endif
+  for (; t < n_tiles; t += G, b ^= 1) {
+#ifdef EXP_FS_STAMPS
+    const long long c0 = clock64();
+#endif
+    lds_barrier();           // tile t's planes are in buffer b; every wave has left buffer b ^ 1 (tile t - G)
+    const unsigned char* cur = lds + b * BUF + r * XS + 16 * h;
+    const int nxt = (b ^ 1) * BUF;
+    const uint32_t row = (uint32_t)t * 32u + r;
+    const uint32_t cur_y = row < n_rows ? row * ldy4 + col0 : kNoRow;
+    const uint32_t cur_g = row < n_rows ? row * ldg4 + col0 : kNoRow;
+    f32x16 acc[NCT][NPAR];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int q = 0; q < NPAR; ++q)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[ct][q][e] = 0.f;
+    u32x4 xf[2][3];                                // B-fragments (hi, mid, lo) of this and the next k-step
+#pragma unroll
+    for (int q = 0; q < 3; ++q) xf[0][q] = *reinterpret_cast<const u32x4*>(cur + q * PLANE);
+#ifdef EXP_FS_STAMPS
+    long long c1 = 0, c2 = 0, c3 = 0;
+#endif
+    static_for_wgs<NKS>([&](auto s_c) {
+      constexpr int s = decltype(s_c)::value;
+#ifdef EXP_FS_STAMPS
+      if constexpr (s == 0) { c1 = clock64(); }
+      if constexpr (s == HEAD) { c2 = clock64(); }
+      if constexpr (s == HEAD + NP) { c3 = clock64(); }
+#endif
+      if constexpr (s + 1 < NKS) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) xf[(s + 1) & 1][q] = *reinterpret_cast<const u32x4*>(cur + q * PLANE + 32 * (s + 1));
+      }
+      __builtin_amdgcn_sched_barrier(0);           // (the scheduler would sink each read to just before its MFMA)
+      // the six products of this k-step, smallest terms first: (w lo, x hi) (w hi, x lo) (w mid, x mid) (w mid, x hi)
+      // (w hi, x mid) (w hi, x hi)
+      auto mf = [&](auto i_c) {
+        constexpr int i = decltype(i_c)::value;
+        constexpr int wq = i == 0 ? 2 : (i == 2 || i == 3) ? 1 : 0;
+        constexpr int xq = i == 1 ? 2 : (i == 2 || i == 4) ? 1 : 0;
+#ifdef EXP_FS_ONEMFMA
+        if constexpr (i != 5) return;
+#endif
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) acc[ct][s % NPAR] = mfma_bf16(wf[wq][ct][s], xf[s & 1][xq], acc[ct][s % NPAR]);
+      };
+      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+      using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+      // In-order issue: an MFMA behind an MFMA waits out the first one's 8 passes, with everything behind it.  The k-step's
+      // side work only runs in the shadow of the matrix pipe if it sits BETWEEN the MFMAs -- and at this register count the
+      // machine scheduler keeps the source order (it reverts its own schedule when that raises the pressure), so the source
+      // IS the schedule: each k-step below is MFMA, a few VALU, MFMA, ...
+      if constexpr (s < HEAD && GATE != 0 && 2 * s + 1 < 16) {
+        // the stored tile's gate factors, two values per k-step (packed fp32): pend *= act'(gate)
+        const f32x4 gv = gq[s / 2];
+        const pk2 x = (s & 1) ? pk2{gv.z, gv.w} : pk2{gv.x, gv.y};
+        pk2 g;
+        if constexpr (GATE == 1) {                   // common.h gelu_erf_grad, in stages, on register pairs
+          mf(I0{});
+          const pk2 sa = pk2{fminf(fabsf(x.x), 5.656854249f), fminf(fabsf(x.y), 5.656854249f)};
+          const pk2 t = x * x * -0.72134752044448170f;
+          const pk2 pdf = pk2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} * 0.3989422804014327f;
+          mf(I1{});
+          pk2 q = pk2{-2.855192741e-06f, -2.855192741e-06f};
+          q = __builtin_elementwise_fma(q, sa, pk2{3.960562235e-05f, 3.960562235e-05f});
+          q = __builtin_elementwise_fma(q, sa, pk2{-1.871826931e-04f, -1.871826931e-04f});
+          q = __builtin_elementwise_fma(q, sa, pk2{-1.347308812e-04f, -1.347308812e-04f});
+          q = __builtin_elementwise_fma(q, sa, pk2{7.060847394e-03f, 7.060847394e-03f});
+          mf(I2{});
+          q = __builtin_elementwise_fma(q, sa, pk2{-5.249462857e-02f, -5.249462857e-02f});
+          q = __builtin_elementwise_fma(q, sa, pk2{-4.592086259e-01f, -4.592086259e-01f});
+          q = __builtin_elementwise_fma(q, sa, pk2{-1.151105166e+00f, -1.151105166e+00f});
+          q = q * sa;
+          mf(I3{});
+          const pk2 half = pk2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)} * 0.5f;
+          mf(I4{});
+          const pk2 cdf = pk2{x.x < 0.f ? half.x : 1.0f - half.x, x.y < 0.f ? half.y : 1.0f - half.y};
+          mf(I5{});
+          g = __builtin_elementwise_fma(x, pdf, cdf);
+        } else {                                     // common.h silu_grad
+          mf(I0{});
+          const pk2 t = x * -1.4426950408889634f;
+          const pk2 en = pk2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+          mf(I1{});
+          const pk2 sg = pk2{__builtin_amdgcn_rcpf(en.x), __builtin_amdgcn_rcpf(en.y)};
+          mf(I2{});
+          g = sg * (x * (1.0f - sg) + 1.0f);
+          mf(I3{}); mf(I4{}); mf(I5{});
+        }
+        pend[0][2 * s] *= g.x;
+        pend[0][2 * s + 1] *= g.y;
+      } else if constexpr (s >= HEAD && s - HEAD < NP) {
+        // one piece per k-step: the next tile's rows -> planes (split4, in stages), its register refilled at once with the
+        // rows of the tile after that (a piece is in flight for a whole tile); before the first of them this tile's gate
+        // values on their way, after the last the previous tile stored
+        constexpr int jp = s - HEAD;
+        if constexpr (jp == 0) load_gate(cur_g);
+        const f32x4 v = raw[jp];
+        const pk2 va = pk2{v.x, v.y}, vb = pk2{v.z, v.w};
+        mf(I0{});
+        const uint32_t h0 = Vec8<bf16_t>::pack(v.x, v.y), h1 = Vec8<bf16_t>::pack(v.z, v.w);
+        auto up = [](uint32_t w) { float a, b; Vec8<bf16_t>::unpack2(w, a, b); return pk2{a, b}; };
+        pk2 ua = up(h0), ub = up(h1);
+        mf(I1{});
+        const pk2 ra = va - ua, rb = vb - ub;            // (exact: the remainders of a round-to-nearest)
+        const uint32_t m0 = Vec8<bf16_t>::pack(ra.x, ra.y), m1 = Vec8<bf16_t>::pack(rb.x, rb.y);
+        mf(I2{});
+        ua = up(m0); ub = up(m1);
+        const pk2 la = ra - ua, lb = rb - ub;
+        const uint32_t l0 = Vec8<bf16_t>::pack(la.x, la.y), l1 = Vec8<bf16_t>::pack(lb.x, lb.y);
+        mf(I3{});
+        unsigned char* d = cbase + nxt + (jp / CPL) * 8 * XS + (jp % CPL) * 256;
+#ifdef EXP_FS_NOSPLIT
+        *reinterpret_cast<u32x2s*>(d) = u32x2s{__float_as_uint(v.x), __float_as_uint(v.y)};
+        *reinterpret_cast<u32x2s*>(d + PLANE) = u32x2s{__float_as_uint(v.z), __float_as_uint(v.w)};
+        *reinterpret_cast<u32x2s*>(d + 2 * PLANE) = u32x2s{__float_as_uint(v.x) + 1u, __float_as_uint(v.w)};
+#else
+        *reinterpret_cast<u32x2s*>(d) = u32x2s{h0, h1};
+        *reinterpret_cast<u32x2s*>(d + PLANE) = u32x2s{m0, m1};
+        *reinterpret_cast<u32x2s*>(d + 2 * PLANE) = u32x2s{l0, l1};
+#endif
+        mf(I4{});
+        fetch_piece(t + 2 * G, jp);
+        mf(I5{});
+#ifndef EXP_FS_NOSTORE
+        if constexpr (jp == NP - 1) store_pend();
+#endif
+      } else {
+        mf(I0{}); mf(I1{}); mf(I2{}); mf(I3{}); mf(I4{}); mf(I5{});
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) {
+      pend[ct] = acc[ct][0];
+      if constexpr (NPAR == 2) pend[ct] = pend[ct] + acc[ct][1];
+    }
+    pend_y = cur_y;
+#ifdef EXP_FS_STAMPS
+    { const long long c4 = clock64(); st_bar += c1 - c0; st_head += c2 - c1; st_commit += c3 - c2; st_tail += c4 - c3; ++st_n; }
+#endif
+  }
+#ifdef EXP_FS_STAMPS
+  if (blockIdx.x == 7 && lane == 0)
+    printf("wave %d: %lld tiles, per tile: barrier %lld head %lld commit %lld tail %lld; total %lld clocks\n", wave, st_n, st_bar / st_n,
+           st_head / st_n, st_commit / st_n, st_tail / st_n, (long long)(clock64() - st_t0));
+#endif
+#pragma unroll
+  for (int e = 0; e < 16; ++e) gate_apply(e);
+  store_pend();
+}
+
 } }  // namespace segger::(anonymous)
 
 extern "C" int segger_f32_split_planes(const float* w, int32_t rows, int32_t cols, int32_t transpose, void* planes,
@@ -585,7 +886,21 @@ static int split_fwd_launch(const float* x, int64_t ldx, const void* w3, const f
   const int64_t nb = (n_rows + 127) / 128;
   SEGGER_REQUIRE(nb <= 0x7fffffffLL, "segger_linear_fwd_f32_split: too many rows");
   SplitParams p{x, ldx, static_cast<const bf16_t*>(w3), bias, y, ldy, n_rows, m_out, rowbias, rowidx, ld_rb, gate, ld_gate, gate_kind};
-  if (k_in == 128) hipLaunchKernelGGL((linear_f32_split_kernel<128>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
+#ifndef SEGGER_FS_WRES
+#define SEGGER_FS_WRES 1                   // the two K * M = 49152 shapes on the W-resident kernel
+#endif
+  const int64_t n_tiles = (n_rows + 31) / 32;
+  const unsigned wres_grid = (unsigned)std::min<int64_t>(n_tiles, device_cu_count());
+  // (the W-resident kernels address x, y and the gate with 31-bit byte offsets)
+  const bool wres_ok = SEGGER_FS_WRES && !bias && !rowbias && n_rows * ldx * 4 < 0x7ffff000LL && n_rows * ldy * 4 < 0x7ffff000LL &&
+                       (!gate || n_rows * ld_gate * 4 < 0x7ffff000LL);
+  if (wres_ok && k_in == 384 && m_out == 128 && gate && gate_kind == 1)
+    hipLaunchKernelGGL((linear_f32_split_wres_kernel<384, 128, 1>), dim3(wres_grid), dim3(256), 0, (hipStream_t)stream, p, (int)n_tiles);
+  else if (wres_ok && k_in == 384 && m_out == 128 && gate)
+    hipLaunchKernelGGL((linear_f32_split_wres_kernel<384, 128, 2>), dim3(wres_grid), dim3(256), 0, (hipStream_t)stream, p, (int)n_tiles);
+  else if (wres_ok && k_in == 384 && m_out == 128)
+    hipLaunchKernelGGL((linear_f32_split_wres_kernel<384, 128, 0>), dim3(wres_grid), dim3(256), 0, (hipStream_t)stream, p, (int)n_tiles);
+  else if (k_in == 128) hipLaunchKernelGGL((linear_f32_split_kernel<128>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((linear_f32_split_kernel<384>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
   SEGGER_LAUNCH_CHECK("linear_f32_split_kernel");
   return SEGGER_OK;

@@ -424,7 +424,8 @@ def test_linear_pair_equals_two_launches(cuda, dtype, k, ma, mb, na, nb):
         assert torch.equal(p_, s_)
 
 
-@pytest.mark.parametrize("k,m,n", [(128, 384, 4133), (128, 64, 1), (128, 128, 129), (384, 128, 3001)])
+@pytest.mark.parametrize("k,m,n", [(128, 384, 4133), (128, 64, 1), (128, 128, 129), (384, 128, 3001), (128, 384, 40037), (384, 128, 40037),
+                                   (384, 128, 31), (128, 384, 8192)])
 def test_linear_fp32_split_within_the_exact_kernels_error(cuda, k, m, n):
     """segger_linear_fwd_f32_split (fp32 operands as three bf16 parts, six partial products on the bf16 MFMA, fp32
     accumulation) against fp64: its error, relative to sum |x||w| (what fp32 rounding scales with), stays within twice the
