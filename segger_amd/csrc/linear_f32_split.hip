@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void f32_split_planes_kernel(const float* __re
 // and the gate loads of tile t; the wait before the split of tile t + 1's rows is then vmcnt(stores + gate loads issued
 // after them): the loads have had a whole tile to arrive and no store is ever waited for.  All of it branch-free (buffer
 // loads / stores: rows past the end are out of range, dropped by the memory unit) so the counter arithmetic stays exact.
-template <int K, int M, int GATE>                     // GATE: 0 none, 1 GELU, 2 SiLU (p.gate_kind at compile time: no branch in the loop)
+template <int K, int M, int GATE, bool BIAS>          // GATE: 0 none, 1 GELU, 2 SiLU (p.gate_kind at compile time: no branch in the loop)
 __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitParams p, int n_tiles) {
   static_assert(K * M == 384 * 128 && K % 128 == 0 && M % 128 == 0, "W must fill 288 registers per lane");
   constexpr int NKS = K / 16;                  // k-steps of a tile: 24 / 8
@@ -544,12 +544,16 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
   constexpr int HEAD = NKS / 3;                // k-steps before the split starts
   static_assert(HEAD + NP <= NKS, "the split must fit behind the head");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+  __shared__ __attribute__((aligned(16))) float lds_bias[BIAS ? M : 4];     // (no global load in the store path: see below)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int l32 = tid & 31, rg = tid >> 5;
   const int G = gridDim.x;
   int t = blockIdx.x;
   if (t >= n_tiles) return;
+  if constexpr (BIAS) {
+    for (int c = tid; c < M; c += 256) lds_bias[c] = p.bias[c];            // (ordered before its first read by the loop's barrier)
+  }
 
   u32x4 wf[3][NCT][NKS];
 #pragma unroll
@@ -784,6 +788,13 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
     for (int ct = 0; ct < NCT; ++ct) {
       pend[ct] = acc[ct][0];
       if constexpr (NPAR == 2) pend[ct] = pend[ct] + acc[ct][1];
+      if constexpr (BIAS) {                        // (last, as in the exact kernels: the products' small terms were summed first)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(lds_bias + (wave * NCT + ct) * 32 + 8 * g + 4 * h);
+          pend[ct][4 * g] += bv.x; pend[ct][4 * g + 1] += bv.y; pend[ct][4 * g + 2] += bv.z; pend[ct][4 * g + 3] += bv.w;
+        }
+      }
     }
     pend_y = cur_y;
 #ifdef EXP_FS_STAMPS
@@ -892,14 +903,17 @@ static int split_fwd_launch(const float* x, int64_t ldx, const void* w3, const f
   const int64_t n_tiles = (n_rows + 31) / 32;
   const unsigned wres_grid = (unsigned)std::min<int64_t>(n_tiles, device_cu_count());
   // (the W-resident kernels address x, y and the gate with 31-bit byte offsets)
-  const bool wres_ok = SEGGER_FS_WRES && !bias && !rowbias && n_rows * ldx * 4 < 0x7ffff000LL && n_rows * ldy * 4 < 0x7ffff000LL &&
+  const bool wres_ok = SEGGER_FS_WRES && !rowbias && n_rows * ldx * 4 < 0x7ffff000LL && n_rows * ldy * 4 < 0x7ffff000LL &&
                        (!gate || n_rows * ld_gate * 4 < 0x7ffff000LL);
-  if (wres_ok && k_in == 384 && m_out == 128 && gate && gate_kind == 1)
-    hipLaunchKernelGGL((linear_f32_split_wres_kernel<384, 128, 1>), dim3(wres_grid), dim3(256), 0, (hipStream_t)stream, p, (int)n_tiles);
-  else if (wres_ok && k_in == 384 && m_out == 128 && gate)
-    hipLaunchKernelGGL((linear_f32_split_wres_kernel<384, 128, 2>), dim3(wres_grid), dim3(256), 0, (hipStream_t)stream, p, (int)n_tiles);
-  else if (wres_ok && k_in == 384 && m_out == 128)
-    hipLaunchKernelGGL((linear_f32_split_wres_kernel<384, 128, 0>), dim3(wres_grid), dim3(256), 0, (hipStream_t)stream, p, (int)n_tiles);
+#define WRES(KK, MM, GG, BB) hipLaunchKernelGGL((linear_f32_split_wres_kernel<KK, MM, GG, BB>), dim3(wres_grid), dim3(256), 0, \
+                                                (hipStream_t)stream, p, (int)n_tiles)
+  if (wres_ok && k_in == 384 && m_out == 128 && !bias && gate && gate_kind == 1) WRES(384, 128, 1, false);
+  else if (wres_ok && k_in == 384 && m_out == 128 && !bias && gate) WRES(384, 128, 2, false);
+  else if (wres_ok && k_in == 384 && m_out == 128 && !bias) WRES(384, 128, 0, false);
+  else if (wres_ok && k_in == 384 && m_out == 128 && !gate) WRES(384, 128, 0, true);
+  else if (wres_ok && k_in == 128 && m_out == 384 && !gate && bias) WRES(128, 384, 0, true);
+  else if (wres_ok && k_in == 128 && m_out == 384 && !gate) WRES(128, 384, 0, false);
+#undef WRES
   else if (k_in == 128) hipLaunchKernelGGL((linear_f32_split_kernel<128>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((linear_f32_split_kernel<384>), dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p);
   SEGGER_LAUNCH_CHECK("linear_f32_split_kernel");

@@ -504,7 +504,7 @@ def test_wgrad_fp32_split_within_the_exact_kernels_error(cuda, m, k, n, monkeypa
 
 @pytest.mark.parametrize("kind", ["gelu", "silu"])
 @pytest.mark.parametrize("k,m,n,split", [(384, 128, 3001, True), (384, 128, 3001, False), (64, 64, 4097, False), (128, 128, 130, True),
-                                         (256, 64, 77, False)])
+                                         (256, 64, 77, False), (384, 128, 40037, True), (384, 128, 1, True)])
 def test_linear_f32_gate_epilogue(cuda, k, m, n, split, kind, monkeypatch):
     """segger_linear_fwd_f32_gate: (x @ W^T) * act'(gate) in one kernel (exact-fp32 MFMA or the bf16x3 split) against torch's
     matmul + gelu_backward / silu_backward in float64; gate and x as views with a row stride."""
