@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 25
+#define SEGGER_ABI_VERSION 26
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -830,6 +830,10 @@ int segger_posfreq(const float* pos, const int64_t* batch, const float* mins, co
  *   sum dz1 -- autograd's two `grad.t() @ x`, two `grad.sum(0)`, the `grad @ W` and the SiLU backward of
  *   ist_encoder.py:45-49, 76-79.  w2_t = W2^T [64, 64] row-major in `dtype`; outputs fp32; workspace
  *   segger_posmlp_bwd_workspace_bytes(n_rows); deterministic (per-workgroup partials summed in order).
+ * segger_posmlp_bwd_pair: the same for TWO row sets in one launch and one sum of partials -- ISTEncoder embeds the
+ *   transcripts' and the boundaries' positions with the same Positional2dEmbedder (reference ist_encoder.py:314-318), so
+ *   its four parameters receive ONE gradient (autograd would add the two calls' gradients with four more launches).
+ *   Either side may be empty (n_rows 0, pointers ignored); workspace segger_posmlp_bwd_pair_workspace_bytes(n_a, n_b).
  * Covered: frequency_embedding_size 256, hidden_size 128 (segger's in_channels default): segger_posmlp_supported.
  */
 int segger_posmlp_supported(int32_t freq_dim, int32_t dim, int32_t dtype);
@@ -840,6 +844,12 @@ size_t segger_posmlp_bwd_workspace_bytes(int64_t n_rows);
 int segger_posmlp_bwd(const void* g, int64_t ld_g, const void* z1, const float* pn, const void* w2_t, int64_t n_rows,
                       float max_period, int32_t dtype, float* grad_w0, float* grad_b0, float* grad_w2, float* grad_b2,
                       void* workspace, size_t workspace_bytes, segger_stream_t stream);
+size_t segger_posmlp_bwd_pair_workspace_bytes(int64_t n_rows_a, int64_t n_rows_b);
+int segger_posmlp_bwd_pair(const void* g_a, int64_t ld_ga, const void* z1_a, const float* pn_a, int64_t n_rows_a,
+                           const void* g_b, int64_t ld_gb, const void* z1_b, const float* pn_b, int64_t n_rows_b,
+                           const void* w2_t, float max_period, int32_t dtype, float* grad_w0, float* grad_b0,
+                           float* grad_w2, float* grad_b2, void* workspace, size_t workspace_bytes,
+                           segger_stream_t stream);
 int segger_posmlp_wgrad(const void* dz1, int64_t ld_dz1, const float* pn, int64_t n_rows, float max_period,
                         int32_t dtype, float* grad_w0, float* grad_b0, void* workspace, size_t workspace_bytes,
                         segger_stream_t stream);

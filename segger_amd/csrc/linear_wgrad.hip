@@ -463,8 +463,14 @@ __device__ __forceinline__ float sigmoid_fast(float z) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
 }
 
+// Two row sets (the transcripts' and the boundaries' positions: the embedder is called once per node type on large batches)
+// share ONE launch and ONE sum of partials: blocks [0, n_first) work on `pa`, the rest on `pb`, whose partial rows follow
+// pa's -- the embedder's four parameters receive one gradient each (no accumulation launches behind autograd's two nodes).
 template <typename T>
-__global__ __launch_bounds__(512, 2) void posmlp_bwd_kernel(PosBwdParams p) {
+__global__ __launch_bounds__(512, 2) void posmlp_bwd_kernel(PosBwdParams pa, PosBwdParams pb, int n_first) {
+  const bool second = (int)blockIdx.x >= n_first;              // (uniform)
+  const PosBwdParams& p = second ? pb : pa;
+  const int bid = second ? (int)blockIdx.x - n_first : (int)blockIdx.x;
   // 8 waves: wave w stages DMA chunk w of every stage and owns feature tile w of dW0 (both 32-row tiles of dz1
   // columns); waves 0..3 also produce the dz1 tile (16 columns each) and own one tile of dW2, waves 4..7 produce the
   // h1 tile.  ~110 registers per lane -> 4 waves per SIMD: the loop is a dependent VALU / transcendental stream
@@ -478,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void posmlp_bwd_kernel(PosBwdParams p) {
   const T* __restrict__ gp = static_cast<const T*>(p.g);
   const T* __restrict__ zp = static_cast<const T*>(p.z1);
 
-  const int64_t s_beg = (int64_t)blockIdx.x * p.stages_per_block;
+  const int64_t s_beg = (int64_t)bid * p.stages_per_block;
   int64_t s_end = s_beg + p.stages_per_block;
   if (s_end > p.n_stages) s_end = p.n_stages;
   const int n_local = (int)(s_end > s_beg ? s_end - s_beg : 0);
@@ -630,8 +636,8 @@ __global__ __launch_bounds__(512, 2) void posmlp_bwd_kernel(PosBwdParams p) {
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);                      // the ring ran kPbAhead stages past the slab
 
-  float* out2 = p.part2 + (int64_t)blockIdx.x * kPbWidth2;
-  float* out0 = p.part0 + (int64_t)blockIdx.x * kPbWidth0;
+  float* out2 = p.part2 + (int64_t)bid * kPbWidth2;
+  float* out0 = p.part0 + (int64_t)bid * kPbWidth0;
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -1083,47 +1089,72 @@ static int64_t posmlp_bwd_grid(int64_t n_rows) {
   return want < cap ? (want < 1 ? 1 : want) : cap;
 }
 
-extern "C" size_t segger_posmlp_bwd_workspace_bytes(int64_t n_rows) {
-  if (n_rows <= 0) return 16;
-  return (size_t)(posmlp_bwd_grid(n_rows) + kRedGroups) * (size_t)(kPbWidth2 + kPbWidth0) * sizeof(float);
+extern "C" size_t segger_posmlp_bwd_pair_workspace_bytes(int64_t n_rows_a, int64_t n_rows_b) {
+  const int64_t grid = (n_rows_a > 0 ? posmlp_bwd_grid(n_rows_a) : 0) + (n_rows_b > 0 ? posmlp_bwd_grid(n_rows_b) : 0);
+  if (grid == 0) return 16;
+  return (size_t)(grid + kRedGroups) * (size_t)(kPbWidth2 + kPbWidth0) * sizeof(float);
 }
+extern "C" size_t segger_posmlp_bwd_workspace_bytes(int64_t n_rows) { return segger_posmlp_bwd_pair_workspace_bytes(n_rows, 0); }
 
-extern "C" int segger_posmlp_bwd(const void* g, int64_t ld_g, const void* z1, const float* pn, const void* w2_t,
-                                 int64_t n_rows, float max_period, int32_t dtype, float* grad_w0, float* grad_b0,
-                                 float* grad_w2, float* grad_b2, void* workspace, size_t workspace_bytes,
-                                 segger_stream_t stream_) {
+extern "C" int segger_posmlp_bwd_pair(const void* g_a, int64_t ld_ga, const void* z1_a, const float* pn_a, int64_t n_rows_a,
+                                      const void* g_b, int64_t ld_gb, const void* z1_b, const float* pn_b, int64_t n_rows_b,
+                                      const void* w2_t, float max_period, int32_t dtype, float* grad_w0, float* grad_b0,
+                                      float* grad_w2, float* grad_b2, void* workspace, size_t workspace_bytes,
+                                      segger_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  SEGGER_REQUIRE(n_rows >= 0, "segger_posmlp_bwd: negative size");
+  SEGGER_REQUIRE(n_rows_a >= 0 && n_rows_b >= 0, "segger_posmlp_bwd: negative size");
   SEGGER_REQUIRE(dtype == SEGGER_BF16 || dtype == SEGGER_F16, "segger_posmlp_bwd: bf16 / f16 only");
   SEGGER_REQUIRE(grad_w0 && grad_b0 && grad_w2 && grad_b2, "segger_posmlp_bwd: NULL output");
-  if (n_rows == 0) {
+  if (n_rows_a == 0 && n_rows_b == 0) {
     SEGGER_HIP(hipMemsetAsync(grad_w0, 0, (size_t)kPbD * kPbF * sizeof(float), stream));
     SEGGER_HIP(hipMemsetAsync(grad_b0, 0, (size_t)kPbD * sizeof(float), stream));
     SEGGER_HIP(hipMemsetAsync(grad_w2, 0, (size_t)kPbD * kPbD * sizeof(float), stream));
     SEGGER_HIP(hipMemsetAsync(grad_b2, 0, (size_t)kPbD * sizeof(float), stream));
     return SEGGER_OK;
   }
-  SEGGER_REQUIRE(g && z1 && pn && w2_t, "segger_posmlp_bwd: NULL input");
-  SEGGER_REQUIRE(aligned16(g) && aligned16(z1) && aligned16(pn) && aligned16(w2_t) && ld_g >= kPbD && (ld_g * 2) % 16 == 0,
-                 "segger_posmlp_bwd: rows must be 16-byte aligned");
-  const size_t need = segger_posmlp_bwd_workspace_bytes(n_rows);
+  SEGGER_REQUIRE(w2_t && aligned16(w2_t), "segger_posmlp_bwd: NULL / misaligned W2^T");
+  const size_t need = segger_posmlp_bwd_pair_workspace_bytes(n_rows_a, n_rows_b);
   if (workspace == nullptr || workspace_bytes < need) {
     set_error("segger_posmlp_bwd: workspace %zu < %zu bytes", workspace_bytes, need);
     return SEGGER_EWORKSPACE;
   }
-  const int64_t grid = posmlp_bwd_grid(n_rows);
-  const int64_t stages = (n_rows + kStageRows - 1) / kStageRows;
-  SEGGER_REQUIRE(((stages + grid - 1) / grid + kPbAhead) * kStageRows * ld_g * 2 < (int64_t)kOutOfRange,
-                 "segger_posmlp_bwd: a workgroup's row slab exceeds 1 GiB");
+  const int64_t grid_a = n_rows_a > 0 ? posmlp_bwd_grid(n_rows_a) : 0, grid_b = n_rows_b > 0 ? posmlp_bwd_grid(n_rows_b) : 0;
+  const int64_t grid = grid_a + grid_b;
   float* part2 = static_cast<float*>(workspace);
   float* part0 = part2 + (size_t)(grid + kRedGroups) * kPbWidth2;
-  PosBwdParams p{g, ld_g, z1, pn, w2_t, n_rows, stages, (stages + grid - 1) / grid, part2, part0, logf(max_period)};
+  const float lmp = logf(max_period);
+  auto side = [&](const void* g, int64_t ld_g, const void* z1, const float* pn, int64_t n_rows, int64_t grid_s, int64_t first,
+                  PosBwdParams& out) -> int {
+    if (n_rows == 0) { out = PosBwdParams{nullptr, kPbD, nullptr, nullptr, w2_t, 0, 0, 0, part2, part0, lmp}; return SEGGER_OK; }
+    SEGGER_REQUIRE(g && z1 && pn, "segger_posmlp_bwd: NULL input");
+    SEGGER_REQUIRE(aligned16(g) && aligned16(z1) && aligned16(pn) && ld_g >= kPbD && (ld_g * 2) % 16 == 0,
+                   "segger_posmlp_bwd: rows must be 16-byte aligned");
+    const int64_t stages = (n_rows + kStageRows - 1) / kStageRows;
+    SEGGER_REQUIRE(((stages + grid_s - 1) / grid_s + kPbAhead) * kStageRows * ld_g * 2 < (int64_t)kOutOfRange,
+                   "segger_posmlp_bwd: a workgroup's row slab exceeds 1 GiB");
+    out = PosBwdParams{g, ld_g, z1, pn, w2_t, n_rows, stages, (stages + grid_s - 1) / grid_s, part2 + (size_t)first * kPbWidth2,
+                       part0 + (size_t)first * kPbWidth0, lmp};
+    return SEGGER_OK;
+  };
+  PosBwdParams pa, pb;
+  int rc = side(g_a, ld_ga, z1_a, pn_a, n_rows_a, grid_a, 0, pa);
+  if (rc != SEGGER_OK) return rc;
+  rc = side(g_b, ld_gb, z1_b, pn_b, n_rows_b, grid_b, grid_a, pb);
+  if (rc != SEGGER_OK) return rc;
   if (dtype == SEGGER_BF16)
-    hipLaunchKernelGGL((posmlp_bwd_kernel<bf16_t>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((posmlp_bwd_kernel<bf16_t>), dim3((unsigned)grid), dim3(512), 0, stream, pa, pb, (int)grid_a);
   else
-    hipLaunchKernelGGL((posmlp_bwd_kernel<f16_t>), dim3((unsigned)grid), dim3(512), 0, stream, p);
+    hipLaunchKernelGGL((posmlp_bwd_kernel<f16_t>), dim3((unsigned)grid), dim3(512), 0, stream, pa, pb, (int)grid_a);
   SEGGER_LAUNCH_CHECK("posmlp_bwd_kernel");
-  const int rc = reduce_partials(part2, grid, kPbD, kPbD, grad_w2, grad_b2, stream);
+  rc = reduce_partials(part2, grid, kPbD, kPbD, grad_w2, grad_b2, stream);
   if (rc != SEGGER_OK) return rc;
   return reduce_partials(part0, grid, kPbD, kPbF, grad_w0, grad_b0, stream);
+}
+
+extern "C" int segger_posmlp_bwd(const void* g, int64_t ld_g, const void* z1, const float* pn, const void* w2_t,
+                                 int64_t n_rows, float max_period, int32_t dtype, float* grad_w0, float* grad_b0,
+                                 float* grad_w2, float* grad_b2, void* workspace, size_t workspace_bytes,
+                                 segger_stream_t stream_) {
+  return segger_posmlp_bwd_pair(g, ld_g, z1, pn, n_rows, nullptr, kPbD, nullptr, nullptr, 0, w2_t, max_period, dtype, grad_w0,
+                                grad_b0, grad_w2, grad_b2, workspace, workspace_bytes, stream_);
 }

@@ -138,6 +138,20 @@ class Positional2dEmbedder(Module):
         return F.gelu(h) if gelu else h
 
 
+def _pair_node(emb: "Positional2dEmbedder", pos_a, batch_a, pos_b, batch_b, num_graphs, dtype):
+    """``((gelu(pe_a), pe_a), pe_b)`` from ONE autograd node (``ops.posmlp_pair``), or None where that route does not
+    apply -- then the caller embeds each node type by its own call."""
+    fd = emb.frequency_embedding_size
+    l0, l2 = emb.mlp[0], emb.mlp[2]
+    if not (POS_PAIR_NODE and emb.fused and pos_a.is_cuda and fd % 16 == 0 and batch_a is not None and batch_b is not None
+            and num_graphs is not None and ops.posmlp_pair_supported(l0.weight, l0.bias, l2.weight, l2.bias, dtype)):
+        return None
+    mm_a = ops.segment_minmax(pos_a, batch_a, num_graphs, keep_empty=True)
+    mm_b = ops.segment_minmax(pos_b, batch_b, num_graphs, keep_empty=True)
+    return ops.posmlp_pair(pos_a, batch_a, mm_a[0], mm_a[1], pos_b, batch_b, mm_b[0], mm_b[1], l0.weight, l0.bias, l2.weight,
+                           l2.bias, dtype, eps=1e-8, max_period=10000.0)
+
+
 class _SplitRows(torch.autograd.Function):
     """[n_a + n_b, D] -> ([n_a, D], [n_b, D]) as views; backward = one ``cat`` (autograd's own slicing would zero-fill
     and add a full-size matrix per slice)."""
@@ -161,6 +175,7 @@ class _SplitRows(torch.autograd.Function):
 
 MERGED_POS_EMBED = True     # one embedder call for both node types (tools flip it for A/B runs)
 FRONT_JOIN = True           # ... and one gather / concat / GELU launch for both (ops.front_join); False: per type, torch on 'bd'
+POS_PAIR_NODE = True        # large batches (one embedder call per type): both calls behind one autograd node (ops.posmlp_pair)
 
 
 class GATv2Conv(Module):
@@ -390,6 +405,11 @@ class ISTEncoder(Module):
         # (large batches -- the `split` route -- keep one call per type: there the launches do not matter, and joining
         # the two gradients of the embedder's output would copy a [n_tx, D] matrix)
         if staged is None and (not MERGED_POS_EMBED or gelu or b_tx is None or b_bd is None or num_graphs is None):
+            if gelu and bd_plain:
+                # one call per type, ONE autograd node: the embedder's parameters receive one gradient (16-bit fused route)
+                both = _pair_node(self.pos_emb, pos_dict["tx"], b_tx, pos_dict["bd"], b_bd, num_graphs, dt)
+                if both is not None:
+                    return both[0], both[1], None, True
             one = lambda k, g=gelu, **kw: self.pos_emb(pos_dict[k], batch_dict.get(k), num_graphs=num_graphs, dtype=dt,
                                                        gelu=g, **kw)
             return (one("tx", return_pre=True) if gelu else one("tx")), one("bd", gelu and not bd_plain), None, bd_plain or not gelu

@@ -2333,6 +2333,104 @@ class _PosMlp(torch.autograd.Function):
                 gb0 if need[10] else None, gw2 if need[11] else None, gb2 if need[12] else None)
 
 
+def _posmlp_fwd_launch(pos, batch, mins, maxs, eps, max_period, dtype, train, gelu, pk0, pk2, d):
+    """One ``segger_posmlp_fwd`` launch -> (pe, z1, pn, pre): what ``_PosMlp`` / ``_PosMlpPair`` keep of a row set (the
+    one-pass backward recomputes h1)."""
+    dev = pos.device
+    pos = pos.to(torch.float32).contiguous()
+    n = int(pos.shape[0])
+    if batch is not None:
+        batch = batch.to(device=dev, dtype=torch.int64).contiguous()
+    pe = torch.empty((n, 2 * d), dtype=dtype, device=dev)
+    z1 = torch.empty((2 * n, d), dtype=dtype, device=dev) if train else None
+    pn = torch.empty(2 * n, dtype=torch.float32, device=dev) if train else None
+    pre = torch.empty_like(pe) if (train and gelu) else None
+    with _lib.on_device(dev):
+        rc = _lib.load().segger_posmlp_fwd(pos.data_ptr(), _lib.ptr(batch), mins.data_ptr(), maxs.data_ptr(), n, float(eps),
+                                           float(max_period), pk0.w.data_ptr(), pk0.b.data_ptr(), pk2.w.data_ptr(),
+                                           pk2.b.data_ptr(), pe.data_ptr(), _lib.ptr(z1), _lib.ptr(pn), None, _lib.ptr(pre),
+                                           int(gelu), DTYPE_CODE[dtype], _lib.stream_ptr(dev))
+    _lib.check(rc, "segger_posmlp_fwd")
+    return pe, z1, pn, pre
+
+
+class _PosMlpPair(torch.autograd.Function):
+    """``Positional2dEmbedder`` of TWO row sets as one autograd node: a = the transcripts (GELU applied in the kernel,
+    ``(gelu(pre), pre)`` out as ``posmlp(return_pre=True)``), b = the boundaries (plain).  Two forward launches; the
+    backward is ONE ``segger_posmlp_bwd_pair`` launch whose partial sums cover both sets, so the embedder's parameters get a
+    single gradient each -- two ``_PosMlp`` nodes cost four accumulation launches behind autograd."""
+
+    @staticmethod
+    def forward(ctx, pos_a, batch_a, mins_a, maxs_a, pos_b, batch_b, mins_b, maxs_b, eps, max_period, dtype, w0, b0, w2, b2):
+        _lib.require_cuda(pos_a, pos_b, w0)
+        dev = pos_a.device
+        d = int(w0.shape[0])
+        pk0 = _pack_for((w0,), (b0,)).get(dtype, dev)
+        pk2 = _pack_for((w2,), (b2,)).get(dtype, dev)
+        ctx.set_materialize_grads(False)
+        pe_a, z1_a, pn_a, pre_a = _posmlp_fwd_launch(pos_a, batch_a, mins_a, maxs_a, eps, max_period, dtype, True, 2, pk0, pk2, d)
+        pe_b, z1_b, pn_b, _ = _posmlp_fwd_launch(pos_b, batch_b, mins_b, maxs_b, eps, max_period, dtype, True, 0, pk0, pk2, d)
+        ctx.save_for_backward(z1_a, pn_a, z1_b, pn_b)
+        ctx.pk2, ctx.key2, ctx.max_period = pk2, pk2.key, float(max_period)
+        ctx.mark_non_differentiable(pe_a)                    # gelu(pre) leaves as a constant; `pre` carries the gradient
+        return pe_a, pre_a, pe_b
+
+    @staticmethod
+    def backward(ctx, _gpe_a, gpre_a, gpe_b):
+        z1_a, pn_a, z1_b, pn_b = ctx.saved_tensors
+        if gpre_a is None and gpe_b is None:
+            return (None,) * 15
+        if ctx.pk2.key != ctx.key2:
+            raise RuntimeError("the positional MLP's weights changed between this forward and its backward")
+        dt, d, dev = z1_a.dtype, int(z1_a.shape[1]), z1_a.device
+        lib = _lib.load()
+
+        def rows(g):
+            if g is None:
+                return None, d, 0
+            g = g.to(dt).reshape(-1, d)
+            if g.shape[0] > 1 and g.stride(1) != 1:
+                g = g.contiguous()
+            gp, ldg = _rows(g, d, "g")
+            return (g, gp), ldg, int(g.shape[0])
+        ga, lda, na = rows(gpre_a)
+        gb, ldb, nb = rows(gpe_b)
+        gw0 = torch.empty((d, 4 * d), dtype=torch.float32, device=dev)
+        gb0 = torch.empty(d, dtype=torch.float32, device=dev)
+        gw2 = torch.empty((d, d), dtype=torch.float32, device=dev)
+        gb2 = torch.empty(d, dtype=torch.float32, device=dev)
+        ws_bytes = lib.segger_posmlp_bwd_pair_workspace_bytes(na, nb)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _lib.on_device(dev):
+            rc = lib.segger_posmlp_bwd_pair(ga[1] if ga else None, lda, z1_a.data_ptr(), pn_a.data_ptr(), na,
+                                            gb[1] if gb else None, ldb, z1_b.data_ptr(), pn_b.data_ptr(), nb,
+                                            ctx.pk2.wt.data_ptr(), ctx.max_period, DTYPE_CODE[dt], gw0.data_ptr(), gb0.data_ptr(),
+                                            gw2.data_ptr(), gb2.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_posmlp_bwd_pair")
+        _defer_keep(ws, gw0, gb0, gw2, gb2, ga, gb)
+        need = ctx.needs_input_grad
+        return (None,) * 11 + (gw0 if need[11] else None, gb0 if need[12] else None, gw2 if need[13] else None,
+                               gb2 if need[14] else None)
+
+
+def posmlp_pair_supported(w0: Tensor, b0, w2: Tensor, b2, dtype: torch.dtype) -> bool:
+    """The one-node route of :func:`posmlp_pair`: the fused 16-bit embedder with its one-pass backward, training."""
+    return (FUSED_POSMLP_BWD and b0 is not None and b2 is not None and posmlp_supported(w0.shape[1], w0.shape[0], dtype)
+            and tuple(w2.shape) == (w0.shape[0], w0.shape[0]) and torch.is_grad_enabled()
+            and any(t.requires_grad for t in (w0, b0, w2, b2)))
+
+
+def posmlp_pair(pos_a: Tensor, batch_a, mins_a: Tensor, maxs_a: Tensor, pos_b: Tensor, batch_b, mins_b: Tensor, maxs_b: Tensor,
+                w0: Tensor, b0: Tensor, w2: Tensor, b2: Tensor, dtype: torch.dtype, eps: float = 1e-8, max_period: float = 10000.0):
+    """``((gelu(pe_a), pe_a), pe_b)``: :func:`posmlp` of two row sets (``a`` as ``gelu=True, return_pre=True``, ``b`` plain)
+    behind ONE autograd node (:class:`_PosMlpPair`); see :func:`posmlp_pair_supported`."""
+    if not posmlp_pair_supported(w0, b0, w2, b2, dtype):
+        raise ValueError("posmlp_pair: unsupported (see posmlp_pair_supported)")
+    act_a, pre_a, pe_b = _PosMlpPair.apply(pos_a, batch_a, mins_a, maxs_a, pos_b, batch_b, mins_b, maxs_b, eps, max_period, dtype,
+                                           w0, b0, w2, b2)
+    return (act_a, pre_a), pe_b
+
+
 def posmlp(pos: Tensor, batch: Optional[Tensor], mins: Tensor, maxs: Tensor, w0: Tensor, b0: Tensor, w2: Tensor,
            b2: Tensor, dtype: torch.dtype, eps: float = 1e-8, max_period: float = 10000.0, gelu: bool = False,
            return_pre: bool = False):

@@ -606,6 +606,58 @@ def test_fused_positional_embedder_matches_unfused_route(cuda, dtype, n):
         assert torch.equal(emb(pos, batch, num_graphs=3, dtype=dtype), pe)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("na,nb", [(40_003, 517), (1000, 1), (7, 5000)])
+def test_positional_embedder_pair_is_one_node_with_the_summed_gradients(cuda, dtype, na, nb):
+    """ops.posmlp_pair (two row sets, ONE autograd node, ONE segger_posmlp_bwd_pair launch) against two ops.posmlp nodes:
+    outputs bit-identical (same forward kernel), parameter gradients equal to the sum autograd forms from the two nodes up to
+    the order of the fp32 partial sums; one side without a gradient; the encoder's large-batch route takes it."""
+    from segger_amd import ops
+    from segger_amd.ist_encoder import Positional2dEmbedder
+    g = torch.Generator().manual_seed(na + nb)
+    pos_a = (torch.rand(na, 2, generator=g) * 500).to(cuda)
+    pos_b = (torch.rand(nb, 2, generator=g) * 500).to(cuda)
+    ba = torch.sort(torch.randint(0, 3, (na,), generator=g)).values.to(cuda)
+    bb = torch.sort(torch.randint(0, 3, (nb,), generator=g)).values.to(cuda)
+    emb = Positional2dEmbedder(128).to(cuda)
+    with torch.no_grad():
+        for p_ in emb.parameters():
+            p_.mul_(3.0)
+    l0, l2 = emb.mlp[0], emb.mlp[2]
+    mm_a, mm_b = ops.segment_minmax(pos_a, ba, 3, keep_empty=True), ops.segment_minmax(pos_b, bb, 3, keep_empty=True)
+    args = (l0.weight, l0.bias, l2.weight, l2.bias, dtype)
+    gen = torch.Generator(device=cuda).manual_seed(2)
+    g_a = torch.randn(na, 128, device=cuda, generator=gen).to(dtype)
+    g_b = torch.randn(nb, 128, device=cuda, generator=gen).to(dtype)
+
+    def separate(use_a=True, use_b=True):
+        emb.zero_grad()
+        act, pre = ops.posmlp(pos_a, ba, mm_a[0], mm_a[1], *args, gelu=True, return_pre=True)
+        pe_b = ops.posmlp(pos_b, bb, mm_b[0], mm_b[1], *args)
+        torch.autograd.backward([t for t, u in ((pre, use_a), (pe_b, use_b)) if u], [t for t, u in ((g_a, use_a), (g_b, use_b)) if u])
+        return act, pre.detach(), pe_b.detach(), [p_.grad.clone() for p_ in emb.parameters()]
+
+    def pair(use_a=True, use_b=True):
+        emb.zero_grad()
+        (act, pre), pe_b = ops.posmlp_pair(pos_a, ba, mm_a[0], mm_a[1], pos_b, bb, mm_b[0], mm_b[1], *args)
+        assert not act.requires_grad and pre.grad_fn is pe_b.grad_fn          # one node
+        torch.autograd.backward([t for t, u in ((pre, use_a), (pe_b, use_b)) if u], [t for t, u in ((g_a, use_a), (g_b, use_b)) if u])
+        return act, pre.detach(), pe_b.detach(), [p_.grad.clone() for p_ in emb.parameters()]
+
+    for use in ((True, True), (True, False), (False, True)):
+        ref, got = separate(*use), pair(*use)
+        for a, b in zip(ref[:3], got[:3]):
+            assert torch.equal(a, b)
+        for a, b in zip(ref[3], got[3]):
+            assert (a - b).abs().max().item() <= 2e-6 * a.abs().max().item() + 1e-7
+    # the encoder: one call per node type on the split route -> one node when the switch is on, same step either way
+    import segger_amd.ist_encoder as ie
+    assert ie._pair_node(emb, pos_a, ba, pos_b, bb, 3, dtype) is not None
+    assert ie._pair_node(emb, pos_a, ba, pos_b, bb, 3, torch.float32) is None          # (the fused embedder is 16-bit)
+    with torch.no_grad():
+        assert ie._pair_node(emb, pos_a, ba, pos_b, bb, 3, dtype) is None              # (nothing to differentiate)
+
+
 def test_step_draws_equal_the_separate_launches(cuda):
     """segger_step_draws (all random draws of a training step in one launch: bit planes of the edge views, both triplet
     samplers, the negative boundaries, + the increment of Adam's step counters) against dropout_bits_many, triplet_sample x 2
