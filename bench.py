@@ -1021,8 +1021,9 @@ def main():
             torch.cuda.synchronize()
             d32 = (time.perf_counter() - t0) / n32
             f32 = {"ms_per_step": d32 * 1e3, "value": 2.0 * etb / d32, "unit": "edges/s", "steps": n32,
-                   "note": "same tile and step, activations stored in fp32 (projections on the exact-fp32 MFMA kernels, "
-                           "csrc/linear_f32.hip)"}
+                   "note": "same tile and step, activations stored in fp32; projections on the bf16x3 split of the fp32 operands "
+                           "(csrc/linear_f32_split.hip: error within the exact-fp32 MFMA kernels' own), "
+                           + ("the default" if ops.F32_SPLIT else "switched off: exact-fp32 MFMA kernels, csrc/linear_f32.hip")}
             log(f"[bench] f32 step {d32 * 1e3:.2f} ms")
         except Exception as e:  # noqa: BLE001  (secondary figure, single process)
             log(f"[bench] f32 figure skipped: {type(e).__name__}: {e}")
