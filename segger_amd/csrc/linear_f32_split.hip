@@ -607,7 +607,7 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
   };
   // the finished tile waiting for its store: accumulators, byte offsets of this lane's row in y / gate (~0: no row), gate
   f32x16 pend[NCT];
-  uint32_t pend_y = kNoRow, pend_g = kNoRow;
+  uint32_t pend_y = kNoRow;
   f32x4 gq[GATE ? NCT * 4 : 1];
 #pragma unroll
   for (int ct = 0; ct < NCT; ++ct)

@@ -84,3 +84,14 @@ def test_flagship_aggregation_and_projection_kernels_use_no_scratch(table):
     for n in want:
         assert n in table, n
         assert table[n]["scratch"] == 0, (n, table[n])
+
+
+def test_w_resident_fp32_split_kernels_fit_their_register_file(table):
+    """linear_f32_split_wres_kernel keeps 288 registers of weight fragments per lane at one wave per SIMD (512 registers): a
+    spill there is a scratch round trip inside the MFMA loop -- and its LDS tiles (two buffers of three planes) must fit
+    the CU's 160 KB."""
+    names = [n for n in table if n.startswith("linear_f32_split_wres_kernel<")]
+    assert len(names) >= 6, names
+    for n in names:
+        r = table[n]
+        assert r["scratch"] == 0 and r["vgpr"] <= 512 and r["lds"] <= 160 * 1024, (n, r)
