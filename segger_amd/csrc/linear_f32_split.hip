@@ -309,9 +309,11 @@ __global__ __launch_bounds__(NW * 64) void wgrad_f32_split_kernel(WgSplitParams 
   constexpr int SY = M * 2 + 64, SX = K * 2 + 64;                 // bytes per row of a plane
   constexpr int PY = kWgRows * SY, PX = kWgRows * SX;             // one plane of a stage
   constexpr int BUF = 3 * PY + 3 * PX;
-  constexpr int PPR = (M + K) / 4;                                // 16-byte pieces per stage row (dY then X)
-  static_assert((kWgRows * PPR) % NT == 0, "pieces do not split evenly over the workgroup");
-  constexpr int PIECES = kWgRows * PPR / NT;
+  // 16-byte pieces of a stage per thread: first its dY pieces, then its X pieces (which matrix piece j belongs to is a
+  // compile-time fact: no per-lane pointer select, no branch around the bias sums)
+  static_assert((kWgRows * M / 4) % NT == 0 && (kWgRows * K / 4) % NT == 0, "pieces do not split evenly over the workgroup");
+  constexpr int NPY = kWgRows * M / 4 / NT, NPX = kWgRows * K / 4 / NT;
+  constexpr int PIECES = NPY + NPX;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -327,11 +329,11 @@ __global__ __launch_bounds__(NW * 64) void wgrad_f32_split_kernel(WgSplitParams 
   bool pis_y[PIECES];
 #pragma unroll
   for (int j = 0; j < PIECES; ++j) {
-    const int q = tid + j * NT, row = q / PPR, c = q % PPR;
-    prow[j] = row;
-    pis_y[j] = c < M / 4;
-    pcol[j] = pis_y[j] ? 4 * c : 4 * (c - M / 4);
-    pdst[j] = pis_y[j] ? row * SY + pcol[j] * 2 : 3 * PY + row * SX + pcol[j] * 2;
+    pis_y[j] = j < NPY;
+    const int q = tid + (pis_y[j] ? j : j - NPY) * NT, ppr = (pis_y[j] ? M : K) / 4;
+    prow[j] = q / ppr;
+    pcol[j] = 4 * (q % ppr);
+    pdst[j] = pis_y[j] ? prow[j] * SY + pcol[j] * 2 : 3 * PY + prow[j] * SX + pcol[j] * 2;
   }
 #ifndef SEGGER_WGS_AHEAD
 #define SEGGER_WGS_AHEAD 1                     // stages of global loads in flight (register slots): 1M x (384, 128) on one
@@ -425,12 +427,116 @@ __global__ __launch_bounds__(NW * 64) void wgrad_f32_split_kernel(WgSplitParams 
         acc[a][b] = c;
       }
   };
+#ifndef SEGGER_WGS_PIPE
+#define SEGGER_WGS_PIPE 1                      // stage s's MFMAs with stage s + 1's split between them (below)
+#endif
+#if SEGGER_WGS_PIPE && SEGGER_WGS_AHEAD == 1
+  // The form above runs a VALU phase (the split: ~170 instructions) and an MFMA phase (36 x 8 passes) per stage one after
+  // the other -- and the workgroup's barrier keeps both waves of a SIMD in the SAME phase, so nothing overlaps them
+  // (measured 0.55 ms = their sum, against 0.33 for the MFMAs alone at the clock this data allows).  Software pipeline:
+  // iteration s reads stage s's fragments (written to buffer s & 1 during iteration s - 1) and issues its MFMAs with the
+  // split of stage s + 1's rows -- into the other buffer, whose readers all passed this iteration's barrier -- between
+  // them, a few VALU per MFMA (one wave issues in order: only what sits BETWEEN two MFMAs runs in the first one's shadow),
+  // each ring register refilled with stage s + 2's piece right after its split.  Still one barrier per stage.
+  constexpr int NCH = PIECES * 5;              // side chunks of an iteration: per piece 3 of arithmetic, 1 of LDS writes, 1 load
+  constexpr int NMF = MT * KT * 6;
+  pk2 sva[PIECES], svb[PIECES], sra[PIECES], srb[PIECES];
+  uint32_t sh[PIECES][2], sm[PIECES][2], sl[PIECES][2];
+  auto up = [](uint32_t w) { float a, b; Vec8<bf16_t>::unpack2(w, a, b); return pk2{a, b}; };
+  // the block's slab of each matrix as a raw buffer (rows past the matrix: out of range = zeros; stages past the slab: the
+  // out-of-range sentinel): 32-bit offsets inside the slab, no clamp and no select on loaded data
+  const int64_t slab_row = s_beg * kWgRows;
+  auto slab = [&](const float* base, int64_t ld) {
+    const int64_t left = p.n_rows > slab_row ? (p.n_rows - slab_row) * ld * 4 : 0;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + slab_row * ld), 0, (int)(uint32_t)(left < 0xfffff000LL ? left : 0xfffff000LL),
+                                             0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t yb = slab(p.dy, p.ld_dy), xb = slab(p.x, p.ld_x);
+  uint32_t poff[PIECES];
+#pragma unroll
+  for (int j = 0; j < PIECES; ++j) poff[j] = (uint32_t)(prow[j] * (pis_y[j] ? p.ld_dy : p.ld_x) + pcol[j]) * 4u;
+  const uint32_t sy4 = (uint32_t)(kWgRows * p.ld_dy * 4), sx4 = (uint32_t)(kWgRows * p.ld_x * 4);
+  auto fetch_piece = [&](int j, int64_t st) {                   // st: absolute stage
+    const uint32_t sl_ = (uint32_t)(st - s_beg);
+    const uint32_t off = st < s_end ? poff[j] + sl_ * (pis_y[j] ? sy4 : sx4) : 0xfffff000u;
+    ring[0][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(pis_y[j] ? yb : xb, off, 0, 0));
+  };
+  auto side = [&](auto c_c, unsigned char* nbuf, int64_t st) {  // st: the stage whose MFMAs run; the ring holds stage st + 1
+    constexpr int c = decltype(c_c)::value;
+    if constexpr (c < NCH) {
+      constexpr int j = c / 5, ph = c % 5;
+      if constexpr (ph == 0) {
+        const f32x4 v = ring[0][j];
+        sva[j] = pk2{v.x, v.y}; svb[j] = pk2{v.z, v.w};
+        if (pis_y[j]) dbp[j] = dbp[j] + v;
+        sh[j][0] = Vec8<bf16_t>::pack(v.x, v.y); sh[j][1] = Vec8<bf16_t>::pack(v.z, v.w);
+      } else if constexpr (ph == 1) {
+        sra[j] = sva[j] - up(sh[j][0]); srb[j] = svb[j] - up(sh[j][1]);
+        sm[j][0] = Vec8<bf16_t>::pack(sra[j].x, sra[j].y); sm[j][1] = Vec8<bf16_t>::pack(srb[j].x, srb[j].y);
+      } else if constexpr (ph == 2) {
+        const pk2 la = sra[j] - up(sm[j][0]), lb = srb[j] - up(sm[j][1]);
+        sl[j][0] = Vec8<bf16_t>::pack(la.x, la.y); sl[j][1] = Vec8<bf16_t>::pack(lb.x, lb.y);
+      } else if constexpr (ph == 3) {
+        const int plane = pis_y[j] ? PY : PX;
+        *reinterpret_cast<u32x2s*>(nbuf + pdst[j]) = u32x2s{sh[j][0], sh[j][1]};
+        *reinterpret_cast<u32x2s*>(nbuf + pdst[j] + plane) = u32x2s{sm[j][0], sm[j][1]};
+        *reinterpret_cast<u32x2s*>(nbuf + pdst[j] + 2 * plane) = u32x2s{sl[j][0], sl[j][1]};
+      } else {
+        fetch_piece(j, st + 2);
+      }
+    }
+  };
+  // prologue: stage s_beg's planes into buffer 0, stage s_beg + 1's rows into the ring
+#pragma unroll
+  for (int j = 0; j < PIECES; ++j) fetch_piece(j, s_beg);
+  static_for_wgs<NCH>([&](auto c_c) {
+    if constexpr (decltype(c_c)::value % 5 != 4) side(c_c, lds, s_beg - 1);
+  });
+#pragma unroll
+  for (int j = 0; j < PIECES; ++j) { fetch_piece(j, s_beg + 1); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll 1
+  for (int64_t s = s_beg; s < s_end; ++s) {
+    unsigned char* buf = lds + ((s - s_beg) & 1) * BUF;
+    unsigned char* nbuf = lds + (((s - s_beg) & 1) ^ 1) * BUF;
+    lds_barrier();             // stage s's planes are complete; every wave has left the other buffer (stage s - 1)
+    u32x4 fa[3][MT], fb[3][KT];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+#pragma unroll
+      for (int a = 0; a < MT; ++a) {
+        const u32x2s lo = lds_read_tr_s(buf + q * PY + off_y + a * 64);
+        const u32x2s hi = lds_read_tr_s(buf + q * PY + off_y + a * 64 + 4 * SY);
+        fa[q][a] = u32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+#pragma unroll
+      for (int b = 0; b < KT; ++b) {
+        const u32x2s lo = lds_read_tr_s(buf + q * PX + off_x + b * 64);
+        const u32x2s hi = lds_read_tr_s(buf + q * PX + off_x + b * 64 + 4 * SX);
+        fb[q][b] = u32x4{lo.x, lo.y, hi.x, hi.y};
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    static_for_wgs<NMF>([&](auto i_c) {
+      constexpr int i = decltype(i_c)::value;
+      constexpr int tile = i / 6, pr = i % 6, a = tile / KT, b = tile % KT;
+      constexpr int qa = pr == 0 ? 2 : (pr == 2 || pr == 3) ? 1 : 0;       // smallest terms first (as above)
+      constexpr int qb = pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
+      acc[a][b] = mfma_bf16(fa[qa][a], fb[qb][b], acc[a][b]);
+      // chunks [i * NCH / NMF, (i + 1) * NCH / NMF) of the side work behind this MFMA
+      static_for_wgs<(i + 1) * NCH / NMF - i * NCH / NMF>([&](auto d_c) {
+        side(std::integral_constant<int, i * NCH / NMF + decltype(d_c)::value>{}, nbuf, s);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  }
+#else
   static_for_wgs<AH>([&](auto d) { fetch(d, s_beg + decltype(d)::value); });
   int64_t s = s_beg;
 #pragma unroll 1
   for (; s + AH <= s_end; s += AH)
     static_for_wgs<AH>([&](auto d) { stage(d, s + decltype(d)::value); });
   static_for_wgs<AH>([&](auto d) { if (s + decltype(d)::value < s_end) stage(d, s + decltype(d)::value); });
+#endif
 
   // acc tile (a, b) element e of lane l is dW[m][k]: m = 32 (wm MT + a) + (e & 3) + 8 (e >> 2) + 4 (l >> 5), k = 32 (wk KT + b) + (l & 31)
   float* out = p.partial + (int64_t)blockIdx.x * ((int64_t)M * K + M);
@@ -484,6 +590,9 @@ int wgrad_f32_split_launch(const float* dy, int64_t ld_dy, const float* x, int64
   WgSplitParams p{dy, ld_dy, x, ld_x, n_rows, (n_rows + kWgRows - 1) / kWgRows, 0, partial};
   p.stages_per_block = (p.n_stages + grid - 1) / grid;
   *n_slabs = grid;
+  // (the kernel addresses a workgroup's slab of rows with 32-bit byte offsets)
+  SEGGER_REQUIRE((p.stages_per_block + 2) * kWgRows * (ld_dy > ld_x ? ld_dy : ld_x) * 4 < 0xfffff000LL,
+                 "segger_linear_wgrad_f32_split: a workgroup's row slab exceeds 4 GiB");
 #define CASE(MM, KK) if (m_out == MM && k_in == KK) { \
     hipLaunchKernelGGL((wgrad_f32_split_kernel<MM, KK, split_waves(MM, KK)>), dim3((unsigned)grid), dim3(split_waves(MM, KK) * 64), 0, stream, p); \
     SEGGER_LAUNCH_CHECK("wgrad_f32_split_kernel"); return SEGGER_OK; }
