@@ -783,6 +783,105 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
 #ifdef EXP_FS_STAMPS
     long long c1 = 0, c2 = 0, c3 = 0;
 #endif
+    // In-order issue: an MFMA behind an MFMA waits out the first one's 8 passes, with everything behind it.  The side work
+    // only runs in the shadow of the matrix pipe if it sits BETWEEN the MFMAs (about 4 VALU fit free, tools/micro/
+    // mfma_shadow.hip) -- and at this register count the machine scheduler keeps the source order (it reverts its own
+    // schedule when that raises the pressure; sched_group_barrier pipelines were ignored), so the source IS the schedule.
+    // A tile is NKS x 6 x NCT MFMA slots.  Behind slot i:
+    //   * gated form, k-steps below HEAD: one stage of the stored tile's gate factors (two values per k-step, register pairs)
+    //   * from slot S0 on (0 un-gated, HEAD x 6 gated), spread evenly over SPAN slots: the NP pieces of the next tile's rows
+    //     -> planes, eight chunks each (six of the split's arithmetic, the LDS writes, the refill of the piece's register
+    //     with the rows of the tile after that: a piece is in flight for a whole tile); before the first chunk this tile's
+    //     gate values on their way, behind the last one the previous tile's stores.
+    // (NCT = 3: a slot is three MFMAs, there the pieces stay on k-steps HEAD .. HEAD + NP - 1 -- spread over the whole tile the
+    //  forward measured 5 % slower)
+    constexpr int S0 = (GATE != 0 || NCT > 1) ? HEAD * 6 : 0, SPAN = NCT > 1 ? NP * 6 : NKS * 6 - S0, CPP = 8, NCHK = NP * CPP;
+    static_assert(S0 + SPAN <= NKS * 6, "the split must end with the tile");
+    pk2 gx, gsa, gpdf, gq2, ghalf, gcdf;           // the gate stages' values of the k-step in progress
+    pk2 cva, cvb, cra, crb;                        // the split's values of the piece in progress
+    uint32_t ch0 = 0, ch1 = 0, cm0 = 0, cm1 = 0, cl0 = 0, cl1 = 0;
+    auto up = [](uint32_t w) { float a, b; Vec8<bf16_t>::unpack2(w, a, b); return pk2{a, b}; };
+    auto chunk = [&](auto g_c) {                   // CPP chunks per piece, each about what fits one MFMA's shadow
+      constexpr int g = decltype(g_c)::value, jp = g / CPP, c = g % CPP;
+      if constexpr (g == 0) load_gate(cur_g);
+      if constexpr (c == 0) {
+        cva = pk2{raw[jp].x, raw[jp].y};
+        ch0 = Vec8<bf16_t>::pack(cva.x, cva.y);
+      } else if constexpr (c == 1) {
+        cvb = pk2{raw[jp].z, raw[jp].w};
+        ch1 = Vec8<bf16_t>::pack(cvb.x, cvb.y);
+      } else if constexpr (c == 2) {
+        cra = cva - up(ch0);                                // (exact: the remainder of a round-to-nearest)
+        cm0 = Vec8<bf16_t>::pack(cra.x, cra.y);
+      } else if constexpr (c == 3) {
+        crb = cvb - up(ch1);
+        cm1 = Vec8<bf16_t>::pack(crb.x, crb.y);
+      } else if constexpr (c == 4) {
+        const pk2 la = cra - up(cm0);
+        cl0 = Vec8<bf16_t>::pack(la.x, la.y);
+      } else if constexpr (c == 5) {
+        const pk2 lb = crb - up(cm1);
+        cl1 = Vec8<bf16_t>::pack(lb.x, lb.y);
+      } else if constexpr (c == 6) {
+        unsigned char* d = cbase + nxt + (jp / CPL) * 8 * XS + (jp % CPL) * 256;
+#ifdef EXP_FS_NOSPLIT
+        *reinterpret_cast<u32x2s*>(d) = u32x2s{__float_as_uint(cva.x), __float_as_uint(cva.y)};
+        *reinterpret_cast<u32x2s*>(d + PLANE) = u32x2s{__float_as_uint(cvb.x), __float_as_uint(cvb.y)};
+        *reinterpret_cast<u32x2s*>(d + 2 * PLANE) = u32x2s{__float_as_uint(cva.x) + 1u, __float_as_uint(cvb.y)};
+#else
+        *reinterpret_cast<u32x2s*>(d) = u32x2s{ch0, ch1};
+        *reinterpret_cast<u32x2s*>(d + PLANE) = u32x2s{cm0, cm1};
+        *reinterpret_cast<u32x2s*>(d + 2 * PLANE) = u32x2s{cl0, cl1};
+#endif
+      } else {
+        fetch_piece(t + 2 * G, jp);
+#ifndef EXP_FS_NOSTORE
+        if constexpr (g == NCHK - 1) store_pend();
+#endif
+      }
+    };
+    auto gate_stage = [&](auto s_c, auto i_c) {      // common.h gelu_erf_grad / silu_grad in six stages, values 2 s, 2 s + 1
+      constexpr int s = decltype(s_c)::value, i = decltype(i_c)::value;
+      if constexpr (GATE == 1) {
+        if constexpr (i == 0) {
+          const f32x4 gv = gq[s / 2];
+          gx = (s & 1) ? pk2{gv.z, gv.w} : pk2{gv.x, gv.y};
+          gsa = pk2{fminf(fabsf(gx.x), 5.656854249f), fminf(fabsf(gx.y), 5.656854249f)};
+          const pk2 tt = gx * gx * -0.72134752044448170f;
+          gpdf = pk2{__builtin_amdgcn_exp2f(tt.x), __builtin_amdgcn_exp2f(tt.y)} * 0.3989422804014327f;
+        } else if constexpr (i == 1) {
+          gq2 = pk2{-2.855192741e-06f, -2.855192741e-06f};
+          gq2 = __builtin_elementwise_fma(gq2, gsa, pk2{3.960562235e-05f, 3.960562235e-05f});
+          gq2 = __builtin_elementwise_fma(gq2, gsa, pk2{-1.871826931e-04f, -1.871826931e-04f});
+          gq2 = __builtin_elementwise_fma(gq2, gsa, pk2{-1.347308812e-04f, -1.347308812e-04f});
+          gq2 = __builtin_elementwise_fma(gq2, gsa, pk2{7.060847394e-03f, 7.060847394e-03f});
+        } else if constexpr (i == 2) {
+          gq2 = __builtin_elementwise_fma(gq2, gsa, pk2{-5.249462857e-02f, -5.249462857e-02f});
+          gq2 = __builtin_elementwise_fma(gq2, gsa, pk2{-4.592086259e-01f, -4.592086259e-01f});
+          gq2 = __builtin_elementwise_fma(gq2, gsa, pk2{-1.151105166e+00f, -1.151105166e+00f});
+          gq2 = gq2 * gsa;
+        } else if constexpr (i == 3) {
+          ghalf = pk2{__builtin_amdgcn_exp2f(gq2.x), __builtin_amdgcn_exp2f(gq2.y)} * 0.5f;
+        } else if constexpr (i == 4) {
+          gcdf = pk2{gx.x < 0.f ? ghalf.x : 1.0f - ghalf.x, gx.y < 0.f ? ghalf.y : 1.0f - ghalf.y};
+        } else {
+          const pk2 g2 = __builtin_elementwise_fma(gx, gpdf, gcdf);
+          pend[0][2 * s] *= g2.x; pend[0][2 * s + 1] *= g2.y;
+        }
+      } else if constexpr (GATE == 2) {
+        if constexpr (i == 0) {
+          const f32x4 gv = gq[s / 2];
+          gx = (s & 1) ? pk2{gv.z, gv.w} : pk2{gv.x, gv.y};
+          const pk2 tt = gx * -1.4426950408889634f;
+          gsa = pk2{__builtin_amdgcn_exp2f(tt.x), __builtin_amdgcn_exp2f(tt.y)} + 1.0f;
+        } else if constexpr (i == 1) {
+          gpdf = pk2{__builtin_amdgcn_rcpf(gsa.x), __builtin_amdgcn_rcpf(gsa.y)};      // sigmoid
+        } else if constexpr (i == 2) {
+          const pk2 g2 = gpdf * (gx * (1.0f - gpdf) + 1.0f);
+          pend[0][2 * s] *= g2.x; pend[0][2 * s + 1] *= g2.y;
+        }
+      }
+    };
     static_for_wgs<NKS>([&](auto s_c) {
       constexpr int s = decltype(s_c)::value;
 #ifdef EXP_FS_STAMPS
@@ -795,102 +894,31 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
         for (int q = 0; q < 3; ++q) xf[(s + 1) & 1][q] = *reinterpret_cast<const u32x4*>(cur + q * PLANE + 32 * (s + 1));
       }
       __builtin_amdgcn_sched_barrier(0);           // (the scheduler would sink each read to just before its MFMA)
-      // the six products of this k-step, smallest terms first: (w lo, x hi) (w hi, x lo) (w mid, x mid) (w mid, x hi)
-      // (w hi, x mid) (w hi, x hi)
-      auto mf = [&](auto i_c) {
-        constexpr int i = decltype(i_c)::value;
+      static_for_wgs<6>([&](auto i_c) {
+        constexpr int i = decltype(i_c)::value, slot = s * 6 + i;
+        // the six products of a k-step, smallest terms first: (w lo, x hi) (w hi, x lo) (w mid, x mid) (w mid, x hi)
+        // (w hi, x mid) (w hi, x hi)
         constexpr int wq = i == 0 ? 2 : (i == 2 || i == 3) ? 1 : 0;
         constexpr int xq = i == 1 ? 2 : (i == 2 || i == 4) ? 1 : 0;
 #ifdef EXP_FS_ONEMFMA
-        if constexpr (i != 5) return;
+        if constexpr (i == 5)
 #endif
+        {
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) acc[ct][s % NPAR] = mfma_bf16(wf[wq][ct][s], xf[s & 1][xq], acc[ct][s % NPAR]);
-      };
-      using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-      using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
-      // In-order issue: an MFMA behind an MFMA waits out the first one's 8 passes, with everything behind it.  The k-step's
-      // side work only runs in the shadow of the matrix pipe if it sits BETWEEN the MFMAs -- and at this register count the
-      // machine scheduler keeps the source order (it reverts its own schedule when that raises the pressure), so the source
-      // IS the schedule: each k-step below is MFMA, a few VALU, MFMA, ...
-      if constexpr (s < HEAD && GATE != 0 && 2 * s + 1 < 16) {
-        // the stored tile's gate factors, two values per k-step (packed fp32): pend *= act'(gate)
-        const f32x4 gv = gq[s / 2];
-        const pk2 x = (s & 1) ? pk2{gv.z, gv.w} : pk2{gv.x, gv.y};
-        pk2 g;
-        if constexpr (GATE == 1) {                   // common.h gelu_erf_grad, in stages, on register pairs
-          mf(I0{});
-          const pk2 sa = pk2{fminf(fabsf(x.x), 5.656854249f), fminf(fabsf(x.y), 5.656854249f)};
-          const pk2 t = x * x * -0.72134752044448170f;
-          const pk2 pdf = pk2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} * 0.3989422804014327f;
-          mf(I1{});
-          pk2 q = pk2{-2.855192741e-06f, -2.855192741e-06f};
-          q = __builtin_elementwise_fma(q, sa, pk2{3.960562235e-05f, 3.960562235e-05f});
-          q = __builtin_elementwise_fma(q, sa, pk2{-1.871826931e-04f, -1.871826931e-04f});
-          q = __builtin_elementwise_fma(q, sa, pk2{-1.347308812e-04f, -1.347308812e-04f});
-          q = __builtin_elementwise_fma(q, sa, pk2{7.060847394e-03f, 7.060847394e-03f});
-          mf(I2{});
-          q = __builtin_elementwise_fma(q, sa, pk2{-5.249462857e-02f, -5.249462857e-02f});
-          q = __builtin_elementwise_fma(q, sa, pk2{-4.592086259e-01f, -4.592086259e-01f});
-          q = __builtin_elementwise_fma(q, sa, pk2{-1.151105166e+00f, -1.151105166e+00f});
-          q = q * sa;
-          mf(I3{});
-          const pk2 half = pk2{__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)} * 0.5f;
-          mf(I4{});
-          const pk2 cdf = pk2{x.x < 0.f ? half.x : 1.0f - half.x, x.y < 0.f ? half.y : 1.0f - half.y};
-          mf(I5{});
-          g = __builtin_elementwise_fma(x, pdf, cdf);
-        } else {                                     // common.h silu_grad
-          mf(I0{});
-          const pk2 t = x * -1.4426950408889634f;
-          const pk2 en = pk2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
-          mf(I1{});
-          const pk2 sg = pk2{__builtin_amdgcn_rcpf(en.x), __builtin_amdgcn_rcpf(en.y)};
-          mf(I2{});
-          g = sg * (x * (1.0f - sg) + 1.0f);
-          mf(I3{}); mf(I4{}); mf(I5{});
+          for (int ct = 0; ct < NCT; ++ct) acc[ct][s % NPAR] = mfma_bf16(wf[wq][ct][s], xf[s & 1][xq], acc[ct][s % NPAR]);
         }
-        pend[0][2 * s] *= g.x;
-        pend[0][2 * s + 1] *= g.y;
-      } else if constexpr (s >= HEAD && s - HEAD < NP) {
-        // one piece per k-step: the next tile's rows -> planes (split4, in stages), its register refilled at once with the
-        // rows of the tile after that (a piece is in flight for a whole tile); before the first of them this tile's gate
-        // values on their way, after the last the previous tile stored
-        constexpr int jp = s - HEAD;
-        if constexpr (jp == 0) load_gate(cur_g);
-        const f32x4 v = raw[jp];
-        const pk2 va = pk2{v.x, v.y}, vb = pk2{v.z, v.w};
-        mf(I0{});
-        const uint32_t h0 = Vec8<bf16_t>::pack(v.x, v.y), h1 = Vec8<bf16_t>::pack(v.z, v.w);
-        auto up = [](uint32_t w) { float a, b; Vec8<bf16_t>::unpack2(w, a, b); return pk2{a, b}; };
-        pk2 ua = up(h0), ub = up(h1);
-        mf(I1{});
-        const pk2 ra = va - ua, rb = vb - ub;            // (exact: the remainders of a round-to-nearest)
-        const uint32_t m0 = Vec8<bf16_t>::pack(ra.x, ra.y), m1 = Vec8<bf16_t>::pack(rb.x, rb.y);
-        mf(I2{});
-        ua = up(m0); ub = up(m1);
-        const pk2 la = ra - ua, lb = rb - ub;
-        const uint32_t l0 = Vec8<bf16_t>::pack(la.x, la.y), l1 = Vec8<bf16_t>::pack(lb.x, lb.y);
-        mf(I3{});
-        unsigned char* d = cbase + nxt + (jp / CPL) * 8 * XS + (jp % CPL) * 256;
-#ifdef EXP_FS_NOSPLIT
-        *reinterpret_cast<u32x2s*>(d) = u32x2s{__float_as_uint(v.x), __float_as_uint(v.y)};
-        *reinterpret_cast<u32x2s*>(d + PLANE) = u32x2s{__float_as_uint(v.z), __float_as_uint(v.w)};
-        *reinterpret_cast<u32x2s*>(d + 2 * PLANE) = u32x2s{__float_as_uint(v.x) + 1u, __float_as_uint(v.w)};
-#else
-        *reinterpret_cast<u32x2s*>(d) = u32x2s{h0, h1};
-        *reinterpret_cast<u32x2s*>(d + PLANE) = u32x2s{m0, m1};
-        *reinterpret_cast<u32x2s*>(d + 2 * PLANE) = u32x2s{l0, l1};
-#endif
-        mf(I4{});
-        fetch_piece(t + 2 * G, jp);
-        mf(I5{});
-#ifndef EXP_FS_NOSTORE
-        if constexpr (jp == NP - 1) store_pend();
-#endif
-      } else {
-        mf(I0{}); mf(I1{}); mf(I2{}); mf(I3{}); mf(I4{}); mf(I5{});
-      }
+        if constexpr (GATE != 0 && s < HEAD && 2 * s + 1 < 16) {
+          gate_stage(s_c, i_c);
+          __builtin_amdgcn_sched_barrier(0);       // (pinned: left alone, the scheduler gathers the MFMAs of a k-step)
+        }
+        if constexpr (slot >= S0 && slot < S0 + SPAN) {
+          constexpr int g0 = (slot - S0) * NCHK / SPAN, g1 = (slot + 1 - S0) * NCHK / SPAN;
+          if constexpr (g1 > g0) {
+            static_for_wgs<g1 - g0>([&](auto d_c) { chunk(std::integral_constant<int, g0 + decltype(d_c)::value>{}); });
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      });
       __builtin_amdgcn_sched_barrier(0);
     });
 #pragma unroll
