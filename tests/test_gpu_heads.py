@@ -607,7 +607,7 @@ def test_fused_positional_embedder_matches_unfused_route(cuda, dtype, n):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("na,nb", [(40_003, 517), (1000, 1), (7, 5000)])
+@pytest.mark.parametrize("na,nb", [(40_003, 517), (1000, 1), (7, 5000), (300, 0), (0, 41)])
 def test_positional_embedder_pair_is_one_node_with_the_summed_gradients(cuda, dtype, na, nb):
     """ops.posmlp_pair (two row sets, ONE autograd node, ONE segger_posmlp_bwd_pair launch) against two ops.posmlp nodes:
     outputs bit-identical (same forward kernel), parameter gradients equal to the sum autograd forms from the two nodes up to
