@@ -530,6 +530,22 @@ def test_wgrad_fp32_split_within_the_exact_kernels_error(cuda, m, k, n, monkeypa
         assert torch.equal(out[True][0], out[False][0]) != took_split      # (it did take the other kernel)
 
 
+@pytest.mark.parametrize("m,k", [(384, 128), (64, 256)])
+def test_wgrad_fp32_split_at_c2_size(cuda, m, k):
+    """The software-pipelined split weight gradient at 1M rows (every workgroup runs ~244 stages: the ring refill and the
+    two LDS buffers in steady state, a partial last stage) against fp64."""
+    from segger_amd import ops
+    n = 1_000_003
+    g = torch.Generator(device=cuda).manual_seed(m * k)
+    gy = torch.randn(n, m, device=cuda, generator=g)
+    x = torch.randn(n, k, device=cuda, generator=g)
+    gw, gb = ops.linear_wgrad_launch(gy, x)
+    ref_w = gy.double().t() @ x.double()
+    bound = gy.double().abs().t() @ x.double().abs()
+    assert ((gw.double() - ref_w).abs() / bound).max().item() <= 2.0 ** -24
+    assert ((gb.double() - gy.double().sum(0)).abs() / gy.double().abs().sum(0)).max().item() <= 2.0 ** -22
+
+
 @pytest.mark.parametrize("kind", ["gelu", "silu"])
 @pytest.mark.parametrize("k,m,n,split", [(384, 128, 3001, True), (384, 128, 3001, False), (64, 64, 4097, False), (128, 128, 130, True),
                                          (256, 64, 77, False), (384, 128, 40037, True), (384, 128, 1, True)])
