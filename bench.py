@@ -126,6 +126,44 @@ def time_kernel(fn, iters=20, warm=3):
     return t0.elapsed_time(t1) / iters
 
 
+def f32_projection_kernels(dev, n, ops):
+    """The fp32-storage projections of one layer at C2 size, each against BOTH of its roofs: the fp32 operand bytes at 8 TB/s
+    and six bf16 products per fp32 product on the dense bf16 matrix pipe (2.5 PFLOP/s; the pipe's clock is data dependent:
+    profiles/r05_micro_mfma_shadow.txt)."""
+    gen = torch.Generator(device=dev).manual_seed(7)
+    out = {}
+
+    def entry(name, k, m, fn, note):
+        ms = time_kernel(fn, iters=10, warm=2)
+        flops = 6 * 2.0 * n * k * m
+        byts = 4.0 * n * (k + m)
+        out[name] = {"ms_per_launch": ms, "mfma": {"achieved": flops / (ms * 1e-3) / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                                   "frac": flops / (ms * 1e-3) / 2.5e15},
+                     "hbm": {"achieved": byts / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": byts / (ms * 1e-3) / 8e12},
+                     "note": note}
+
+    x = torch.randn(n, 128, device=dev, generator=gen)
+    w = torch.randn(384, 128, device=dev, generator=gen) / 128 ** 0.5
+    b = torch.randn(384, device=dev, generator=gen)
+    w3 = ops.f32_split_planes(w)
+    entry("forward_128_to_384", 128, 384, lambda: ops.linear_f32_split_launch(x, w3, b),
+          "stacked lin_l | lin_r | lin_l; W-resident split kernel (segger_linear_fwd_f32_split)")
+    gy = torch.randn(n, 384, device=dev, generator=gen)
+    gate = torch.randn(n, 128, device=dev, generator=gen)
+    wt3 = ops.f32_split_planes(w, transposed=True)
+    lib, _l = ops._lib.load(), ops._lib
+    y = torch.empty(n, 128, device=dev)
+
+    def dx():
+        _l.check(lib.segger_linear_fwd_f32_gate(gy.data_ptr(), 384, wt3.data_ptr(), 1, gate.data_ptr(), 128, 1, y.data_ptr(), 128, n,
+                                                384, 128, _l.stream_ptr(dev)), "segger_linear_fwd_f32_gate")
+    entry("data_gradient_384_to_128_gelu_gate", 384, 128, dx,
+          "dX = (dY W) * gelu'(gate), W-resident split kernel (segger_linear_fwd_f32_gate; + 4 n m gate bytes not counted)")
+    entry("weight_gradient_384x128", 128, 384, lambda: ops.linear_wgrad_launch(gy, x),
+          "dW = dY^T X, db; software-pipelined split kernel (segger_linear_wgrad_f32_split) + the sum of its partials")
+    return out
+
+
 def other_kernel_classes(dev, n, etb, hc, elem, gen, ops, batch):
     """HBM-roofline entries of the step's non-aggregation kernel classes at C2 size (bytes formulas: module docstring)."""
     import torch
@@ -1025,6 +1063,8 @@ def main():
                            "(csrc/linear_f32_split.hip: error within the exact-fp32 MFMA kernels' own), "
                            + ("the default" if ops.F32_SPLIT else "switched off: exact-fp32 MFMA kernels, csrc/linear_f32.hip")}
             log(f"[bench] f32 step {d32 * 1e3:.2f} ms")
+            if ops.F32_SPLIT:
+                f32["projection_kernels"] = f32_projection_kernels(dev, spec.n_tx, ops)
         except Exception as e:  # noqa: BLE001  (secondary figure, single process)
             log(f"[bench] f32 figure skipped: {type(e).__name__}: {e}")
             f32 = {"error": f"{type(e).__name__}: {e}"}
