@@ -494,11 +494,21 @@ __global__ __launch_bounds__(NW * 64) void wgrad_f32_split_kernel(WgSplitParams 
   });
 #pragma unroll
   for (int j = 0; j < PIECES; ++j) { fetch_piece(j, s_beg + 1); __builtin_amdgcn_sched_barrier(0); }
+#ifdef EXP_WGS_STAMPS
+  long long st_bar = 0, st_tot = 0, st_n = 0, st_prev = clock64();
+#endif
 #pragma unroll 1
   for (int64_t s = s_beg; s < s_end; ++s) {
     unsigned char* buf = lds + ((s - s_beg) & 1) * BUF;
     unsigned char* nbuf = lds + (((s - s_beg) & 1) ^ 1) * BUF;
+#ifdef EXP_WGS_STAMPS
+    const long long wc0 = clock64();
+#endif
     lds_barrier();             // stage s's planes are complete; every wave has left the other buffer (stage s - 1)
+#ifdef EXP_WGS_STAMPS
+    const long long wc1 = clock64();
+    st_bar += wc1 - wc0; st_tot += wc1 - st_prev; st_prev = wc1; ++st_n;
+#endif
     u32x4 fa[3][MT], fb[3][KT];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
@@ -529,6 +539,10 @@ __global__ __launch_bounds__(NW * 64) void wgrad_f32_split_kernel(WgSplitParams 
       __builtin_amdgcn_sched_barrier(0);
     });
   }
+#ifdef EXP_WGS_STAMPS
+  if (blockIdx.x == 5 && lane == 0 && st_n > 0)
+    printf("wave %d: %lld stages, per stage %lld clocks, of which at the barrier %lld\n", wave, st_n, st_tot / st_n, st_bar / st_n);
+#endif
 #else
   static_for_wgs<AH>([&](auto d) { fetch(d, s_beg + decltype(d)::value); });
   int64_t s = s_beg;
