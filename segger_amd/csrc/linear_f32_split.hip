@@ -509,26 +509,34 @@ __global__ __launch_bounds__(NW * 64) void wgrad_f32_split_kernel(WgSplitParams 
     const long long wc1 = clock64();
     st_bar += wc1 - wc0; st_tot += wc1 - st_prev; st_prev = wc1; ++st_n;
 #endif
+    // fragments in the order the tiles need them: the first MFMA waits for one row and one column block, the rest arrive
+    // under the MFMAs in front of their first use (both waves of a SIMD leave the barrier together: with all 30 reads first
+    // the matrix pipe idles through them)
     u32x4 fa[3][MT], fb[3][KT];
+    auto read_a = [&](int a) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-#pragma unroll
-      for (int a = 0; a < MT; ++a) {
+      for (int q = 0; q < 3; ++q) {
         const u32x2s lo = lds_read_tr_s(buf + q * PY + off_y + a * 64);
         const u32x2s hi = lds_read_tr_s(buf + q * PY + off_y + a * 64 + 4 * SY);
         fa[q][a] = u32x4{lo.x, lo.y, hi.x, hi.y};
       }
+    };
+    auto read_b = [&](int b) {
 #pragma unroll
-      for (int b = 0; b < KT; ++b) {
+      for (int q = 0; q < 3; ++q) {
         const u32x2s lo = lds_read_tr_s(buf + q * PX + off_x + b * 64);
         const u32x2s hi = lds_read_tr_s(buf + q * PX + off_x + b * 64 + 4 * SX);
         fb[q][b] = u32x4{lo.x, lo.y, hi.x, hi.y};
       }
-    }
+    };
+    read_a(0); read_b(0);
     __builtin_amdgcn_sched_barrier(0);
     static_for_wgs<NMF>([&](auto i_c) {
       constexpr int i = decltype(i_c)::value;
       constexpr int tile = i / 6, pr = i % 6, a = tile / KT, b = tile % KT;
+      // column block b + 1 behind the first MFMA of row block 0; row block a + 1 behind the first MFMA of row block a's second tile
+      if constexpr (a == 0 && pr == 1 && b + 1 < KT) read_b(b + 1);
+      if constexpr (pr == 1 && b == (KT > 1 ? 1 : 0) && a + 1 < MT) read_a(a + 1);
       constexpr int qa = pr == 0 ? 2 : (pr == 2 || pr == 3) ? 1 : 0;       // smallest terms first (as above)
       constexpr int qb = pr == 1 ? 2 : (pr == 2 || pr == 4) ? 1 : 0;
       acc[a][b] = mfma_bf16(fa[qa][a], fb[qb][b], acc[a][b]);
