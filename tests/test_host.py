@@ -336,3 +336,21 @@ def test_edge_csr_struct_cache_follows_the_storage_not_the_object_id():
     g.eid = torch.tensor([1, 0], dtype=torch.int32)         # replaced field
     c2 = g.c_struct()
     assert c2 is not c1 and c2.eid == g.eid.data_ptr()
+
+
+def test_embedder_pair_route_declines_what_it_does_not_cover():
+    """ist_encoder._pair_node (both node types' positional embeddings behind one autograd node) applies to the fused 16-bit
+    embedder on the GPU with batch vectors and a graph count; anywhere else it returns None and the caller embeds each type
+    by its own call -- no CPU route, no silent fp32 substitute."""
+    import torch
+    import segger_amd.ist_encoder as ie
+    emb = ie.Positional2dEmbedder(128)
+    pos_a, pos_b = torch.rand(10, 2), torch.rand(4, 2)
+    ba, bb = torch.zeros(10, dtype=torch.int64), torch.zeros(4, dtype=torch.int64)
+    assert ie._pair_node(emb, pos_a, ba, pos_b, bb, 1, torch.bfloat16) is None          # CPU tensors
+    assert ie.POS_PAIR_NODE is True
+    from segger_amd import ops
+    l0, l2 = emb.mlp[0], emb.mlp[2]
+    assert not ops.posmlp_pair_supported(l0.weight, l0.bias, l2.weight, l2.bias, torch.float32)
+    with torch.no_grad():
+        assert not ops.posmlp_pair_supported(l0.weight, l0.bias, l2.weight, l2.bias, torch.bfloat16)
