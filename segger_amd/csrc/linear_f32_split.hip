@@ -755,14 +755,14 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
       pend[0][e] *= gate_grad(gq[e / 4][e % 4], GATE);
     }
   };
+  auto store_piece = [&](int q) {                // 16 bytes of the stored tile: column tile q / 4, group q % 4
+    const int ct = q / 4, g = q % 4;
+    const f32x4 v = f32x4{pend[ct][4 * g], pend[ct][4 * g + 1], pend[ct][4 * g + 2], pend[ct][4 * g + 3]};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yb, pend_y + (ct * 32 + 8 * g) * 4, 0, 0);
+  };
   auto store_pend = [&]() {
 #pragma unroll
-    for (int ct = 0; ct < NCT; ++ct)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 v = f32x4{pend[ct][4 * g], pend[ct][4 * g + 1], pend[ct][4 * g + 2], pend[ct][4 * g + 3]};
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yb, pend_y + (ct * 32 + 8 * g) * 4, 0, 0);
-      }
+    for (int q = 0; q < NCT * 4; ++q) store_piece(q);
   };
   auto load_gate = [&](uint32_t off) {
     if constexpr (GATE) {
@@ -819,6 +819,10 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
     //  forward measured 5 % slower)
     constexpr int S0 = (GATE != 0 || NCT > 1) ? HEAD * 6 : 0, SPAN = NCT > 1 ? NP * 6 : NKS * 6 - S0, CPP = 8, NCHK = NP * CPP;
     static_assert(S0 + SPAN <= NKS * 6, "the split must end with the tile");
+    // NCT = 3 stores twelve 1-KB pieces per wave and tile: issued in one burst behind the last chunk they held the wave for
+    // thousands of cycles (in-kernel stamps: 3.0 - 6.8 k cycles for the four k-steps around them, 2.3 k of MFMAs) -- one piece
+    // behind each of the slots that follow the split
+    constexpr bool SPREAD_STORES = NCT > 1 && S0 + SPAN + NCT * 4 <= NKS * 6;
     pk2 gx, gsa, gpdf, gq2, ghalf, gcdf;           // the gate stages' values of the k-step in progress
     pk2 cva, cvb, cra, crb;                        // the split's values of the piece in progress
     uint32_t ch0 = 0, ch1 = 0, cm0 = 0, cm1 = 0, cl0 = 0, cl1 = 0;
@@ -858,7 +862,7 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
       } else {
         fetch_piece(t + 2 * G, jp);
 #ifndef EXP_FS_NOSTORE
-        if constexpr (g == NCHK - 1) store_pend();
+        if constexpr (g == NCHK - 1 && !SPREAD_STORES) store_pend();
 #endif
       }
     };
@@ -940,6 +944,12 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
             __builtin_amdgcn_sched_barrier(0);
           }
         }
+#ifndef EXP_FS_NOSTORE
+        if constexpr (SPREAD_STORES && slot >= S0 + SPAN && slot - (S0 + SPAN) < NCT * 4) {
+          store_piece(slot - (S0 + SPAN));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
       });
       __builtin_amdgcn_sched_barrier(0);
     });
