@@ -676,6 +676,13 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
   static_assert(HEAD + NP <= NKS, "the split must fit behind the head");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
   __shared__ __attribute__((aligned(16))) float lds_bias[BIAS ? M : 4];     // (no global load in the store path: see below)
+  // K = 128 leaves LDS for the finished tile: it waits for its stores THERE, in row-major order, and leaves as full 128-byte
+  // lines (8 lanes x 16 bytes per row and instruction).  From the accumulator layout a store instruction touches 32 rows
+  // with 32 bytes each, and the per-CU write path takes a store by the line: in-kernel stamps showed ~210 cycles of issue
+  // per such store, 12 of them per wave and tile -- as much as the tile's MFMAs.
+  constexpr bool LDS_OUT = K == 128;
+  constexpr int OS = 36;                                                    // floats per row of an output tile in LDS (32 + pad)
+  __shared__ __attribute__((aligned(16))) float lds_out[LDS_OUT ? 4 * NCT * 32 * OS : 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int l32 = tid & 31, rg = tid >> 5;
@@ -760,9 +767,26 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
     const f32x4 v = f32x4{pend[ct][4 * g], pend[ct][4 * g + 1], pend[ct][4 * g + 2], pend[ct][4 * g + 3]};
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), yb, pend_y + (ct * 32 + 8 * g) * 4, 0, 0);
   };
+  // LDS_OUT: piece q = rows 8 (q % 4) .. + 8 of column tile q / 4, read back row-major (lane: row lane / 8, 16 bytes lane % 8)
+  float* const out_w = lds_out + (LDS_OUT ? wave * NCT * 32 * OS : 0);
+  uint32_t pend_row0 = kNoRow;                   // first row of the tile waiting in LDS (kNoRow: none)
+  f32x4 ov[3];                                   // (read two slots ahead of its store: an LDS read under load outlasts one slot)
+  auto out_read = [&](int q) {
+    ov[q % 3] = *reinterpret_cast<const f32x4*>(out_w + ((q / 4) * 32 + 8 * (q % 4) + (lane >> 3)) * OS + 4 * (lane & 7));
+  };
+  auto out_store = [&](int q) {
+    const uint32_t row = pend_row0 + 8 * (q % 4) + (lane >> 3);
+    const uint32_t off = (pend_row0 != kNoRow && row < n_rows) ? row * ldy4 + ((wave * NCT + q / 4) * 32 + 4 * (lane & 7)) * 4u : kNoRow;
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov[q % 3]), yb, off, 0, 0);
+  };
   auto store_pend = [&]() {
+    if constexpr (LDS_OUT) {
 #pragma unroll
-    for (int q = 0; q < NCT * 4; ++q) store_piece(q);
+      for (int q = 0; q < NCT * 4; ++q) { out_read(q); out_store(q); }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NCT * 4; ++q) store_piece(q);
+    }
   };
   auto load_gate = [&](uint32_t off) {
     if constexpr (GATE) {
@@ -945,8 +969,14 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
           }
         }
 #ifndef EXP_FS_NOSTORE
-        if constexpr (SPREAD_STORES && slot >= S0 + SPAN && slot - (S0 + SPAN) < NCT * 4) {
+        if constexpr (SPREAD_STORES && !LDS_OUT && slot >= S0 + SPAN && slot - (S0 + SPAN) < NCT * 4) {
           store_piece(slot - (S0 + SPAN));
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (SPREAD_STORES && LDS_OUT && slot >= S0 + SPAN - 2 && slot - (S0 + SPAN - 2) <= NCT * 4 + 1) {
+          constexpr int q = slot - (S0 + SPAN - 2);          // read piece q, store piece q - 2 (its read is two slots old)
+          if constexpr (q < NCT * 4) out_read(q);
+          if constexpr (q > 1) out_store(q - 2);
           __builtin_amdgcn_sched_barrier(0);
         }
 #endif
@@ -955,17 +985,19 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
     });
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct) {
-      pend[ct] = acc[ct][0];
-      if constexpr (NPAR == 2) pend[ct] = pend[ct] + acc[ct][1];
-      if constexpr (BIAS) {                        // (last, as in the exact kernels: the products' small terms were summed first)
+      f32x16 o = acc[ct][0];
+      if constexpr (NPAR == 2) o = o + acc[ct][1];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(lds_bias + (wave * NCT + ct) * 32 + 8 * g + 4 * h);
-          pend[ct][4 * g] += bv.x; pend[ct][4 * g + 1] += bv.y; pend[ct][4 * g + 2] += bv.z; pend[ct][4 * g + 3] += bv.w;
-        }
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
+        if constexpr (BIAS)                        // (last, as in the exact kernels: the products' small terms were summed first)
+          v = v + *reinterpret_cast<const f32x4*>(lds_bias + (wave * NCT + ct) * 32 + 8 * g + 4 * h);
+        if constexpr (LDS_OUT) *reinterpret_cast<f32x4*>(out_w + (ct * 32 + r) * OS + 8 * g + 4 * h) = v;
+        else { pend[ct][4 * g] = v.x; pend[ct][4 * g + 1] = v.y; pend[ct][4 * g + 2] = v.z; pend[ct][4 * g + 3] = v.w; }
       }
     }
     pend_y = cur_y;
+    pend_row0 = (uint32_t)t * 32u;
 #ifdef EXP_FS_STAMPS
     { const long long c4 = clock64(); st_bar += c1 - c0; st_head += c2 - c1; st_commit += c3 - c2; st_tail += c4 - c3; ++st_n; }
 #endif
