@@ -11,6 +11,7 @@
 //
 //   segger_linear_fwd_f32_split:  Y[n, M] = X[n, K] W^T + b,  W given as three bf16 planes [3][M][K] (hi, mid, lo)
 //     K = 128 (forward of the 128 -> M projections), or K = 384 with M = 128 (their data gradient dX = dY W: W^T planes)
+#include <cstdlib>
 #include "common.h"
 
 namespace segger {
@@ -1104,7 +1105,9 @@ static int split_fwd_launch(const float* x, int64_t ldx, const void* w3, const f
   const int64_t n_tiles = (n_rows + 31) / 32;
   const unsigned wres_grid = (unsigned)std::min<int64_t>(n_tiles, device_cu_count());
   // (the W-resident kernels address x, y and the gate with 31-bit byte offsets)
-  const bool wres_ok = SEGGER_FS_WRES && !rowbias && n_rows * ldx * 4 < 0x7ffff000LL && n_rows * ldy * 4 < 0x7ffff000LL &&
+  // (SEGGER_AMD_F32_WRES=0 in the environment: the chunked kernels for every shape -- A/B runs without a rebuild)
+  static const bool wres_env = [] { const char* e = getenv("SEGGER_AMD_F32_WRES"); return !(e && e[0] == '0'); }();
+  const bool wres_ok = SEGGER_FS_WRES && wres_env && !rowbias && n_rows * ldx * 4 < 0x7ffff000LL && n_rows * ldy * 4 < 0x7ffff000LL &&
                        (!gate || n_rows * ld_gate * 4 < 0x7ffff000LL);
 #define WRES(KK, MM, GG, BB) hipLaunchKernelGGL((linear_f32_split_wres_kernel<KK, MM, GG, BB>), dim3(wres_grid), dim3(256), 0, \
                                                 (hipStream_t)stream, p, (int)n_tiles)
