@@ -775,7 +775,15 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
   auto out_read = [&](int q) {
     ov[q % 3] = *reinterpret_cast<const f32x4*>(out_w + ((q / 4) * 32 + 8 * (q % 4) + (lane >> 3)) * OS + 4 * (lane & 7));
   };
+  // (LDS_OUT: the bias joins at the store, on the row-major piece -- the epilogue then moves the accumulators to LDS as they
+  //  are, no copy to arithmetic registers and no add between the tile's last MFMA and the next tile's first)
+  f32x4 bias_rm[LDS_OUT && BIAS ? NCT : 1];
+  if constexpr (LDS_OUT && BIAS) {
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) bias_rm[ct] = *reinterpret_cast<const f32x4*>(p.bias + (wave * NCT + ct) * 32 + 4 * (lane & 7));
+  }
   auto out_store = [&](int q) {
+    if constexpr (LDS_OUT && BIAS) ov[q % 3] = ov[q % 3] + bias_rm[q / 4];
     const uint32_t row = pend_row0 + 8 * (q % 4) + (lane >> 3);
     const uint32_t off = (pend_row0 != kNoRow && row < n_rows) ? row * ldy4 + ((wave * NCT + q / 4) * 32 + 4 * (lane & 7)) * 4u : kNoRow;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov[q % 3]), yb, off, 0, 0);
@@ -991,7 +999,7 @@ __global__ __launch_bounds__(256, 1) void linear_f32_split_wres_kernel(SplitPara
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         f32x4 v = f32x4{o[4 * g], o[4 * g + 1], o[4 * g + 2], o[4 * g + 3]};
-        if constexpr (BIAS)                        // (last, as in the exact kernels: the products' small terms were summed first)
+        if constexpr (BIAS && !LDS_OUT)            // (last, as in the exact kernels: the products' small terms were summed first)
           v = v + *reinterpret_cast<const f32x4*>(lds_bias + (wave * NCT + ct) * 32 + 8 * g + 4 * h);
         if constexpr (LDS_OUT) *reinterpret_cast<f32x4*>(out_w + (ct * 32 + r) * OS + 8 * g + 4 * h) = v;
         else { pend[ct][4 * g] = v.x; pend[ct][4 * g + 1] = v.y; pend[ct][4 * g + 2] = v.z; pend[ct][4 * g + 3] = v.w; }
