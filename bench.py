@@ -101,6 +101,174 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+CONTRACT_LINE_MAX = 8192       # bytes: the driver keeps a bounded tail of stdout; round 5's 20 890-byte line was not recovered
+DETAILS_FILE = os.path.join(ROOT, "bench_details.json")
+
+
+def _sig(x, digits=6):
+    """Floats to `digits` significant digits (a 17-digit double costs 18 bytes on the line), everything else as is."""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float(f"{x:.{digits}g}")
+
+
+def _pick(d, *keys):
+    """{k: d[k]} for the keys that exist, scalars only (floats shortened); {} for a missing / failed record."""
+    if not isinstance(d, dict):
+        return {}
+    out = {k: _sig(d[k]) for k in keys if k in d and not isinstance(d[k], (dict, list, tuple))}
+    if "error" in d:
+        out["error"] = str(d["error"])[:120]
+    return out
+
+
+def _roof(d, short=False):
+    if not isinstance(d, dict):
+        return None
+    keys = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "ms_per_launch",
+            "traffic_source")
+    if short:
+        keys = ("kernel", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch", "ms_per_launch")
+    r = _pick(d, *keys)
+    if "kernel" in r:
+        r["kernel"] = str(r["kernel"])[:96]
+    if "traffic_source" in r:
+        r["traffic_source"] = str(r["traffic_source"])[:64]
+    if not short:
+        r.setdefault("traffic", None)
+    return r
+
+
+def _auroc_summary(a):
+    """auroc{...} -> max |delta| per dtype over the three legs, the largest share of edges beyond the elementwise
+    tolerance, and `met`."""
+    if not isinstance(a, dict):
+        return None
+    if "error" in a and "dtype" not in a:
+        return {"error": str(a["error"])[:120]}
+    legs = {"seed0": a, "trained": a.get("trained_weights"), "fov_tiles": a.get("fov_tiles")}
+    out = {"bar_delta": 1e-3, "met": True, "max_abs_delta": {}, "max_frac_over_atol": {}, "legs": {}}
+    for name, leg in legs.items():
+        if not isinstance(leg, dict) or not isinstance(leg.get("dtype"), dict):
+            if isinstance(leg, dict) and "error" in leg:
+                out["legs"][name] = {"error": str(leg["error"])[:80]}
+                out["met"] = False
+            continue
+        out["legs"][name] = {"n_edges": leg.get("n_edges", a.get("n_edges")), "met": bool(leg.get("met"))}
+        out["met"] = out["met"] and bool(leg.get("met"))
+        for dt, e in leg["dtype"].items():
+            if not isinstance(e, dict):
+                continue
+            if e.get("delta") is not None:
+                out["max_abs_delta"][dt] = _sig(max(out["max_abs_delta"].get(dt, 0.0), abs(float(e["delta"]))), 3)
+            if e.get("frac_over_atol") is not None:
+                out["max_frac_over_atol"][dt] = _sig(max(out["max_frac_over_atol"].get(dt, 0.0), float(e["frac_over_atol"])), 3)
+            out.setdefault("frac_over_atol_bound", {})[dt] = e.get("frac_over_atol_bound")
+    out["oracle_auroc"] = _sig(((a.get("fov_tiles") or {}).get("dtype") or {}).get("f32", {}).get("oracle"))
+    return out
+
+
+def contract_line(res: dict) -> str:
+    """The ONE stdout line of a run: the task contract's keys, `roofline` (+ the time-dominant aggregation kernels under
+    `roofline.dominant` / `roofline.source_pass`), `cpu_baseline`, and SCALAR summaries of the secondary records.  Everything
+    else (notes, worst edges, per-layer tables, per-kernel records) is in `bench_details.json` next to this script and on
+    stderr.  Asserted <= CONTRACT_LINE_MAX bytes; `tests/test_host.py` feeds round 5's 21 KB record through it."""
+    c = {k: _sig(res.get(k), 10) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                            "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = dict(res.get("config") or {})
+    cfg["workload"] = str(cfg.get("workload", ""))[:260]
+    c["config"] = cfg
+    roof = _roof(res.get("roofline"))
+    if roof is not None:
+        for k in ("dominant", "source_pass"):
+            sub = _roof((res.get("roofline") or {}).get(k), short=True)
+            if sub:
+                roof[k] = sub
+    c["roofline"] = roof
+    cpu = res.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        cb = _pick(cpu, "value", "unit", "cores", "kind", "sample", "size_ratio_to_gpu_workload", "mp_edges_per_s")
+        if "sample" in cb:
+            cb["sample"] = str(cb["sample"])[:200]
+        host = cpu.get("host")
+        if isinstance(host, dict):
+            cb["host"] = _pick(host, "cpu", "os_cpu_count", "threads_used")
+        if isinstance(cpu.get("default_batch"), dict):
+            cb["default_batch_value"] = _sig(cpu["default_batch"].get("value"))
+        c["cpu_baseline"] = cb
+    else:
+        c["cpu_baseline"] = None
+    for k in ("mp_edges_per_s", "loss", "csr_build_ms", "step_algorithmic_frac", "step_algorithmic_bytes",
+              "strong_value", "strong_graphed_value"):
+        if res.get(k) is not None:
+            c[k] = _sig(res[k])
+    if isinstance(res.get("untimed_setup"), dict):
+        c["untimed_setup"] = _pick(res["untimed_setup"], "csr_build_ms", "uncached_step_ms", "first_step_ms")
+    if isinstance(res.get("roofline_other"), dict):
+        c["roofline_other"] = {k: _sig(v.get("frac"), 4) for k, v in res["roofline_other"].items()
+                               if isinstance(v, dict) and v.get("frac") is not None}
+    if isinstance(res.get("predict"), dict):
+        c["predict"] = _pick(res["predict"], "ms_per_batch", "edges_scored_per_s")
+    f32 = res.get("f32")
+    if isinstance(f32, dict):
+        c["f32"] = _pick(f32, "ms_per_step", "value", "unit", "steps", "projections")
+        pk = f32.get("projection_kernels")
+        if isinstance(pk, dict):
+            c["f32"]["projection_kernels_ms"] = {k: _sig(v.get("ms_per_launch"), 4) for k, v in pk.items() if isinstance(v, dict)}
+    st = res.get("strong")
+    if isinstance(st, dict):
+        s = _pick(st, "scaling", "n_gpus", "world_size", "n_ranks_seen", "batches", "steps_per_rank", "epoch_s", "value", "unit",
+                  "ms_per_step", "mp_edges_per_s", "peak_hbm_gib")
+        s["census"] = st.get("census")
+        for k in ("graphed", "graphed_f32", "graphed_dp_world1"):
+            if isinstance(st.get(k), dict):
+                s[k] = _pick(st[k], "value", "ms_per_step", "epoch_s", "shape_buckets", "dtype", "n_ranks_seen",
+                             "overhead_ms_per_step_vs_graphed", "allreduce_plus_divide_ms", "backend")
+        if isinstance(st.get("resident"), dict):
+            s["resident"] = _pick(st["resident"], "tiles", "tiles_total", "bytes", "generation", "build_peak_hbm_gib")
+        if isinstance(st.get("predicted"), dict):
+            s["predicted_speedup"] = {k: _sig(v.get("predicted_speedup"), 4) for k, v in st["predicted"].items()
+                                      if isinstance(v, dict)}
+            s["predicted_note"] = "upper bound from dp.rank_schedule; N > 1 unmeasured on hardware"
+        c["strong"] = s
+    c["auroc"] = _auroc_summary(res.get("auroc"))
+    if isinstance(res.get("c5"), dict):
+        c["c5"] = _pick(res["c5"], "dtype", "edges_per_s", "ms", "buckets")
+    if isinstance(res.get("c5_100m"), dict):
+        c["c5_100m"] = _pick(res["c5_100m"], "dtype", "edges_per_s", "ms", "buckets", "batches", "edges_scored",
+                             "transcripts_out", "fov_build_s", "peak_hbm_gib")
+    if isinstance(res.get("default_dropin"), dict):
+        c["default_dropin"] = _pick(res["default_dropin"], "ms_per_step", "value", "dtype", "batches")
+    if isinstance(res.get("c2_oracle_parity"), dict):
+        c["c2_oracle_parity"] = _pick(res["c2_oracle_parity"], "rows", "max_err_over_tol", "met")
+    c["details"] = "bench_details.json (next to bench.py) + stderr"
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) > CONTRACT_LINE_MAX:           # never lose the contract to a diagnostic: drop summaries, largest first
+        for k in sorted((k for k in c if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                                                    "roofline", "cpu_baseline")),
+                        key=lambda k: -len(json.dumps(c[k]))):
+            c[k] = "dropped: see bench_details.json"
+            line = json.dumps(c, separators=(",", ":"))
+            if len(line) <= CONTRACT_LINE_MAX:
+                break
+    assert len(line) <= CONTRACT_LINE_MAX, f"contract line is {len(line)} bytes (> {CONTRACT_LINE_MAX})"
+    return line
+
+
+def emit_result(res: dict) -> None:
+    """Full record -> bench_details.json (+ stderr); compact contract line -> the real stdout."""
+    try:
+        with open(DETAILS_FILE, "w") as f:
+            json.dump(res, f, indent=1)
+    except OSError as e:                        # a read-only checkout must not cost the line
+        log(f"[bench] could not write {DETAILS_FILE}: {e}")
+    log("[bench] full record: " + json.dumps(res))
+    print(contract_line(res), file=RESULT_OUT, flush=True)
+
+
 def gat_fwd_algorithmic_bytes(n_edges, n_dst, hc, elem):
     """E*(HC*s + 4) + Nd*(2*HC*s + 4)."""
     return n_edges * (hc * elem + 4) + n_dst * (2 * hc * elem + 4)
@@ -1000,6 +1168,39 @@ def main():
                     roof["traffic_source"] = "profiles/hbm_traffic.json (rocprofv3 --pmc, separate run)"
             except Exception:  # noqa: BLE001
                 pass
+        # the two kernels of the backward one at a time (args.passes: 1 = destination pass, 2 = source pass over the
+        # grad_pre / dsum it left): the destination pass is the time-dominant kernel of the whole step
+        scratch = ops.gatv2_bwd_launch.scratch
+        bwd_dst = lambda: ops.gatv2_bwd_launch(g_tt, xp[:, :hc], xp[:, hc:2 * hc], att, bias, H, C, gy, pre, lse,
+                                               gxp[:, :hc], gxp[:, hc:2 * hc], apply_gelu=True, dropout_p=drop, seed=11,
+                                               keep_bits=kb, passes=1, scratch=scratch)
+        bwd_src = lambda: ops.gatv2_bwd_launch(g_tt, xp[:, :hc], xp[:, hc:2 * hc], att, bias, H, C, gy, pre, lse,
+                                               gxp[:, :hc], gxp[:, hc:2 * hc], apply_gelu=True, dropout_p=drop, seed=11,
+                                               keep_bits=kb, passes=2, scratch=scratch)
+        ms_dst, ms_src = time_kernel(bwd_dst), time_kernel(bwd_src)
+        # SURVEY.md 8(d)'s B_bwd split by pass: the destination pass gathers x_l once per edge (+ column id) and per
+        # destination reads grad_out, x_r, pre (bias subtraction) and writes grad_pre... of which 8(d) counts 3 rows + the
+        # softmax statistics; the source pass re-gathers per edge and writes grad_x_l once per source
+        b_dst = ett * (hc * elem + 4) + n_tx * (3 * hc * elem + 16 * H)
+        b_src = b_bwd - b_dst
+        traffic = {}
+        try:
+            meas = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+            w = meas.get("workload", {})
+            if (w.get("n_tx"), w.get("k"), w.get("dtype"), w.get("dropout")) == (args.n_tx, args.k, args.dtype, drop):
+                traffic = meas
+        except Exception:  # noqa: BLE001
+            pass
+        for key, name, nbytes, ms, tkey in (("dominant", "gatv2_bwd_dst_kernel", b_dst, ms_dst, "gatv2_bwd_dst_bytes_per_launch"),
+                                            ("source_pass", "gatv2_bwd_src_kernel", b_src, ms_src, "gatv2_bwd_src_bytes_per_launch")):
+            a_ = nbytes / (ms * 1e-3) / 1e9
+            roof[key] = {"kernel": f"{name}<{args.dtype},H=2,C=64> (tx-neighbors-tx, dropout {drop})", "achieved": a_,
+                         "frac": a_ / HBM_PEAK_GBS, "traffic": traffic.get(tkey), "algorithmic_bytes_per_launch": nbytes,
+                         "ms_per_launch": ms}
+        roof["dominant"]["note"] = ("the kernel with the largest share of the step (4 launches); algorithmic bytes "
+                                    "E (HC s + 4) + Nd (3 HC s + 16 H), the source pass has the rest of SURVEY 8(d)'s B_bwd")
+        log(f"[bench] gatv2 bwd_dst {ms_dst:.3f} ms (frac {roof['dominant']['frac']:.3f}), bwd_src {ms_src:.3f} ms "
+            f"(frac {roof['source_pass']['frac']:.3f})")
         ach_b = b_bwd / (ms_bwd * 1e-3) / 1e9
         extra = {"gatv2_bwd_tx_tx": {"achieved": ach_b, "frac": ach_b / HBM_PEAK_GBS, "unit": "GB/s",
                                      "algorithmic_bytes_per_launch": b_bwd, "ms_per_launch": ms_bwd,
@@ -1079,7 +1280,8 @@ def main():
         from segger_amd.fov import batch_weights, build_fov_batches
         del batch, batch_cpu
         if rank == 0:
-            del xp, out, pre, lse, gy, gxp, g_tt, fwd, bwd, kb
+            del xp, out, pre, lse, gy, gxp, g_tt, fwd, bwd, kb, bwd_dst, bwd_src, scratch
+            ops.gatv2_bwd_launch.scratch = None
         opt.zero_grad(set_to_none=True)
         torch.cuda.empty_cache()
         t = time.perf_counter()
@@ -1314,7 +1516,7 @@ def main():
                                  + gat_fwd_algorithmic_bytes(etb, args.n_bd, 128, 2) + gat_bwd_algorithmic_bytes(etb, args.n_bd, args.n_tx, 128, 2, 2))
             res["step_algorithmic_frac"] = b_step / (dt / args.steps) / 1e9 / HBM_PEAK_GBS   # per GPU (weak scaling)
             res["step_algorithmic_bytes"] = b_step
-        print(json.dumps(res), file=RESULT_OUT, flush=True)
+        emit_result(res)
     if world > 1:
         dist.destroy_process_group()
 

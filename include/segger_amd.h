@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 26
+#define SEGGER_ABI_VERSION 27
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -223,6 +223,11 @@ typedef struct segger_gatv2_bwd_args {
                              fills the tx-belongs-bd window of the stacked projection gradient) */
   int64_t ld_zero;
   int32_t grad_xl_zeroed; /* one-pass form (src_unique): grad_xl already holds zeros (see zero_rows_out): skip the fill */
+  int32_t passes;         /* segger_gatv2_bwd only -- 0: the whole backward (default); 1: the destination-side pass alone
+                             (grad_pre, dsum, grad_xr, grad_att, grad_bias; grad_xl too in the one-pass form); 2: the
+                             source-side pass alone (grad_xl from the grad_pre / dsum an earlier passes = 1 call left in
+                             the same buffers).  1 then 2 == 0; exists so that a profiler / bench.py can time the two
+                             kernels of the backward separately (roofline.dominant). */
 } segger_gatv2_bwd_args;
 
 size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads, int32_t channels);

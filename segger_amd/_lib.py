@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
@@ -68,7 +68,7 @@ class GatBwdArgs(C.Structure):
         ("workspace", vp), ("workspace_bytes", C.c_size_t),
         ("keep_bits_dst", vp), ("keep_bits_src", vp),
         ("src_unique", C.c_int32),
-        ("zero_rows_out", vp), ("ld_zero", C.c_int64), ("grad_xl_zeroed", C.c_int32),
+        ("zero_rows_out", vp), ("ld_zero", C.c_int64), ("grad_xl_zeroed", C.c_int32), ("passes", C.c_int32),
     ]
 
 

@@ -344,8 +344,11 @@ def _gat_bwd_args(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optio
                   heads: int, channels: int, grad_out: Tensor, pre: Tensor, lse: Tensor,
                   grad_xl: Tensor, grad_xr: Tensor, *, apply_gelu: bool, negative_slope: float = 0.2,
                   dropout_p: float = 0.0, seed: int = 0, keep_bits: Optional[Tuple] = None,
-                  zero_rows_out: Optional[Tensor] = None, grad_xl_zeroed: bool = False):
-    """-> (segger_gatv2_bwd_args, gparams [2, HC] fp32, the tensors the struct points at)."""
+                  zero_rows_out: Optional[Tensor] = None, grad_xl_zeroed: bool = False, passes: int = 0,
+                  scratch: Optional[Tuple[Tensor, Tensor]] = None):
+    """-> (segger_gatv2_bwd_args, gparams [2, HC] fp32, the tensors the struct points at).  ``passes`` (1: destination
+    pass alone, 2: source pass alone over the ``scratch`` = (grad_pre, dsum) a passes = 1 call returned in
+    ``gatv2_bwd_launch.scratch``): timing hooks of bench.py, see include/segger_amd.h."""
     _lib.require_cuda(xl, xr, grad_out)
     lib = _lib.load()
     hc = heads * channels
@@ -381,8 +384,13 @@ def _gat_bwd_args(g: EdgeGraph, xl: Tensor, xr: Tensor, att: Tensor, bias: Optio
     a.grad_out, a.ld_go = _rows(grad_out, hc, "grad_out")
     a.pre, a.ld_pre = _rows(pre, hc, "pre")
     a.lse = lse.data_ptr()
-    grad_pre = torch.empty((n_dst, hc), dtype=dt, device=dev)
-    dsum = torch.empty((n_dst, heads, 2), dtype=torch.float32, device=dev)     # (lse, D) pairs for the source pass
+    if scratch is not None:
+        grad_pre, dsum = scratch
+    else:
+        grad_pre = torch.empty((n_dst, hc), dtype=dt, device=dev)
+        dsum = torch.empty((n_dst, heads, 2), dtype=torch.float32, device=dev)     # (lse, D) pairs for the source pass
+    a.passes = int(passes)
+    gatv2_bwd_launch.scratch = (grad_pre, dsum)
     a.grad_pre, a.ld_gp = _rows(grad_pre, hc, "grad_pre")
     a.dsum = dsum.data_ptr()
     a.grad_xl, a.ld_gxl = _rows(grad_xl, hc, "grad_xl")

@@ -354,3 +354,63 @@ def test_embedder_pair_route_declines_what_it_does_not_cover():
     assert not ops.posmlp_pair_supported(l0.weight, l0.bias, l2.weight, l2.bias, torch.float32)
     with torch.no_grad():
         assert not ops.posmlp_pair_supported(l0.weight, l0.bias, l2.weight, l2.bias, torch.bfloat16)
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("segger_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_contract_line_is_compact_and_complete():
+    """Round 5's driver record was lost because bench.py printed ONE 20 890-byte stdout line.  The contract line is now a
+    compact summary (diagnostics go to bench_details.json + stderr): round 5's own full record through the formatter gives
+    valid JSON of at most 8 KB with every contract key, `roofline` and `cpu_baseline`."""
+    import json
+    bench = _load_bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+    assert len(json.dumps(full)) > 16384                     # the record that broke the driver's parser
+    line = bench.contract_line(full)
+    assert "\n" not in line and len(line) <= bench.CONTRACT_LINE_MAX == 8192
+    c = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in c, k
+    assert c["config"]["workload"].startswith("C2") and "model" not in c["config"]
+    assert abs(c["value"] - full["value"]) <= 1e-6 * full["value"] and abs(c["ms_per_step"] - full["ms_per_step"]) < 1e-6
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "algorithmic_bytes_per_launch", "ms_per_launch"):
+        assert k in c["roofline"], k
+    assert abs(c["roofline"]["frac"] - c["roofline"]["achieved"] / c["roofline"]["peak"]) < 1e-4
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c["cpu_baseline"], k
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["host"]["threads_used"] == c["cpu_baseline"]["cores"]
+    # scalar summaries only: no nested record deeper than two levels below a top-level key, no lists of dicts
+    def depth(o):
+        return 0 if not isinstance(o, dict) else 1 + max([depth(v) for v in o.values()] or [0])
+    assert depth(c) <= 4
+    assert c["auroc"]["met"] is True and set(c["auroc"]["max_abs_delta"]) == {"f32", "bf16", "f16"}
+    assert all(isinstance(v, float) for v in c["roofline_other"].values())
+    assert c["strong"]["graphed"]["ms_per_step"] == pytest.approx(full["strong"]["graphed"]["ms_per_step"], rel=1e-5)
+
+
+def test_bench_contract_line_survives_oversized_and_failed_records():
+    """A secondary record that failed (error strings) or grew (a future diagnostic) never costs the contract keys: the
+    formatter truncates / drops summaries, largest first, and still asserts the bound."""
+    import json
+    bench = _load_bench()
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line.json")))
+    full["f32"] = {"error": "RuntimeError: " + "x" * 5000}
+    full["auroc"] = {"error": "boom " * 1000}
+    full["roofline_other"] = {f"kernel_class_{i:04d}_with_a_long_name": {"frac": 0.5} for i in range(400)}
+    full["roofline"]["dominant"] = {"kernel": "gatv2_bwd_dst_kernel<bf16,H=2,C=64>", "achieved": 5400.0, "frac": 0.675,
+                                    "traffic": 1890440434, "algorithmic_bytes_per_launch": 4700000000, "ms_per_launch": 0.87,
+                                    "note": "n" * 3000}
+    line = bench.contract_line(full)
+    assert len(line) <= 8192
+    c = json.loads(line)
+    assert c["roofline"]["dominant"]["frac"] == 0.675 and "note" not in c["roofline"]["dominant"]
+    assert c["cpu_baseline"]["value"] and c["value"] == pytest.approx(full["value"])
+    assert isinstance(c["roofline_other"], str) and "dropped" in c["roofline_other"]
+    assert len(c["f32"]["error"]) <= 120
