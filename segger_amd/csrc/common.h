@@ -212,13 +212,21 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 // exact (erf) GELU, torch.nn.functional.gelu(approximate='none')
 // Standard normal CDF without erff (ocml's erff is ~45 VALU ops with two branches; GELU is evaluated for every
 // output channel of every layer, inside kernels that are VALU-bound):
-//   erfc(|x|/sqrt2) = exp2(s * Q(s)),  s = min(|x|, 4 sqrt2),  Phi(x) = x < 0 ? erfc/2 : 1 - erfc/2.
+//   erfc(|x|/sqrt2) = exp2(s * Q(s)),  s = |x|,  Phi(x) = x < 0 ? erfc/2 : 1 - erfc/2.
 // Q is the degree-7 minimax fit of log2(erfc(s/sqrt2))/s on [0, 4 sqrt2], weighted by the error it causes in
 // erf (fit error 1.6e-8); evaluated in fp32 the GELU built on it is within 4e-7 (absolute) of the exact
 // value on [-8, 8] -- torch's own fp32 gelu is within 1.2e-6.  (The fit bounds the ABSOLUTE error; the relative
 // error of the vanishing negative tail, |gelu| < 1e-5, reaches 1 %.)
-__device__ __forceinline__ float normal_cdf(float x) {
-  const float s = fminf(fabsf(x), 5.656854249f);
+// Shaped for the VALU's issue costs (profiles/r02_valu_probe.txt: v_max / v_min / v_cmp / v_cndmask cost 4+ cycles and a
+// select on vcc needs wait states; an fma with |x| as a source modifier costs 2.5): the argument is |x| in every fma (no
+// explicit abs), there is NO clamp -- beyond 4 sqrt2 the fit keeps falling (s Q(s) <= -26, monotone: exp2 -> 0; +-inf
+// gives Q = -inf, exp2 = 0) -- and no compare / select: with d = Phi(|x|) - 1/2 = 1/2 - erfc/2 in [0, 1/2],
+//   gelu(x)  = x Phi(x)      = x/2 + |x| d                  (x sign(x) = |x|)
+//   Phi(x)   = 1/2 + copysign(d, x)                           (one v_bfi_b32)
+// (Measured: profiles/r06_aggregation_valu_budget.txt.)  The negative tail is
+// formed by cancellation (x/2 + |x| d): absolute error <= |x| 3e-8, inside the 4e-7 bound above.
+__device__ __forceinline__ float normal_cdf_minus_half_abs(float x) {     // Phi(|x|) - 1/2
+  const float s = __builtin_fabsf(x);
   float q = -2.855192741e-06f;
   q = fmaf(q, s, 3.960562235e-05f);
   q = fmaf(q, s, -1.871826931e-04f);
@@ -227,13 +235,13 @@ __device__ __forceinline__ float normal_cdf(float x) {
   q = fmaf(q, s, -5.249462857e-02f);
   q = fmaf(q, s, -4.592086259e-01f);
   q = fmaf(q, s, -1.151105166e+00f);
-  const float half = 0.5f * __builtin_amdgcn_exp2f(q * s);
-  return x < 0.f ? half : 1.0f - half;
+  return fmaf(__builtin_amdgcn_exp2f(q * s), -0.5f, 0.5f);
 }
-__device__ __forceinline__ float gelu_erf(float x) { return x * normal_cdf(x); }
+__device__ __forceinline__ float normal_cdf(float x) { return 0.5f + __builtin_copysignf(normal_cdf_minus_half_abs(x), x); }
+__device__ __forceinline__ float gelu_erf(float x) { return fmaf(__builtin_fabsf(x), normal_cdf_minus_half_abs(x), 0.5f * x); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float pdf = 0.3989422804014327f * __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);
-  return normal_cdf(x) + x * pdf;
+  const float e = __builtin_amdgcn_exp2f((-0.72134752044448170f * x) * x);
+  return fmaf(0.3989422804014327f * x, e, normal_cdf(x));
 }
 
 __device__ __forceinline__ float silu_grad(float z) {             // d/dz z sigmoid(z)

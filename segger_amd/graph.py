@@ -22,11 +22,22 @@ from . import _lib
 from .hetero import EdgeType
 
 
-# Degree-balanced row visiting order (segger_csr_row_order).  Measured on the C2 tile (rocprofv3 PMC, window 64): 8 %
-# fewer VALU instructions in the forward (lane efficiency 0.79 -> 0.89) but 34 % more L2 requests -- neighbouring rows
-# share neighbours, and rows that sit in one wave share cache lines within an instruction -- and the kernels got 3-10 %
-# SLOWER.  Kept as an option (``EdgeCSR.balanced_order(window)``) for graphs without that locality; off by default.
-ROW_ORDER_WINDOW = 0         # rows per balancing window (power of two <= 64); 0 = natural order
+# Degree-balanced row visiting order (segger_csr_row_order): within windows of 64 consecutive rows the rows are visited by
+# descending degree, so the four rows that share a wave have near-equal length.  A wave walks 4-edge batches until its
+# LONGEST row is done; on the C2 tile's by-destination view (kNN in-degrees: mean 15, sd 3.9) that costs 12.9 % of the
+# forward's / destination pass's batch iterations, the window order leaves 2.1 % (profiles/r06_aggregation_valu_budget.txt:
+# SQ_INSTS_VALU -8.7 % / -8.9 %, destination pass 0.871 -> 0.817 ms, forward 0.634 -> 0.618).  Round 2 had measured the
+# same order 3-10 % SLOWER (34 % more L2 requests: rows of one wave no longer adjacent) with the kernels of that round; with
+# prefetching walks and 4 rows in flight the instruction count decides.  By-source views of a kNN graph have constant
+# out-degree (nothing to balance: 0.655 -> 0.650 ms) and stay in natural order; small views (captured 1M-edge batches:
+# kernels of 10-40 us) too.
+ROW_ORDER_WINDOW = 0         # by-source views: rows per balancing window (power of two <= 64); 0 = natural order
+ROW_ORDER_WINDOW_DST = 64    # by-destination views of at least ROW_ORDER_MIN_ROWS rows
+ROW_ORDER_MIN_ROWS = 1 << 17
+# ... and only the BACKWARD's destination pass follows it: inside the training step the forward (pair launch) measured
+# 617 -> 652 us per layer with the order while the destination pass gained 837 -> 807 (rocprofv3 kernel trace of
+# tools/bench_step.py, both orders on one box) -- alone, the forward had gained 3 %.
+ROW_ORDER_FORWARD = False
 WAVE_PER_ROW_DEGREE = 32     # csrc/gatv2.hip kWavePerRowDegree: from this average degree a whole wave walks one row
 
 
@@ -43,26 +54,32 @@ class EdgeCSR:
     def n_edges(self) -> int:
         return int(self.col.shape[0])
 
-    def c_struct(self) -> _lib.Csr:
+    def c_struct(self, ordered: bool = True) -> _lib.Csr:
+        """``ordered=False``: the same view without its visiting order (the forward walks natural order, see
+        ``ROW_ORDER_FORWARD``)."""
         # built once per view (4 layers x 3 passes ask for it every step) and kept while the arrays are the SAME tensor
         # objects at the SAME addresses: the entry holds the tensors themselves (an id() of a freed tensor can be reused by
         # a new one) and their data pointers (resize_ / set_ / `.data =` keep the object and move the storage)
-        hit = self.__dict__.get("_c_struct")
+        order = self.order if ordered else None
+        slot = "_c_struct" if ordered else "_c_struct_natural"
+        hit = self.__dict__.get(slot)
         if hit is not None:
             ts, ptrs, dims, c = hit
-            if (ts[0] is self.indptr and ts[1] is self.col and ts[2] is self.eid and ts[3] is self.order
+            if (ts[0] is self.indptr and ts[1] is self.col and ts[2] is self.eid and ts[3] is order
                     and dims == (self.n_rows, self.n_cols)
-                    and ptrs == (self.indptr.data_ptr(), self.col.data_ptr(), self.eid.data_ptr(), _lib.ptr(self.order))):
+                    and ptrs == (self.indptr.data_ptr(), self.col.data_ptr(), self.eid.data_ptr(), _lib.ptr(order))):
                 return c
-        ptrs = (self.indptr.data_ptr(), self.col.data_ptr(), self.eid.data_ptr(), _lib.ptr(self.order))
+        ptrs = (self.indptr.data_ptr(), self.col.data_ptr(), self.eid.data_ptr(), _lib.ptr(order))
         c = _lib.Csr(ptrs[0], ptrs[1] if self.n_edges else None, ptrs[2] if self.n_edges else None,
                      self.n_rows, self.n_cols, self.n_edges, ptrs[3])
-        self.__dict__["_c_struct"] = ((self.indptr, self.col, self.eid, self.order), ptrs, (self.n_rows, self.n_cols), c)
+        self.__dict__[slot] = ((self.indptr, self.col, self.eid, order), ptrs, (self.n_rows, self.n_cols), c)
         return c
 
-    def balanced_order(self, window: int = ROW_ORDER_WINDOW) -> "EdgeCSR":
+    def balanced_order(self, window: Optional[int] = None) -> "EdgeCSR":
         """Attach the visiting order of ``segger_csr_row_order`` (rows of near-equal degree share a wave; computed
         once per view, results never depend on it).  Skipped for views the kernels walk one row per wave."""
+        if window is None:
+            window = ROW_ORDER_WINDOW
         if (window > 0 and self.order is None and self.n_rows > 0
                 and self.n_edges < WAVE_PER_ROW_DEGREE * self.n_rows):
             order = torch.empty(self.n_rows, dtype=torch.int32, device=self.indptr.device)
@@ -242,7 +259,10 @@ def build_edge_graph(edge_index: Tensor, n_src: int, n_dst: int, *, need_by_dst:
     """``need_by_src``: True, False, or ``"lazy"`` (see :class:`EdgeGraph`).  ``known_unique``: the caller vouches that
     no source has two out-edges (e.g. checked once for the whole slide): "lazy" then needs no check of its own."""
     src, dst = edge_index[0], edge_index[1]
-    by_dst = csr_from_coo(dst, src, n_dst, n_src, validate).balanced_order() if need_by_dst else None
+    by_dst = None
+    if need_by_dst:
+        by_dst = csr_from_coo(dst, src, n_dst, n_src, validate)
+        by_dst.balanced_order(ROW_ORDER_WINDOW_DST if n_dst >= ROW_ORDER_MIN_ROWS else ROW_ORDER_WINDOW)
     if need_by_src == "lazy" and known_unique:
         return EdgeGraph(by_dst, None, n_src, n_dst, int(edge_index.shape[1]), edge_index, True)
     if need_by_src == "lazy":

@@ -14,6 +14,7 @@ from torch import Tensor
 
 from . import _lib
 from ._lib import DTYPE_CODE
+from . import graph as _graph
 from .graph import EdgeCSR, EdgeGraph
 
 
@@ -284,7 +285,7 @@ def _gat_fwd_args(by_dst: EdgeCSR, xl: Tensor, xr: Tensor, att: Tensor, bias: Op
     if not (xl.dtype == xr.dtype == out.dtype) or xl.dtype not in DTYPE_CODE:
         raise TypeError(f"gatv2: x_l/x_r/out must share a dtype in {list(DTYPE_CODE)}")
     a = _lib.GatFwdArgs()
-    a.by_dst = by_dst.c_struct()
+    a.by_dst = by_dst.c_struct(ordered=_graph.ROW_ORDER_FORWARD)
     a.x_l, a.ld_xl = _rows(xl, hc, "x_l")
     a.x_r, a.ld_xr = _rows(xr, hc, "x_r")
     if xl.shape[0] != by_dst.n_cols or xr.shape[0] != by_dst.n_rows or out.shape[0] != by_dst.n_rows:

@@ -32,8 +32,13 @@ def step():
 
 def apply(flags):
     ops.FUSED_WGRAD_DX = bool(int(flags.get("FUSED_DX", 1)))
+    if "ROW_ORDER" in flags:                  # window of the by-destination visiting order (graph.ROW_ORDER_WINDOW_DST); 0 = off
+        from segger_amd import graph
+        graph.ROW_ORDER_WINDOW_DST = int(flags["ROW_ORDER"])
+        graph.ROW_ORDER_FORWARD = bool(int(flags.get("ORDER_FWD", 0)))
+        graph.batch_cache(batch).clear()      # the sorted views are cached on the batch: rebuild them under the new setting
     for k, v in flags.items():
-        if k != "FUSED_DX" and hasattr(ops, k):
+        if k not in ("FUSED_DX", "ROW_ORDER", "ORDER_FWD") and hasattr(ops, k):
             setattr(ops, k, type(getattr(ops, k))(int(v)))
 
 
