@@ -167,6 +167,10 @@ def _auroc_summary(a):
                 out["max_frac_over_atol"][dt] = _sig(max(out["max_frac_over_atol"].get(dt, 0.0), float(e["frac_over_atol"])), 3)
             out.setdefault("frac_over_atol_bound", {})[dt] = e.get("frac_over_atol_bound")
     out["oracle_auroc"] = _sig(((a.get("fov_tiles") or {}).get("dtype") or {}).get("f32", {}).get("oracle"))
+    rb = (a.get("trained_weights") or {}).get("relative_bar")
+    if isinstance(rb, dict):
+        out["bf16_share_vs_oracle_at_bf16_storage"] = {k: _sig(v, 3) for k, v in rb.items()}
+    out["elementwise_bar"] = "a SHARE of edges beyond atol 2e-2 (16-bit), not every edge: DESIGN.md 1"
     return out
 
 
@@ -722,6 +726,16 @@ def auroc_vs_oracle(ctx, dev, trained=None):
             out["trained_weights"]["elementwise"] = {"error": f"{type(e).__name__}: {e}"}
         trained.train(was_training)
         out["trained_weights"]["met"] = all(v["met"] for v in out["trained_weights"]["dtype"].values())
+        # the bf16 share pinned to the REFERENCE'S OWN arithmetic at 16-bit storage (oracle `storage_round`, no HIP kernel):
+        # the HIP path may miss atol 2e-2 on at most twice the share of edges the oracle itself misses it on (+ 1e-4) --
+        # a bar derived from the model's sensitivity on these weights, not a constant picked after seeing the results
+        ew = out["trained_weights"]["elementwise"]
+        ref16 = (ew.get("oracle_with_16bit_storage_vs_oracle") or {}).get("frac_over_atol") if isinstance(ew, dict) else None
+        if ref16 is not None:
+            got = out["trained_weights"]["dtype"]["bf16"]["frac_over_atol"]
+            out["trained_weights"]["relative_bar"] = {"hip_bf16_frac_over_atol": got, "oracle_bf16_storage_frac_over_atol": ref16,
+                                                      "bound": 2.0 * ref16 + 1e-4, "met": bool(got <= 2.0 * ref16 + 1e-4)}
+            out["trained_weights"]["met"] = out["trained_weights"]["met"] and out["trained_weights"]["relative_bar"]["met"]
         out["met"] = out["met"] and out["trained_weights"]["met"]
     return out
 
@@ -1260,6 +1274,7 @@ def main():
             torch.cuda.synchronize()
             d32 = (time.perf_counter() - t0) / n32
             f32 = {"ms_per_step": d32 * 1e3, "value": 2.0 * etb / d32, "unit": "edges/s", "steps": n32,
+                   "projections": "bf16x3-split" if ops.F32_SPLIT else "exact-f32-mfma (SEGGER_AMD_F32_EXACT=1)",
                    "note": "same tile and step, activations stored in fp32; projections on the bf16x3 split of the fp32 operands "
                            "(csrc/linear_f32_split.hip: error within the exact-fp32 MFMA kernels' own), "
                            + ("the default" if ops.F32_SPLIT else "switched off: exact-fp32 MFMA kernels, csrc/linear_f32.hip")}
@@ -1413,6 +1428,28 @@ def main():
         else:
             strong["graphed"] = {"value": None, "error": err or "another rank failed its pre-flight"}
         del trainer
+        # ---- the reference's own arithmetic width, captured: fp32 storage + one hipGraph per step
+        # (LitISTEncoder.enable_graphed_training() / SEGGER_AMD_GRAPHED=1: INTEGRATION.md 1), next to default_dropin --------
+        if rank == 0 and world == 1 and not args.no_default_dropin and strong["graphed"].get("value"):
+            try:
+                model.model.compute_dtype = torch.float32
+                tr32 = GraphedTrainer(model, gopt)
+                rec_f = strong_scaling_epoch(weights_all, lambda k, i: tr32.step(part.batch(local_batches[k])),
+                                             lambda k: units_of[k], sync=torch.cuda.synchronize, device=dev, warmup=-1)
+                etb_f32, _ = rec_f["units_total"]
+                strong["graphed_f32"] = {
+                    "what": "the same epoch at fp32 storage (the reference's width), each training step one hipGraph replay: "
+                            "LitISTEncoder.enable_graphed_training() / SEGGER_AMD_GRAPHED=1 -- same arithmetic as "
+                            "default_dropin, captured",
+                    "dtype": "f32", "value": 2.0 * etb_f32 / rec_f["epoch_s"], "unit": "edges/s", "epoch_s": rec_f["epoch_s"],
+                    "ms_per_step": rec_f["epoch_s"] / max(rec_f["steps_per_rank"], 1) * 1e3,
+                    "shape_buckets": len(tr32.buckets)}
+                log(f"[bench] strong.graphed_f32: {strong['graphed_f32']}")
+                del tr32
+            except Exception as e:  # noqa: BLE001  (single process: nobody waits in a collective)
+                strong["graphed_f32"] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                model.model.compute_dtype = dtype
         # ---- what ONE GPU can measure of N > 1: the data-parallel route's per-step overhead (two graphs + one RCCL
         # all-reduce + divide between them, here on a one-rank communicator) and the schedule's predicted imbalance ----
         if rank == 0 and world == 1 and strong["graphed"].get("value"):

@@ -704,7 +704,13 @@ int segger_gene_table_bwd(const segger_gene_table_args* args, segger_stream_t st
  * sites (ist_encoder.py:111-124,282-286 under a default fp32 Trainer, cli/segment.py:400-405): error ~2^-22 relative to
  * sum |x||w| instead of fp32 rounding only, at 6/16 of the bf16 MFMA rate instead of the 157 TFLOP/s fp32 pipe.
  *   x [n, k_in] fp32, y [n, m_out] fp32 (16-byte aligned rows); w3 = bf16 [3][m_out][k_in]: hi = bf16(w), mid = bf16(w - hi),
- *   lo = bf16(w - hi - mid).  Covered: k_in 128 with m_out a multiple of 64; k_in 384 with m_out 128 (dX = dY W on W^T planes). */
+ *   lo = bf16(w - hi - mid).  Covered: k_in 128 with m_out a multiple of 64; k_in 384 with m_out 128 (dX = dY W on W^T planes).
+ * RANGE: not range-equivalent to the exact kernel.  bf16 has fp32's exponent range but rounds up at the top: an operand with
+ * |v| > 0x7F7F8000 as fp32 bits (3.3895e38: within 2^-9 of FLT_MAX) rounds its hi plane to +-inf and the result is NaN
+ * (inf - inf in the mid plane) where the exact kernel stays finite; sub-normal operands lose the planes below 2^-133.  Node
+ * features behind a GELU / L2 normalisation are nowhere near either end; callers that cannot promise it select the exact
+ * kernels (host side: SEGGER_AMD_F32_EXACT=1 / ops.F32_SPLIT = False -- the active mode is recorded on bench.py's line,
+ * f32.projections). */
 int segger_linear_fwd_f32_split_supported(int32_t k_in, int32_t m_out);
 int segger_linear_fwd_f32_split(const float* x, int64_t ldx, const void* w3, const float* bias, float* y, int64_t ldy,
                                 int64_t n_rows, int32_t k_in, int32_t m_out, segger_stream_t stream);

@@ -533,8 +533,23 @@ __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid)
   }
 
   const float lse = m + fast_log2(s);                 // -inf for a destination without in-edges
-  const float inv = s > 0.f ? 1.0f / s : 0.f;
+  const float inv = s > 0.f ? fast_rcp(s) : 0.f;      // (v_rcp_f32: 1 ulp; the IEEE division is ten instructions per row)
+  // fp32 rows: the epilogue's lane offset recomputed from a fresh lane id -- kept live across the edge walk as a
+  // zero-extended 64-bit pair it was what the allocator spilled at 4 waves per SIMD (12-20 B of scratch in the
+  // <float, 2, 8> forward kernels; outside the edge loops, but scratch all the same: tests/test_kernel_resources.py)
+  // ... and so was the row id (a sign-extended 64-bit pair in group-per-row mode): re-derived from the scalar block /
+  // wave position and the fresh lane id (one more read of order[] where a visiting order is attached)
+  int ch0e = L.ch0, rowe = row;
+  if constexpr (sizeof(T) == 4) {
+    const int lane_f = lane_id_fresh();
+    ch0e = L.lane_on ? (lane_f % GS) * 8 : 0;
+    if constexpr (!WPR) {
+      const int64_t pos_f = (blk * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * NG + lane_f / GS;
+      rowe = visit_row<false>(p.order, pos_f, pos_f < p.n_rows);
+    }
+  }
   if (row_ok && L.lane_on && (!WPR || L.grp == 0)) {
+    const int ch0 = ch0e, row = rowe;                 // (shadow the function-scope values)
     f32x2 o[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

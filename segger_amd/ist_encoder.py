@@ -464,7 +464,10 @@ class ISTEncoder(Module):
                 # one embedder call per type: the boundary side alone through the join (no transcript rows, no table gradient)
                 _, x_bd = ops.front_join(emb.weight.detach(), x_dict["tx"][:0], x_bd, pe_bd, None)
             elif pe_all is None:
-                x_bd = torch.cat((F.gelu(x_bd), pe_bd), -1) if split else F.gelu(torch.cat((x_bd, pe_bd), -1))
+                # `bd_plain`: pe_bd came back WITHOUT its GELU (the join applies it), whatever `split` says for the
+                # transcripts -- keyed on the flag the embedder returned, not on `split` (ist_encoder.py:320)
+                gelu_on_pe = bd_plain or not split
+                x_bd = F.gelu(torch.cat((x_bd, pe_bd), -1)) if gelu_on_pe else torch.cat((F.gelu(x_bd), pe_bd), -1)
             if fused_tx:
                 # gather + concat + GELU in one kernel; its table gradient sums over rows grouped by gene id: one
                 # sort per batch (not needed without grad), cached with the batch or supplied with `graphs`

@@ -121,8 +121,13 @@ class LitISTEncoder(_Base):
         self._graphed_kw: Optional[dict] = None        # enable_graphed_training()
         self._graphed_trainer = None
         import os
-        if os.environ.get("SEGGER_AMD_FAST", "").strip().lower() in ("1", "true", "yes", "on"):
+        on = lambda name: os.environ.get(name, "").strip().lower() in ("1", "true", "yes", "on")
+        if on("SEGGER_AMD_FAST"):
             self.fast()            # `SEGGER_AMD_FAST=1 segger segment ...`: the CLI builds the module from parsed arguments only
+        elif on("SEGGER_AMD_GRAPHED"):
+            # captured steps WITHOUT changing the arithmetic width: the reference's fp32 storage, every training step one
+            # hipGraph replay -- the recommended drop-in (bench.py `strong.graphed_f32`)
+            self.enable_graphed_training()
 
     # ------------------------------------------------------------------ setup
     def set_similarities(self, tx_similarity: Tensor, bd_similarity: Tensor) -> None:

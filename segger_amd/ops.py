@@ -1734,9 +1734,29 @@ def linear_wgrad_pair_launch(sides, dx: bool):
     return outs
 
 
+# ---- "the hand-written path is off": vendor-GEMM use is counted and announced once per (site, K, M, dtype) ------------------
+# The MFMA projection kernels cover segger's CLI widths (hidden 64 / 128, heads x channels = 128, 16-bit and fp32).  Another
+# width (say hidden_channels=96) still WORKS -- through torch's library GEMM -- but not on this project's kernels.
+# ``ops.vendor_gemm_calls`` counts those calls per (site, K, M, dtype); the first one of each kind warns.
+vendor_gemm_calls: dict = {}
+
+
+def _vendor_gemm(site: str, k_in: int, m_out: int, dtype) -> None:
+    key = (site, int(k_in), int(m_out), str(dtype).replace("torch.", ""))
+    seen = vendor_gemm_calls.get(key, 0)
+    vendor_gemm_calls[key] = seen + 1
+    if not seen:
+        import warnings
+        warnings.warn(f"segger_amd: {site} for K={k_in} -> M={m_out} ({key[3]}) is not covered by the hand-written MFMA "
+                      f"kernels (segger_linear_supported / segger_linear_wgrad_supported) and runs on the vendor GEMM; "
+                      f"covered widths: include/segger_amd.h. Counted in segger_amd.ops.vendor_gemm_calls.",
+                      RuntimeWarning, stacklevel=3)
+
+
 def _weight_grad_gemm(gy: Tensor, x: Tensor) -> Tensor:
     """dW[M, K] = gy^T x as a plain library GEMM: shapes the MFMA weight-gradient kernel does not cover
     (``linear_wgrad_supported``).  fp32 result."""
+    _vendor_gemm("weight gradient dW = dY^T X", x.shape[1], gy.shape[1], x.dtype)
     return (gy.t() @ x).float()
 
 
@@ -2054,6 +2074,7 @@ def _linear_backward(st, x, gy, need_x: bool, need_params, pre=None) -> tuple:
         elif linear_supported(m, k, dt):
             gx = linear_fwd_launch(gy, wt, None)
         else:
+            _vendor_gemm("data gradient dX = dY W", m, k, dt)
             gx = gy @ w
     if gw is not None:
         pass
@@ -2199,6 +2220,8 @@ def linear(x: Tensor, weight, bias) -> Tensor:
         y = _Linear.apply(x2, len(weights), *weights, *biases)
     else:
         _lib.require_cuda(x2)
+        if x2.shape[0] > 0:
+            _vendor_gemm("projection y = x W^T", x2.shape[1], m_out, x2.dtype)
         w = weights[0] if len(weights) == 1 else torch.cat(weights, 0)
         b = None
         if any(bb is not None for bb in biases):
@@ -2668,6 +2691,7 @@ def embed_linear(x: "EmbedInput", weight, bias) -> Tensor:
             and all(b is None or (b.dtype == torch.float32 and b.is_contiguous()) for b in biases)):
         return _EmbedLinear.apply(x.act_pe, x.pre_pe, x.table, x.ids, x.by_gene, len(weights), *weights, *biases)
     w = weights[0] if len(weights) == 1 else torch.cat(weights, 0)                # [M, 2D] fp32 master weights
+    _vendor_gemm("per-gene table T = gelu(E) Wa^T (torch-composed first layer)", d, w.shape[0], torch.float32)
     tab = torch.nn.functional.gelu(x.table) @ w[:, :d].t()                         # [G, M]
     if any(b is not None for b in biases):
         tab = tab + torch.cat([b if b is not None else ww.new_zeros(ww.shape[0]) for ww, b in zip(weights, biases)], 0)

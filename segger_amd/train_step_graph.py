@@ -285,9 +285,15 @@ class GraphedTrainStep:
             return
         if adv:
             raise RuntimeError("the step advanced Adam's counters for segger_adam_step, which then refused the optimizer")
-        if self._hyper_on_device and torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("segger_adam_step refused an optimizer whose hyper-parameters this step stages on the device "
-                               "(non-fp32 / non-contiguous parameters or gradients, an AMP grad scaler attached)")
+        if self._hyper_on_device:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("segger_adam_step refused an optimizer whose hyper-parameters this step stages on the "
+                                   "device (non-fp32 / non-contiguous parameters or gradients, an AMP grad scaler attached)")
+            # eager warm-up, optimizer state present, and the kernel still declines (what adam_hyper() cannot see from the
+            # param_group: gradient dtype / layout, a GradScaler's grad_scale / found_inf): take the route that works from
+            # here on -- torch's own step inside the capture, (lr, betas, eps) baked in and part of the re-capture key
+            if any(self.opt.state.get(p) for g in self.opt.param_groups for p in g["params"]):
+                self._hyper_on_device = False
         self.opt.step()
         if inc:
             ops.step_advance(enc._step_dev, inc)

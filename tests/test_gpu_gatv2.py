@@ -418,3 +418,99 @@ def test_dropout_mask_known_answer_on_device(cuda):
     att = (torch.randn(H * C, generator=g) * 0.3).to(cuda)
     _, alpha = ops.gatv2_aggregate(x, x, att, None, graph, H, C, dropout_p=0.2, seed=5, return_alpha=True)
     assert torch.equal((alpha != 0).cpu(), keep)
+
+
+# ---- the roofline kernels at BASELINE's full C2 size against the oracle (round-5 review, item 3) -----------------------
+_C2 = {}
+
+
+def _c2_tile(cuda):
+    """The bench's own C2 tile (1M transcripts, k = 15 kNN: variable in-degrees, so the window-64 visiting order of the
+    destination pass is active), built once per session."""
+    if "ei" not in _C2:
+        from segger_amd import TX_TX
+        from segger_amd.graph import build_edge_graph
+        from segger_amd.synthetic import SyntheticSpec, make_graph
+        n = 1_000_000
+        b = make_graph(SyntheticSpec(n_tx=n, n_bd=n // 100, k_tx=15, seed=0))
+        ei = b[TX_TX].edge_index.to(cuda)
+        _C2.update(n=n, ei=ei, graph=build_edge_graph(ei, n, n))
+    return _C2["n"], _C2["ei"], _C2["graph"]
+
+
+def _subgraph(ei, rows_flag_dst):
+    """Edges whose destination is flagged -> (edge ids, unique sources, local source index, unique destinations, local
+    destination index); everything on the device."""
+    sel = rows_flag_dst[ei[1]].nonzero().squeeze(1)
+    src, dst = ei[0, sel], ei[1, sel]
+    us, ls = torch.unique(src, return_inverse=True)
+    ud, ld = torch.unique(dst, return_inverse=True)
+    return sel, us, ls, ud, ld
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.2])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_c2_layer_against_oracle_on_sampled_rows(oracle, cuda, dtype, dropout):
+    """One tx-neighbors-tx layer at C2 size (1M rows, 15M edges, general att and bias, GELU, dropout off and on with the
+    step's bit planes): 2000 sampled destination rows (first, last and the highest in-degree row among them) and 1000
+    sampled source rows are checked against ``oracle.gatv2_conv`` in float64 on the sub-graphs that determine them --
+    `out`, `alpha` and `grad_xr` of a destination depend on its in-edges only; `grad_xl` of a source on ALL in-edges of
+    every destination it points to.  Tolerances: the per-kernel ones of this file."""
+    from segger_amd import ops
+    n, ei, graph = _c2_tile(cuda)
+    H, C = 2, 64
+    hc, E = H * C, int(ei.shape[1])
+    assert graph.by_dst.order is not None and graph.by_src.order is None        # graph.ROW_ORDER_WINDOW_DST at this size
+    gen = torch.Generator(device=cuda).manual_seed(11)
+    xl = torch.randn(n, hc, device=cuda, generator=gen).to(dtype).requires_grad_(True)
+    xr = torch.randn(n, hc, device=cuda, generator=gen).to(dtype).requires_grad_(True)
+    att = (torch.randn(hc, device=cuda, generator=gen) * 0.3).requires_grad_(True)
+    bias = (torch.randn(hc, device=cuda, generator=gen) * 0.1).requires_grad_(True)
+    gy = torch.randn(n, hc, device=cuda, generator=gen).to(dtype)
+    seed = 0x5EED_0000_0C2
+    bits = None
+    if dropout > 0:
+        bits = (ops.dropout_bits(graph.by_dst, H, dropout, [seed])[0], ops.dropout_bits(graph.by_src, H, dropout, [seed])[0])
+    y, alpha = ops.gatv2_aggregate(xl, xr, att, bias, graph, H, C, apply_gelu=True, dropout_p=dropout, seed=seed,
+                                   return_alpha=True, keep_bits=bits)
+    y.backward(gy)
+    torch.cuda.synchronize()
+
+    deg = torch.bincount(ei[1], minlength=n)
+    pick = torch.randperm(n, device=cuda, generator=gen)
+    dsts = torch.cat([pick[:1997], torch.tensor([0, n - 1], device=cuda), deg.argmax().view(1)]).unique()
+    srcs = pick[2000:3000]
+    keep_all = oracle.dropout_keep_mask(seed, E, H, dropout) if dropout > 0 else None
+
+    def run_oracle(flag):
+        sel, us, ls, ud, ld = _subgraph(ei, flag)
+        o = [t.detach().double().cpu().requires_grad_(True) for t in (xl[us], xr[ud], att, bias)]
+        sub = torch.stack([ls, ld]).cpu()
+        keep = keep_all[sel.cpu()] if keep_all is not None else None
+        eye, zero = torch.eye(hc, dtype=torch.float64), torch.zeros(hc, dtype=torch.float64)
+        pre, a = oracle.gatv2_conv(o[0], o[1], sub, eye, zero, eye, zero, o[2], o[3], H, dropout_p=dropout,
+                                   dropout_keep=keep, return_alpha=True)
+        out = torch.nn.functional.gelu(pre)
+        out.backward(gy[ud].double().cpu())
+        return sel, us, ud, out, a, o
+
+    # ---- destinations: out, alpha, grad_xr -------------------------------------------------------------------------------
+    flag = torch.zeros(n, dtype=torch.bool, device=cuda); flag[dsts] = True
+    sel, us, ud, out_ref, a_ref, o = run_oracle(flag)
+    assert torch.equal(ud, dsts) and int(deg[dsts].max()) == int(deg.max()) and int(deg[dsts].min()) >= 0
+    close(y[ud], out_ref, dtype, what="out (C2 rows)")
+    close(alpha[sel], a_ref, torch.float32 if dtype == torch.float32 else dtype, what="alpha (C2 edges)")
+    if dropout > 0:
+        assert torch.equal(alpha[sel].cpu() != 0, keep_all[sel.cpu()] & (a_ref != 0)), "dropout mask differs at C2 size"
+    k_eff = float(deg[dsts].float().mean())
+    close(xr.grad[ud], o[1].grad, dtype, scale=4.0 * max(1.0, k_eff) ** 0.5, what="grad_xr (C2 rows)")
+
+    # ---- sources: grad_xl needs every in-edge of every destination a sampled source points to ----------------------------
+    sflag = torch.zeros(n, dtype=torch.bool, device=cuda); sflag[srcs] = True
+    touched = ei[1, sflag[ei[0]].nonzero().squeeze(1)]
+    flag = torch.zeros(n, dtype=torch.bool, device=cuda); flag[touched] = True
+    sel, us, ud, out_ref, a_ref, o = run_oracle(flag)
+    local = torch.searchsorted(us, srcs.sort().values)
+    assert torch.equal(us[local], srcs.sort().values)               # every sampled source is a source of the sub-graph (self edge)
+    close(xl.grad[srcs.sort().values], o[0].grad[local.cpu()], dtype, scale=4.0, what="grad_xl (C2 rows)")
+    close(y[ud], out_ref, dtype, what="out (rows around the sampled sources)")

@@ -414,3 +414,32 @@ def test_bench_contract_line_survives_oversized_and_failed_records():
     assert c["cpu_baseline"]["value"] and c["value"] == pytest.approx(full["value"])
     assert isinstance(c["roofline_other"], str) and "dropped" in c["roofline_other"]
     assert len(c["f32"]["error"]) <= 120
+
+
+def test_cli_default_widths_never_leave_the_hand_written_gemms():
+    """Every projection of the encoder at segger's CLI defaults (in 128, hidden 64 x 2 heads, out 64; ist_encoder.py:219-287)
+    -- forward, data gradient (K and M swapped) and weight gradient, in fp32 / bf16 / f16 -- is covered by the MFMA kernels,
+    so ``ops.vendor_gemm_calls`` stays empty there; an uncovered width is counted and announced once (RuntimeWarning), not
+    served silently."""
+    import warnings
+    from segger_amd import ops
+    fwd = [(128, 128),              # lin_first.bd (PCA 128 -> in 128)
+           (256, 64), (64, 64),     # positional MLP
+           (256, 384), (256, 128),  # conv 0: stacked lin_l | lin_r | lin_l over gelu(cat(E[g], pe)); lin_r(bd)
+           (128, 384), (128, 128),  # conv 1..3
+           (128, 64)]               # lin_last
+    for dt in (torch.float32, torch.bfloat16, torch.float16):
+        for k, m in fwd:
+            assert ops.linear_supported(k, m, dt), ("forward", k, m, dt)
+            assert ops.linear_wgrad_supported(m, k, dt), ("weight gradient", m, k, dt)
+            if k != 256:            # (the first layer's input needs no data gradient beyond the positional half: K = 128)
+                assert ops.linear_supported(m, k, dt), ("data gradient", m, k, dt)
+    ops.vendor_gemm_calls.clear()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ops._vendor_gemm("projection y = x W^T", 96, 192, torch.bfloat16)
+        ops._vendor_gemm("projection y = x W^T", 96, 192, torch.bfloat16)
+    assert len(w) == 1 and "K=96 -> M=192" in str(w[0].message) and issubclass(w[0].category, RuntimeWarning)
+    assert ops.vendor_gemm_calls == {("projection y = x W^T", 96, 192, "bfloat16"): 2}
+    assert not ops.linear_supported(96, 192, torch.bfloat16)
+    ops.vendor_gemm_calls.clear()

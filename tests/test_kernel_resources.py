@@ -36,11 +36,14 @@ def _norm(name: str) -> str:
 def table():
     if shutil.which("make") is None or not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc: the assembly cannot be produced here")
-    subprocess.run(["make", "-C", os.path.join(ROOT, "segger_amd", "csrc"), "asm", "-j8"], check=True,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+    # incremental: with build/asm up to date (tools / an earlier test run) this is a no-op; from scratch it compiles every
+    # translation unit to assembly (~2 minutes on 8 cores).  SEGGER_SKIP_ASM_BUILD=1 audits a prebuilt build/asm as is.
+    if not os.environ.get("SEGGER_SKIP_ASM_BUILD"):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "segger_amd", "csrc"), "asm", "-j8"], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     import kernel_resources
     rows = kernel_resources.kernels()
-    assert len(rows) > 300
+    assert rows, "build/asm holds no kernel descriptors"
     return {_norm(r["name"]): r for r in rows}
 
 
@@ -73,9 +76,13 @@ def test_kernels_of_the_timed_steps_use_no_scratch(table, pattern):
 
 
 def test_flagship_aggregation_and_projection_kernels_use_no_scratch(table):
-    """H = 2, C = 64 (segger's CLI defaults) at every storage type the encoder runs 16-bit; the persistent projection at
-    every shipped (K, M)."""
+    """H = 2, C = 64 (segger's CLI defaults) at every storage type -- fp32 included since round 6: the reference's own
+    arithmetic width is what the import swap runs by default; the persistent projection at every shipped (K, M)."""
     want = []
+    for t in ("float",):
+        want += [f"gatv2_fwd_kernel<{t},2,8,false>", f"gatv2_fwd_kernel<{t},2,8,true>", f"gatv2_fwd_pair_kernel<{t},2,8>",
+                 f"gatv2_bwd_dst_kernel<{t},2,8,false,false>", f"gatv2_bwd_dst_kernel<{t},2,8,true,true>",
+                 f"gatv2_bwd_src_kernel<{t},2,8,false>", f"gatv2_bwd_src_dst_pair_kernel<{t},2,8>"]
     for t in ("bf16_t", "f16_t"):
         want += [f"gatv2_fwd_kernel<{t},2,8,false>", f"gatv2_fwd_kernel<{t},2,8,true>", f"gatv2_fwd_pair_kernel<{t},2,8>",
                  f"gatv2_bwd_dst_kernel<{t},2,8,false,false>", f"gatv2_bwd_dst_kernel<{t},2,8,true,true>",
