@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 27
+#define SEGGER_ABI_VERSION 28
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -674,6 +674,18 @@ int segger_linear_fwd_f32_gate(const float* x, int64_t ldx, const void* w, int32
  * fp32 row-major, laid out as w or, transpose != 0, as w^T [cols, rows]: the weight operand of segger_linear_fwd_f32_split,
  * refreshed after every optimizer step. */
 int segger_f32_split_planes(const float* w, int32_t rows, int32_t cols, int32_t transpose, void* planes, segger_stream_t stream);
+/* ... for up to SEGGER_PLANES_MAX_JOBS matrices in ONE launch (every fp32 weight pack of a model after an optimizer step:
+ * nn.Linear / GATv2Conv.lin_l / lin_r weights of ist_encoder.py:111-124,261,282-286); per job the arguments of
+ * segger_f32_split_planes. */
+#define SEGGER_PLANES_MAX_JOBS 32
+typedef struct segger_planes_job {
+  const float* w;      /* [rows, cols] fp32, contiguous */
+  int32_t rows, cols;
+  int32_t transpose;   /* non-zero: planes of w^T */
+  int32_t reserved_;
+  void* planes;        /* bf16 [3][rows * cols] */
+} segger_planes_job;
+int segger_f32_split_planes_many(const segger_planes_job* jobs, int32_t n_jobs, segger_stream_t stream);
 int segger_linear_wgrad_f32_split_supported(int32_t m_out, int32_t k_in);
 int segger_linear_wgrad_f32_split(const float* dy, int64_t ld_dy, const float* x, int64_t ld_x, int64_t n_rows, int32_t m_out,
                                   int32_t k_in, float* grad_w, float* grad_b, void* workspace, size_t workspace_bytes,

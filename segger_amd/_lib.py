@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
@@ -85,6 +85,14 @@ class StageSeg(C.Structure):
         ("dst_bytes", C.c_int32), ("src_bytes", C.c_int32),
         ("fill", C.c_int32), ("copy_add", C.c_int32),
     ]
+
+
+class PlanesJob(C.Structure):
+    _fields_ = [("w", vp), ("rows", C.c_int32), ("cols", C.c_int32), ("transpose", C.c_int32), ("reserved_", C.c_int32),
+                ("planes", vp)]
+
+
+PLANES_MAX_JOBS = 32        # SEGGER_PLANES_MAX_JOBS
 
 
 class TransposeSeg(C.Structure):
@@ -280,6 +288,7 @@ EXPORTS = {
     "segger_linear_fwd_f32_act": (C.c_int, [vp, C.c_int64, vp, vp, vp, C.c_int64, vp, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, vp]),
     "segger_linear_fwd_f32_gate": (C.c_int, [vp, C.c_int64, vp, C.c_int32, vp, C.c_int64, C.c_int32, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp]),
     "segger_f32_split_planes": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp]),
+    "segger_f32_split_planes_many": (C.c_int, [vp, C.c_int32, vp]),
     "segger_linear_wgrad_f32_split_supported": (C.c_int, [C.c_int32, C.c_int32]),
     "segger_linear_wgrad_f32_split": (C.c_int, [vp, C.c_int64, vp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, vp, vp, vp, C.c_size_t, vp]),
     "segger_gene_table_fwd": (C.c_int, [C.POINTER(GeneTableArgs), vp]),

@@ -646,6 +646,26 @@ __global__ __launch_bounds__(256) void f32_split_planes_kernel(const float* __re
   out[o].v = (uint16_t)(h & 0xffffu); out[n + o].v = (uint16_t)(m & 0xffffu); out[2 * n + o].v = (uint16_t)(l & 0xffffu);
 }
 
+struct PlanesJobs { segger_planes_job job[SEGGER_PLANES_MAX_JOBS]; };
+// the same for several matrices: blockIdx.y = job, blockIdx.x over the largest job's elements (smaller jobs' extra blocks exit)
+__global__ __launch_bounds__(256) void f32_split_planes_many_kernel(PlanesJobs all) {
+  const segger_planes_job& j = all.job[blockIdx.y];
+  const int rows = j.rows, cols = j.cols;
+  const int64_t n = (int64_t)rows * cols, o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= n) return;
+  const float* __restrict__ w = j.w;
+  bf16_t* __restrict__ out = static_cast<bf16_t*>(j.planes);
+  const float v = j.transpose ? w[(o % rows) * cols + o / rows] : w[o];
+  const uint32_t h = Vec8<bf16_t>::pack(v, 0.f);
+  float hf, mf, z;
+  Vec8<bf16_t>::unpack2(h, hf, z);
+  const float r = v - hf;
+  const uint32_t m = Vec8<bf16_t>::pack(r, 0.f);
+  Vec8<bf16_t>::unpack2(m, mf, z);
+  const uint32_t l = Vec8<bf16_t>::pack(r - mf, 0.f);
+  out[o].v = (uint16_t)(h & 0xffffu); out[n + o].v = (uint16_t)(m & 0xffffu); out[2 * n + o].v = (uint16_t)(l & 0xffffu);
+}
+
 // ------------------------------------------------------------------------------- W resident in registers (K * M = 49152)
 // The two big shapes -- 128 -> 384 (stacked lin_l | lin_r | lin_l) and its data gradient 384 -> 128 -- spent their time in
 // SERIES: the bounding builds of linear_f32_split_kernel<384> (tools/ab_fs384.sh; 0.872 ms at 1M rows) give back 0.19 ms
@@ -1033,6 +1053,26 @@ extern "C" int segger_f32_split_planes(const float* w, int32_t rows, int32_t col
   hipLaunchKernelGGL(f32_split_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, rows, cols,
                      transpose, static_cast<bf16_t*>(planes));
   SEGGER_LAUNCH_CHECK("f32_split_planes_kernel");
+  return SEGGER_OK;
+}
+
+extern "C" int segger_f32_split_planes_many(const segger_planes_job* jobs, int32_t n_jobs, segger_stream_t stream) {
+  SEGGER_REQUIRE(jobs && n_jobs > 0 && n_jobs <= SEGGER_PLANES_MAX_JOBS, "segger_f32_split_planes_many: 1..32 jobs");
+  PlanesJobs all{};
+  int64_t most = 0;
+  for (int i = 0; i < n_jobs; ++i) {
+    const segger_planes_job& j = jobs[i];
+    SEGGER_REQUIRE(j.rows >= 0 && j.cols >= 0, "segger_f32_split_planes_many: negative size");
+    const int64_t n = (int64_t)j.rows * j.cols;
+    SEGGER_REQUIRE(n == 0 || (j.w && j.planes), "segger_f32_split_planes_many: NULL pointer");
+    SEGGER_REQUIRE(n < (int64_t)0x7fffffff * 256, "segger_f32_split_planes_many: matrix too large");
+    all.job[i] = j;
+    if (n > most) most = n;
+  }
+  if (most == 0) return SEGGER_OK;
+  hipLaunchKernelGGL(f32_split_planes_many_kernel, dim3((unsigned)((most + 255) / 256), (unsigned)n_jobs), dim3(256), 0,
+                     (hipStream_t)stream, all);
+  SEGGER_LAUNCH_CHECK("f32_split_planes_many_kernel");
   return SEGGER_OK;
 }
 

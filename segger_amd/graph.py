@@ -24,7 +24,7 @@ from .hetero import EdgeType
 
 # Degree-balanced row visiting order (segger_csr_row_order): within windows of 64 consecutive rows the rows are visited by
 # descending degree, so the four rows that share a wave have near-equal length.  A wave walks 4-edge batches until its
-# LONGEST row is done; on the C2 tile's by-destination view (kNN in-degrees: mean 15, sd 3.9) that costs 12.9 % of the
+# LONGEST row is done; on the C2 tile's by-destination view (kNN in-degrees: mean 15, sd 3.3) that costs 12.9 % of the
 # forward's / destination pass's batch iterations, the window order leaves 2.1 % (profiles/r06_aggregation_valu_budget.txt:
 # SQ_INSTS_VALU -8.7 % / -8.9 %, destination pass 0.871 -> 0.817 ms, forward 0.634 -> 0.618).  Round 2 had measured the
 # same order 3-10 % SLOWER (34 % more L2 requests: rows of one wave no longer adjacent) with the kernels of that round; with

@@ -330,6 +330,10 @@ class ISTEncoder(Module):
         # tiny launches (table GEMM, weight slices) only pay for themselves on large batches
         self.split_first_layer = True
         self.split_first_layer_min_rows = 200_000
+        # fp32 storage: the un-split first layer is a K = 256 GEMM on the exact-fp32 MFMA pipe (157 TFLOP/s) forward, backward
+        # and for its weight gradient -- 0.6 ms of the captured 1M-edge step's 2.4 (profiles/r06_small_batch_step_f32_*.txt) --
+        # while the split form's K = 128 shapes run on the bf16x3 kernels: worth it from far fewer rows
+        self.split_first_layer_min_rows_f32 = 4_096
         self.lin_first = ModuleDict({"tx": Embedding(n_genes, in_channels)})
         if bd_in_channels is not None:
             self.lin_first["bd"] = Linear(bd_in_channels, in_channels)
@@ -447,7 +451,8 @@ class ISTEncoder(Module):
                                                         first[TX_BD].lin_l.weight))
                 probe = ops.EmbedInput(emb.weight, x_dict["tx"], x_bd[:0, : self.in_channels], None)
                 split = (self.split_first_layer
-                         and x_dict["tx"].shape[0] >= self.split_first_layer_min_rows
+                         and x_dict["tx"].shape[0] >= (self.split_first_layer_min_rows_f32 if dt == torch.float32
+                                                       else self.split_first_layer_min_rows)
                          and ops.embed_linear_supported(probe, m_first))
             # ONE embedder call for both node types (the reference calls it per type, ist_encoder.py:314-318): graph ids
             # of the boundaries are offset by num_graphs, so the per-graph min / max stay per type.  Half the launches

@@ -1946,6 +1946,27 @@ def _refresh_stale_packs(requester: "_Pack") -> None:
         live.append((pk, key))
     if dsts:
         _copy_groups(dsts, srcs)
+    # fp32 packs that serve the bf16x3 split kernels: the plane sets they already hold (normal and / or transposed) are
+    # rebuilt for ALL of them by ONE launch (segger_f32_split_planes_many) into the same buffers -- lazily, one launch per
+    # pack and orientation, they were 16-18 launches of 5 us in a captured 1M-edge step at fp32 storage
+    jobs = []
+    for pk, key in live:
+        if pk.w.is_cuda and pk.w.dtype == torch.float32:
+            for slot, tr in (("_planes", 0), ("_planes_t", 1)):
+                hit = pk.__dict__.get(slot)
+                if hit is not None and hit[1].is_cuda and hit[1].device == pk.w.device:
+                    jobs.append((pk, slot, tr, key, hit[1]))
+    for j0 in range(0, len(jobs), _lib.PLANES_MAX_JOBS):
+        chunk = jobs[j0:j0 + _lib.PLANES_MAX_JOBS]
+        arr = (_lib.PlanesJob * len(chunk))()
+        for a, (pk, slot, tr, key, buf) in zip(arr, chunk):
+            a.w, a.rows, a.cols, a.transpose, a.planes = pk.w.data_ptr(), int(pk.w.shape[0]), int(pk.w.shape[1]), tr, buf.data_ptr()
+        dev = chunk[0][0].w.device
+        with _lib.on_device(dev):
+            rc = _lib.load().segger_f32_split_planes_many(arr, len(chunk), _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_f32_split_planes_many")
+        for pk, slot, tr, key, buf in chunk:
+            pk.__dict__[slot] = (key, buf)
     done_t = set()
     for dt in {pk.w.dtype for pk, _ in one_launch}:
         # casts into the stacked buffers, transposed copies and bias copies of every stale pack: ONE launch
@@ -2066,13 +2087,14 @@ def _linear_backward(st, x, gy, need_x: bool, need_params, pre=None) -> tuple:
         if st.wt_of.key != st.w_key:
             raise RuntimeError("the projection weights changed between this forward and its backward "
                                "(optimizer step in between?): run backward before stepping")
-        wt = st.wt_of.wt                                                   # [K, M]: dX = dY @ W
+        # (st.wt_of.wt = W^T [K, M], dX = dY @ W -- asked for only where it is read: at fp32 storage the split kernels take
+        #  the transposed PLANES instead, and the property's transposing copy was one stray launch per projection and step)
         if (FUSED_WGRAD_DX and (want_w or want_b) and x.shape[0] > 0 and linear_wgrad_dx_supported(m, k, dt)):
-            gx, gw, gb = linear_wgrad_dx_launch(gy, x, wt, want_bias=want_b)    # dY read ONCE for dX, dW and db
+            gx, gw, gb = linear_wgrad_dx_launch(gy, x, st.wt_of.wt, want_bias=want_b)    # dY read ONCE for dX, dW and db
         elif F32_SPLIT and dt == torch.float32 and linear_f32_split_supported(m, k):
             gx = linear_f32_split_launch(gy, st.wt_of.planes(transposed=True), None)
         elif linear_supported(m, k, dt):
-            gx = linear_fwd_launch(gy, wt, None)
+            gx = linear_fwd_launch(gy, st.wt_of.wt, None)
         else:
             _vendor_gemm("data gradient dX = dY W", m, k, dt)
             gx = gy @ w
