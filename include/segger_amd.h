@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 28
+#define SEGGER_ABI_VERSION 29
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -860,6 +860,31 @@ int segger_posfreq(const float* pos, const int64_t* batch, const float* mins, co
  * Covered: frequency_embedding_size 256, hidden_size 128 (segger's in_channels default): segger_posmlp_supported.
  */
 int segger_posmlp_supported(int32_t freq_dim, int32_t dim, int32_t dtype);
+/*
+ * segger_posenc_poly_*: the first Linear of Positional2dEmbedder (ist_encoder.py:45-49 `mlp[0]` applied to the sinusoid of
+ * :22-31) at fp32 storage WITHOUT the [2n, freq_dim] feature matrix and without a GEMM.  The embedder's argument is a min-max
+ * NORMALISED coordinate p in [0, 1] (:62-64, :74) and every frequency is <= 1, so |w_j p| <= 1: cos / sin equal their Taylor
+ * series through p^12 to 1/13! = 1.6e-10, and the sum over the features can be taken first:
+ *   z1[row, m] = sum_{d=0..12} coef[m, d] p^d,   coef[m, d] = [d = 0] b0[m] + (-1)^floor(d/2)/d! sum_j W0[m, (d odd ? half : 0) + j] w_j^d
+ * segger_posenc_poly_coef: coef [dim][16] fp32 (13 terms + padding) from W0 [dim, freq_dim] / b0 (NULL: none), in float64;
+ *   once per step.
+ * segger_posenc_poly_fwd: z1 [2n, dim] fp32 (row = 2 * node + axis), optionally h1 = SiLU(z1) and pn [2n] (the normalised
+ *   coordinate, all the weight gradient needs); exact fp32 FMA arithmetic.
+ * segger_posenc_poly_wgrad: dW0 [dim, freq_dim] = dz1^T F and db0 [dim] = sum dz1 as  M V^T  with the 13 moments
+ *   M[m, d] = sum_rows dz1[row, m] pn[row]^d (fp32 per lane, float64 across workgroups, fixed order: deterministic) and V
+ *   the features' Taylor coefficients; dz1 [n_rows, dim] fp32 (row stride ld); workspace
+ *   segger_posenc_poly_wgrad_workspace_bytes(n_rows, dim).
+ * Covered: dim 32 / 64 / 128, even freq_dim <= 4096 (segger: 64, 256), max_period > 1: segger_posenc_poly_supported.
+ */
+int segger_posenc_poly_supported(int32_t freq_dim, int32_t dim);
+int segger_posenc_poly_coef(const float* w0, const float* b0, int32_t freq_dim, int32_t dim, float max_period, float* coef,
+                            segger_stream_t stream);
+int segger_posenc_poly_fwd(const float* pos, const int64_t* batch, const float* mins, const float* maxs, int64_t n, float eps,
+                           const float* coef, int32_t dim, float* z1, float* h1, float* pn, segger_stream_t stream);
+size_t segger_posenc_poly_wgrad_workspace_bytes(int64_t n_rows, int32_t dim);
+int segger_posenc_poly_wgrad(const float* dz1, int64_t ld, const float* pn, int64_t n_rows, int32_t freq_dim, int32_t dim,
+                             float max_period, float* grad_w0, float* grad_b0, void* workspace, size_t workspace_bytes,
+                             segger_stream_t stream);
 int segger_posmlp_fwd(const float* pos, const int64_t* batch, const float* mins, const float* maxs, int64_t n, float eps,
                       float max_period, const void* w0, const float* b0, const void* w2, const float* b2, void* pe,
                       void* z1, float* pn, void* h1, void* pe_pre, int32_t gelu, int32_t dtype, segger_stream_t stream);

@@ -112,6 +112,17 @@ class Positional2dEmbedder(Module):
                 # registers (and stored once for the weight gradient when training) instead of written and re-read
                 return ops.posmlp(pos, batch, mins, maxs, l0.weight, l0.bias, l2.weight, l2.bias, dtype,
                                   eps=eps_n, max_period=10000.0, gelu=gelu, return_pre=return_pre and gelu)
+            if (dtype == torch.float32 and ops.F32_GATE_EPILOGUE and l0.bias is not None and l2.bias is not None
+                    and ops.pos_poly_mlp_f32_supported(pos, l0.weight, l2.weight)):
+                # fp32 storage: the first Linear as a polynomial of the normalised coordinate (no feature matrix, no K = 256
+                # GEMM: csrc/posenc_poly.hip), SiLU and the 64-wide second Linear (+ the GELU that follows) behind one node
+                if gelu and return_pre:
+                    h, gh = ops.pos_poly_mlp_f32(pos, batch, mins, maxs, l0.weight, l0.bias, l2.weight, l2.bias, eps=eps_n,
+                                                 max_period=10000.0, gelu_out=True)
+                    return gh.reshape(n, -1), h.reshape(n, -1)
+                h = ops.pos_poly_mlp_f32(pos, batch, mins, maxs, l0.weight, l0.bias, l2.weight, l2.bias, eps=eps_n,
+                                         max_period=10000.0).reshape(n, -1)
+                return F.gelu(h) if gelu else h
             freq = ops.posfreq(pos, batch, mins, maxs, fd, dtype, eps=eps_n, max_period=10000.0)
         else:
             pos = self.normalize(pos, batch, num_graphs)

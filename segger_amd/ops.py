@@ -1534,6 +1534,84 @@ def mlp_silu_f32(x: Tensor, w0, b0, w2, b2, gelu_out: bool = False):
     return _MlpSiluF32.apply(x, w0, b0, w2, b2, gelu_out)
 
 
+# fp32 storage: the positional embedder's first Linear as a degree-12 polynomial of the normalised coordinate
+# (csrc/posenc_poly.hip) -- no [2n, 256] feature matrix (2 GB at C2: segger_posfreq wrote it, two exact-fp32 GEMMs read it)
+# and no K = 256 GEMM, forward or weight gradient.  False: posfreq + _MlpSiluF32 (round 5's route).
+POS_POLY_F32 = True
+
+
+def pos_poly_mlp_f32_supported(pos: Tensor, w0: Tensor, w2: Tensor) -> bool:
+    dim, fd = int(w0.shape[0]), int(w0.shape[1])
+    return (POS_POLY_F32 and pos.is_cuda and pos.dim() == 2 and pos.shape[1] == 2 and pos.shape[0] > 0 and not pos.requires_grad
+            and w0.dtype == torch.float32 and w2.dtype == torch.float32 and tuple(w2.shape) == (dim, dim)
+            and bool(_lib.load().segger_posenc_poly_supported(fd, dim))
+            and linear_supported(dim, dim, torch.float32) and linear_wgrad_supported(dim, dim, torch.float32)
+            and linear_f32_gate_supported(dim, dim) and dim % 64 == 0)
+
+
+class _PosPolyMlpF32(torch.autograd.Function):
+    """``Linear -> SiLU -> Linear`` of ``Positional2dEmbedder`` on the sinusoid of the normalised coordinates at fp32 storage,
+    from the POSITIONS (ist_encoder.py:57-79 in one autograd node): the first layer by ``segger_posenc_poly_fwd`` (13
+    coefficients per channel, refreshed from W0 / b0 by ``segger_posenc_poly_coef``), its weight gradient by
+    ``segger_posenc_poly_wgrad`` (13 moments per channel); the 64-wide second layer on the exact-fp32 kernels as before."""
+
+    @staticmethod
+    def forward(ctx, pos, batch, mins, maxs, eps, max_period, w0, b0, w2, b2, gelu_out=False):
+        lib = _lib.load()
+        dev = pos.device
+        pos = pos.detach().to(torch.float32).contiguous()
+        if batch is not None:
+            batch = batch.to(device=dev, dtype=torch.int64).contiguous()
+        n, dim, fd = int(pos.shape[0]), int(w0.shape[0]), int(w0.shape[1])
+        w0d, w2d, b0d = w0.detach().contiguous(), w2.detach().contiguous(), b0.detach().float().contiguous()
+        coef = torch.empty((dim, 16), dtype=torch.float32, device=dev)
+        z1 = torch.empty((2 * n, dim), dtype=torch.float32, device=dev)
+        h1 = torch.empty_like(z1)
+        pn = torch.empty(2 * n, dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            st = _lib.stream_ptr(dev)
+            rc = lib.segger_posenc_poly_coef(w0d.data_ptr(), b0d.data_ptr(), fd, dim, float(max_period), coef.data_ptr(), st)
+            _lib.check(rc, "segger_posenc_poly_coef")
+            rc = lib.segger_posenc_poly_fwd(pos.data_ptr(), _lib.ptr(batch), mins.data_ptr(), maxs.data_ptr(), n, float(eps),
+                                            coef.data_ptr(), dim, z1.data_ptr(), h1.data_ptr(), pn.data_ptr(), st)
+            _lib.check(rc, "segger_posenc_poly_fwd")
+        ctx.save_for_backward(pn, z1, h1, w2)
+        ctx.cfg = (fd, dim, float(max_period))
+        if gelu_out:                                                  # (y, gelu(y)): the second a constant for autograd
+            y, gy_ = linear_f32_act_launch(h1, w2d, b2, "gelu")
+            ctx.mark_non_differentiable(gy_)
+            return y, gy_
+        return linear_fwd_launch(h1, w2d, b2.detach())
+
+    @staticmethod
+    def backward(ctx, gy, _unused=None):
+        pn, z1, h1, w2 = ctx.saved_tensors
+        fd, dim, max_period = ctx.cfg
+        lib = _lib.load()
+        dev = gy.device
+        gy = gy.contiguous()
+        gw2, gb2 = linear_wgrad_launch(gy, h1)
+        dz1 = linear_f32_gate_launch(gy, w2.detach().t().contiguous(), z1, "silu")
+        gw0 = torch.empty((dim, fd), dtype=torch.float32, device=dev)
+        gb0 = torch.empty(dim, dtype=torch.float32, device=dev)
+        rows = int(dz1.shape[0])
+        ws_bytes = int(lib.segger_posenc_poly_wgrad_workspace_bytes(rows, dim))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        with _lib.on_device(dev):
+            rc = lib.segger_posenc_poly_wgrad(dz1.data_ptr(), dim, pn.data_ptr(), rows, fd, dim, max_period, gw0.data_ptr(),
+                                              gb0.data_ptr(), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev))
+        _lib.check(rc, "segger_posenc_poly_wgrad")
+        _defer_keep(ws)
+        return None, None, None, None, None, None, gw0, gb0, gw2, gb2, None
+
+
+def pos_poly_mlp_f32(pos: Tensor, batch: Optional[Tensor], mins: Tensor, maxs: Tensor, w0, b0, w2, b2, *, eps: float = 1e-8,
+                     max_period: float = 10000.0, gelu_out: bool = False):
+    """[n, 2] positions -> the embedder's MLP output as coordinate rows [2n, dim] (``gelu_out``: ``(y, gelu(y))``, the GELU a
+    constant for autograd as in :func:`mlp_silu_f32`)."""
+    return _PosPolyMlpF32.apply(pos, batch, mins, maxs, eps, max_period, w0, b0, w2, b2, gelu_out)
+
+
 def linear_f32_split_supported(k_in: int, m_out: int) -> bool:
     return bool(_lib.load().segger_linear_fwd_f32_split_supported(int(k_in), int(m_out)))
 

@@ -548,3 +548,50 @@ def test_first_layer_table_route_one_node_equals_the_torch_composed_route(cuda, 
         # (fp32: the table comes from exact fp32 FMAs here and from the vendor GEMM there -- two summation orders, carried
         #  through four layers' backward)
         assert (g1 - g0).abs().max().item() <= (2e-3 if dtype == torch.float32 else 6e-2) * max(g0.abs().max().item(), 1e-3), k
+
+
+@pytest.mark.parametrize("batched", [True, False])
+def test_fp32_positional_embedder_polynomial_form(oracle, cuda, batched):
+    """fp32 storage, hidden 128 (the CLI default): the first Linear of ``Positional2dEmbedder`` as a degree-12 polynomial of the
+    normalised coordinate (csrc/posenc_poly.hip) against (a) the float64 oracle -- itself pinned by the reference class's own
+    outputs (tests/golden/reference_heads.npz) -- output 2e-5 as for the golden test, and (b) round 5's route (feature matrix +
+    exact-fp32 GEMMs), output and all four parameter gradients."""
+    from segger_amd import ops
+    from segger_amd.ist_encoder import Positional2dEmbedder
+    g = torch.Generator().manual_seed(5)
+    n, n_graphs = 7001, 3
+    pos = torch.rand(n, 2, generator=g) * torch.tensor([4000.0, 2500.0]) + torch.tensor([100.0, -50.0])
+    batch = torch.sort(torch.randint(0, n_graphs, (n,), generator=g)).values if batched else None
+    torch.manual_seed(3)
+    emb = Positional2dEmbedder(128).to(cuda)
+    gy = torch.randn(n, 128, generator=g).to(cuda)
+    w = [p.detach().double().cpu() for p in (emb.mlp[0].weight, emb.mlp[0].bias, emb.mlp[2].weight, emb.mlp[2].bias)]
+    ref = oracle.positional_2d_embed(pos.double(), batch, *w, freq_dim=256)
+
+    def run(flag):
+        keep = ops.POS_POLY_F32
+        ops.POS_POLY_F32 = flag
+        try:
+            emb.zero_grad(set_to_none=True)
+            out = emb(pos.to(cuda), None if batch is None else batch.to(cuda), num_graphs=n_graphs if batched else None,
+                      dtype=torch.float32)
+            out.backward(gy)
+            torch.cuda.synchronize()
+            return out.detach(), [p.grad.detach().clone() for p in emb.parameters()]
+        finally:
+            ops.POS_POLY_F32 = keep
+
+    assert ops.pos_poly_mlp_f32_supported(pos.to(cuda), emb.mlp[0].weight, emb.mlp[2].weight)
+    out_p, grads_p = run(True)
+    out_m, grads_m = run(False)
+    assert (out_p.double().cpu() - ref).abs().max() < 2e-5
+    assert (out_p - out_m).abs().max() < 5e-6
+    for gp, gm, name in zip(grads_p, grads_m, ("w0", "b0", "w2", "b2")):
+        scale = float(gm.abs().max()) + 1e-12
+        assert float((gp - gm).abs().max()) <= 2e-5 * scale + 1e-6, (name, float((gp - gm).abs().max()), scale)
+    # float64 autograd of the oracle for the first layer's weight gradient: the polynomial moments against the real thing
+    wd = [t.clone().requires_grad_(True) for t in w]
+    oracle.positional_2d_embed(pos.double(), batch, *wd, freq_dim=256).backward(gy.double().cpu())
+    for gp, gr, name in zip(grads_p, [t.grad for t in wd], ("w0", "b0", "w2", "b2")):
+        scale = float(gr.abs().max()) + 1e-12
+        assert float((gp.double().cpu() - gr).abs().max()) <= 5e-5 * scale, (name, float((gp.double().cpu() - gr).abs().max()), scale)
