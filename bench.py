@@ -12,7 +12,11 @@ One step = one pass of the hot path over one synthetic tile per rank (weak
 scaling: every rank owns a tile of the same size, different seed): encoder
 forward, the three losses, backward, one flat-bucket gradient all-reduce (N>1),
 Adam.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE
-JSON line:
+JSON line on stdout -- the COMPACT contract line (`contract_line()`: the contract keys, `roofline` with
+`roofline.dominant` (the destination pass of the backward: the kernel with the largest share of the step) and
+`roofline.source_pass`, `cpu_baseline`, and scalar summaries of everything else; asserted <= 8 KB, round 5's 21 KB line was
+not recovered by the driver) -- and writes the FULL record described below to `bench_details.json` next to this script
+(and to stderr):
 
   metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling ("weak") /
   vs_baseline / dtype / data / config {workload, tiles_per_step, parallelism}      -- the task contract
@@ -76,6 +80,12 @@ JSON line:
       first sweep and the second sweep is timed; 4 batches are compared with the eager predict_step.
   default_dropin {ms_per_step, value, batches, dtype "f32"}
       (N = 1)  what INTEGRATION.md's import swap alone gives: fp32 storage, eager steps, 1M-edge batches (100 of the FOV's)
+  strong.graphed_f32 {ms_per_step, value, epoch_s, shape_buckets, dtype "f32"}
+      (N = 1)  the same arithmetic captured: fp32 storage, every step one hipGraph replay (enable_graphed_training() /
+      SEGGER_AMD_GRAPHED=1), one epoch over the FOV's batches
+  roofline.dominant / roofline.source_pass {kernel, achieved, frac, traffic, algorithmic_bytes_per_launch, ms_per_launch}
+      the two kernels of the tx-neighbors-tx backward timed one at a time (segger_gatv2_bwd_args.passes); algorithmic bytes
+      E (HC s + 4) + Nd (3 HC s + 16 H) for the destination pass, the rest of SURVEY 8(d)'s B_bwd for the source pass
 """
 from __future__ import annotations
 
