@@ -550,8 +550,9 @@ def test_first_layer_table_route_one_node_equals_the_torch_composed_route(cuda, 
         assert (g1 - g0).abs().max().item() <= (2e-3 if dtype == torch.float32 else 6e-2) * max(g0.abs().max().item(), 1e-3), k
 
 
+@pytest.mark.parametrize("hidden", [128, 256])
 @pytest.mark.parametrize("batched", [True, False])
-def test_fp32_positional_embedder_polynomial_form(oracle, cuda, batched):
+def test_fp32_positional_embedder_polynomial_form(oracle, cuda, batched, hidden):
     """fp32 storage, hidden 128 (the CLI default): the first Linear of ``Positional2dEmbedder`` as a degree-12 polynomial of the
     normalised coordinate (csrc/posenc_poly.hip) against (a) the float64 oracle -- itself pinned by the reference class's own
     outputs (tests/golden/reference_heads.npz) -- output 2e-5 as for the golden test, and (b) round 5's route (feature matrix +
@@ -563,8 +564,8 @@ def test_fp32_positional_embedder_polynomial_form(oracle, cuda, batched):
     pos = torch.rand(n, 2, generator=g) * torch.tensor([4000.0, 2500.0]) + torch.tensor([100.0, -50.0])
     batch = torch.sort(torch.randint(0, n_graphs, (n,), generator=g)).values if batched else None
     torch.manual_seed(3)
-    emb = Positional2dEmbedder(128).to(cuda)
-    gy = torch.randn(n, 128, generator=g).to(cuda)
+    emb = Positional2dEmbedder(hidden).to(cuda)                  # dim 64 (the CLI default) / 128: both kernel instantiations
+    gy = torch.randn(n, hidden, generator=g).to(cuda)
     w = [p.detach().double().cpu() for p in (emb.mlp[0].weight, emb.mlp[0].bias, emb.mlp[2].weight, emb.mlp[2].bias)]
     ref = oracle.positional_2d_embed(pos.double(), batch, *w, freq_dim=256)
 
