@@ -885,3 +885,38 @@ def test_encoder_front_join_equals_the_per_type_route(cuda, dtype, monkeypatch):
     for k, g1 in out[True][2].items():
         g0 = out[False][2][k]
         assert (g1 - g0).abs().max().item() <= (1e-4 if dtype == torch.float32 else 6e-2) * max(g0.abs().max().item(), 1e-3), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+def test_edge_cos_argmax_at_c2_size(oracle, cuda, dtype):
+    """Rows a8 / a11 at BASELINE C2 size: the C2 tile's own 2.4M tx-neighbors-bd candidate edges (1M transcripts, 10k nuclei;
+    transcripts without a candidate included), random unit embeddings: cosine scores, per-transcript maximum, arg-max edge
+    (first maximum = torch_scatter's CPU semantics, evaluated on the HIP scores) and assignments (with a similarity
+    threshold) against the float64 oracle on the SAME storage-rounded inputs."""
+    from segger_amd import ops, TX_NB_BD
+    from segger_amd.graph import csr_from_coo
+    from segger_amd.synthetic import SyntheticSpec, make_graph
+    n_tx, n_bd, C = 1_000_000, 10_000, 64
+    ei = make_graph(SyntheticSpec(n_tx=n_tx, n_bd=n_bd, k_tx=15, seed=0))[TX_NB_BD].edge_index
+    src, dst = ei[0], ei[1]
+    g = torch.Generator().manual_seed(8)
+    z_tx = torch.nn.functional.normalize(torch.randn(n_tx, C, generator=g), dim=-1).to(dtype)
+    z_bd = torch.nn.functional.normalize(torch.randn(n_bd, C, generator=g), dim=-1).to(dtype)
+    bd_index = torch.randperm(n_bd, generator=g).to(torch.int32) + 7
+    by_src = csr_from_coo(src.to(cuda), dst.to(cuda), n_tx, n_bd)
+    has = torch.bincount(src, minlength=n_tx) > 0
+    assert int(ei.shape[1]) > 2_000_000 and int((~has).sum()) > 0
+    for min_sim in (None, 0.05):
+        seg_ref, max_ref = oracle.predict_assign(z_tx.double(), z_bd.double(), ei, bd_index, min_sim)
+        sim_ref = oracle.edge_scores(z_tx.double(), z_bd.double(), ei)
+        max_sim, max_eid, seg, sim = ops.edge_cos_argmax(by_src, z_tx.to(cuda), z_bd.to(cuda), dst_index=bd_index.to(cuda),
+                                                         min_similarity=min_sim, return_sim=True)
+        tol = 2e-6 if dtype == torch.float32 else 1e-5
+        assert torch.allclose(sim.cpu().double(), sim_ref, atol=tol)
+        assert torch.allclose(max_sim.cpu().double(), max_ref, atol=tol)
+        _, arg_ref = oracle.scatter_max(sim.cpu(), src, n_tx)
+        assert torch.equal(max_eid.cpu(), arg_ref)
+        assert (max_eid.cpu()[~has] == ei.shape[1]).all() and (seg.cpu()[~has] == -1).all() and (max_sim.cpu()[~has] == 0).all()
+        # assignments may differ from float64 only where the two best candidates (or the threshold) are within tol
+        differ = seg.cpu() != seg_ref
+        assert float(differ.float().mean()) < 1e-4, float(differ.float().mean())
