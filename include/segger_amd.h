@@ -43,7 +43,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SEGGER_ABI_VERSION 29
+#define SEGGER_ABI_VERSION 30
 
 enum segger_status {
   SEGGER_OK = 0,
@@ -76,7 +76,24 @@ typedef struct segger_csr {
   int64_t n_edges;
   const int32_t* row_order; /* [n_rows] or NULL: the order in which kernels visit the rows (a permutation of
                                0..n_rows-1 from segger_csr_row_order); results never depend on it */
+  /* optional block tables (segger_csr_block_tables; all three or none): per workgroup of SEGGER_BLOCK_ROWS consecutive
+   * visiting positions the DISTINCT column ids its rows gather -- staged in LDS once, then gathered from there */
+  const int32_t* blk_cnt;   /* [ceil(n_rows / SEGGER_BLOCK_ROWS)]: number of distinct ids, <= SEGGER_BLOCK_CAP */
+  const int32_t* blk_src;   /* [n_blocks][SEGGER_BLOCK_CAP]: the ids (slot order arbitrary) */
+  const uint8_t* col_local; /* [n_edges]: per CSR slot, the LDS slot of col[slot] in its block's table */
 } segger_csr;
+#define SEGGER_BLOCK_ROWS 16
+#define SEGGER_BLOCK_CAP 128
+/*
+ * segger_csr_block_tables: the block tables of a CSR view in a given visiting order (row_order NULL: natural).  A kNN graph
+ * over spatially sorted nodes re-uses its gathered rows heavily inside a workgroup (C2 tile: the 16 rows of a workgroup
+ * gather 240 rows of which 58 are distinct), so the aggregation kernels can load each distinct row ONCE per workgroup,
+ * coalesced, into LDS and gather from there instead of issuing 240 row gathers through the texture addresser.
+ * *overflow (device int32, zeroed by the caller) is set when some block has more than SEGGER_BLOCK_CAP distinct ids or more
+ * than 1024 edges: the tables are then unusable and the caller keeps the plain kernels.
+ */
+int segger_csr_block_tables(const int64_t* indptr, const int32_t* col, const int32_t* row_order, int64_t n_rows, int64_t n_edges,
+                            int32_t* blk_cnt, int32_t* blk_src, uint8_t* col_local, int32_t* overflow, segger_stream_t stream);
 
 /*
  * segger_csr_from_coo: stable sort of COO edges by `row`, producing indptr /

@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must be imported first: the library binds to torch'
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # SEGGER_AMD_LIB selects another build of the same library (kernel A/B experiments)
 LIB_PATH = os.environ.get("SEGGER_AMD_LIB") or os.path.join(_HERE, "libsegger_amd.so")
-ABI_VERSION = 29
+ABI_VERSION = 30
 
 SEGGER_F32, SEGGER_BF16, SEGGER_F16 = 0, 1, 2
 DTYPE_CODE = {torch.float32: SEGGER_F32, torch.bfloat16: SEGGER_BF16, torch.float16: SEGGER_F16}
@@ -31,7 +31,8 @@ vp = C.c_void_p
 
 class Csr(C.Structure):
     _fields_ = [("indptr", vp), ("col", vp), ("eid", vp),
-                ("n_rows", C.c_int64), ("n_cols", C.c_int64), ("n_edges", C.c_int64), ("row_order", vp)]
+                ("n_rows", C.c_int64), ("n_cols", C.c_int64), ("n_edges", C.c_int64), ("row_order", vp),
+                ("blk_cnt", vp), ("blk_src", vp), ("col_local", vp)]
 
 
 class GatFwdArgs(C.Structure):
@@ -212,6 +213,7 @@ class WgradArgs(C.Structure):
 # every symbol include/segger_amd.h declares: name -> (restype, argtypes)
 EXPORTS = {
     "segger_abi_version": (C.c_int, []),
+    "segger_csr_block_tables": (C.c_int, [vp, vp, vp, C.c_int64, C.c_int64, vp, vp, vp, vp, vp]),
     "segger_last_error": (C.c_char_p, []),
     "segger_csr_from_coo_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int64]),
     "segger_csr_from_coo": (C.c_int, [vp, vp, C.c_int64, C.c_int64, C.c_int64, vp, vp, vp, vp, vp, C.c_size_t, vp]),

@@ -135,6 +135,86 @@ extern "C" int segger_csr_from_coo(const int64_t* row, const int64_t* colv, int6
   return SEGGER_OK;
 }
 
+// ---- block tables: the distinct column ids of SEGGER_BLOCK_ROWS consecutive visiting positions ---------------------------
+namespace segger { namespace {
+constexpr int kTabSlots = 2048;                 // hash table (open addressing) for <= 1024 edges of a block
+__global__ __launch_bounds__(256) void csr_block_tables_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ col,
+                                                              const int32_t* __restrict__ order, int64_t n_rows,
+                                                              int32_t* __restrict__ blk_cnt, int32_t* __restrict__ blk_src,
+                                                              uint8_t* __restrict__ col_local, int32_t* __restrict__ overflow) {
+  __shared__ int32_t keys[kTabSlots];
+  __shared__ int32_t ids[kTabSlots];
+  __shared__ int64_t rbeg[SEGGER_BLOCK_ROWS];
+  __shared__ int32_t rlen[SEGGER_BLOCK_ROWS];
+  __shared__ int32_t counter, total;
+  const int64_t blk = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kTabSlots; i += 256) keys[i] = -1;
+  if (tid == 0) { counter = 0; total = 0; }
+  __syncthreads();
+  if (tid < SEGGER_BLOCK_ROWS) {
+    const int64_t pos = blk * SEGGER_BLOCK_ROWS + tid;
+    int64_t b = 0; int32_t len = 0;
+    if (pos < n_rows) {
+      const int64_t row = order ? (int64_t)order[pos] : pos;
+      b = indptr[row]; len = (int32_t)(indptr[row + 1] - b);
+    }
+    rbeg[tid] = b; rlen[tid] = len;
+    atomicAdd(&total, len);
+  }
+  __syncthreads();
+  if (total > 1024) {                            // (the table could fill up: such a block keeps the plain gathers)
+    if (tid == 0) { blk_cnt[blk] = -1; *overflow = 1; }
+    return;
+  }
+  const int g = tid >> 4, l = tid & 15;          // 16 lanes per row
+  auto slot_of = [](int32_t v) { return (int)(((uint32_t)v * 2654435761u) >> 21) & (kTabSlots - 1); };
+  for (int e = l; e < rlen[g]; e += 16) {
+    const int32_t v = col[rbeg[g] + e];
+    int h = slot_of(v);
+    while (true) {
+      const int32_t old = atomicCAS(&keys[h], -1, v);
+      if (old == -1 || old == v) break;
+      h = (h + 1) & (kTabSlots - 1);
+    }
+  }
+  __syncthreads();
+  for (int sl = tid; sl < kTabSlots; sl += 256) {
+    if (keys[sl] != -1) {
+      const int id = atomicAdd(&counter, 1);     // (which slot number a row gets varies from build to build; results do not)
+      ids[sl] = id;
+      if (id < SEGGER_BLOCK_CAP) blk_src[blk * SEGGER_BLOCK_CAP + id] = keys[sl];
+    }
+  }
+  __syncthreads();
+  const int n = counter;
+  if (tid == 0) {
+    blk_cnt[blk] = n <= SEGGER_BLOCK_CAP ? n : -1;
+    if (n > SEGGER_BLOCK_CAP) *overflow = 1;
+  }
+  for (int e = l; e < rlen[g]; e += 16) {
+    const int32_t v = col[rbeg[g] + e];
+    int h = slot_of(v);
+    while (keys[h] != v) h = (h + 1) & (kTabSlots - 1);
+    const int id = ids[h];
+    col_local[rbeg[g] + e] = (uint8_t)(id < SEGGER_BLOCK_CAP ? id : 0);
+  }
+}
+} }  // namespace segger::(anonymous)
+
+extern "C" int segger_csr_block_tables(const int64_t* indptr, const int32_t* col, const int32_t* row_order, int64_t n_rows,
+                                       int64_t n_edges, int32_t* blk_cnt, int32_t* blk_src, uint8_t* col_local, int32_t* overflow,
+                                       segger_stream_t stream) {
+  SEGGER_REQUIRE(n_rows >= 0 && n_edges >= 0 && n_rows < 0x7fffffffLL, "segger_csr_block_tables: bad sizes");
+  if (n_rows == 0) return SEGGER_OK;
+  SEGGER_REQUIRE(indptr && blk_cnt && blk_src && overflow && (n_edges == 0 || (col && col_local)), "segger_csr_block_tables: NULL pointer");
+  const int64_t nblk = (n_rows + SEGGER_BLOCK_ROWS - 1) / SEGGER_BLOCK_ROWS;
+  hipLaunchKernelGGL(csr_block_tables_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, indptr, col, row_order, n_rows,
+                     blk_cnt, blk_src, col_local, overflow);
+  SEGGER_LAUNCH_CHECK("csr_block_tables_kernel");
+  return SEGGER_OK;
+}
+
 extern "C" int segger_csr_row_order(const int64_t* indptr, int64_t n_rows, int32_t window, int32_t* order_out,
                                     segger_stream_t stream) {
   SEGGER_REQUIRE(n_rows >= 0 && n_rows < 0x7fffffffLL, "segger_csr_row_order: bad n_rows");

@@ -138,6 +138,9 @@ static int fwd_params(const segger_gatv2_fwd_args* a, GatParams& p, bool* empty)
   p = GatParams{};
   p.indptr = a->by_dst.indptr; p.col = a->by_dst.col; p.eid = a->by_dst.eid; p.order = a->by_dst.row_order;
   p.n_rows = a->by_dst.n_rows; p.n_edges = a->by_dst.n_edges;
+  if (a->by_dst.blk_cnt && a->by_dst.blk_src && a->by_dst.col_local) {
+    p.blk_cnt = a->by_dst.blk_cnt; p.blk_src = a->by_dst.blk_src; p.col_local = a->by_dst.col_local;
+  }
   p.xl = a->x_l; p.ld_xl = a->ld_xl; p.xr = a->x_r; p.ld_xr = a->ld_xr;
   p.att = a->att; p.bias = a->bias;
   p.out = a->out; p.ld_out = a->ld_out; p.pre = a->pre; p.ld_pre = a->ld_pre;

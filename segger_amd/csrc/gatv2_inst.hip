@@ -53,6 +53,18 @@ namespace {
     p.gxl = scratch; p.ld_gxl = 3 * H * LPH * 8;                                                                   \
     hipLaunchKernelGGL((INST_KERNEL<INST_T, H, LPH, WPR>), dim3((unsigned)(EXP_GRID)), dim3(256), 0, stream, p);  \
   } while (0)
+#elif SEGGER_INST_PASS == 0 && SEGGER_INST_DTYPE != 0
+// 16-bit forward: the LDS-gather kernel where the view carries block tables (flagship geometry, no attention output)
+#define INST_LAUNCH(H, LPH, WPR)                                                                                       \
+  do {                                                                                                                 \
+    if constexpr (H == 2 && LPH == 8 && !WPR) {                                                                        \
+      if (p.blk_cnt && !p.alpha && !p.order) {                                                                         \
+        hipLaunchKernelGGL((gatv2_fwd_lds_kernel<INST_T, H, LPH>), dim3((unsigned)p.nblocks_padded), dim3(256), 0, stream, p); \
+        break;                                                                                                         \
+      }                                                                                                                \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((INST_KERNEL<INST_T, H, LPH, WPR>), dim3((unsigned)p.nblocks_padded), dim3(256), 0, stream, p); \
+  } while (0)
 #else
 #define INST_LAUNCH(H, LPH, WPR) \
   hipLaunchKernelGGL((INST_KERNEL<INST_T, H, LPH, WPR>), dim3((unsigned)p.nblocks_padded), dim3(256), 0, stream, p)

@@ -64,6 +64,8 @@ struct GatParams {
   const int32_t* eid;
   const uint8_t* bits;           // nullable: per slot, bit h = dropout keep of head h (segger_dropout_bits): replaces the hash
   const int32_t* order;          // nullable: position -> row (degree-balanced visiting order, group-per-row mode)
+  // block tables (segger_csr_block_tables; LDSG kernels): the distinct gathered rows of a workgroup's 16 positions
+  const int32_t* blk_cnt; const int32_t* blk_src; const uint8_t* col_local;
   int64_t n_rows;
   int64_t n_edges;
   // features
@@ -196,8 +198,8 @@ __device__ __forceinline__ void walk_row(const int32_t* __restrict__ col, const 
 // gathers, all wait for the texture addresser to work through them (~16 cycles per 1-KB gather, ~1000 cycles per
 // round and CU), all compute.  With the gathers compiled out the forward takes 0.50 ms instead of 0.66, with every
 // gather an L1 hit (`GRAPH=band`) still 0.655: it is this serialisation, not latency, that the prefetch overlaps.
-template <int GS, bool WPR, int META, int U, typename Issue, typename Compute>
-__device__ __forceinline__ void walk_row_prefetch(const int32_t* __restrict__ col, const void* __restrict__ meta,
+template <int GS, bool WPR, int META, int U, typename ColT, typename Issue, typename Compute>
+__device__ __forceinline__ void walk_row_prefetch(const ColT* __restrict__ col, const void* __restrict__ meta,
                                                   int64_t beg, int64_t end, int lane, int grp, int gl,
                                                   Issue&& issue, Compute&& compute) {
   constexpr bool NEED_EID = META != kMetaNone;
@@ -411,9 +413,16 @@ __device__ __forceinline__ void load_att(const float* att, int ch0, float slope,
 // ============================================================================
 // Forward
 // ============================================================================
-template <typename T, int H, int LPH, bool WPR>
+// LDSG (group-per-row, 16-bit rows of exactly 16 lanes): the workgroup's 16 rows gather from the <= SEGGER_BLOCK_CAP DISTINCT
+// source rows listed in its block table.  They are loaded once, coalesced, into LDS (ceil(cnt / 16) row loads per 16-lane
+// loader instead of one per edge: 58 instead of 240 on the C2 tile) and the edge walk gathers with ds_read_b128 from slot
+// numbers (col_local) -- no per-edge work for the texture addresser, a 32-bit LDS address instead of a 64-bit pointer.
+template <typename T, int H, int LPH, bool WPR, bool LDSG = false>
 __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid) {
   using G = Geo<H, LPH>;
+  static_assert(!LDSG || (!WPR && G::LPR == 16 && sizeof(T) == 2), "LDS gathers: group-per-row, 256-byte rows");
+  constexpr int ROWB = G::HC * (int)sizeof(T);
+  __shared__ __attribute__((aligned(16))) unsigned char tile[LDSG ? SEGGER_BLOCK_CAP * ROWB : 16];
   // wave-per-row: 2 rows in flight per group (NG groups: 2 NG edges per wave batch) -- the merge of the groups' states and
   // the wave-wide id hand-off need the registers the second pair of row buffers would take (4 in flight spills at 4 waves
   // per SIMD; these rows are the few-thousand-block tx-belongs-bd side, latency-bound beside the tx-neighbors-tx blocks)
@@ -450,12 +459,37 @@ __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid)
 
   float m = -INFINITY, s = 0.f;                       // online softmax state
 
+  if constexpr (LDSG) {
+    // stage the block's distinct source rows: 16 loaders of 16 lanes, one 256-byte row each per round
+    const int cnt = p.blk_cnt[blk];
+    const int32_t* __restrict__ srcs = p.blk_src + blk * SEGGER_BLOCK_CAP;
+    const int ldr = threadIdx.x >> 4, piece = (threadIdx.x & 15) * 16;
+    // all of a loader's ids first, then all of its rows, then the LDS writes: two memory latencies per workgroup, not two per
+    // round (slots past `cnt` load row 0 and are not written)
+    constexpr int ROUNDS = SEGGER_BLOCK_CAP / 16;
+    int sid[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k) sid[k] = ldr + 16 * k < cnt ? srcs[ldr + 16 * k] : 0;
+    u32x4 sv[ROUNDS];
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k)
+      sv[k] = *reinterpret_cast<const u32x4*>(static_cast<const char*>(p.xl) + (uint64_t)(uint32_t)sid[k] * ld_xl + piece);
+#pragma unroll
+    for (int k = 0; k < ROUNDS; ++k)
+      if (ldr + 16 * k < cnt) *reinterpret_cast<u32x4*>(tile + (ldr + 16 * k) * ROWB + piece) = sv[k];
+    __syncthreads();
+  }
+  const uint32_t lds_lane = (uint32_t)ch0 * (uint32_t)sizeof(T);
+
   const int hbit = 1 << h;
   Raw8<T> rawbuf[2][U];                               // gathered rows of the batch in work and of the next one
   auto issue = [&](auto buf_c, const int (&nbr)[U]) {
     constexpr int B = decltype(buf_c)::value;
 #pragma unroll
-    for (int u = 0; u < U; ++u) rawbuf[B][u].load(row_ptr(xl, nbr[u], ld_xl));   // invalid slots read row 0 / a row of the chunk
+    for (int u = 0; u < U; ++u) {
+      if constexpr (LDSG) rawbuf[B][u].r = *reinterpret_cast<const u32x4*>(tile + (uint32_t)nbr[u] * ROWB + lds_lane);
+      else rawbuf[B][u].load(row_ptr(xl, nbr[u], ld_xl));   // invalid slots read row 0 / a row of the chunk
+    }
   };
   auto body = [&](auto buf_c, auto meta_c, const bool (&valid)[U], const int (&ed)[U]) {
     constexpr int META = decltype(meta_c)::value;
@@ -506,7 +540,8 @@ __device__ __forceinline__ void gatv2_fwd_body(SEGGER_BODY_PARAM p, int64_t bid)
   };
   auto walk = [&](auto meta_c, const void* meta) {
     constexpr int META = decltype(meta_c)::value;
-    if constexpr (sizeof(T) == 2) walk_row_prefetch<GS, WPR, META, U>(p.col, meta, beg, end, L.lane, L.grp, L.gl, issue, body);
+    if constexpr (LDSG) walk_row_prefetch<GS, WPR, META, U>(p.col_local, meta, beg, end, L.lane, L.grp, L.gl, issue, body);
+    else if constexpr (sizeof(T) == 2) walk_row_prefetch<GS, WPR, META, U>(p.col, meta, beg, end, L.lane, L.grp, L.gl, issue, body);
     else walk_row<GS, WPR, META, U>(p.col, meta, beg, end, L.lane, L.grp, L.gl, plain);
   };
   if (want_alpha || (dropout && !p.bits)) walk(std::integral_constant<int, kMetaEid>{}, p.eid);
@@ -594,6 +629,11 @@ __global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_kernel(GatPar
 #else
   gatv2_fwd_body<T, H, LPH, WPR>(p, blockIdx.x);
 #endif
+}
+
+template <typename T, int H, int LPH>
+__global__ __launch_bounds__(256, SEGGER_FWD_WAVES) void gatv2_fwd_lds_kernel(GatParams p) {
+  gatv2_fwd_body<T, H, LPH, false, true>(p, blockIdx.x);
 }
 
 // Two edge types of one hetero layer in ONE launch: the blocks of `b` (wave-per-row: tx-belongs-bd, a few thousand short

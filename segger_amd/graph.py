@@ -49,6 +49,8 @@ class EdgeCSR:
     n_rows: int
     n_cols: int
     order: Optional[Tensor] = None   # int32 [n_rows]: degree-balanced visiting order (balanced_order), or None
+    # block tables of the NATURAL visiting order (block_tables()): (blk_cnt, blk_src, col_local) or None
+    tables: Optional[tuple] = None
 
     @property
     def n_edges(self) -> int:
@@ -61,19 +63,42 @@ class EdgeCSR:
         # objects at the SAME addresses: the entry holds the tensors themselves (an id() of a freed tensor can be reused by
         # a new one) and their data pointers (resize_ / set_ / `.data =` keep the object and move the storage)
         order = self.order if ordered else None
+        tables = self.tables if not ordered else None           # (the tables describe the natural order)
         slot = "_c_struct" if ordered else "_c_struct_natural"
         hit = self.__dict__.get(slot)
         if hit is not None:
             ts, ptrs, dims, c = hit
-            if (ts[0] is self.indptr and ts[1] is self.col and ts[2] is self.eid and ts[3] is order
+            if (ts[0] is self.indptr and ts[1] is self.col and ts[2] is self.eid and ts[3] is order and ts[4] is tables
                     and dims == (self.n_rows, self.n_cols)
                     and ptrs == (self.indptr.data_ptr(), self.col.data_ptr(), self.eid.data_ptr(), _lib.ptr(order))):
                 return c
         ptrs = (self.indptr.data_ptr(), self.col.data_ptr(), self.eid.data_ptr(), _lib.ptr(order))
         c = _lib.Csr(ptrs[0], ptrs[1] if self.n_edges else None, ptrs[2] if self.n_edges else None,
                      self.n_rows, self.n_cols, self.n_edges, ptrs[3])
-        self.__dict__[slot] = ((self.indptr, self.col, self.eid, order), ptrs, (self.n_rows, self.n_cols), c)
+        if tables is not None:
+            c.blk_cnt, c.blk_src, c.col_local = (t.data_ptr() for t in tables)
+        self.__dict__[slot] = ((self.indptr, self.col, self.eid, order, tables), ptrs, (self.n_rows, self.n_cols), c)
         return c
+
+    def block_tables(self) -> "EdgeCSR":
+        """Attach the block tables of ``segger_csr_block_tables`` (natural visiting order): per 16-row workgroup the distinct
+        column ids its rows gather + the LDS slot of every edge.  One host read of the overflow flag (a block with more than
+        128 distinct ids / 1024 edges: the view then keeps the plain kernels)."""
+        if self.tables is None and self.n_rows > 0 and self.n_edges > 0:
+            dev = self.indptr.device
+            nblk = (self.n_rows + 15) // 16
+            cnt = torch.empty(nblk, dtype=torch.int32, device=dev)
+            src = torch.empty((nblk, 128), dtype=torch.int32, device=dev)
+            loc = torch.empty(self.n_edges, dtype=torch.uint8, device=dev)
+            over = torch.zeros(1, dtype=torch.int32, device=dev)
+            with _lib.on_device(dev):
+                rc = _lib.load().segger_csr_block_tables(self.indptr.data_ptr(), self.col.data_ptr(), None, self.n_rows,
+                                                         self.n_edges, cnt.data_ptr(), src.data_ptr(), loc.data_ptr(),
+                                                         over.data_ptr(), _lib.stream_ptr(dev))
+            _lib.check(rc, "segger_csr_block_tables")
+            if int(over.item()) == 0:
+                self.tables = (cnt, src, loc)
+        return self
 
     def balanced_order(self, window: Optional[int] = None) -> "EdgeCSR":
         """Attach the visiting order of ``segger_csr_row_order`` (rows of near-equal degree share a wave; computed

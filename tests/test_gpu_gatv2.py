@@ -565,3 +565,45 @@ def test_c2_belongs_layer_against_oracle(oracle, cuda, dtype, dropout):
     close(xr.grad, o[1].grad, dtype, scale=4.0 * deg ** 0.5, what="grad_xr (tx-belongs-bd, C2)")
     close(att.grad, o[2].grad, dtype, scale=4.0 * E ** 0.5, what="grad_att (tx-belongs-bd, C2)")
     close(bias.grad, o[3].grad, dtype, scale=4.0 * n_dst ** 0.5, what="grad_bias (tx-belongs-bd, C2)")
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_lds_gather_forward_is_bit_identical(cuda, dtype):
+    """Opt-in block tables (``EdgeCSR.block_tables()`` -> ``gatv2_fwd_lds_kernel``): every workgroup stages the DISTINCT source
+    rows of its 16 destination rows in LDS once and gathers from there.  Same values, same order of accumulation: outputs,
+    pre-activations and softmax statistics equal the plain kernel's bit for bit -- on the C2 tile (dropout bit planes on) and
+    on a small random graph with empty rows; a graph whose workgroups gather more than 128 distinct rows gets no tables."""
+    from segger_amd import ops
+    from segger_amd.graph import build_edge_graph
+    H, C = 2, 64
+    hc = H * C
+    n, ei, _ = _c2_tile(cuda)
+    small = random_graph(5000, 3001, 40_000, seed=4).to(cuda)
+    small = small[:, torch.argsort(small[1] // 16 * 100_000 + small[0] % 97)]          # (few distinct sources per 16 rows)
+    small[0] = (small[1] // 16) * 8 % 4900 + small[0] % 97
+    for n_src, n_dst, edges, p in ((n, n, ei, 0.2), (5000, 3001, small, 0.0)):
+        g0 = build_edge_graph(edges, n_src, n_dst)
+        g1 = build_edge_graph(edges, n_src, n_dst)
+        g1.by_dst.block_tables()
+        assert g1.by_dst.tables is not None and g0.by_dst.tables is None
+        gen = torch.Generator(device=cuda).manual_seed(2)
+        xl = torch.randn(n_src, hc, device=cuda, generator=gen).to(dtype)
+        xr = torch.randn(n_dst, hc, device=cuda, generator=gen).to(dtype)
+        att = torch.randn(hc, device=cuda, generator=gen) * 0.3
+        bias = torch.randn(hc, device=cuda, generator=gen) * 0.1
+        res = []
+        for g in (g0, g1):
+            out = torch.empty(n_dst, hc, dtype=dtype, device=cuda)
+            pre = torch.empty_like(out)
+            lse = torch.empty(n_dst, H, device=cuda)
+            bits = ops.dropout_bits(g.by_dst, H, p, [9])[0] if p > 0 else None
+            ops.gatv2_fwd_launch(g.by_dst, xl, xr, att, bias, H, C, out, pre=pre, lse=lse, apply_gelu=True, dropout_p=p, seed=9,
+                                 keep_bits=bits)
+            res.append((out, pre, lse))
+        torch.cuda.synchronize()
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+    wide = torch.stack([torch.randperm(4000, device=cuda)[:3200], torch.arange(3200, device=cuda) % 16])   # 200 sources per row
+    gw = build_edge_graph(wide, 4000, 16)
+    gw.by_dst.block_tables()
+    assert gw.by_dst.tables is None

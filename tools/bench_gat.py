@@ -18,6 +18,9 @@ elif mode == 'random':                           # uniformly random neighbours: 
 g = build_edge_graph(ei, n, n)
 if os.environ.get('ORDER', '1') == '0':          # A/B of the degree-balanced visiting order
     g.by_dst.order = g.by_src.order = None
+if os.environ.get('LDSG', '0') == '1':           # block tables: the forward gathers from LDS
+    g.by_dst.block_tables()
+    print('block tables:', g.by_dst.tables is not None, flush=True)
 H, C = 2, 64; hc = H * C
 dt = {'bf16': torch.bfloat16, 'f16': torch.float16, 'f32': torch.float32}[os.environ.get('DTYPE', 'bf16')]
 gen = torch.Generator(device=dev).manual_seed(0)
