@@ -1205,7 +1205,7 @@ def main():
         scratch = ops.gatv2_bwd_launch.scratch
         bwd_dst = lambda: ops.gatv2_bwd_launch(g_tt, xp[:, :hc], xp[:, hc:2 * hc], att, bias, H, C, gy, pre, lse,
                                                gxp[:, :hc], gxp[:, hc:2 * hc], apply_gelu=True, dropout_p=drop, seed=11,
-                                               keep_bits=kb, passes=1, scratch=scratch)
+                                               keep_bits=kb, passes=3, scratch=scratch)   # the kernel alone (1 = + the two slab-sum launches)
         bwd_src = lambda: ops.gatv2_bwd_launch(g_tt, xp[:, :hc], xp[:, hc:2 * hc], att, bias, H, C, gy, pre, lse,
                                                gxp[:, :hc], gxp[:, hc:2 * hc], apply_gelu=True, dropout_p=drop, seed=11,
                                                keep_bits=kb, passes=2, scratch=scratch)

@@ -244,7 +244,9 @@ typedef struct segger_gatv2_bwd_args {
                              (grad_pre, dsum, grad_xr, grad_att, grad_bias; grad_xl too in the one-pass form); 2: the
                              source-side pass alone (grad_xl from the grad_pre / dsum an earlier passes = 1 call left in
                              the same buffers).  1 then 2 == 0; exists so that a profiler / bench.py can time the two
-                             kernels of the backward separately (roofline.dominant). */
+                             kernels of the backward separately (roofline.dominant).  3: the destination KERNEL alone --
+                             as 1 without the two small launches that sum its per-workgroup grad_att / grad_bias partials
+                             (those two outputs are then not written): timing only. */
 } segger_gatv2_bwd_args;
 
 size_t segger_gatv2_bwd_workspace_bytes(int64_t n_dst, int32_t heads, int32_t channels);

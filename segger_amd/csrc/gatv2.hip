@@ -325,7 +325,7 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
   hipStream_t stream = (hipStream_t)stream_;
   BwdState s;
   CHECK_RC(bwd_prepare(a, s));
-  SEGGER_REQUIRE(a->passes >= 0 && a->passes <= 2, "segger_gatv2_bwd: passes must be 0 (both), 1 (destination) or 2 (source)");
+  SEGGER_REQUIRE(a->passes >= 0 && a->passes <= 3, "segger_gatv2_bwd: passes must be 0 (both), 1 (destination), 2 (source) or 3");
   // ---- destination side ------------------------------------------------------
   if (a->passes != 2) {
     bwd_dst_params(a, s);
@@ -333,13 +333,13 @@ extern "C" int segger_gatv2_bwd(const segger_gatv2_bwd_args* a, segger_stream_t 
     if (s.n_dst > 0) {
       GenericOut gen; gen.grad_att = a->grad_att; gen.grad_bias = a->grad_bias;
       CHECK_RC(launch(Pass::BwdDst, s.p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_dst), stream, gen));
-      CHECK_RC(bwd_reduce_slab(a, s, stream));
+      if (a->passes != 3) CHECK_RC(bwd_reduce_slab(a, s, stream));
     } else {
       CHECK_RC(bwd_no_destinations(a, stream));
     }
   }
   // ---- source side -----------------------------------------------------------
-  if (s.direct || a->passes == 1) return SEGGER_OK;
+  if (s.direct || a->passes == 1 || a->passes == 3) return SEGGER_OK;
   bwd_src_params(a, s);
   if (s.n_src > 0) CHECK_RC(launch(Pass::BwdSrc, s.p, a->dtype, a->heads, a->channels, use_wave_per_row(a->by_src), stream));
   return SEGGER_OK;
