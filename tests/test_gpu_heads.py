@@ -265,7 +265,9 @@ def test_one_launch_loss_head_equals_the_kernel_by_kernel_head(cuda, dtype, C, k
     ltol = 2e-6 if dtype == torch.float32 else (2e-2 if dtype == torch.bfloat16 else 3e-3)
     assert torch.allclose(out[True][0], out[False][0], rtol=ltol, atol=ltol * 1e-2)
     # fp32: two orders of the same sums; 16-bit: normalised rows and the stored gradient are rounded to the storage type once
-    tol = 2e-5 if dtype == torch.float32 else (3e-2 if dtype == torch.bfloat16 else 4e-3)
+    # (fp32 bound: a hot row adds up to 400 fp32 atomics in whatever order they arrive, in BOTH heads -- 400 x 2^-24 = 2.4e-5
+    #  of the row's magnitude in the worst case; 2e-5 held in hundreds of runs and missed once by 5 %: 5e-5)
+    tol = 5e-5 if dtype == torch.float32 else (3e-2 if dtype == torch.bfloat16 else 4e-3)
     for k in (1, 2):
         scale = out[False][k].abs().max().item()
         assert scale > 0 and (out[True][k] - out[False][k]).abs().max().item() <= tol * scale, (k, scale)
